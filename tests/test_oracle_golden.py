@@ -1,0 +1,90 @@
+"""Pin the oracle (oracle/vec2wav_oracle.py) against every fixture captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vec2wav_oracle as O
+from tests.golden_util import golden_names, load_golden, case_setup, probe_summary, tol_for
+
+
+def run_oracle(meta, h, sd, inp, inp2, dtype=torch.float32):
+    mode = meta['mode']
+    probes = {}
+    extra = {}
+    if mode == 'evalcal':
+        O.calibrate_running_stats(sd, h, *inp, dtype=dtype)
+        y, nb = O.generator_forward(sd, h, *inp, training=False, dtype=dtype, probes=probes)
+    elif mode == 'eval':
+        y, nb = O.generator_forward(sd, h, *inp, training=False, dtype=dtype, probes=probes)
+    elif mode == 'train2':
+        y1, nb1 = O.generator_forward(sd, h, *inp, training=True, dtype=dtype)
+        extra['y_step1'] = y1
+        O.apply_buffers(sd, nb1)
+        y, nb = O.generator_forward(sd, h, *inp2, training=True, dtype=dtype, probes=probes)
+    elif mode == 'train_rmwn':
+        sd2 = O.remove_weight_norm_sd(sd)
+        extra['keys_after_rmwn'] = list(sd2.keys())
+        y, nb = O.generator_forward(sd2, h, *inp, training=True, dtype=dtype, probes=probes)
+    else:
+        y, nb = O.generator_forward(sd, h, *inp, training=True, dtype=dtype, probes=probes)
+    O.apply_buffers(sd, nb)
+    return y, probes, extra
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_oracle_matches_reference_golden(name):
+    torch.set_num_threads(8)
+    z, meta = load_golden(name)
+    h, sd, inp, inp2 = case_setup(meta)
+    y, probes, extra = run_oracle(meta, h, sd, inp, inp2)
+    tol = tol_for(meta)
+    # tighter than the product bar: oracle and reference are the same arithmetic up to summation order
+    otol = 2e-5 if meta['mode'] != 'eval' else tol
+    d = np.abs(y.numpy() - z['y']).max()
+    assert y.shape == z['y'].shape
+    assert d <= otol, f'{name}: max|dy|={d}'
+    if 'y_step1' in extra:
+        assert np.abs(extra['y_step1'].numpy() - z['y_step1']).max() <= otol
+    if 'keys_after_rmwn' in extra:
+        assert extra['keys_after_rmwn'] == [str(k) for k in z['keys_after_rmwn']]
+    # per-layer probes
+    for pname, t in probes.items():
+        s = probe_summary(t)
+        scale = max(1.0, float(np.abs(z[f'probe/{pname}/head']).max()))
+        ptol = (1e-3 if meta['mode'] != 'eval' else 5e-2) * scale
+        assert np.abs(s['head'] - z[f'probe/{pname}/head']).max() <= ptol, pname
+        assert np.abs(s['tail'] - z[f'probe/{pname}/tail']).max() <= ptol, pname
+        ref_abs = float(z[f'probe/{pname}/abssum'])
+        assert abs(s['abssum'] - ref_abs) <= 1e-4 * ref_abs + 1e-3, pname
+    # post-forward buffers (running stats, num_batches_tracked, spectral-norm u/v)
+    for k in z.files:
+        if k.startswith('buf/'):
+            ref = z[k]
+            got = sd[k[4:]].numpy()
+            assert got.shape == ref.shape, k
+            if ref.dtype.kind == 'i':
+                assert (got == ref).all(), k
+            else:
+                assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+
+
+def test_state_dict_spec_matches_reference_keys():
+    from wavthruvec_pytorch_amd import synthetic
+    z, meta = load_golden('rb2_train_b2_t8')
+    h = synthetic.make_hparams(**meta['hp'])
+    spec = synthetic.state_dict_spec(h)
+    assert [k for k, _, _ in spec] == [str(k) for k in z['meta_keys']]
+    assert [','.join(map(str, s)) for _, s, _ in spec] == [str(s) for s in z['meta_shapes']]
+    z1, meta1 = load_golden('rb1_train_b2_t8')
+    h1 = synthetic.make_hparams(**meta1['hp'])
+    assert [k for k, _, _ in synthetic.state_dict_spec(h1)] == [str(k) for k in z1['meta_keys']]
+
+
+def test_fp64_oracle_noise_floor():
+    """fp32 oracle vs fp64 oracle in train mode: the path's own noise floor is ~1e-6."""
+    z, meta = load_golden('rb2_train_b2_t8')
+    h, sd, inp, _ = case_setup(meta)
+    y32, _ = O.generator_forward(sd, h, *inp, training=True, dtype=torch.float32)
+    y64, _ = O.generator_forward(sd, h, *inp, training=True, dtype=torch.float64)
+    assert (y32.double() - y64).abs().max().item() < 5e-6
+    assert np.abs(y64.numpy() - z['y']).max() < 5e-6
