@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Vec2Wav generator forward benchmark on MI355X (BASELINE.json metric: audio samples/sec).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one `Generator.forward` (train-mode CondBN: batch statistics, spectral-norm power iteration,
+weight-norm fold all inside the timed region) over one synthetic batch resident in HBM.
+Workload = BASELINE.json configs[1]: B=32 per GPU, T=256 frames, 768-d latents, x320, fp32, ResBlock2 (default hparams).
+N>1: one process per GPU, weak scaling (B=32 per rank), CondBN statistics all-reduced over RCCL each stage.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+from statistics import mean
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DOMINANT_PREFIXES = ('resblocks.', 'conv_pre')   # launches of conv_tile_kernel<...,U=1,...> (implicit-GEMM conv)
+
+
+def cpu_baseline(h, threads):
+    """The oracle (CPU restatement of the reference forward) timed on this box's host cores: a reported baseline."""
+    from oracle import vec2wav_oracle as O
+    from wavthruvec_pytorch_amd import synthetic
+    torch.set_num_threads(threads)
+    sd = synthetic.make_state_dict(h, seed=0)
+    B, T = 4, 256
+    inp = synthetic.make_inputs(h, B, T, seed=1234)
+    O.generator_forward(sd, h, *inp, training=True)   # warm-up
+    times = []
+    t_end = time.time() + 20.0
+    while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+        t0 = time.perf_counter()
+        O.generator_forward(sd, h, *inp, training=True)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=B * T * synthetic.total_upsample(h) / med, unit='samples/s', cores=threads, kind='port',
+                sample=f'oracle (torch CPU fp32 restatement), train-mode forward, B={B} T={T} 768-d, median of {len(times)}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (cfg2: 32)')
+    ap.add_argument('--frames', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--algo', default='auto', choices=['auto', 'direct'])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the Vec2Wav HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from wavthruvec_pytorch_amd import Generator, synthetic, workmodel, hipops
+
+    h = synthetic.make_hparams(num_wv_feat=768)
+    B, T = args.batch, args.frames
+    g = Generator(h)
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+    g = g.to(dev).train()
+    g.algo = hipops.ALGO_DIRECT if args.algo == 'direct' else hipops.ALGO_AUTO
+    if world > 1:
+        g.enable_sync_batchnorm()
+    x, spk, nz = synthetic.make_inputs(h, B, T, seed=1234 + rank, device=dev)
+    samples_per_step = world * B * T * synthetic.total_upsample(h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            g(x, spk, nz)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g(x, spk, nz)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- roofline of the dominant kernel: events around every conv launch, on the launching stream, live
+    roof = None
+    if rank == 0:
+        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
+        per = {}
+        with torch.no_grad():
+            for _ in range(3):
+                g._profile = []
+                g(x, spk, nz)
+                torch.cuda.synchronize()
+                for tag, e0, e1 in g._profile:
+                    per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
+            g._profile = None
+        dom = [n for n in per if n.startswith(DOMINANT_PREFIXES)]
+        dom_t = sum(mean(per[n]) for n in dom)
+        dom_f = sum(layers[n]['flops'] for n in dom)
+        # the single most expensive instantiation: conv_tile_kernel<32,1,2,2,2,2,8> (C_out multiple of 128: conv_pre, stages 0-1)
+        big = [n for n in dom if layers[n]['cout'] % 128 == 0]
+        big_t = sum(mean(per[n]) for n in big)
+        big_f = sum(layers[n]['flops'] for n in big)
+        all_t = sum(mean(v) for v in per.values())
+        tot_f, tot_b = workmodel.totals(h, B, T)
+        roof = dict(bound='mfma', kernel='conv_tile_kernel<32,1,2,2,2,2,8> (f32 MFMA implicit-GEMM conv, C_out%128==0)',
+                    achieved=big_f / big_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=big_f / big_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                    launches_per_step=len(big), avg_launch_us=big_t / len(big) * 1e6,
+                    all_conv_launches=dict(achieved=dom_f / dom_t / 1e12, frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                           launches_per_step=len(dom)),
+                    whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
+                                       mfma_frac=tot_f / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                       hbm_frac=tot_b / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS),
+                    per_stage_ms={k: round(sum(mean(per[n]) for n in per if n.startswith(k)) * 1e3, 4)
+                                  for k in ['conv_pre', 'ups.', 'resblocks.', 'conv_post']})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(h, os.cpu_count() or 1)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            'metric': 'audio samples/sec (16 kHz) Vec2Wav generator forward',
+            'value': samples_per_step * args.steps / elapsed,
+            'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: B={B}/GPU x T={T} frames, 768-d latents, upsample (5,4,4,2,2) x320, '
+                                   'ResBlock2, train-mode CondBN, fp32', 'global_batch': B * world, 'frames': T,
+                       'parallelism': f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else 'single GPU'},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

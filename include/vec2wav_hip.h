@@ -1,0 +1,144 @@
+/*
+ * vec2wav_hip.h - C ABI of libvec2wav_hip.so: the Vec2Wav generator forward path as
+ * hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * The reference (p1an-lin-jung/WavThruVec_pytorch) has no FFI/operator layer: its boundary is
+ * the Python nn.Module surface (vec2wav/models.py:77-156, vec2wav/modules.py:5-30) and everything
+ * underneath is stock torch ops.  Each entry point below therefore cites the reference statement
+ * (file:line under /root/reference) whose arithmetic it replaces; the Python mirror of the
+ * reference surface (wavthruvec_pytorch_amd/models.py) is the only caller.  INTEGRATION.md shows
+ * the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch types; every pointer is a DEVICE pointer unless said
+ *     otherwise; activations are fp32, channels-first, contiguous (B, C, L);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are asynchronous,
+ *     nothing allocates, nothing synchronises, no ownership is transferred;
+ *   - return value: 0 = enqueued; < 0 = bad argument (V2W_E_*); > 0 = a hipError_t from the launch;
+ *   - no global mutable state: safe to call concurrently on distinct streams.
+ *
+ * Folded weight layout ("wf"): fp32 [k][C_in][C_out] (C_out fastest) for both Conv1d and
+ * ConvTranspose1d, produced by v2w_wn_fold_* from the reference's weight_g/weight_v parameters.
+ */
+#ifndef VEC2WAV_HIP_H
+#define VEC2WAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2W_ABI_VERSION 1
+
+#define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
+#define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
+#define V2W_E_ALGO     (-3)  /* unknown algorithm id */
+
+/* algorithm selector of the conv entry points */
+#define V2W_ALGO_AUTO   0    /* MFMA tile kernel when the shape allows, else the direct kernel */
+#define V2W_ALGO_DIRECT 1    /* one-thread-per-output scalar FMA kernel: any shape; cross-check */
+#define V2W_ALGO_MFMA   2    /* f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) implicit GEMM; V2W_E_SHAPE if unsupported */
+
+int         v2w_abi_version(void);
+const char* v2w_build_arch(void);       /* "gfx950" */
+
+/* ---- K0: weight-norm fold (torch.nn.utils.weight_norm pre-forward hook, dim=0; triggered by
+ * models.py:18-33,58-61,83,90-92,100).  w = g * v / ||v||, norm over all dims but 0.
+ * conv : v (C_out, C_in, k), g (C_out)  -> wf [k][C_in][C_out]      (norm per C_out)
+ * convt: v (C_in, C_out, k), g (C_in)   -> wf [k][C_in][C_out]      (norm per C_in)
+ * g == NULL means "weight norm already removed" (models.py:149-156): v is the plain weight, relayout only.
+ * scratch: >= rows floats (rows = C_out for conv, C_in for convt). */
+int v2w_wn_fold_conv (const float* v, const float* g, float* wf, float* scratch,
+                      int c_out, int c_in, int k, void* stream);
+int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
+                      int c_in, int c_out, int k, void* stream);
+
+/* ---- K1/K5/K6/K7: fused [per-(b,c) affine] -> leaky_relu -> dilated Conv1d -> +bias [-> +residual]
+ * [-> += out] [-> / out_div].  Replaces F.leaky_relu + Conv1d (+ `xt + x`, `xs += ...`, `xs / num_kernels`)
+ * of models.py:37-44 (ResBlock1), 65-70 (ResBlock2), 123 (conv_pre), 135-141 (mean over kernels).
+ *   in   (B, C_in, L)     in_a/in_s   (B, C_in)  or NULL : x = in_a*in + in_s before the activation
+ *                                                          (the CondBN affine of modules.py:25-28 folded into the load)
+ *   res  (B, C_out, L) or NULL; res_a/res_s (B, C_out) or NULL : residual = res_a*res + res_s
+ *   out  (B, C_out, L);   padding = dil*(k-1)/2 (utils.py:35-36), k odd
+ *   slope: leaky_relu negative slope applied to the conv operand (1.0f = none)
+ *   accumulate != 0: out = out_old + value ; out_div != 0: out = value / out_div (applied last) */
+typedef struct {
+    const float* in;   const float* in_a;  const float* in_s;
+    const float* wf;   const float* bias;
+    const float* res;  const float* res_a; const float* res_s;
+    float*       out;
+    int32_t B, C_in, C_out, L, k, dil;
+    float   slope;
+    int32_t accumulate;
+    float   out_div;
+    int32_t algo;
+} v2w_conv1d_args;
+int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
+
+/* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
+ * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */
+typedef struct {
+    const float* in; const float* wf; const float* bias; float* out;
+    int32_t B, C_in, C_out, L, k, u;
+    float   slope;
+    int32_t algo;
+} v2w_convt1d_args;
+int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
+
+/* ---- K3: per-stage conditioning  z = fcs[i](cat(spk, noise))  (models.py:120,131), legacy
+ * spectral_norm power iteration on cbns[i].layer (modules.py:16,24) and [gamma|beta] = (W/sigma) z + b.
+ * One call serves every stage (they depend on spk/noise only).  Arrays of n_stages DEVICE pointers are
+ * passed by value inside the struct (HOST struct).
+ *   spk (B, spk_dim), noise (B, noise_dim); fc_w[i] (128, spk_dim+noise_dim), fc_b[i] (128)
+ *   sn_w[i] (2C_i, 128) = weight_orig, sn_b[i] (2C_i), sn_u[i] (2C_i), sn_v[i] (128)
+ *   training != 0: one power iteration, u and v are UPDATED IN PLACE (as the reference's hook does)
+ *   gb[i] (B, 2C_i): gamma = gb[:, :C], beta = gb[:, C:]   (chunk(2,1), modules.py:24)
+ *   z_ws: workspace of n_stages*B*128 floats; sigma_ws: n_stages floats
+ *   fc_w[i] == fc_b[i] == NULL: no fcs layer, z = cat(spk, noise) itself (needs spk_dim+noise_dim == 128;
+ *   noise may be NULL with noise_dim == 0) - ConditionalBatchNorm1d.forward(inputs, noise) used on its own. */
+#define V2W_MAX_STAGES 8
+typedef struct {
+    const float* spk; const float* noise;
+    const float* fc_w[V2W_MAX_STAGES]; const float* fc_b[V2W_MAX_STAGES];
+    const float* sn_w[V2W_MAX_STAGES]; const float* sn_b[V2W_MAX_STAGES];
+    float* sn_u[V2W_MAX_STAGES]; float* sn_v[V2W_MAX_STAGES];
+    float* gb[V2W_MAX_STAGES];
+    int32_t C[V2W_MAX_STAGES];
+    float* z_ws; float* sigma_ws;
+    int32_t n_stages, B, spk_dim, noise_dim, training;
+} v2w_cond_args;
+int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream);
+
+/* ---- K4: BatchNorm1d(affine=False) statistics and finalisation (modules.py:14,23).
+ * v2w_bn_stats   : x (B,C,L) -> stats[2C] doubles = [sum_c | sumsq_c] over (B,L); deterministic two-level
+ *                  reduction; partial_ws >= 2*C*V2W_BN_SPLITS doubles.
+ *                  In data-parallel runs the host all-reduces `stats` (RCCL, sum) between the two calls.
+ * v2w_bn_finalize: training: mean/biased var from stats (count = stats[2C]), running_mean/var
+ *                  momentum update with the unbiased var, num_batches_tracked += 1 (int64);
+ *                  eval: running stats are used, nothing is written.
+ *                  Then the folded per-sample affine  a[b,c] = gamma*rstd, s[b,c] = beta - gamma*mean*rstd
+ *                  (so that CondBN(x) = a*x + s, modules.py:23-28) from gb (B, 2C). */
+#define V2W_BN_SPLITS 64
+/* stats: 2C+1 doubles = [sum_c | sumsq_c | count]; count = B*L is written by the kernel so that one
+ * all-reduce(sum) of the whole array yields the global sums AND the global element count. */
+int v2w_bn_stats(const float* x, double* stats, double* partial_ws, int B, int C, int L, void* stream);
+int v2w_bn_finalize(const double* stats, const float* gb,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* a_out, float* s_out, int B, int C, int training,
+                    float momentum, float eps, void* stream);
+
+/* ---- K5 (standalone form): out = a[b,c]*x + s[b,c] over (B,C,L).  Only ConditionalBatchNorm1d.forward used on
+ * its own (modules.py:20-30) materialises the normalised tensor; Generator.forward folds the affine into its
+ * consumers' loads instead. */
+int v2w_affine_apply(const float* x, const float* a, const float* s, float* out, int B, int C, int L, void* stream);
+
+/* ---- K8: leaky_relu(slope) -> Conv1d(C_in -> 1, k, pad (k-1)/2) -> +bias -> tanh  (models.py:143-145).
+ * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
+int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
+                       int B, int C_in, int L, int k, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEC2WAV_HIP_H */

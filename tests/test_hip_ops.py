@@ -1,0 +1,264 @@
+"""GPU parity of every C-ABI entry point against the oracle's arithmetic on the same seeded inputs.
+
+All calls go through the C ABI (ctypes) of libvec2wav_hip.so.  The expected values come from the oracle
+(oracle/vec2wav_oracle.py) or, for a single floating-point op, from the stock fp32 torch op it restates."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vec2wav_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    from wavthruvec_pytorch_amd import _hip
+    _hip.load()
+    return torch.device('cuda:0')
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _relayout(w_conv):  # (Cout, Cin, k) -> [k][Cin][Cout]
+    return w_conv.permute(2, 1, 0).contiguous()
+
+
+@pytest.mark.parametrize('cout,cin,k', [(512, 768, 7), (256, 256, 11), (16, 16, 3), (1, 16, 7), (24, 40, 5)])
+def test_wn_fold_conv(dev, cout, cin, k):
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(1)
+    v = r.standard_normal((cout, cin, k), dtype=np.float32)
+    g = (1 + 0.1 * r.standard_normal((cout, 1, 1))).astype(np.float32)
+    want = _relayout(O.fold_weight_norm(torch.from_numpy(g), torch.from_numpy(v)))
+    got = hipops.fold_conv_weight(_t(v, dev), _t(g, dev)).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 2e-7 * want.abs().max().item() + 1e-9
+    plain = hipops.fold_conv_weight(_t(v, dev), None).cpu()       # after remove_weight_norm: relayout only
+    assert torch.equal(plain, _relayout(torch.from_numpy(v)))
+
+
+@pytest.mark.parametrize('cin,cout,k', [(512, 256, 11), (32, 16, 4), (512, 256, 16), (20, 12, 6)])
+def test_wn_fold_convt(dev, cin, cout, k):
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(2)
+    v = r.standard_normal((cin, cout, k), dtype=np.float32)
+    g = (1 + 0.1 * r.standard_normal((cin, 1, 1))).astype(np.float32)
+    w = O.fold_weight_norm(torch.from_numpy(g), torch.from_numpy(v))   # (Cin, Cout, k), norm per Cin
+    want = w.permute(2, 0, 1).contiguous()                                # [k][Cin][Cout]
+    got = hipops.fold_convt_weight(_t(v, dev), _t(g, dev)).cpu()
+    assert (got - want).abs().max().item() <= 2e-7 * want.abs().max().item() + 1e-9
+
+
+CONV_CASES = [
+    # B, Cin, Cout, L, k, dil
+    (2, 768, 512, 50, 7, 1),      # conv_pre, ragged L
+    (2, 256, 256, 250, 3, 1),     # stage 0, L not a multiple of the tile
+    (2, 256, 256, 250, 11, 3),
+    (1, 128, 128, 1000, 7, 5),    # ResBlock1 dilation 5
+    (2, 64, 64, 700, 11, 3),
+    (3, 32, 32, 1000, 3, 1),
+    (2, 16, 16, 3000, 11, 3),
+    (2, 16, 16, 5, 7, 3),         # shorter than the receptive field
+    (1, 16, 16, 1, 3, 1),         # single sample
+    (2, 24, 40, 100, 5, 2),       # shape with no MFMA tile config -> direct kernel
+]
+
+
+@pytest.mark.parametrize('algo', ['auto', 'direct'])
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', CONV_CASES)
+def test_conv1d_fused(dev, algo, B, cin, cout, L, k, dil):
+    """[affine] -> lrelu -> conv -> +bias -> +residual(affine) -> += out -> / div, all flags on."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(3)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    ia, is_ = (1 + 0.2 * r.standard_normal((B, cin))).astype(np.float32), (0.3 * r.standard_normal((B, cin))).astype(np.float32)
+    res = r.standard_normal((B, cout, L), dtype=np.float32)
+    ra, rs = (1 + 0.2 * r.standard_normal((B, cout))).astype(np.float32), (0.3 * r.standard_normal((B, cout))).astype(np.float32)
+    prev = r.standard_normal((B, cout, L), dtype=np.float32)
+    tx, tw = torch.from_numpy(x), torch.from_numpy(w)
+    xin = torch.from_numpy(ia)[:, :, None] * tx + torch.from_numpy(is_)[:, :, None]
+    want = F.conv1d(F.leaky_relu(xin, 0.1), tw, torch.from_numpy(bias), padding=dil * (k - 1) // 2, dilation=dil)
+    want = want + (torch.from_numpy(ra)[:, :, None] * torch.from_numpy(res) + torch.from_numpy(rs)[:, :, None])
+    want = (want + torch.from_numpy(prev)) / 3.0
+    out = _t(prev, dev).clone()
+    a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
+    hipops.conv1d(_t(x, dev), _t(_relayout(tw).numpy(), dev), _t(bias, dev), out, k=k, dil=dil, slope=0.1,
+                  in_affine=(_t(ia, dev), _t(is_, dev)), res=_t(res, dev), res_affine=(_t(ra, dev), _t(rs, dev)),
+                  accumulate=True, out_div=3.0, algo=a)
+    err = (out.cpu() - want).abs().max().item()
+    assert err <= 2e-5, f'max err {err}'
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', CONV_CASES[:7])
+def test_conv1d_plain_and_mfma_forced(dev, B, cin, cout, L, k, dil):
+    """No optional inputs; V2W_ALGO_MFMA must accept every generator shape and agree with the direct kernel."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(4)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    want = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), None, padding=dil * (k - 1) // 2, dilation=dil)
+    wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+    o1 = torch.full((B, cout, L), float('nan'), device=dev)
+    o2 = torch.full((B, cout, L), float('nan'), device=dev)
+    hipops.conv1d(_t(x, dev), wf, None, o1, k=k, dil=dil, slope=1.0, algo=hipops.ALGO_MFMA)
+    hipops.conv1d(_t(x, dev), wf, None, o2, k=k, dil=dil, slope=1.0, algo=hipops.ALGO_DIRECT)
+    assert (o1.cpu() - want).abs().max().item() <= 2e-5
+    assert (o2.cpu() - want).abs().max().item() <= 2e-5
+
+
+def test_conv1d_rejects_bad_arguments(dev):
+    from wavthruvec_pytorch_amd import hipops, _hip
+    x = torch.zeros((1, 24, 10), device=dev)
+    wf = torch.zeros((5, 24, 40), device=dev)
+    out = torch.zeros((1, 40, 10), device=dev)
+    with pytest.raises(_hip.HipLibraryError):
+        hipops.conv1d(x, wf, None, out, k=5, algo=hipops.ALGO_MFMA)     # no tile config for 24 -> 40
+    with pytest.raises(_hip.HipLibraryError):
+        hipops.conv1d(x, wf, None, out, k=4)                            # even kernel size
+    with pytest.raises(_hip.HipLibraryError):
+        hipops.conv1d(x, wf, None, out, k=5, algo=7)
+
+
+CONVT_CASES = [
+    # B, Cin, Cout, L, k, u
+    (2, 512, 256, 50, 11, 5),
+    (2, 256, 128, 250, 8, 4),
+    (2, 128, 64, 333, 8, 4),
+    (2, 64, 32, 1001, 4, 2),
+    (2, 32, 16, 2000, 4, 2),
+    (2, 512, 256, 17, 16, 8),     # x640 variant, first stage
+    (2, 256, 128, 136, 11, 5),    # x640 variant, second stage
+    (1, 512, 256, 1, 11, 5),      # single frame
+    (2, 20, 12, 40, 6, 2),        # no tile config -> direct
+    (2, 64, 32, 100, 9, 3),       # stride without a tile instantiation -> direct
+]
+
+
+@pytest.mark.parametrize('algo', ['auto', 'direct'])
+@pytest.mark.parametrize('B,cin,cout,L,k,u', CONVT_CASES)
+def test_convt1d(dev, algo, B, cin, cout, L, k, u):
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(5)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cin, cout, k)) / np.sqrt(cin * k / u)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    want = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x), 0.1), torch.from_numpy(w), torch.from_numpy(bias),
+                              stride=u, padding=(k - u) // 2)
+    assert want.shape[2] == L * u
+    wf = _t(torch.from_numpy(w).permute(2, 0, 1).contiguous().numpy(), dev)
+    out = torch.full((B, cout, L * u), float('nan'), device=dev)
+    a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
+    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a)
+    err = (out.cpu() - want).abs().max().item()
+    assert err <= 2e-5, f'max err {err}'
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_cond_gamma_beta(dev, training):
+    """fcs[i] + spectral-norm power iteration + Linear for all five stages in one call; u/v mutate in train only."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(6)
+    B = 5
+    Cs = [256, 128, 64, 32, 16]
+    spk = r.standard_normal((B, 192), dtype=np.float32)
+    nz = r.standard_normal((B, 192), dtype=np.float32)
+    spk_noise = torch.from_numpy(np.concatenate([spk, nz], 1))
+    fc_w, fc_b, sn_w, sn_b, sn_u, sn_v, gb, want_gb, want_u, want_v = [], [], [], [], [], [], [], [], [], []
+    for C in Cs:
+        fw = (r.standard_normal((128, 384)) / np.sqrt(384)).astype(np.float32)
+        fb = (0.1 * r.standard_normal(128)).astype(np.float32)
+        w = (1 + 0.02 * r.standard_normal((2 * C, 128))).astype(np.float32)
+        b = (0.1 * r.standard_normal(2 * C)).astype(np.float32)
+        u = r.standard_normal(2 * C); u = (u / np.linalg.norm(u)).astype(np.float32)
+        v = r.standard_normal(128); v = (v / np.linalg.norm(v)).astype(np.float32)
+        z = F.linear(spk_noise, torch.from_numpy(fw), torch.from_numpy(fb))
+        w_sn, u2, v2 = O.spectral_norm_weight(torch.from_numpy(w), torch.from_numpy(u), torch.from_numpy(v), training)
+        want_gb.append(F.linear(z, w_sn, torch.from_numpy(b)))
+        want_u.append(u2); want_v.append(v2)
+        fc_w.append(_t(fw, dev)); fc_b.append(_t(fb, dev)); sn_w.append(_t(w, dev)); sn_b.append(_t(b, dev))
+        sn_u.append(_t(u, dev)); sn_v.append(_t(v, dev)); gb.append(torch.empty((B, 2 * C), device=dev))
+    z_ws = torch.empty((5 * B * 128,), device=dev)
+    sg = torch.empty((5,), device=dev)
+    hipops.cond_gamma_beta(_t(spk, dev), _t(nz, dev), fc_w, fc_b, sn_w, sn_b, sn_u, sn_v, gb, z_ws, sg, training)
+    for i in range(5):
+        scale = want_gb[i].abs().max().item()
+        assert (gb[i].cpu() - want_gb[i]).abs().max().item() <= 2e-5 * max(1.0, scale)
+        assert (sn_u[i].cpu() - want_u[i]).abs().max().item() <= 1e-6
+        assert (sn_v[i].cpu() - want_v[i]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('B,C,L', [(3, 256, 250), (2, 16, 100000), (1, 32, 1), (4, 64, 4097)])
+def test_bn_stats_and_finalize(dev, B, C, L):
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(7)
+    x = (r.standard_normal((B, C, L)) * 2 + 0.5).astype(np.float32)
+    gbv = r.standard_normal((B, 2 * C), dtype=np.float32)
+    rm0 = (0.1 * r.standard_normal(C)).astype(np.float32)
+    rv0 = r.uniform(0.5, 1.5, C).astype(np.float32)
+    tx = torch.from_numpy(x)
+    stats = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
+    part = torch.empty((2 * C * 64,), device=dev, dtype=torch.float64)
+    xd = _t(x, dev)
+    hipops.bn_stats(xd, stats, part)
+    st = stats.cpu()
+    s1 = tx.double().sum(dim=(0, 2)); s2 = tx.double().pow(2).sum(dim=(0, 2))
+    assert (st[:C] - s1).abs().max().item() <= 1e-6 * max(1.0, s1.abs().max().item()) * 10
+    assert (st[C:2 * C] - s2).abs().max().item() <= 1e-6 * s2.abs().max().item()
+    assert st[2 * C].item() == B * L
+    for training in (True, False):
+        rm, rv = _t(rm0, dev), _t(rv0, dev)
+        nbt = torch.tensor(7, device=dev, dtype=torch.long)
+        a = torch.empty((B, C), device=dev); s = torch.empty((B, C), device=dev)
+        hipops.bn_finalize(stats if training else None, _t(gbv, dev), rm, rv, nbt, a, s, training=training)
+        xhat, rm_w, rv_w = O.batch_norm_no_affine(tx, torch.from_numpy(rm0), torch.from_numpy(rv0), training)
+        gamma, beta = torch.from_numpy(gbv).chunk(2, 1)
+        want = gamma[:, :, None] * xhat + beta[:, :, None]
+        got = hipops.affine_apply(xd, a, s, torch.empty_like(xd)).cpu()
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+        assert (rm.cpu() - rm_w).abs().max().item() <= 1e-6
+        assert (rv.cpu() - rv_w).abs().max().item() <= 1e-5
+        assert nbt.item() == (8 if training else 7)
+
+
+@pytest.mark.parametrize('B,C,L,k', [(2, 16, 8000, 7), (1, 16, 3, 7), (2, 16, 1025, 7), (2, 8, 500, 3)])
+def test_conv_post_tanh(dev, B, C, L, k):
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(8)
+    x = r.standard_normal((B, C, L), dtype=np.float32)
+    w = (r.standard_normal((1, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    bias = r.standard_normal(1).astype(np.float32)
+    want = torch.tanh(F.conv1d(F.leaky_relu(torch.from_numpy(x)), torch.from_numpy(w), torch.from_numpy(bias), padding=(k - 1) // 2))
+    out = torch.empty((B, 1, L), device=dev)
+    hipops.conv_post_tanh(_t(x, dev), _t(_relayout(torch.from_numpy(w)).numpy(), dev), _t(bias, dev), out, k=k, slope=0.01)
+    assert (out.cpu() - want).abs().max().item() <= 2e-6
+
+
+def test_conditional_batchnorm_module(dev):
+    """`ConditionalBatchNorm1d(num_features).forward(inputs, noise)` standalone (reference modules.py:32-40 smoke shape)."""
+    from wavthruvec_pytorch_amd import ConditionalBatchNorm1d
+    torch.manual_seed(0)
+    m = ConditionalBatchNorm1d(64)
+    x = torch.randn(4, 64, 80); z = torch.randn(4, 128)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    xhat, rm, rv = O.batch_norm_no_affine(x, sd['batch_nrom.running_mean'], sd['batch_nrom.running_var'], True)
+    w_sn, u2, v2 = O.spectral_norm_weight(sd['layer.weight_orig'], sd['layer.weight_u'], sd['layer.weight_v'], True)
+    gamma, beta = F.linear(z, w_sn, sd['layer.bias']).chunk(2, 1)
+    want = gamma[:, :, None] * xhat + beta[:, :, None]
+    m = m.to(dev).train()
+    got = m(x.to(dev), z.to(dev)).cpu()
+    assert got.shape == (4, 64, 80)
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert (m.layer.weight_u.cpu() - u2).abs().max().item() <= 1e-6
+    assert (m.batch_nrom.running_mean.cpu() - rm).abs().max().item() <= 1e-6
+    assert m.batch_nrom.num_batches_tracked.item() == 1

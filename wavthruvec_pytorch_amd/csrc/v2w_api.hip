@@ -1,0 +1,45 @@
+// extern "C" dispatch of the conv entry points declared in include/vec2wav_hip.h.
+#include "v2w_common.h"
+
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream);
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream);
+int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream);
+int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream);
+
+extern "C" int v2w_abi_version(void) { return V2W_ABI_VERSION; }
+extern "C" const char* v2w_build_arch(void) { return "gfx950"; }
+
+extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
+    if (!a || !a->in || !a->wf || !a->out) return V2W_E_ARG;
+    if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->dil <= 0) return V2W_E_ARG;
+    if ((a->k & 1) == 0) return V2W_E_SHAPE;                       // padding d*(k-1)/2 keeps the length only for odd k
+    if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
+    if ((a->res_a == nullptr) != (a->res_s == nullptr)) return V2W_E_ARG;
+    if (a->res_a && !a->res) return V2W_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->algo) {
+        case V2W_ALGO_DIRECT: return v2w_conv1d_direct(a, st);
+        case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, st);
+        case V2W_ALGO_AUTO: {
+            const int rc = v2w_conv1d_mfma(a, st);
+            return rc == V2W_E_SHAPE ? v2w_conv1d_direct(a, st) : rc;
+        }
+        default: return V2W_E_ALGO;
+    }
+}
+
+extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
+    if (!a || !a->in || !a->wf || !a->out) return V2W_E_ARG;
+    if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 0) return V2W_E_ARG;
+    if (a->k < a->u || ((a->k - a->u) & 1)) return V2W_E_SHAPE;    // L_out = u*L needs k-u even
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->algo) {
+        case V2W_ALGO_DIRECT: return v2w_convt1d_direct(a, st);
+        case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st);
+        case V2W_ALGO_AUTO: {
+            const int rc = v2w_convt1d_mfma(a, st);
+            return rc == V2W_E_SHAPE ? v2w_convt1d_direct(a, st) : rc;
+        }
+        default: return V2W_E_ALGO;
+    }
+}

@@ -1,0 +1,136 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/vec2wav_hip.h).
+
+torch is plumbing here: it owns device memory and the stream; every arithmetic step runs in the
+HIP kernels.  All wrappers require fp32 contiguous CUDA(ROCm) tensors and raise otherwise -
+there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _hip
+
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must live on a GPU: the Vec2Wav HIP path has no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def fold_conv_weight(v, g, out=None, scratch=None):
+    """weight_v (C_out,C_in,k), weight_g (C_out,1,1)|None -> wf [k][C_in][C_out]."""
+    _chk(v, 'v'); _chk(g, 'g')
+    co, ci, k = v.shape
+    if out is None:
+        out = torch.empty((k, ci, co), device=v.device, dtype=torch.float32)
+    if scratch is None:
+        scratch = torch.empty((co,), device=v.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_wn_fold_conv(v.data_ptr(), _hip.ptr(g), out.data_ptr(), scratch.data_ptr(),
+                                            co, ci, k, _stream(v)), 'v2w_wn_fold_conv')
+    return out
+
+
+def fold_convt_weight(v, g, out=None, scratch=None):
+    """ConvTranspose1d weight_v (C_in,C_out,k), weight_g (C_in,1,1)|None -> wf [k][C_in][C_out]."""
+    _chk(v, 'v'); _chk(g, 'g')
+    ci, co, k = v.shape
+    if out is None:
+        out = torch.empty((k, ci, co), device=v.device, dtype=torch.float32)
+    if scratch is None:
+        scratch = torch.empty((ci,), device=v.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_wn_fold_convt(v.data_ptr(), _hip.ptr(g), out.data_ptr(), scratch.data_ptr(),
+                                             ci, co, k, _stream(v)), 'v2w_wn_fold_convt')
+    return out
+
+
+def conv1d(x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
+           accumulate=False, out_div=0.0, algo=ALGO_AUTO):
+    """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out] [/ out_div]; see the header."""
+    B, ci, L = x.shape
+    co = out.shape[1]
+    a = _hip.Conv1dArgs()
+    a.in_ = x.data_ptr()
+    a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
+    a.wf = wf.data_ptr(); a.bias = _hip.ptr(bias)
+    a.res = _hip.ptr(res)
+    a.res_a, a.res_s = (_hip.ptr(res_affine[0]), _hip.ptr(res_affine[1])) if res_affine is not None else (None, None)
+    a.out = out.data_ptr()
+    a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, co, L, k, dil
+    a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
+    _hip.check(_hip.load().v2w_conv1d_fwd(C.byref(a), _stream(x)), 'v2w_conv1d_fwd')
+    return out
+
+
+def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO):
+    """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias."""
+    B, ci, L = x.shape
+    a = _hip.ConvT1dArgs()
+    a.in_ = x.data_ptr(); a.wf = wf.data_ptr(); a.bias = _hip.ptr(bias); a.out = out.data_ptr()
+    a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
+    a.slope = slope; a.algo = algo
+    _hip.check(_hip.load().v2w_convt1d_fwd(C.byref(a), _stream(x)), 'v2w_convt1d_fwd')
+    return out
+
+
+def cond_gamma_beta(spk, noise, fc_w: Sequence, fc_b: Sequence, sn_w: Sequence, sn_b: Sequence,
+                    sn_u: Sequence, sn_v: Sequence, gb: Sequence, z_ws, sigma_ws, training: bool):
+    """All stages' [gamma|beta] in one call; sn_u / sn_v are updated in place when training."""
+    n = len(fc_w)
+    if n > _hip.V2W_MAX_STAGES:
+        raise ValueError(f'at most {_hip.V2W_MAX_STAGES} upsample stages are supported')
+    a = _hip.CondArgs()
+    a.spk = spk.data_ptr(); a.noise = noise.data_ptr()
+    for i in range(n):
+        a.fc_w[i] = fc_w[i].data_ptr(); a.fc_b[i] = fc_b[i].data_ptr()
+        a.sn_w[i] = sn_w[i].data_ptr(); a.sn_b[i] = sn_b[i].data_ptr()
+        a.sn_u[i] = sn_u[i].data_ptr(); a.sn_v[i] = sn_v[i].data_ptr()
+        a.gb[i] = gb[i].data_ptr()
+        a.C[i] = sn_w[i].shape[0] // 2
+    a.z_ws = z_ws.data_ptr(); a.sigma_ws = sigma_ws.data_ptr()
+    a.n_stages = n; a.B = spk.shape[0]; a.spk_dim = spk.shape[1]; a.noise_dim = noise.shape[1]
+    a.training = int(training)
+    _hip.check(_hip.load().v2w_cond_gamma_beta(C.byref(a), _stream(spk)), 'v2w_cond_gamma_beta')
+
+
+def bn_stats(x, stats, partial_ws):
+    """x (B,C,L) -> stats[2C+1] fp64 = [sum | sumsq | count]."""
+    B, Cc, L = x.shape
+    _hip.check(_hip.load().v2w_bn_stats(x.data_ptr(), stats.data_ptr(), partial_ws.data_ptr(), B, Cc, L, _stream(x)),
+               'v2w_bn_stats')
+    return stats
+
+
+def bn_finalize(stats, gb, running_mean, running_var, num_batches_tracked, a_out, s_out, *, training: bool,
+                momentum=0.1, eps=1e-5):
+    B, C2 = gb.shape
+    _hip.check(_hip.load().v2w_bn_finalize(_hip.ptr(stats), gb.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                           _hip.ptr(num_batches_tracked), a_out.data_ptr(), s_out.data_ptr(),
+                                           B, C2 // 2, int(training), momentum, eps, _stream(gb)), 'v2w_bn_finalize')
+
+
+def affine_apply(x, a, s, out):
+    B, Cc, L = x.shape
+    _hip.check(_hip.load().v2w_affine_apply(x.data_ptr(), a.data_ptr(), s.data_ptr(), out.data_ptr(), B, Cc, L, _stream(x)),
+               'v2w_affine_apply')
+    return out
+
+
+def conv_post_tanh(x, wf, bias, out, *, k, slope):
+    B, ci, L = x.shape
+    _hip.check(_hip.load().v2w_conv_post_tanh(x.data_ptr(), wf.data_ptr(), _hip.ptr(bias), out.data_ptr(),
+                                              B, ci, L, k, slope, _stream(x)), 'v2w_conv_post_tanh')
+    return out
