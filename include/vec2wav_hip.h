@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 1
+#define V2W_ABI_VERSION 2
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -54,6 +54,13 @@ int v2w_wn_fold_conv (const float* v, const float* g, float* wf, float* scratch,
 int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
                       int c_in, int c_out, int k, void* stream);
 
+/* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same weights in MFMA A-fragment order
+ * (float4 #((mb*k + t)*G + g)*64 + lane holds W[t][g*CKG + j*KSTEP + lane/MF][mb*MF + lane%MF], j = 0..3;
+ * MF = 32 / KSTEP = 2 for C_out % 32 == 0, MF = 16 / KSTEP = 4 for C_out == 16; CKG = 4*KSTEP, G = C_in/CKG).
+ * wp has k*C_in*C_out floats.  Returns V2W_E_SHAPE when the layer has no MFMA tile configuration
+ * (C_in % 16 != 0, or C_out neither 16 nor a multiple of 32): such layers run on the direct kernel with wp = NULL. */
+int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, void* stream);
+
 /* ---- K1/K5/K6/K7: fused [per-(b,c) affine] -> leaky_relu -> dilated Conv1d -> +bias [-> +residual]
  * [-> += out] [-> / out_div].  Replaces F.leaky_relu + Conv1d (+ `xt + x`, `xs += ...`, `xs / num_kernels`)
  * of models.py:37-44 (ResBlock1), 65-70 (ResBlock2), 123 (conv_pre), 135-141 (mean over kernels).
@@ -65,7 +72,9 @@ int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
  *   accumulate != 0: out = out_old + value ; out_div != 0: out = value / out_div (applied last) */
 typedef struct {
     const float* in;   const float* in_a;  const float* in_s;
-    const float* wf;   const float* bias;
+    const float* wf;   /* [k][C_in][C_out]: read by the direct kernel; may be NULL when algo == V2W_ALGO_MFMA */
+    const float* wp;   /* v2w_pack_mfma() form: read by the MFMA kernel; NULL -> direct kernel under V2W_ALGO_AUTO */
+    const float* bias;
     const float* res;  const float* res_a; const float* res_s;
     float*       out;
     int32_t B, C_in, C_out, L, k, dil;
@@ -79,7 +88,7 @@ int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST p
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */
 typedef struct {
-    const float* in; const float* wf; const float* bias; float* out;
+    const float* in; const float* wf; const float* wp; const float* bias; float* out;
     int32_t B, C_in, C_out, L, k, u;
     float   slope;
     int32_t algo;

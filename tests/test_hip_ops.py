@@ -93,9 +93,10 @@ def test_conv1d_fused(dev, algo, B, cin, cout, L, k, dil):
     want = (want + torch.from_numpy(prev)) / 3.0
     out = _t(prev, dev).clone()
     a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
-    hipops.conv1d(_t(x, dev), _t(_relayout(tw).numpy(), dev), _t(bias, dev), out, k=k, dil=dil, slope=0.1,
+    wf = _t(_relayout(tw).numpy(), dev)
+    hipops.conv1d(_t(x, dev), wf, _t(bias, dev), out, k=k, dil=dil, slope=0.1,
                   in_affine=(_t(ia, dev), _t(is_, dev)), res=_t(res, dev), res_affine=(_t(ra, dev), _t(rs, dev)),
-                  accumulate=True, out_div=3.0, algo=a)
+                  accumulate=True, out_div=3.0, algo=a, wp=hipops.pack_mfma(wf))
     err = (out.cpu() - want).abs().max().item()
     assert err <= 2e-5, f'max err {err}'
 
@@ -111,7 +112,9 @@ def test_conv1d_plain_and_mfma_forced(dev, B, cin, cout, L, k, dil):
     wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
     o1 = torch.full((B, cout, L), float('nan'), device=dev)
     o2 = torch.full((B, cout, L), float('nan'), device=dev)
-    hipops.conv1d(_t(x, dev), wf, None, o1, k=k, dil=dil, slope=1.0, algo=hipops.ALGO_MFMA)
+    wp = hipops.pack_mfma(wf)
+    assert wp is not None
+    hipops.conv1d(_t(x, dev), None, None, o1, k=k, dil=dil, slope=1.0, algo=hipops.ALGO_MFMA, wp=wp)
     hipops.conv1d(_t(x, dev), wf, None, o2, k=k, dil=dil, slope=1.0, algo=hipops.ALGO_DIRECT)
     assert (o1.cpu() - want).abs().max().item() <= 2e-5
     assert (o2.cpu() - want).abs().max().item() <= 2e-5
@@ -122,8 +125,9 @@ def test_conv1d_rejects_bad_arguments(dev):
     x = torch.zeros((1, 24, 10), device=dev)
     wf = torch.zeros((5, 24, 40), device=dev)
     out = torch.zeros((1, 40, 10), device=dev)
+    assert hipops.pack_mfma(wf) is None                                 # no MFMA tile config for 24 -> 40
     with pytest.raises(_hip.HipLibraryError):
-        hipops.conv1d(x, wf, None, out, k=5, algo=hipops.ALGO_MFMA)     # no tile config for 24 -> 40
+        hipops.conv1d(x, wf, None, out, k=5, algo=hipops.ALGO_MFMA)
     with pytest.raises(_hip.HipLibraryError):
         hipops.conv1d(x, wf, None, out, k=4)                            # even kernel size
     with pytest.raises(_hip.HipLibraryError):
@@ -159,7 +163,7 @@ def test_convt1d(dev, algo, B, cin, cout, L, k, u):
     wf = _t(torch.from_numpy(w).permute(2, 0, 1).contiguous().numpy(), dev)
     out = torch.full((B, cout, L * u), float('nan'), device=dev)
     a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
-    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a)
+    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a, wp=hipops.pack_mfma(wf))
     err = (out.cpu() - want).abs().max().item()
     assert err <= 2e-5, f'max err {err}'
 
@@ -225,7 +229,10 @@ def test_bn_stats_and_finalize(dev, B, C, L):
         gamma, beta = torch.from_numpy(gbv).chunk(2, 1)
         want = gamma[:, :, None] * xhat + beta[:, :, None]
         got = hipops.affine_apply(xd, a, s, torch.empty_like(xd)).cpu()
-        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+        # var == 0 (one value per channel) makes rstd = 1/sqrt(eps) = 316: the folded a*x + s form then carries
+        # |a*x| * 2^-24 of rounding where the reference's (x - mean) is exactly 0
+        tol = 2e-5 if B * L > 1 else 2e-4
+        assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
         assert (rm.cpu() - rm_w).abs().max().item() <= 1e-6
         assert (rv.cpu() - rv_w).abs().max().item() <= 1e-5
         assert nbt.item() == (8 if training else 7)

@@ -12,6 +12,7 @@ import os
 
 from . import build as _build
 
+ABI_VERSION = 2
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
@@ -20,7 +21,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 
 
 class Conv1dArgs(C.Structure):
-    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wf', _fp), ('bias', _fp),
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp),
                 ('res', _fp), ('res_a', _fp), ('res_s', _fp), ('out', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
@@ -28,7 +29,7 @@ class Conv1dArgs(C.Structure):
 
 
 class ConvT1dArgs(C.Structure):
-    _fields_ = [('in_', _fp), ('wf', _fp), ('bias', _fp), ('out', _fp),
+    _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32)]
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     'v2w_build_arch': (C.c_char_p, []),
     'v2w_wn_fold_conv': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wn_fold_convt': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
@@ -90,8 +92,8 @@ def load():
             raise HipLibraryError(f'{path} does not export {name}') from e
         fn.restype = res
         fn.argtypes = args
-    if lib.v2w_abi_version() != 1:
-        raise HipLibraryError(f'ABI version mismatch: library {lib.v2w_abi_version()}, binding 1')
+    if lib.v2w_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f'ABI version mismatch: library {lib.v2w_abi_version()}, binding {ABI_VERSION}')
     _lib = lib
     return lib
 

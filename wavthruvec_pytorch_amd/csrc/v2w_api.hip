@@ -10,7 +10,7 @@ extern "C" int v2w_abi_version(void) { return V2W_ABI_VERSION; }
 extern "C" const char* v2w_build_arch(void) { return "gfx950"; }
 
 extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
-    if (!a || !a->in || !a->wf || !a->out) return V2W_E_ARG;
+    if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->dil <= 0) return V2W_E_ARG;
     if ((a->k & 1) == 0) return V2W_E_SHAPE;                       // padding d*(k-1)/2 keeps the length only for odd k
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
@@ -18,27 +18,27 @@ extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
     if (a->res_a && !a->res) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (a->algo) {
-        case V2W_ALGO_DIRECT: return v2w_conv1d_direct(a, st);
+        case V2W_ALGO_DIRECT: return a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG;
         case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, st);
         case V2W_ALGO_AUTO: {
             const int rc = v2w_conv1d_mfma(a, st);
-            return rc == V2W_E_SHAPE ? v2w_conv1d_direct(a, st) : rc;
+            return rc == V2W_E_SHAPE ? (a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG) : rc;
         }
         default: return V2W_E_ALGO;
     }
 }
 
 extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
-    if (!a || !a->in || !a->wf || !a->out) return V2W_E_ARG;
+    if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 0) return V2W_E_ARG;
     if (a->k < a->u || ((a->k - a->u) & 1)) return V2W_E_SHAPE;    // L_out = u*L needs k-u even
     hipStream_t st = (hipStream_t)stream;
     switch (a->algo) {
-        case V2W_ALGO_DIRECT: return v2w_convt1d_direct(a, st);
+        case V2W_ALGO_DIRECT: return a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG;
         case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st);
         case V2W_ALGO_AUTO: {
             const int rc = v2w_convt1d_mfma(a, st);
-            return rc == V2W_E_SHAPE ? v2w_convt1d_direct(a, st) : rc;
+            return rc == V2W_E_SHAPE ? (a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG) : rc;
         }
         default: return V2W_E_ALGO;
     }

@@ -57,15 +57,27 @@ def fold_convt_weight(v, g, out=None, scratch=None):
     return out
 
 
+def pack_mfma(wf, out=None):
+    """wf [k][C_in][C_out] -> the same weights in MFMA A-fragment order, or None when the layer has no MFMA tile."""
+    k, ci, co = wf.shape
+    if out is None:
+        out = torch.empty((k * ci * co,), device=wf.device, dtype=torch.float32)
+    rc = _hip.load().v2w_pack_mfma(wf.data_ptr(), out.data_ptr(), k, ci, co, _stream(wf))
+    if rc == -2:
+        return None
+    _hip.check(rc, 'v2w_pack_mfma')
+    return out
+
+
 def conv1d(x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
-           accumulate=False, out_div=0.0, algo=ALGO_AUTO):
+           accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None):
     """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out] [/ out_div]; see the header."""
     B, ci, L = x.shape
     co = out.shape[1]
     a = _hip.Conv1dArgs()
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
-    a.wf = wf.data_ptr(); a.bias = _hip.ptr(bias)
+    a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
     a.res = _hip.ptr(res)
     a.res_a, a.res_s = (_hip.ptr(res_affine[0]), _hip.ptr(res_affine[1])) if res_affine is not None else (None, None)
     a.out = out.data_ptr()
@@ -75,11 +87,11 @@ def conv1d(x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, r
     return out
 
 
-def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO):
+def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None):
     """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias."""
     B, ci, L = x.shape
     a = _hip.ConvT1dArgs()
-    a.in_ = x.data_ptr(); a.wf = wf.data_ptr(); a.bias = _hip.ptr(bias); a.out = out.data_ptr()
+    a.in_ = x.data_ptr(); a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias); a.out = out.data_ptr()
     a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
     a.slope = slope; a.algo = algo
     _hip.check(_hip.load().v2w_convt1d_fwd(C.byref(a), _stream(x)), 'v2w_convt1d_fwd')

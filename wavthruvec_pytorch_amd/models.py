@@ -230,10 +230,11 @@ class Generator(nn.Module):
                     yield f'resblocks.{i}.convs.{n}', m
         yield 'conv_post', self.conv_post
 
-    def _fold_weights(self, device) -> Dict[str, torch.Tensor]:
-        """K0: weight-norm fold + relayout of every conv into [k][C_in][C_out]; skipped for a layer whose
-        parameters are unchanged (storage pointer and in-place version counter) unless `always_refold` in train mode."""
-        out = {}
+    def _fold_weights(self, device):
+        """K0: weight-norm fold + relayout of every conv into [k][C_in][C_out] (`wf`) and into MFMA A-fragment order
+        (`wp`, None for a layer without an MFMA tile configuration); skipped for a layer whose parameters are
+        unchanged (storage pointer and in-place version counter) unless `always_refold` in train mode."""
+        out, packed = {}, {}
         force = self.training and self.always_refold
         for name, m in self._conv_layers():
             if m.weight_normed:
@@ -251,10 +252,13 @@ class Generator(nn.Module):
                     hipops.fold_convt_weight(vd, gd, wf, scratch)
                 else:
                     hipops.fold_conv_weight(vd, gd, wf, scratch)
+                wp = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
+                self._fold_key[name + '.wp'] = hipops.pack_mfma(wf, wp) if name != 'conv_post' else None
                 self._fold_key[name] = key
                 self._fold_key[name + '.ptr'] = wf.data_ptr()
             out[name] = wf
-        return out
+            packed[name] = self._fold_key[name + '.wp']
+        return out, packed
 
     # -------------------------------------------------------------------------------------------
     def forward(self, x, spk_emb=None, noise=None):
@@ -283,7 +287,7 @@ class Generator(nn.Module):
         c0 = self.h.upsample_initial_channel
 
         with torch.no_grad():
-            wf = self._fold_weights(dev)
+            wf, wp = self._fold_weights(dev)
 
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
             ns = self.num_upsamples
@@ -300,7 +304,7 @@ class Generator(nn.Module):
             # ---- K1: conv_pre (no activation in front of it)
             cur = self._buf('act.pre', (B, c0, T), device=dev)
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
-                        slope=1.0, algo=algo)
+                        slope=1.0, algo=algo, wp=wp['conv_pre'])
             L = T
             for i in range(ns):
                 up = self.ups[i]
@@ -309,7 +313,7 @@ class Generator(nn.Module):
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
                 xr = self._buf(f'act.up{i}', (B, C, Lo), device=dev)
                 self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
-                            u=up.stride, slope=LRELU_SLOPE, algo=algo)
+                            u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'])
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 cbn = self.cbns[i]
                 bn = cbn.batch_nrom
@@ -336,9 +340,10 @@ class Generator(nn.Module):
                     if isinstance(rb, ResBlock2):
                         c1, c2 = rb.convs[0], rb.convs[1]
                         self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
-                                    dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo)
+                                    dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                    wp=wp[name + '.convs.0'])
                         self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
-                                    dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, **last)
+                                    dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, wp=wp[name + '.convs.1'], **last)
                     else:
                         xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
                         xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
@@ -347,10 +352,12 @@ class Generator(nn.Module):
                         for n in range(3):
                             c1, c2 = rb.convs1[n], rb.convs2[n]
                             self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
-                                        k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo)
+                                        k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                        wp=wp[f'{name}.convs1.{n}'])
                             extra = last if n == 2 else {}
                             self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
-                                        dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo, **extra)
+                                        dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo,
+                                        wp=wp[f'{name}.convs2.{n}'], **extra)
                             src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
