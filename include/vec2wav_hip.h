@@ -54,12 +54,13 @@ int v2w_wn_fold_conv (const float* v, const float* g, float* wf, float* scratch,
 int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
                       int c_in, int c_out, int k, void* stream);
 
-/* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same weights in MFMA A-fragment order
- * (float4 #((mb*k + t)*G + g)*64 + lane holds W[t][g*CKG + j*KSTEP + lane/MF][mb*MF + lane%MF], j = 0..3;
- * MF = 32 / KSTEP = 2 for C_out % 32 == 0, MF = 16 / KSTEP = 4 for C_out == 16; CKG = 4*KSTEP, G = C_in/CKG).
- * wp has k*C_in*C_out floats.  Returns V2W_E_SHAPE when the layer has no MFMA tile configuration
- * (C_in % 16 != 0, or C_out neither 16 nor a multiple of 32): such layers run on the direct kernel with wp = NULL. */
-int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, void* stream);
+/* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same k*C_in*C_out weights as a stream of 1 KiB MFMA A-fragments
+ * (64 lanes x float4 = four consecutive MFMA k-steps) in exactly the order the tile kernel of that layer consumes them:
+ * [row block mb][C_in chunk][tap, phase-major for a transposed conv][fragment]; the kernel reads it strictly
+ * sequentially.  u = 1 for Conv1d, the stride for ConvTranspose1d.  Returns V2W_E_SHAPE when the layer has no MFMA
+ * tile configuration (C_in % 16 != 0, C_out neither 16 nor a multiple of 32, unsupported stride): such layers run on
+ * the direct kernel with wp = NULL. */
+int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream);
 
 /* ---- K1/K5/K6/K7: fused [per-(b,c) affine] -> leaky_relu -> dilated Conv1d -> +bias [-> +residual]
  * [-> += out] [-> / out_div].  Replaces F.leaky_relu + Conv1d (+ `xt + x`, `xs += ...`, `xs / num_kernels`)

@@ -163,7 +163,7 @@ def test_convt1d(dev, algo, B, cin, cout, L, k, u):
     wf = _t(torch.from_numpy(w).permute(2, 0, 1).contiguous().numpy(), dev)
     out = torch.full((B, cout, L * u), float('nan'), device=dev)
     a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
-    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a, wp=hipops.pack_mfma(wf))
+    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a, wp=hipops.pack_mfma(wf, u=u))
     err = (out.cpu() - want).abs().max().item()
     assert err <= 2e-5, f'max err {err}'
 

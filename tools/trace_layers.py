@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-layer view of a rocprofv3 --kernel-trace CSV of bench.py: duration, TFLOP/s and algorithmic GB/s per conv launch."""
+import csv
+import glob
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wavthruvec_pytorch_amd import workmodel, synthetic  # noqa: E402
+
+
+def main(path, B=32, T=256, which=-2):
+    f = glob.glob(os.path.join(path, '**', '*_kernel_trace.csv'), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    idx = [i for i, n in enumerate(names) if 'cond_fc' in n]
+    s, e = idx[which - 1], idx[which]
+    h = synthetic.make_hparams(num_wv_feat=768)
+    layers = workmodel.conv_layers(h, B, T)
+    li = 0
+    tot = 0.0
+    other = {}
+    for r in rows[s:e]:
+        n = r['Kernel_Name']
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        tot += d
+        if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n:
+            l = layers[li]; li += 1
+            short = n.split('::')[-1].split('(')[0][:44]
+            print(f"{l['name']:20s} {short:46s} {d:8.1f} us {l['flops'] / d / 1e6:7.1f} TF {l['bytes'] / d / 1e3:7.0f} GB/s "
+                  f"grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']} agpr={r['Accum_VGPR_Count']}")
+        else:
+            k = n.split('::')[-1].split('(')[0]
+            other[k] = other.get(k, 0) + d
+    for k, v in sorted(other.items(), key=lambda kv: -kv[1]):
+        print(f'  other {k:40s} {v:8.1f} us')
+    print('sum kernel us', round(tot, 1), 'span us', (int(rows[e - 1]['End_Timestamp']) - int(rows[s]['Start_Timestamp'])) / 1e3)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], *(int(a) for a in sys.argv[2:]))

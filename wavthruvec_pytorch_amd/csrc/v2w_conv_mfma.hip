@@ -15,10 +15,12 @@
 // B (signal)   : LDS tile Xs[c][NT + halo], double buffered over C_in chunks.  Lanes read consecutive positions
 //                (conflict-free ds_read_b32); every tap is a column offset into the SAME tile, so each input element
 //                is fetched from HBM once per M-tile and the activation / CondBN affine is applied once, at staging
-//                time.  The next chunk travels global -> registers while the current one computes (one barrier/chunk).
+//                time, by a dedicated LOADER wave that runs one chunk ahead of the MFMA waves (one barrier per chunk):
+//                vmcnt retires in order, so keeping the HBM-latency signal loads out of the MFMA waves lets their
+//                own L2-latency weight prefetch be waited with a counted vmcnt.
 // MFMA         : v_mfma_f32_32x32x2_f32 (C_out >= 32) or v_mfma_f32_16x16x4_f32 (C_out == 16): exact fp32
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
-// Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
+// Waves        : WM x WN MFMA waves (+1 loader wave) per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
 #include "v2w_common.h"
 
@@ -35,7 +37,8 @@ struct TileArgs {
     int hla;      // hl rounded up to a multiple of 4: LDS column 0 <-> position n0 - hla (16-B aligned rows)
     int xw;       // LDS row stride of the input tile (floats)
     int xcols;    // columns actually staged (multiple of 4)
-    int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging with register prefetch
+    int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging
+    int segsh, segw;  // loader: each tile row = 2^segsh segments of segw (<= 64) float4 columns
     int ntl;      // position tiles per batch item
     int ntiles;   // B * ntl
     float slope;
@@ -63,16 +66,17 @@ template <> struct Frag<16> {
     __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
 };
 
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF>
-__global__ void __launch_bounds__(64 * WM * WN)
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NSLOT>
+__global__ void __launch_bounds__(64 * (WM * WN + 1))
 conv_tile_kernel(const TileArgs p) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
+    constexpr int NCW = WM * WN;            // compute waves; wave NCW is the loader
     constexpr int MT = MF * MI * WM;
     constexpr int NT = MF * NI * WN;
-    constexpr int NTHREADS = 64 * WM * WN;
     constexpr int KSTEP = F::KSTEP;
     constexpr int CKG = 4 * KSTEP;          // channels covered by one packed A fragment (4 k-steps)
+    constexpr int GPC = CK / CKG;           // A fragments per chunk and tap
     static_assert(CK % CKG == 0, "chunk must hold whole A fragments");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [CK][xw]
@@ -90,7 +94,78 @@ conv_tile_kernel(const TileArgs p) {
     const int m0 = mt * MT;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xw = p.xw;
+    const int L = p.L, K = p.K;
+    const int nch = p.Cin / CK;
+    const int pos0 = n0 - p.hla;           // position of LDS column 0
+
+    if (wave == NCW) {
+        // =================== loader wave: global -> registers -> activation -> LDS, one chunk ahead of the MFMA waves
+        const float slope = p.slope;
+        const int xw4 = p.xcols >> 2;      // float4 columns staged per row
+        // a row of the tile image is cut into 2^segsh segments of segw (<= 64) float4 columns: one wave-wide load each,
+        // row / segment are wave-uniform (scalar address math, scalar affine loads), only the column is per lane
+        const int segsh = p.segsh, segw = p.segw;
+        const int nvr = CK << segsh;       // segments per chunk
+        constexpr int NB = 16;             // loads in flight per batch (64 VGPRs)
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nch; ++ch) {
+            float* Xs = smem + (ch & 1) * (CK * xw);
+            const int cbase = b * p.Cin + ch * CK;
+            if (p.vec4) {
+                const float* src = p.in + (size_t)cbase * L;
+                for (int vr0 = 0; vr0 < nvr; vr0 += NB) {
+                    f32x4 v[NB];
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) {
+                        const int vr = vr0 + s;
+                        const int row = vr >> segsh, seg = vr & ((1 << segsh) - 1);
+                        const int col4 = seg * segw + lane;
+                        const int pos = pos0 + col4 * 4;
+                        v[s] = zero4;
+                        // L % 4 == 0 and pos % 4 == 0: a float4 is entirely inside [0, L) or entirely padding
+                        if (vr < nvr && lane < segw && col4 < xw4 && pos >= 0 && pos < L)
+                            v[s] = *reinterpret_cast<const f32x4*>(src + (size_t)row * L + pos);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) {
+                        const int vr = vr0 + s;
+                        const int row = vr >> segsh, seg = vr & ((1 << segsh) - 1);
+                        const int col4 = seg * segw + lane;
+                        const int pos = pos0 + col4 * 4;
+                        if (vr >= nvr) continue;
+                        const float av = p.in_a ? p.in_a[cbase + row] : 1.f;   // wave-uniform
+                        const float sv = p.in_s ? p.in_s[cbase + row] : 0.f;
+                        if (lane >= segw || col4 >= xw4) continue;
+                        f32x4 o = zero4;   // padding stays exactly 0 (it pads the ACTIVATED signal)
+                        if (pos >= 0 && pos < L) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = v2w_lrelu(fmaf(av, v[s][e], sv), slope);
+                        }
+                        *reinterpret_cast<f32x4*>(Xs + row * xw + col4 * 4) = o;
+                    }
+                }
+            } else {   // any L / alignment: dword loads
+                for (int c = 0; c < CK; ++c) {
+                    const float* src = p.in + (size_t)(cbase + c) * L;
+                    const float a1 = p.in_a ? p.in_a[cbase + c] : 1.f;
+                    const float s1 = p.in_s ? p.in_s[cbase + c] : 0.f;
+                    for (int j = lane; j < p.xcols; j += 64) {
+                        const int l = pos0 + j;
+                        float o = 0.f;
+                        if (l >= 0 && l < L) o = v2w_lrelu(fmaf(a1, src[l], s1), slope);
+                        Xs[c * xw + j] = o;
+                    }
+                }
+            }
+            __syncthreads();   // chunk ch visible; (for ch >= 1) MFMA waves have finished chunk ch-1
+        }
+        return;
+    }
+
+    // =================== MFMA waves
     const int lr = lane & (MF - 1);       // row (A) / column (B, D) inside the MFMA tile
     const int hk = lane / MF;             // k index inside the MFMA k-step
     const int wm0 = (wave / WN) * (MF * MI);
@@ -106,92 +181,30 @@ conv_tile_kernel(const TileArgs p) {
 #pragma unroll
                 for (int e = 0; e < F::NREG; ++e) acc[r][i][j][e] = 0.f;
 
-    const int xw = p.xw;
-    const int L = p.L, K = p.K;
-    const float slope = p.slope;
-    const int nch = p.Cin / CK;
-    const int G = p.Cin / CKG;             // packed A fragments per tap
-    const int xw4 = p.xcols >> 2;          // float4 columns staged per row
-    const int pos0 = n0 - p.hla;           // position of LDS column 0
-
-    // ---- staging slots of this thread (vec4 path): slot s covers float4 #(tid + s*NTHREADS) of the [CK][xw4] chunk image
-    int s_row[NPF], s_col[NPF];
-    bool s_ok[NPF];
-#pragma unroll
-    for (int s = 0; s < NPF; ++s) {
-        const int idx = tid + s * NTHREADS;
-        s_row[s] = idx / xw4;
-        s_col[s] = (idx % xw4) * 4;
-        s_ok[s] = idx < CK * xw4;
-    }
-    f32x4 pf[NPF];
-    float pf_a[NPF], pf_s[NPF];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto prefetch = [&](int ci0) {       // global -> registers, no wait
-#pragma unroll
-        for (int s = 0; s < NPF; ++s) {
-            const int pos = pos0 + s_col[s];
-            pf[s] = zero4; pf_a[s] = 1.f; pf_s[s] = 0.f;
-            if (s_ok[s] && pos >= 0 && pos < L) {
-                const int ch = b * p.Cin + ci0 + s_row[s];
-                pf[s] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
-                if (p.in_a) { pf_a[s] = p.in_a[ch]; pf_s[s] = p.in_s[ch]; }
-            }
-        }
-    };
-    auto commit = [&](float* Xs) {   // registers -> activation -> LDS
-#pragma unroll
-        for (int s = 0; s < NPF; ++s) {
-            if (!s_ok[s]) continue;
-            const float av = pf_a[s], sv = pf_s[s];
-            const int pos = pos0 + s_col[s];
-            f32x4 v = zero4;
-            if (pos >= 0 && pos < L) {   // whole float4 inside (L % 4 == 0, pos % 4 == 0): padding stays exactly 0
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v2w_lrelu(fmaf(av, pf[s][e], sv), slope);
-            }
-            *reinterpret_cast<f32x4*>(Xs + s_row[s] * xw + s_col[s]) = v;
-        }
-    };
-    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment: dword loads straight into LDS
-        for (int c = wave; c < CK; c += WM * WN) {
-            const int ch = b * p.Cin + ci0 + c;
-            const float* src = p.in + (size_t)ch * L;
-            const float av = p.in_a ? p.in_a[ch] : 1.f;
-            const float sv = p.in_s ? p.in_s[ch] : 0.f;
-            for (int j = lane; j < p.xcols; j += 64) {
-                const int l = pos0 + j;
-                float v = 0.f;
-                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[l], sv), slope);
-                Xs[c * xw + j] = v;
-            }
-        }
-    };
-
-    // ---- packed weights: float4 index = ((mb*K + t)*G + g)*64 + lane, mb = 32- or 16-row block of output channels
-    const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wp);
+    // ---- packed weights (v2w_pack_mfma): per 32-/16-row block mb the fragments lie in exactly the order this loop
+    // consumes them - [chunk][phase-ordered tap][fragment] - 1 KiB (64 lanes x float4) each, so "next" is always +1 KiB
+    const int nfrag = nch * K * GPC;        // fragments per row block
+    const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wp) + lane;
     const int mb0 = (m0 + wm0) / MF;
-    auto load_a = [&](f32x4 (&a)[MI], int t, int g) {
+    const f32x4* ap[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = wp4[((size_t)((mb0 + i) * K + t) * G + g) * 64 + lane];
+    for (int i = 0; i < MI; ++i) ap[i] = wp4 + (size_t)(mb0 + i) * nfrag * 64;
+    int fidx = 0;                           // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
+    auto load_next = [&](f32x4 (&a)[MI]) {
+        const int f = fidx < nfrag ? fidx : nfrag - 1;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = ap[i][(size_t)f * 64];
+        ++fidx;
     };
-
-    // ---- prologue: chunk 0 into buffer 0
-    if (p.vec4) { prefetch(0); commit(smem); }
-    else stage_scalar(0, smem);
-    __syncthreads();
 
     const int colbase = wn0 + lr + p.hla;   // LDS column of this lane's output position (tap offset added per tap)
-    constexpr int GPC = CK / CKG;           // A fragments per chunk and tap
-    auto first_tap = [&](int r) { return U == 1 ? 0 : (r + p.pad) % U; };
-    f32x4 a_cur[MI], a_nxt[MI];
-    load_a(a_cur, first_tap(0), 0);
+    f32x4 a0[MI], a1[MI];                   // ping-pong A fragments: one feeds the MFMAs while the other is in flight
+    load_next(a0);
+    __syncthreads();                        // chunk 0 staged by the loader
+
     for (int ch = 0; ch < nch; ++ch) {
-        float* Xs = smem + (ch & 1) * (CK * xw);
-        float* Xn = smem + ((ch + 1) & 1) * (CK * xw);
+        const float* Xs = smem + (ch & 1) * (CK * xw);
         const bool more = ch + 1 < nch;
-        if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
         const int g0 = ch * GPC;
 
 #pragma unroll
@@ -199,38 +212,37 @@ conv_tile_kernel(const TileArgs p) {
             int t0, tstr, d0, dstr, nt;
             if (U == 1) { t0 = 0; tstr = 1; d0 = -p.hl; dstr = p.dil; nt = K; }
             else { const int rp = r + p.pad; t0 = rp % U; tstr = U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
-            // flattened (tap m, fragment gg) loop; the NEXT A fragment (next iteration, next phase or next chunk)
-            // is always in flight while the current one feeds the MFMAs
-            const int nit = nt * GPC;
+            const int nit = nt * GPC;       // flattened (tap m, fragment gg) loop
             int m = 0, gg = 0;
-            for (int it = 0; it < nit; ++it) {
+            // one step: put the NEXT fragment of the stream in flight into `ld`, then run the 4 k-steps of `use`
+            auto step = [&](const f32x4 (&use)[MI], f32x4 (&ld)[MI]) {
                 int m2 = m, gg2 = gg + 1;
                 if (gg2 == GPC) { gg2 = 0; ++m2; }
-                if (it + 1 < nit) load_a(a_nxt, t0 + m2 * tstr, g0 + gg2);
-                else if (r + 1 < U) load_a(a_nxt, first_tap(r + 1), g0);
-                else if (more) load_a(a_nxt, first_tap(0), g0 + GPC);
+                load_next(ld);
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top of the step: hipcc otherwise sinks it to just before its use
                 const float* xrow = Xs + colbase + d0 + m * dstr + (gg * CKG + hk) * xw;
+                float bb[4][NI];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    float bb[NI];
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) bb[j] = xrow[kk * KSTEP * xw + j * MF];
+                    for (int j = 0; j < NI; ++j) bb[kk][j] = xrow[kk * KSTEP * xw + j * MF];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NI; ++j) acc[r][i][j] = F::mfma(a_cur[i][kk], bb[j], acc[r][i][j]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a_cur[i] = a_nxt[i];
+                        for (int j = 0; j < NI; ++j) acc[r][i][j] = F::mfma(use[i][kk], bb[kk][j], acc[r][i][j]);
                 m = m2; gg = gg2;
+            };
+            int it = 0;
+            for (; it + 1 < nit; it += 2) { step(a0, a1); step(a1, a0); }
+            if (it < nit) {                 // odd count: the in-flight fragment sits in a1; hand it over
+                step(a0, a1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a0[i] = a1[i];
             }
         }
-
-        if (more) {
-            if (p.vec4) commit(Xn);
-            else stage_scalar((ch + 1) * CK, Xn);
-        }
-        __syncthreads();   // Xn complete for the next iteration; everyone done with Xs before it is overwritten again
+        if (more) __syncthreads();          // next chunk staged; everyone done with this buffer before it is refilled
     }
 
     // ---- epilogue: + bias [+ residual] [+ out] [/ out_div]; the U phases of one (co, q) are U consecutive floats.
@@ -273,9 +285,9 @@ conv_tile_kernel(const TileArgs p) {
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK>
 int launch_tile(TileArgs p, hipStream_t stream) {
-    constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * WM * WN;
-    constexpr int HMAX = 32;                                       // largest halo (each side) the slot count covers
-    constexpr int NPF = (CK * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * (WM * WN + 1);
+    constexpr int HMAX = 32;                                       // largest halo (each side) the loader's slots cover
+    constexpr int NSLOT = 0;
     if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
     p.hla = (p.hl + 3) & ~3;
     if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
@@ -286,8 +298,15 @@ int launch_tile(TileArgs p, hipStream_t stream) {
     if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
     p.xw = xw;
     p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
-    const size_t lds = (size_t)2 * CK * xw * sizeof(float);
-    auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF>;
+    {
+        const int xw4 = p.xcols / 4;
+        p.segsh = 0;
+        while (((xw4 + (1 << p.segsh) - 1) >> p.segsh) > 64) ++p.segsh;
+        p.segw = (xw4 + (1 << p.segsh) - 1) >> p.segsh;
+    }
+    const int nbuf = p.Cin / CK > 1 ? 2 : 1;
+    const size_t lds = (size_t)nbuf * CK * xw * sizeof(float);
+    auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NSLOT>;
     const int mtiles = p.Cout / MT;
     const int grid = ((p.ntiles + 7) / 8) * 8 * mtiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, p);
@@ -302,19 +321,33 @@ int launch_convt_u(TileArgs p, hipStream_t stream) {
     return V2W_E_SHAPE;
 }
 
-// wp[((mb*K + t)*G + g)*64 + lane][j] = wf[t][g*CKG + j*KSTEP + lane/MF][mb*MF + lane%MF]
+// wp float index o = ((((mb*nch + ch)*K + ts)*GPC + gg)*64 + lane)*4 + j  holds
+//   wf[tap(ts)][ch*CK + gg*CKG + j*KSTEP + lane/MF][mb*MF + lane%MF]
+// where ts runs over the taps in the order the tile kernel consumes them: 0..K-1 for a conv, phase by phase
+// (r = 0..U-1: t = (r+pad)%U, +U, ...) for a transposed conv.
 __global__ void __launch_bounds__(256)
-pack_mfma_kernel(const float* __restrict__ wf, float* __restrict__ wp, int K, int Cin, int Cout, int MF) {
-    const int KSTEP = MF == 32 ? 2 : 4, CKG = 4 * KSTEP, G = Cin / CKG;
+pack_mfma_kernel(const float* __restrict__ wf, float* __restrict__ wp, int K, int Cin, int Cout, int MF, int CK, int U) {
+    const int KSTEP = MF == 32 ? 2 : 4, CKG = 4 * KSTEP, GPC = CK / CKG, nch = Cin / CK;
+    const int pad = (K - U) / 2;
     const size_t total = (size_t)K * Cin * Cout;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int j = o & 3;
         const int lane = (o >> 2) & 63;
         size_t rest = o >> 8;
-        const int g = rest % G; rest /= G;
-        const int t = rest % K;
-        const int mb = rest / K;
-        const int c = g * CKG + j * KSTEP + lane / MF;
+        const int gg = rest % GPC; rest /= GPC;
+        const int ts = rest % K; rest /= K;
+        const int ch = rest % nch;
+        const int mb = rest / nch;
+        int t = ts;
+        if (U > 1) {   // ts-th tap in phase-major order
+            int left = ts;
+            for (int r = 0; r < U; ++r) {
+                const int t0 = (r + pad) % U, nt = (K - t0 + U - 1) / U;
+                if (left < nt) { t = t0 + left * U; break; }
+                left -= nt;
+            }
+        }
+        const int c = ch * CK + gg * CKG + j * KSTEP + lane / MF;
         const int co = mb * MF + lane % MF;
         wp[o] = wf[((size_t)t * Cin + c) * Cout + co];
     }
@@ -322,41 +355,53 @@ pack_mfma_kernel(const float* __restrict__ wf, float* __restrict__ wp, int K, in
 
 }  // namespace
 
-// Which MFMA fragment the packed weights of a (C_in, C_out) layer use: 32, 16, or 0 when no tile configuration fits.
-int v2w_mfma_frag(int c_in, int c_out) {
-    if (c_out == 16 && c_in % 16 == 0) return 16;
-    if (c_out % 32 == 0 && c_in % 16 == 0) return 32;
-    return 0;
+// Tile configuration of a layer: MFMA fragment (32 / 16, 0 = none) and channel chunk CK.  Shared by v2w_pack_mfma and
+// the launchers so that the packed fragment order always matches the kernel instantiation that consumes it.
+struct LayerCfg { int mf, ck; };
+static LayerCfg v2w_layer_cfg(int c_in, int c_out, int u) {
+    LayerCfg c{0, 0};
+    if (c_in % 16 != 0) return c;
+    if (u == 1) {
+        if (c_out % 128 == 0 && c_in % 32 == 0) c = {32, 32};
+        else if (c_out % 32 == 0) c = {32, 16};
+        else if (c_out == 16) c = {16, 16};
+    } else if (u == 2 || u == 4 || u == 5 || u == 8) {
+        if (c_out % 64 == 0 || c_out == 32) c = {32, 16};
+        else if (c_out == 16) c = {16, 16};
+    }
+    return c;
 }
 
-extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, void* stream) {
-    if (!wf || !wp || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
-    const int mf = v2w_mfma_frag(c_in, c_out);
-    if (!mf) return V2W_E_SHAPE;
+extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream) {
+    if (!wf || !wp || k <= 0 || c_in <= 0 || c_out <= 0 || u <= 0) return V2W_E_ARG;
+    const LayerCfg cfg = v2w_layer_cfg(c_in, c_out, u);
+    if (!cfg.mf) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, mf);
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
     return v2w_launch_status();
 }
 
 // Called by v2w_api.hip.  Returns V2W_E_SHAPE when no tile configuration fits (caller falls back to the direct kernel).
 int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream) {
-    if (!a->wp || !v2w_mfma_frag(a->C_in, a->C_out)) return V2W_E_SHAPE;
+    const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, 1);
+    if (!a->wp || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
     p.in = a->in; p.in_a = a->in_a; p.in_s = a->in_s; p.wp = a->wp; p.bias = a->bias;
     p.res = a->res; p.res_a = a->res_a; p.res_s = a->res_s; p.out = a->out;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = a->dil;
     p.pad = 0; p.hl = p.hr = a->dil * (a->k - 1) / 2;
     p.slope = a->slope; p.accumulate = a->accumulate; p.out_div = a->out_div;
-    if (p.Cout % 128 == 0) return launch_tile<32, 1, 2, 2, 2, 2, 16>(p, stream);
-    if (p.Cout == 64) return launch_tile<32, 1, 2, 2, 1, 4, 16>(p, stream);
-    if (p.Cout % 32 == 0) return launch_tile<32, 1, 1, 2, 1, 4, 16>(p, stream);
-    if (p.Cout == 16) return launch_tile<16, 1, 1, 8, 1, 4, 16>(p, stream);
+    if (cfg.mf == 32 && cfg.ck == 32) return launch_tile<32, 1, 2, 2, 2, 2, 32>(p, stream);
+    if (cfg.mf == 32 && p.Cout % 64 == 0) return launch_tile<32, 1, 2, 2, 1, 4, 16>(p, stream);
+    if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 16>(p, stream);
+    if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(p, stream);
     return V2W_E_SHAPE;
 }
 
 int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream) {
-    if (!a->wp || !v2w_mfma_frag(a->C_in, a->C_out)) return V2W_E_SHAPE;
+    const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, a->u);
+    if (!a->wp || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
     p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = 1;

@@ -57,12 +57,13 @@ def fold_convt_weight(v, g, out=None, scratch=None):
     return out
 
 
-def pack_mfma(wf, out=None):
-    """wf [k][C_in][C_out] -> the same weights in MFMA A-fragment order, or None when the layer has no MFMA tile."""
+def pack_mfma(wf, out=None, u=1):
+    """wf [k][C_in][C_out] -> the same weights as the MFMA A-fragment stream of that layer (u = 1 conv, stride for convT),
+    or None when the layer has no MFMA tile configuration."""
     k, ci, co = wf.shape
     if out is None:
         out = torch.empty((k * ci * co,), device=wf.device, dtype=torch.float32)
-    rc = _hip.load().v2w_pack_mfma(wf.data_ptr(), out.data_ptr(), k, ci, co, _stream(wf))
+    rc = _hip.load().v2w_pack_mfma(wf.data_ptr(), out.data_ptr(), k, ci, co, u, _stream(wf))
     if rc == -2:
         return None
     _hip.check(rc, 'v2w_pack_mfma')

@@ -253,7 +253,7 @@ class Generator(nn.Module):
                 else:
                     hipops.fold_conv_weight(vd, gd, wf, scratch)
                 wp = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
-                self._fold_key[name + '.wp'] = hipops.pack_mfma(wf, wp) if name != 'conv_post' else None
+                self._fold_key[name + '.wp'] = hipops.pack_mfma(wf, wp, u=m.stride) if name != 'conv_post' else None
                 self._fold_key[name] = key
                 self._fold_key[name + '.ptr'] = wf.data_ptr()
             out[name] = wf
