@@ -15,12 +15,12 @@
 // B (signal)   : LDS tile Xs[c][NT + halo], double buffered over C_in chunks.  Lanes read consecutive positions
 //                (conflict-free ds_read_b32); every tap is a column offset into the SAME tile, so each input element
 //                is fetched from HBM once per M-tile and the activation / CondBN affine is applied once, at staging
-//                time, by a dedicated LOADER wave that runs one chunk ahead of the MFMA waves (one barrier per chunk):
-//                vmcnt retires in order, so keeping the HBM-latency signal loads out of the MFMA waves lets their
-//                own L2-latency weight prefetch be waited with a counted vmcnt.
+//                time.  The next chunk travels global -> registers while the current one computes (one barrier per
+//                chunk).  vmcnt retires in order, so the weight stream keeps a 4-deep register ring (three fragments in
+//                flight): a wait on it then tolerates ~3 MFMA steps of latency of the signal prefetch issued before it.
 // MFMA         : v_mfma_f32_32x32x2_f32 (C_out >= 32) or v_mfma_f32_16x16x4_f32 (C_out == 16): exact fp32
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
-// Waves        : WM x WN MFMA waves (+1 loader wave) per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
+// Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
 #include "v2w_common.h"
 
@@ -38,7 +38,7 @@ struct TileArgs {
     int xw;       // LDS row stride of the input tile (floats)
     int xcols;    // columns actually staged (multiple of 4)
     int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging
-    int segsh, segw;  // loader: each tile row = 2^segsh segments of segw (<= 64) float4 columns
+    int atab_off; // LDS offset (floats) of the affine table: after the 1 or 2 signal buffers
     int ntl;      // position tiles per batch item
     int ntiles;   // B * ntl
     float slope;
@@ -66,20 +66,21 @@ template <> struct Frag<16> {
     __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
 };
 
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NSLOT>
-__global__ void __launch_bounds__(64 * (WM * WN + 1))
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING>
+__global__ void __launch_bounds__(64 * WM * WN)
 conv_tile_kernel(const TileArgs p) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
-    constexpr int NCW = WM * WN;            // compute waves; wave NCW is the loader
+    constexpr int NTHREADS = 64 * WM * WN;
     constexpr int MT = MF * MI * WM;
     constexpr int NT = MF * NI * WN;
     constexpr int KSTEP = F::KSTEP;
     constexpr int CKG = 4 * KSTEP;          // channels covered by one packed A fragment (4 k-steps)
     constexpr int GPC = CK / CKG;           // A fragments per chunk and tap
     static_assert(CK % CKG == 0, "chunk must hold whole A fragments");
+    static_assert(RING == 2 || (RING == 4 && U == 1 && GPC == 4), "the 4-deep ring walks exactly one tap per revolution");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [CK][xw]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [CK][xw] signal tiles, then a[Cin], s[Cin]
 
     // ---- which tile: ids that differ by a multiple of 8 tend to share an XCD (and its L2), so the M-tiles that
     // re-read the same input tile are placed 8 apart (speed only, never correctness).
@@ -96,80 +97,16 @@ conv_tile_kernel(const TileArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xw = p.xw;
-    const int L = p.L, K = p.K;
-    const int nch = p.Cin / CK;
-    const int pos0 = n0 - p.hla;           // position of LDS column 0
-
-    if (wave == NCW) {
-        // =================== loader wave: global -> registers -> activation -> LDS, one chunk ahead of the MFMA waves
-        const float slope = p.slope;
-        const int xw4 = p.xcols >> 2;      // float4 columns staged per row
-        // a row of the tile image is cut into 2^segsh segments of segw (<= 64) float4 columns: one wave-wide load each,
-        // row / segment are wave-uniform (scalar address math, scalar affine loads), only the column is per lane
-        const int segsh = p.segsh, segw = p.segw;
-        const int nvr = CK << segsh;       // segments per chunk
-        constexpr int NB = 16;             // loads in flight per batch (64 VGPRs)
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < nch; ++ch) {
-            float* Xs = smem + (ch & 1) * (CK * xw);
-            const int cbase = b * p.Cin + ch * CK;
-            if (p.vec4) {
-                const float* src = p.in + (size_t)cbase * L;
-                for (int vr0 = 0; vr0 < nvr; vr0 += NB) {
-                    f32x4 v[NB];
-#pragma unroll
-                    for (int s = 0; s < NB; ++s) {
-                        const int vr = vr0 + s;
-                        const int row = vr >> segsh, seg = vr & ((1 << segsh) - 1);
-                        const int col4 = seg * segw + lane;
-                        const int pos = pos0 + col4 * 4;
-                        v[s] = zero4;
-                        // L % 4 == 0 and pos % 4 == 0: a float4 is entirely inside [0, L) or entirely padding
-                        if (vr < nvr && lane < segw && col4 < xw4 && pos >= 0 && pos < L)
-                            v[s] = *reinterpret_cast<const f32x4*>(src + (size_t)row * L + pos);
-                    }
-#pragma unroll
-                    for (int s = 0; s < NB; ++s) {
-                        const int vr = vr0 + s;
-                        const int row = vr >> segsh, seg = vr & ((1 << segsh) - 1);
-                        const int col4 = seg * segw + lane;
-                        const int pos = pos0 + col4 * 4;
-                        if (vr >= nvr) continue;
-                        const float av = p.in_a ? p.in_a[cbase + row] : 1.f;   // wave-uniform
-                        const float sv = p.in_s ? p.in_s[cbase + row] : 0.f;
-                        if (lane >= segw || col4 >= xw4) continue;
-                        f32x4 o = zero4;   // padding stays exactly 0 (it pads the ACTIVATED signal)
-                        if (pos >= 0 && pos < L) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = v2w_lrelu(fmaf(av, v[s][e], sv), slope);
-                        }
-                        *reinterpret_cast<f32x4*>(Xs + row * xw + col4 * 4) = o;
-                    }
-                }
-            } else {   // any L / alignment: dword loads
-                for (int c = 0; c < CK; ++c) {
-                    const float* src = p.in + (size_t)(cbase + c) * L;
-                    const float a1 = p.in_a ? p.in_a[cbase + c] : 1.f;
-                    const float s1 = p.in_s ? p.in_s[cbase + c] : 0.f;
-                    for (int j = lane; j < p.xcols; j += 64) {
-                        const int l = pos0 + j;
-                        float o = 0.f;
-                        if (l >= 0 && l < L) o = v2w_lrelu(fmaf(a1, src[l], s1), slope);
-                        Xs[c * xw + j] = o;
-                    }
-                }
-            }
-            __syncthreads();   // chunk ch visible; (for ch >= 1) MFMA waves have finished chunk ch-1
-        }
-        return;
-    }
-
-    // =================== MFMA waves
     const int lr = lane & (MF - 1);       // row (A) / column (B, D) inside the MFMA tile
     const int hk = lane / MF;             // k index inside the MFMA k-step
     const int wm0 = (wave / WN) * (MF * MI);
     const int wn0 = (wave % WN) * (MF * NI);
+    const int xw = p.xw;
+    const int L = p.L, K = p.K;
+    const float slope = p.slope;
+    const int nch = p.Cin / CK;
+    const int pos0 = n0 - p.hla;           // position of LDS column 0
+    float* const atab = smem + p.atab_off;    // folded CondBN affine of this batch item: a[Cin] then s[Cin]
 
     acc_t acc[U][MI][NI];
 #pragma unroll
@@ -181,102 +118,221 @@ conv_tile_kernel(const TileArgs p) {
 #pragma unroll
                 for (int e = 0; e < F::NREG; ++e) acc[r][i][j][e] = 0.f;
 
+    // ---- signal staging, all waves cooperate: slot s of this thread = float4 #(tid + s*NTHREADS) of the [CK][xw4] chunk
+    // image.  prefetch() only issues the global loads; commit() applies affine + leaky_relu and writes LDS a chunk later.
+    const int xw4 = p.xcols >> 2;
+    const unsigned magic = (unsigned)(((1ull << 32) + xw4 - 1) / xw4);   // idx / xw4 == umulhi(idx, magic) for idx < 8192
+    f32x4 pf[NPF];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // slot -> (row, col) is recomputed where needed (a multiply-high and a few adds) instead of living in registers
+    auto slot = [&](int s, int& row, int& col, bool& in_img, bool& in_seq) {
+        int t = tid;
+        asm volatile("" : "+v"(t));     // opaque: keeps hipcc from hoisting 3 registers per slot out of the chunk loop
+        const int idx = t + s * NTHREADS;
+        row = (int)__umulhi((unsigned)idx, magic);
+        col = (idx - row * xw4) * 4;
+        const int pos = pos0 + col;
+        in_img = idx < CK * xw4;
+        // L % 4 == 0 and pos % 4 == 0: a float4 is entirely inside [0, L) or entirely padding
+        in_seq = in_img && pos >= 0 && pos < L;
+    };
+    auto prefetch = [&](int ci0) {
+        const float* src = p.in + (size_t)(b * p.Cin + ci0) * L + pos0;
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            int row, col; bool in_img, in_seq;
+            slot(s, row, col, in_img, in_seq);
+            pf[s] = zero4;
+            if (in_seq) pf[s] = *reinterpret_cast<const f32x4*>(src + (size_t)row * L + col);
+        }
+    };
+    auto commit = [&](int ci0, float* Xs) {
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            int row, col; bool in_img, in_seq;
+            slot(s, row, col, in_img, in_seq);
+            if (!in_img) continue;
+            f32x4 v = zero4;             // padding stays exactly 0 (it pads the ACTIVATED signal)
+            if (in_seq) {
+                const float av = p.in_a ? atab[ci0 + row] : 1.f;
+                const float sv = p.in_a ? atab[p.Cin + ci0 + row] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v2w_lrelu(fmaf(av, pf[s][e], sv), slope);
+            }
+            *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
+        }
+    };
+    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment: dword loads straight into LDS
+        for (int c = wave; c < CK; c += WM * WN) {
+            const int ch = b * p.Cin + ci0 + c;
+            const float* src = p.in + (size_t)ch * L;
+            const float av = p.in_a ? p.in_a[ch] : 1.f;
+            const float sv = p.in_s ? p.in_s[ch] : 0.f;
+            for (int j = lane; j < p.xcols; j += 64) {
+                const int l = pos0 + j;
+                float v = 0.f;
+                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[l], sv), slope);
+                Xs[c * xw + j] = v;
+            }
+        }
+    };
+
     // ---- packed weights (v2w_pack_mfma): per 32-/16-row block mb the fragments lie in exactly the order this loop
     // consumes them - [chunk][phase-ordered tap][fragment] - 1 KiB (64 lanes x float4) each, so "next" is always +1 KiB
     const int nfrag = nch * K * GPC;        // fragments per row block
-    const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wp) + lane;
-    const int mb0 = (m0 + wm0) / MF;
     const f32x4* ap[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) ap[i] = wp4 + (size_t)(mb0 + i) * nfrag * 64;
+    for (int i = 0; i < MI; ++i)
+        ap[i] = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)((m0 + wm0) / MF + i) * nfrag) * 64 + lane;
     int fidx = 0;                           // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
     auto load_next = [&](f32x4 (&a)[MI]) {
         const int f = fidx < nfrag ? fidx : nfrag - 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = ap[i][(size_t)f * 64];
         ++fidx;
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks it to just before its use
+    };
+    // the 4 k-steps of one fragment: B operands are columns of the LDS tile, A operands the 4 floats of the fragment
+    auto mma4 = [&](acc_t (&c)[MI][NI], const f32x4 (&a)[MI], const float* xrow) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float bb[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bb[j] = xrow[kk * KSTEP * xw + j * MF];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) c[i][j] = F::mfma(a[i][kk], bb[j], c[i][j]);
+        }
     };
 
-    const int colbase = wn0 + lr + p.hla;   // LDS column of this lane's output position (tap offset added per tap)
-    f32x4 a0[MI], a1[MI];                   // ping-pong A fragments: one feeds the MFMAs while the other is in flight
+    // ---- prologue: affine table, chunk 0, first fragments
+    if (p.in_a) {
+        for (int c = tid; c < p.Cin; c += NTHREADS) {
+            atab[c] = p.in_a[b * p.Cin + c];
+            atab[p.Cin + c] = p.in_s[b * p.Cin + c];
+        }
+        __syncthreads();
+    }
+    if (p.vec4) { prefetch(0); commit(0, smem); }
+    else stage_scalar(0, smem);
+    f32x4 a0[MI], a1[MI], a2[RING == 4 ? MI : 1], a3[RING == 4 ? MI : 1];
     load_next(a0);
-    __syncthreads();                        // chunk 0 staged by the loader
+    if constexpr (RING == 4) { load_next(a1); load_next(a2); }
+    __syncthreads();
 
+    const int colbase = wn0 + lr + p.hla + hk * xw;   // this lane's LDS column (+ its k row); tap offset added per tap
     for (int ch = 0; ch < nch; ++ch) {
         const float* Xs = smem + (ch & 1) * (CK * xw);
+        float* Xn = smem + ((ch + 1) & 1) * (CK * xw);
         const bool more = ch + 1 < nch;
-        const int g0 = ch * GPC;
+        if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
+        __builtin_amdgcn_sched_barrier(0);
 
+        if constexpr (RING == 4) {
+            // one ring revolution per tap: fragment gg of the tap sits in ring slot gg; three fragments stay in flight, so a
+            // wait on the weight stream (vmcnt retires in order) tolerates ~3 steps of latency of the signal prefetch above
+            for (int t = 0; t < K; ++t) {
+                const float* xt = Xs + colbase - p.hl + t * p.dil;
+                load_next(a3); mma4(acc[0], a0, xt);
+                load_next(a0); mma4(acc[0], a1, xt + CKG * xw);
+                load_next(a1); mma4(acc[0], a2, xt + 2 * CKG * xw);
+                load_next(a2); mma4(acc[0], a3, xt + 3 * CKG * xw);
+            }
+        } else {
 #pragma unroll
-        for (int r = 0; r < U; ++r) {
-            int t0, tstr, d0, dstr, nt;
-            if (U == 1) { t0 = 0; tstr = 1; d0 = -p.hl; dstr = p.dil; nt = K; }
-            else { const int rp = r + p.pad; t0 = rp % U; tstr = U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
-            const int nit = nt * GPC;       // flattened (tap m, fragment gg) loop
-            int m = 0, gg = 0;
-            // one step: put the NEXT fragment of the stream in flight into `ld`, then run the 4 k-steps of `use`
-            auto step = [&](const f32x4 (&use)[MI], f32x4 (&ld)[MI]) {
-                int m2 = m, gg2 = gg + 1;
-                if (gg2 == GPC) { gg2 = 0; ++m2; }
-                load_next(ld);
-                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch at the top of the step: hipcc otherwise sinks it to just before its use
-                const float* xrow = Xs + colbase + d0 + m * dstr + (gg * CKG + hk) * xw;
-                float bb[4][NI];
+            for (int r = 0; r < U; ++r) {
+                int d0, dstr, nt;
+                if (U == 1) { d0 = -p.hl; dstr = p.dil; nt = K; }
+                else { const int rp = r + p.pad, t0 = rp % U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
+                const int nit = nt * GPC;       // flattened (tap m, fragment gg) loop, two-deep ping-pong
+                int m = 0, gg = 0;
+                auto step = [&](const f32x4 (&use)[MI], f32x4 (&ld)[MI]) {
+                    load_next(ld);
+                    mma4(acc[r], use, Xs + colbase + d0 + m * dstr + gg * CKG * xw);
+                    if (++gg == GPC) { gg = 0; ++m; }
+                };
+                int it = 0;
+                for (; it + 1 < nit; it += 2) { step(a0, a1); step(a1, a0); }
+                if (it < nit) {                 // odd count: the in-flight fragment sits in a1; hand it over
+                    step(a0, a1);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) bb[kk][j] = xrow[kk * KSTEP * xw + j * MF];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j) acc[r][i][j] = F::mfma(use[i][kk], bb[kk][j], acc[r][i][j]);
-                m = m2; gg = gg2;
-            };
-            int it = 0;
-            for (; it + 1 < nit; it += 2) { step(a0, a1); step(a1, a0); }
-            if (it < nit) {                 // odd count: the in-flight fragment sits in a1; hand it over
-                step(a0, a1);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a0[i] = a1[i];
+                    for (int i = 0; i < MI; ++i) a0[i] = a1[i];
+                }
             }
         }
-        if (more) __syncthreads();          // next chunk staged; everyone done with this buffer before it is refilled
+
+        if (more) {
+            if (p.vec4) commit((ch + 1) * CK, Xn);
+            else stage_scalar((ch + 1) * CK, Xn);
+            __syncthreads();   // Xn complete for the next iteration; everyone done with Xs before it is overwritten again
+        }
     }
 
     // ---- epilogue: + bias [+ residual] [+ out] [/ out_div]; the U phases of one (co, q) are U consecutive floats.
     const int Lout = L * U;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        if constexpr (U == 1) {
+            // gather the residual / running-sum values of EG accumulator rows first (all loads in flight together), then
+            // combine and store; EG bounds the registers this takes
+            constexpr int EG = 4;
 #pragma unroll
-        for (int e = 0; e < F::NREG; ++e) {
-            const int co = m0 + wm0 + i * MF + F::row(e, hk);
-            const float bias = p.bias ? p.bias[co] : 0.f;
-            const size_t orow = ((size_t)b * p.Cout + co) * Lout;
-            float ra = 1.f, rs = 0.f;
-            if (U == 1 && p.res_a) { ra = p.res_a[b * p.Cout + co]; rs = p.res_s[b * p.Cout + co]; }
+            for (int e0 = 0; e0 < F::NREG; e0 += EG) {
+                float rv[EG][NI], ov[EG][NI];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int q = n0 + wn0 + j * MF + lr;
-                if (q >= L) continue;
-                if constexpr (U == 1) {
-                    float v = acc[0][i][j][e] + bias;
-                    if (p.res) v += fmaf(ra, p.res[orow + q], rs);
-                    if (p.accumulate) v += p.out[orow + q];
-                    if (p.out_div != 0.f) v = v / p.out_div;
-                    p.out[orow + q] = v;
-                } else if constexpr (U == 2) {
-                    f32x2 v; v[0] = acc[0][i][j][e] + bias; v[1] = acc[1][i][j][e] + bias;
-                    *reinterpret_cast<f32x2*>(p.out + orow + (size_t)q * 2) = v;
-                } else if constexpr (U == 4) {
-                    f32x4 v;
+                for (int ee = 0; ee < EG; ++ee) {
+                    const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
+                    const size_t orow = ((size_t)b * p.Cout + co) * Lout;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[r][i][j][e] + bias;
-                    *reinterpret_cast<f32x4*>(p.out + orow + (size_t)q * 4) = v;
-                } else {
+                    for (int j = 0; j < NI; ++j) {
+                        const int q = n0 + wn0 + j * MF + lr;
+                        rv[ee][j] = (p.res && q < L) ? p.res[orow + q] : 0.f;
+                        ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : 0.f;
+                    }
+                }
 #pragma unroll
-                    for (int r = 0; r < U; ++r) p.out[orow + (size_t)q * U + r] = acc[r][i][j][e] + bias;
+                for (int ee = 0; ee < EG; ++ee) {
+                    const int e = e0 + ee;
+                    const int co = m0 + wm0 + i * MF + F::row(e, hk);
+                    const float bias = p.bias ? p.bias[co] : 0.f;
+                    const size_t orow = ((size_t)b * p.Cout + co) * Lout;
+                    float ra = 1.f, rs = 0.f;
+                    if (p.res_a) { ra = p.res_a[b * p.Cout + co]; rs = p.res_s[b * p.Cout + co]; }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int q = n0 + wn0 + j * MF + lr;
+                        if (q >= L) continue;
+                        float v = acc[0][i][j][e] + bias;
+                        if (p.res) v += fmaf(ra, rv[ee][j], rs);
+                        if (p.accumulate) v += ov[ee][j];
+                        if (p.out_div != 0.f) v = v / p.out_div;
+                        p.out[orow + q] = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < F::NREG; ++e) {
+                const int co = m0 + wm0 + i * MF + F::row(e, hk);
+                const float bias = p.bias ? p.bias[co] : 0.f;
+                const size_t orow = ((size_t)b * p.Cout + co) * Lout;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int q = n0 + wn0 + j * MF + lr;
+                    if (q >= L) continue;
+                    if constexpr (U == 2) {
+                        f32x2 v; v[0] = acc[0][i][j][e] + bias; v[1] = acc[1][i][j][e] + bias;
+                        *reinterpret_cast<f32x2*>(p.out + orow + (size_t)q * 2) = v;
+                    } else if constexpr (U == 4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[r][i][j][e] + bias;
+                        *reinterpret_cast<f32x4*>(p.out + orow + (size_t)q * 4) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < U; ++r) p.out[orow + (size_t)q * U + r] = acc[r][i][j][e] + bias;
+                    }
                 }
             }
         }
@@ -285,9 +341,12 @@ conv_tile_kernel(const TileArgs p) {
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK>
 int launch_tile(TileArgs p, hipStream_t stream) {
-    constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * (WM * WN + 1);
-    constexpr int HMAX = 32;                                       // largest halo (each side) the loader's slots cover
-    constexpr int NSLOT = 0;
+    constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * WM * WN;
+    constexpr int HMAX = 32;                                       // largest halo (each side) the staging slots cover
+    constexpr int NPF = (CK * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int KSTEP = MF == 32 ? 2 : 4;
+    constexpr int RING = (U == 1 && CK / (4 * KSTEP) == 4) ? 4 : 2;
+    static_assert(NTHREADS * NPF < 8192, "slot index range of the magic division");
     if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
     p.hla = (p.hl + 3) & ~3;
     if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
@@ -298,15 +357,15 @@ int launch_tile(TileArgs p, hipStream_t stream) {
     if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
     p.xw = xw;
     p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
-    {
-        const int xw4 = p.xcols / 4;
-        p.segsh = 0;
-        while (((xw4 + (1 << p.segsh) - 1) >> p.segsh) > 64) ++p.segsh;
-        p.segw = (xw4 + (1 << p.segsh) - 1) >> p.segsh;
-    }
     const int nbuf = p.Cin / CK > 1 ? 2 : 1;
-    const size_t lds = (size_t)nbuf * CK * xw * sizeof(float);
-    auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NSLOT>;
+    p.atab_off = nbuf * CK * xw;
+    const size_t lds = ((size_t)p.atab_off + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+    auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING>;
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return V2W_E_SHAPE;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     const int mtiles = p.Cout / MT;
     const int grid = ((p.ntiles + 7) / 8) * 8 * mtiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, p);
@@ -362,8 +421,7 @@ static LayerCfg v2w_layer_cfg(int c_in, int c_out, int u) {
     LayerCfg c{0, 0};
     if (c_in % 16 != 0) return c;
     if (u == 1) {
-        if (c_out % 128 == 0 && c_in % 32 == 0) c = {32, 32};
-        else if (c_out % 32 == 0) c = {32, 16};
+        if (c_out % 32 == 0 && c_in % 32 == 0) c = {32, 32};
         else if (c_out == 16) c = {16, 16};
     } else if (u == 2 || u == 4 || u == 5 || u == 8) {
         if (c_out % 64 == 0 || c_out == 32) c = {32, 16};
@@ -392,9 +450,14 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream) {
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = a->dil;
     p.pad = 0; p.hl = p.hr = a->dil * (a->k - 1) / 2;
     p.slope = a->slope; p.accumulate = a->accumulate; p.out_div = a->out_div;
-    if (cfg.mf == 32 && cfg.ck == 32) return launch_tile<32, 1, 2, 2, 2, 2, 32>(p, stream);
-    if (cfg.mf == 32 && p.Cout % 64 == 0) return launch_tile<32, 1, 2, 2, 1, 4, 16>(p, stream);
-    if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 16>(p, stream);
+    if (cfg.mf == 32 && p.Cout % 128 == 0) {
+        // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
+        const long tiles128 = (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
+        if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(p, stream);
+        return launch_tile<32, 1, 2, 1, 2, 2, 32>(p, stream);
+    }
+    if (cfg.mf == 32 && p.Cout % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(p, stream);
+    if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(p, stream);
     if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(p, stream);
     return V2W_E_SHAPE;
 }
