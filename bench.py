@@ -26,7 +26,6 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-DOMINANT_PREFIXES = ('resblocks.', 'conv_pre')   # launches of conv_tile_kernel<...,U=1,...> (implicit-GEMM conv)
 
 
 def usable_cpus() -> int:
@@ -145,26 +144,41 @@ def main():
                 for tag, e0, e1 in g._profile:
                     per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
             g._profile = None
-        dom = [n for n in per if n.startswith(DOMINANT_PREFIXES)]
-        dom_t = sum(mean(per[n]) for n in dom)
-        dom_f = sum(layers[n]['flops'] for n in dom)
-        # the single most expensive instantiation: conv_tile_kernel<32,1,2,2,2,2,8> (C_out multiple of 128: conv_pre, stages 0-1)
-        big = [n for n in dom if layers[n]['cout'] % 128 == 0]
-        big_t = sum(mean(per[n]) for n in big)
-        big_f = sum(layers[n]['flops'] for n in big)
+        # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints)
+        groups = {}
+        for n, l in layers.items():
+            if n == 'conv_post':
+                kname = 'conv_post_tanh_kernel<7>'
+            elif args.algo == 'direct':
+                kname = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
+            else:
+                kname = hipops.conv_tile_config(B, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) \
+                    or ('conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel')
+            groups.setdefault(kname, []).append(n)
+        gtime = {k: sum(mean(per[n]) for n in v) for k, v in groups.items()}
+        dom = max(gtime, key=gtime.get)
+        dom_layers = groups[dom]
+        dom_t, dom_f = gtime[dom], sum(layers[n]['flops'] for n in dom_layers)
+        conv_names = [n for n in layers if n != 'conv_post']
+        conv_t = sum(mean(per[n]) for n in conv_names)
+        conv_f = sum(layers[n]['flops'] for n in conv_names)
         all_t = sum(mean(v) for v in per.values())
         tot_f, tot_b = workmodel.totals(h, B, T)
-        roof = dict(bound='mfma', kernel='conv_tile_kernel<32,1,2,2,2,2,8> (f32 MFMA implicit-GEMM conv, C_out%128==0)',
-                    achieved=big_f / big_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=big_f / big_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                    launches_per_step=len(big), avg_launch_us=big_t / len(big) * 1e6,
-                    all_conv_launches=dict(achieved=dom_f / dom_t / 1e12, frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                           launches_per_step=len(dom)),
+        step_s = elapsed / args.steps
+        roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_layers,
+                    achieved=dom_f / dom_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                    launches_per_step=len(dom_layers), avg_launch_us=dom_t / len(dom_layers) * 1e6,
+                    flops_per_launch_avg=dom_f / len(dom_layers),
+                    per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4),
+                                        tflops=round(sum(layers[n]['flops'] for n in v) / gtime[k] / 1e12, 2),
+                                        algorithmic_gbs=round(sum(layers[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
+                                for k, v in sorted(groups.items(), key=lambda kv: -gtime[kv[0]])},
+                    all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                           launches_per_step=len(conv_names)),
                     whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
-                                       mfma_frac=tot_f / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                       hbm_frac=tot_b / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS),
-                    per_stage_ms={k: round(sum(mean(per[n]) for n in per if n.startswith(k)) * 1e3, 4)
-                                  for k in ['conv_pre', 'ups.', 'resblocks.', 'conv_post']})
+                                       mfma_frac=tot_f / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                       hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -96,6 +96,11 @@ typedef struct {
 } v2w_convt1d_args;
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
 
+/* Introspection for profiling: which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation the MFMA path uses for
+ * this problem (only the sizes of `a` are read).  0 and cfg[9] filled, or V2W_E_SHAPE when the direct kernel would run. */
+int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg);
+int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg);
+
 /* ---- K3: per-stage conditioning  z = fcs[i](cat(spk, noise))  (models.py:120,131), legacy
  * spectral_norm power iteration on cbns[i].layer (modules.py:16,24) and [gamma|beta] = (W/sigma) z + b.
  * One call serves every stage (they depend on spk/noise only).  Arrays of n_stages DEVICE pointers are

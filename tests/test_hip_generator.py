@@ -192,3 +192,56 @@ def test_generator_surface_errors(dev):
     assert y.shape == (1, 1, 4 * 320)
     with pytest.raises(NotImplementedError):
         y.sum().backward()                     # loud, not silent
+
+
+def _dp_worker(rank, world, port, B, T, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from wavthruvec_pytorch_amd.distributed import shard_batch
+    dev = torch.device('cuda:0')
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    g = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    mine = shard_batch(synthetic.make_inputs(h, B, T, seed=1234), rank, world)
+    with torch.no_grad():
+        y = g(*to_dev(mine, dev))
+    torch.save({'y': y.cpu(), 'sd': {k: v.cpu() for k, v in g.state_dict().items() if 'cbns' in k}},
+               os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_condbn_two_ranks_one_gpu(dev, tmp_path):
+    """Two processes (both on cuda:0, gloo rendezvous) each run the HIP forward on their batch shard with the per-stage
+    statistics all-reduced: the gathered output and the post-forward buffers equal the single-process global-batch run."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    B, T, world = 5, 12, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.get_context('spawn')
+    mp.spawn(_dp_worker, args=(world, port, B, T, str(tmp_path)), nprocs=world, join=True)
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    full = synthetic.make_inputs(h, B, T, seed=1234)
+    g = build_generator(h, sd, dev, training=True)
+    with torch.no_grad():
+        y_ref = g(*to_dev(full, dev)).cpu()
+    parts = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(world)]
+    got = torch.cat([p['y'] for p in parts], dim=0)
+    assert (got - y_ref).abs().max().item() <= 2e-6
+    want, _ = O.generator_forward(sd, h, *full, training=True)
+    assert (got - want).abs().max().item() <= TOL
+    ref_sd = g.state_dict()
+    for r in range(world):
+        for k, v in parts[r]['sd'].items():
+            a, b = v, ref_sd[k].cpu()
+            if a.dtype == torch.long:
+                assert a.item() == b.item(), k
+            else:
+                assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k

@@ -1,0 +1,100 @@
+"""CPU tests of the host mirror: reference-compatible state_dict surface, the C ABI library loads and exports every
+symbol of include/vec2wav_hip.h, and the product refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from tests.golden_util import load_golden
+from wavthruvec_pytorch_amd import Generator, ConditionalBatchNorm1d, synthetic, _hip, workmodel, utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('name', ['rb2_train_b2_t8', 'rb1_train_b2_t8', 'rb2_1024_x640_train_b2_t8'])
+def test_state_dict_keys_and_shapes_match_reference(name):
+    z, meta = load_golden(name)
+    h = synthetic.make_hparams(**meta['hp'])
+    g = Generator(h)
+    sd = g.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z['meta_keys']]
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in z['meta_shapes']]
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))          # strict load of a reference-format dict
+
+
+def test_remove_weight_norm_renames_keys_like_reference():
+    z, meta = load_golden('rb2_rmwn_train_b2_t8')
+    h = synthetic.make_hparams(**meta['hp'])
+    g = Generator(h)
+    g.remove_weight_norm()
+    assert list(g.state_dict().keys()) == [str(k) for k in z['keys_after_rmwn']]
+    with pytest.raises(ValueError):
+        g.conv_pre.remove_weight_norm()                                 # already removed, as torch raises
+
+
+def test_default_hparams_select_resblock2():
+    from wavthruvec_pytorch_amd import hparams as hp, ResBlock1, ResBlock2
+    assert hp.resblock == 1 and hp.resblock != '1'
+    g = Generator(synthetic.make_hparams(num_wv_feat=768))
+    assert all(isinstance(r, ResBlock2) for r in g.resblocks) and len(g.resblocks) == 15
+    g1 = Generator(synthetic.make_hparams(num_wv_feat=768, resblock='1'))
+    assert all(isinstance(r, ResBlock1) for r in g1.resblocks)
+    assert sum(p.numel() for p in g.parameters()) == 8581602           # SURVEY.md Q1 (oracle-verified count)
+    assert sum(p.numel() for p in g1.parameters()) == 15926370
+
+
+def test_no_cpu_fallback():
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = Generator(h)
+    x, spk, nz = synthetic.make_inputs(h, 1, 4)
+    with pytest.raises(TypeError):
+        g(x)
+    with pytest.raises(RuntimeError, match='HIP path'):
+        g(x, spk, nz)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ConditionalBatchNorm1d(16)(torch.randn(2, 16, 8), torch.randn(2, 128))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
+    declared = set(re.findall(r'\b(v2w_[a-z0-9_]+)\s*\(', header))
+    declared -= {n for n in declared if n.endswith('_args')}
+    assert declared, 'no prototypes parsed'
+    assert declared == set(_hip.SIGNATURES), (declared ^ set(_hip.SIGNATURES))
+    lib = ctypes.CDLL(_hip.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _hip.load()
+    assert loaded.v2w_abi_version() == _hip.ABI_VERSION
+    assert loaded.v2w_build_arch() == b'gfx950'
+
+
+def test_struct_layouts_match_header_field_order():
+    header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
+    body = header[header.index('typedef struct {', header.index('K1/K5/K6/K7')):header.index('} v2w_conv1d_args;')]
+    names = re.findall(r'\b(?:const\s+)?(?:float|int32_t)\s*\*?\s*([a-zA-Z_]+(?:\s*,\s*[a-zA-Z_]+)*)\s*;', body)
+    flat = [n.strip() for grp in names for n in grp.split(',')]
+    want = [f[0].rstrip('_') for f in _hip.Conv1dArgs._fields_]
+    assert flat == want, (flat, want)
+
+
+def test_workmodel_matches_survey_contract_figures():
+    h = synthetic.make_hparams(num_wv_feat=768)
+    f, b = workmodel.totals(h, 32, 256)
+    n = 32 * 256 * 320
+    assert abs(f / n - 371526.4) < 1 and abs(b / n - 3878.9) < 1       # 371.5 kFLOP, 3 879 B per sample
+    assert abs(f / 1e9 - 973.9) < 0.1 and abs(b / 1e9 - 10.17) < 0.01
+
+
+def test_checkpoint_helpers(tmp_path):
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = Generator(h)
+    p = os.path.join(str(tmp_path), 'g_00005000')
+    utils.save_checkpoint(p, {'generator': g.state_dict()})            # train.py:228-230 format
+    utils.save_checkpoint(os.path.join(str(tmp_path), 'g_00000100'), {'generator': g.state_dict()})
+    assert utils.scan_checkpoint(str(tmp_path), 'g_') == p
+    sd = utils.load_checkpoint(p, 'cpu')['generator']
+    Generator(h).load_state_dict(sd)
+    assert utils.get_padding(11, 3) == 15 and utils.get_padding(7) == 3

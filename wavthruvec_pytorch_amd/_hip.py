@@ -54,6 +54,8 @@ SIGNATURES = {
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
+    'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
+    'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
     'v2w_bn_stats': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,

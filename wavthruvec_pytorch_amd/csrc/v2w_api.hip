@@ -1,8 +1,8 @@
 // extern "C" dispatch of the conv entry points declared in include/vec2wav_hip.h.
 #include "v2w_common.h"
 
-int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream);
-int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream);
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream, int* cfg_out);
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out);
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream);
 int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream);
 
@@ -19,9 +19,9 @@ extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (a->algo) {
         case V2W_ALGO_DIRECT: return a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG;
-        case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, st);
+        case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, st, nullptr);
         case V2W_ALGO_AUTO: {
-            const int rc = v2w_conv1d_mfma(a, st);
+            const int rc = v2w_conv1d_mfma(a, st, nullptr);
             return rc == V2W_E_SHAPE ? (a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG) : rc;
         }
         default: return V2W_E_ALGO;
@@ -35,11 +35,22 @@ extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (a->algo) {
         case V2W_ALGO_DIRECT: return a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG;
-        case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st);
+        case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st, nullptr);
         case V2W_ALGO_AUTO: {
-            const int rc = v2w_convt1d_mfma(a, st);
+            const int rc = v2w_convt1d_mfma(a, st, nullptr);
             return rc == V2W_E_SHAPE ? (a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG) : rc;
         }
         default: return V2W_E_ALGO;
     }
+}
+
+// Which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation V2W_ALGO_AUTO/MFMA picks for this problem
+// (pointers in `a` are not dereferenced).  Returns 0 and fills cfg[9], or V2W_E_SHAPE when the direct kernel is used.
+extern "C" int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    return v2w_conv1d_mfma(a, nullptr, cfg);
+}
+extern "C" int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    return v2w_convt1d_mfma(a, nullptr, cfg);
 }

@@ -44,6 +44,7 @@ struct TileArgs {
     float slope;
     int accumulate;
     float out_div;
+    int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
 };
 
 template <int MF> struct Frag;
@@ -348,6 +349,11 @@ int launch_tile(TileArgs p, hipStream_t stream) {
     constexpr int RING = (U == 1 && CK / (4 * KSTEP) == 4) ? 4 : 2;
     static_assert(NTHREADS * NPF < 8192, "slot index range of the magic division");
     if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
+    if (p.cfg_out) {
+        const int c[9] = {MF, U, MI, NI, WM, WN, CK, NPF, RING};
+        for (int i = 0; i < 9; ++i) p.cfg_out[i] = c[i];
+        return 0;
+    }
     p.hla = (p.hl + 3) & ~3;
     if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
     p.ntl = (p.L + NT - 1) / NT;
@@ -441,10 +447,11 @@ extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_
 }
 
 // Called by v2w_api.hip.  Returns V2W_E_SHAPE when no tile configuration fits (caller falls back to the direct kernel).
-int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream) {
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream, int* cfg_out) {
     const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, 1);
-    if (!a->wp || !cfg.mf) return V2W_E_SHAPE;
+    if ((!a->wp && !cfg_out) || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
+    p.cfg_out = cfg_out;
     p.in = a->in; p.in_a = a->in_a; p.in_s = a->in_s; p.wp = a->wp; p.bias = a->bias;
     p.res = a->res; p.res_a = a->res_a; p.res_s = a->res_s; p.out = a->out;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = a->dil;
@@ -462,10 +469,11 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream) {
     return V2W_E_SHAPE;
 }
 
-int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream) {
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out) {
     const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, a->u);
-    if (!a->wp || !cfg.mf) return V2W_E_SHAPE;
+    if ((!a->wp && !cfg_out) || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
+    p.cfg_out = cfg_out;
     p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = 1;
     p.pad = (a->k - a->u) / 2;

@@ -40,8 +40,15 @@ class BNStatSync:
             raise RuntimeError('torch.distributed is not initialised: call init_process_group first')
         self.group = group
         self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
 
     def __call__(self, stats: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+            if stats.is_cuda and self.backend == 'gloo':
+                # gloo has no device collectives: bounce the <= 4 KiB array through the host (tests / single-GPU multi-rank)
+                host = stats.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                stats.copy_(host)
+            else:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         return stats

@@ -147,3 +147,17 @@ def conv_post_tanh(x, wf, bias, out, *, k, slope):
     _hip.check(_hip.load().v2w_conv_post_tanh(x.data_ptr(), wf.data_ptr(), _hip.ptr(bias), out.data_ptr(),
                                               B, ci, L, k, slope, _stream(x)), 'v2w_conv_post_tanh')
     return out
+
+
+def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
+    """Name of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel)."""
+    cfg = (C.c_int32 * 9)()
+    if u == 1:
+        a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
+        rc = _hip.load().v2w_conv1d_tile_config(C.byref(a), cfg)
+    else:
+        a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
+        rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
+    if rc != 0:
+        return None
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg) + '>'
