@@ -62,6 +62,23 @@ int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
  * the direct kernel with wp = NULL. */
 int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream);
 
+/* Batched form of fold + pack for every MFMA layer of a generator: two launches instead of three per layer.
+ *   v2w_fold_plan       (host only) fills mf/ck of each descriptor and starts[2*(n+1)] (block prefix sums of the scale
+ *                       and of the pack kernel); returns the dynamic-LDS byte count (> 0) the pack kernel needs, or
+ *                       V2W_E_SHAPE when a layer has no MFMA tile configuration (fold such layers one by one).
+ *   v2w_fold_pack_batch descs_dev / starts_dev are DEVICE copies of the planned arrays; nblk_scale = starts[n],
+ *                       nblk_pack = starts[2n+1].
+ * v: weight_v (conv (C_out,C_in,k); transposed (C_in,C_out,k)); g: weight_g or NULL; scale: >= rows floats scratch. */
+typedef struct {
+    const float* v; const float* g; float* wp; float* scale;
+    int32_t c_in, c_out, k, u, transposed;
+    int32_t mf, ck;     /* filled by v2w_fold_plan */
+    int32_t _pad;
+} v2w_fold_desc;
+int v2w_fold_plan(v2w_fold_desc* descs, int n, int32_t* starts);
+int v2w_fold_pack_batch(const v2w_fold_desc* descs_dev, const int32_t* starts_dev, int n,
+                        int nblk_scale, int nblk_pack, int lds_bytes, void* stream);
+
 /* ---- K1/K5/K6/K7: fused [per-(b,c) affine] -> leaky_relu -> dilated Conv1d -> +bias [-> +residual]
  * [-> += out] [-> / out_div].  Replaces F.leaky_relu + Conv1d (+ `xt + x`, `xs += ...`, `xs / num_kernels`)
  * of models.py:37-44 (ResBlock1), 65-70 (ResBlock2), 123 (conv_pre), 135-141 (mean over kernels).
@@ -90,6 +107,8 @@ int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST p
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */
 typedef struct {
     const float* in; const float* wf; const float* wp; const float* bias; float* out;
+    float* stats_part;  /* optional (MFMA path only): [ntiles][C_out][2] per-tile (sum, sumsq) of the output, the fused form of
+                         * v2w_bn_stats; ntiles = cfg[9] of v2w_convt1d_tile_config; reduce with v2w_bn_reduce_partials */
     int32_t B, C_in, C_out, L, k, u;
     float   slope;
     int32_t algo;
@@ -97,7 +116,8 @@ typedef struct {
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
 
 /* Introspection for profiling: which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation the MFMA path uses for
- * this problem (only the sizes of `a` are read).  0 and cfg[9] filled, or V2W_E_SHAPE when the direct kernel would run. */
+ * this problem (only the sizes of `a` are read).  0 and cfg[10] filled (cfg[9] = number of position tiles), or V2W_E_SHAPE
+ * when the direct kernel would run. */
 int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg);
 int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg);
 
@@ -138,6 +158,8 @@ int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream);
 /* stats: 2C+1 doubles = [sum_c | sumsq_c | count]; count = B*L is written by the kernel so that one
  * all-reduce(sum) of the whole array yields the global sums AND the global element count. */
 int v2w_bn_stats(const float* x, double* stats, double* partial_ws, int B, int C, int L, void* stream);
+/* Fixed-order fp64 reduction of the per-tile partials written by v2w_convt1d_fwd(stats_part) -> stats[2C+1]. */
+int v2w_bn_reduce_partials(const float* part, int ntiles, int C, double count, double* stats, void* stream);
 int v2w_bn_finalize(const double* stats, const float* gb,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* a_out, float* s_out, int B, int C, int training,

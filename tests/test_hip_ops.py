@@ -163,9 +163,20 @@ def test_convt1d(dev, algo, B, cin, cout, L, k, u):
     wf = _t(torch.from_numpy(w).permute(2, 0, 1).contiguous().numpy(), dev)
     out = torch.full((B, cout, L * u), float('nan'), device=dev)
     a = hipops.ALGO_AUTO if algo == 'auto' else hipops.ALGO_DIRECT
-    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a, wp=hipops.pack_mfma(wf, u=u))
+    nt = hipops.convt_stats_tiles(B, cin, cout, L, k, u) if algo == 'auto' else 0
+    part = torch.full((nt * cout * 2,), float('nan'), device=dev) if nt else None
+    hipops.convt1d(_t(x, dev), wf, _t(bias, dev), out, k=k, u=u, slope=0.1, algo=a, wp=hipops.pack_mfma(wf, u=u),
+                   stats_part=part)
     err = (out.cpu() - want).abs().max().item()
     assert err <= 2e-5, f'max err {err}'
+    if nt:   # fused BatchNorm statistics of the output: per-tile partials -> fixed-order fp64 reduction
+        stats = torch.empty((2 * cout + 1,), device=dev, dtype=torch.float64)
+        hipops.bn_reduce_partials(part, nt, cout, B * L * u, stats)
+        st = stats.cpu()
+        s1 = want.double().sum(dim=(0, 2)); s2 = want.double().pow(2).sum(dim=(0, 2))
+        assert (st[:cout] - s1).abs().max().item() <= 1e-5 * max(1.0, s2.max().item() ** 0.5 * (B * L * u) ** 0.5)
+        assert ((st[cout:2 * cout] - s2).abs() / s2).max().item() <= 1e-5
+        assert st[2 * cout].item() == B * L * u
 
 
 @pytest.mark.parametrize('training', [True, False])
@@ -238,7 +249,8 @@ def test_bn_stats_and_finalize(dev, B, C, L):
         assert nbt.item() == (8 if training else 7)
 
 
-@pytest.mark.parametrize('B,C,L,k', [(2, 16, 8000, 7), (1, 16, 3, 7), (2, 16, 1025, 7), (2, 8, 500, 3)])
+@pytest.mark.parametrize('B,C,L,k', [(2, 16, 8000, 7), (1, 16, 3, 7), (2, 16, 1025, 7), (2, 8, 500, 3), (3, 16, 4, 7),
+                                     (2, 16, 1000, 9), (1, 16, 640, 11)])
 def test_conv_post_tanh(dev, B, C, L, k):
     from wavthruvec_pytorch_amd import hipops
     r = _rng(8)
@@ -269,3 +281,24 @@ def test_conditional_batchnorm_module(dev):
     assert (m.layer.weight_u.cpu() - u2).abs().max().item() <= 1e-6
     assert (m.batch_nrom.running_mean.cpu() - rm).abs().max().item() <= 1e-6
     assert m.batch_nrom.num_batches_tracked.item() == 1
+
+
+def test_fold_pack_batch_equals_per_layer_path(dev):
+    """v2w_fold_pack_batch (two launches for all layers) == v2w_wn_fold_* followed by v2w_pack_mfma, layer by layer."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(9)
+    specs = [(768, 512, 7, 1, False), (256, 256, 11, 1, False), (16, 16, 3, 1, False), (32, 32, 7, 1, False),
+             (512, 256, 11, 5, True), (32, 16, 4, 2, True), (512, 256, 16, 8, True), (64, 64, 3, 1, False)]
+    layers, want = [], []
+    for ci, co, k, u, tr in specs:
+        shape = (ci, co, k) if tr else (co, ci, k)
+        v = _t(r.standard_normal(shape, dtype=np.float32), dev)
+        g = None if (ci, co) == (64, 64) else _t((1 + 0.1 * r.standard_normal((shape[0], 1, 1))).astype(np.float32), dev)
+        wp = torch.full((k * ci * co,), float('nan'), device=dev)
+        layers.append((v, g, wp, ci, co, k, u, tr))
+        wf = (hipops.fold_convt_weight if tr else hipops.fold_conv_weight)(v, g)
+        want.append(hipops.pack_mfma(wf, u=u))
+    plan = hipops.FoldPlan(layers, dev)
+    plan.run()
+    for (v, g, wp, *_), w in zip(layers, want):
+        assert (wp - w).abs().max().item() <= 2e-7 * w.abs().max().item()

@@ -29,9 +29,15 @@ class Conv1dArgs(C.Structure):
 
 
 class ConvT1dArgs(C.Structure):
-    _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp),
+    _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [('v', _fp), ('g', _fp), ('wp', _fp), ('scale', _fp),
+                ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('u', C.c_int32), ('transposed', C.c_int32),
+                ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32)]
 
 
 _PA = _fp * V2W_MAX_STAGES
@@ -52,12 +58,15 @@ SIGNATURES = {
     'v2w_wn_fold_conv': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wn_fold_convt': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
+    'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
     'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
     'v2w_bn_stats': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),
     'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, _fp]),
     'v2w_affine_apply': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),

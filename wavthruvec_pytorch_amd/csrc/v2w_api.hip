@@ -34,11 +34,11 @@ extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
     if (a->k < a->u || ((a->k - a->u) & 1)) return V2W_E_SHAPE;    // L_out = u*L needs k-u even
     hipStream_t st = (hipStream_t)stream;
     switch (a->algo) {
-        case V2W_ALGO_DIRECT: return a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG;
+        case V2W_ALGO_DIRECT: return (a->wf && !a->stats_part) ? v2w_convt1d_direct(a, st) : V2W_E_ARG;
         case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st, nullptr);
         case V2W_ALGO_AUTO: {
             const int rc = v2w_convt1d_mfma(a, st, nullptr);
-            return rc == V2W_E_SHAPE ? (a->wf ? v2w_convt1d_direct(a, st) : V2W_E_ARG) : rc;
+            return rc == V2W_E_SHAPE ? ((a->wf && !a->stats_part) ? v2w_convt1d_direct(a, st) : V2W_E_ARG) : rc;
         }
         default: return V2W_E_ALGO;
     }
@@ -46,6 +46,7 @@ extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
 
 // Which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation V2W_ALGO_AUTO/MFMA picks for this problem
 // (pointers in `a` are not dereferenced).  Returns 0 and fills cfg[9], or V2W_E_SHAPE when the direct kernel is used.
+// cfg[10]: MF,U,MI,NI,WM,WN,CK,NPF,RING and cfg[9] = number of position tiles
 extern "C" int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg) {
     if (!a || !cfg) return V2W_E_ARG;
     return v2w_conv1d_mfma(a, nullptr, cfg);

@@ -26,71 +26,82 @@ cond_fc_kernel(const v2w_cond_args a) {
     a.z_ws[((size_t)s * a.B + b) * 128 + j] = acc + a.fc_b[s][j];
 }
 
-// ---- legacy torch.nn.utils.spectral_norm hook (n_power_iterations = 1, eps = 1e-12); one block per stage.
+// ---- legacy torch.nn.utils.spectral_norm hook (n_power_iterations = 1, eps = 1e-12); one 1024-thread block per stage.
 //   training: v <- normalize(W^T u); u <- normalize(W v)   (written back in place)
 //   sigma = u . (W v)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 cond_sn_kernel(const v2w_cond_args a) {
     __shared__ float v_s[128];
+    __shared__ float part[8][128];
     __shared__ float red[16];
     extern __shared__ float u_s[];   // [R] then wv[R]
     const int s = blockIdx.x, R = 2 * a.C[s];
     float* wv_s = u_s + R;
     const float* W = a.sn_w[s];
     const int tid = threadIdx.x;
-    for (int r = tid; r < R; r += 256) u_s[r] = a.sn_u[s][r];
+    for (int r = tid; r < R; r += 1024) u_s[r] = a.sn_u[s][r];
     if (tid < 128) v_s[tid] = a.sn_v[s][tid];
     __syncthreads();
     const float eps = 1e-12f;
     if (a.training) {
-        // v = W^T u : thread j < 128 owns column j (coalesced across threads for each row)
+        // v = W^T u : column j = tid % 128, rows r = tid/128 (mod 8): each row read is one coalesced 512-B line
+        const int j = tid & 127, q = tid >> 7;
         float acc = 0.f;
-        if (tid < 128)
-            for (int r = 0; r < R; ++r) acc = fmaf(W[(size_t)r * 128 + tid], u_s[r], acc);
-        const float n2 = v2w_block_sum(tid < 128 ? acc * acc : 0.f, red);
+        for (int r = q; r < R; r += 8) acc = fmaf(W[(size_t)r * 128 + j], u_s[r], acc);
+        part[q][j] = acc;
+        __syncthreads();
+        float col = 0.f;
+        if (tid < 128) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) col += part[k][tid];   // fixed order
+        }
+        const float n2 = v2w_block_sum(tid < 128 ? col * col : 0.f, red);
         const float inv = 1.f / fmaxf(sqrtf(n2), eps);
-        if (tid < 128) v_s[tid] = acc * inv;
+        if (tid < 128) v_s[tid] = col * inv;
         __syncthreads();
     }
     // wv = W v : one wave per row, lanes over the 128 columns
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < R; r += 4) {
+    for (int r = wave; r < R; r += 16) {
         float p = W[(size_t)r * 128 + lane] * v_s[lane] + W[(size_t)r * 128 + 64 + lane] * v_s[64 + lane];
         p = v2w_wave_sum(p);
         if (lane == 0) wv_s[r] = p;
     }
     __syncthreads();
     if (a.training) {
-        float part = 0.f;
-        for (int r = tid; r < R; r += 256) part += wv_s[r] * wv_s[r];
-        const float n2 = v2w_block_sum(part, red);
+        float pp = 0.f;
+        for (int r = tid; r < R; r += 1024) pp += wv_s[r] * wv_s[r];
+        const float n2 = v2w_block_sum(pp, red);
         const float inv = 1.f / fmaxf(sqrtf(n2), eps);
-        for (int r = tid; r < R; r += 256) u_s[r] = wv_s[r] * inv;
+        for (int r = tid; r < R; r += 1024) u_s[r] = wv_s[r] * inv;
         __syncthreads();
-        for (int r = tid; r < R; r += 256) a.sn_u[s][r] = u_s[r];
+        for (int r = tid; r < R; r += 1024) a.sn_u[s][r] = u_s[r];
         if (tid < 128) a.sn_v[s][tid] = v_s[tid];
     }
-    float part = 0.f;
-    for (int r = tid; r < R; r += 256) part += u_s[r] * wv_s[r];
-    const float sigma = v2w_block_sum(part, red);
+    float pp = 0.f;
+    for (int r = tid; r < R; r += 1024) pp += u_s[r] * wv_s[r];
+    const float sigma = v2w_block_sum(pp, red);
     if (tid == 0) a.sigma_ws[s] = sigma;
 }
 
-// ---- gb[s][b][r] = sn_b[r] + (sum_j W[r][j] z[j]) / sigma ; grid (B, n_stages), 256 threads, one wave per row
+// ---- gb[s][b][r] = sn_b[r] + (sum_j W[r][j] z[j]) / sigma ; grid (B, n_stages, row groups of 64), one wave per row
 __global__ void __launch_bounds__(256)
 cond_linear_kernel(const v2w_cond_args a) {
     __shared__ float z_s[128];
     const int b = blockIdx.x, s = blockIdx.y, R = 2 * a.C[s];
+    const int r0 = blockIdx.z * 64;
+    if (r0 >= R) return;
     if (threadIdx.x < 128) z_s[threadIdx.x] = a.z_ws[((size_t)s * a.B + b) * 128 + threadIdx.x];
     __syncthreads();
     const float sigma = a.sigma_ws[s];
     const float* W = a.sn_w[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < R; r += 4) {
-        // (W / sigma) z : the reference divides the weight first; divide each product term's weight the same way
-        float p = (W[(size_t)r * 128 + lane] / sigma) * z_s[lane] + (W[(size_t)r * 128 + 64 + lane] / sigma) * z_s[64 + lane];
+    const float z0 = z_s[lane], z1 = z_s[64 + lane];
+    for (int r = r0 + wave; r < min(R, r0 + 64); r += 4) {
+        // (W / sigma) z == (W z) / sigma up to one rounding of the row sum
+        float p = W[(size_t)r * 128 + lane] * z0 + W[(size_t)r * 128 + 64 + lane] * z1;
         p = v2w_wave_sum(p);
-        if (lane == 0) a.gb[s][(size_t)b * R + r] = p + a.sn_b[s][r];
+        if (lane == 0) a.gb[s][(size_t)b * R + r] = p / sigma + a.sn_b[s][r];
     }
 }
 
@@ -131,6 +142,25 @@ __global__ void bn_reduce_kernel(const double* __restrict__ partial, double* __r
     }
     stats[c] = s1;
     stats[C + c] = s2;
+}
+
+// stats[c] = sum over tiles of part[tile][c][0..1] in fp64, fixed order; one block per channel
+__global__ void __launch_bounds__(256)
+bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ stats, int ntiles, int C, double count) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        s1 += (double)part[((size_t)t * C + c) * 2 + 0];
+        s2 += (double)part[((size_t)t * C + c) * 2 + 1];
+    }
+    const double t1 = v2w_block_sum(s1, red);
+    const double t2 = v2w_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        stats[c] = t1;
+        stats[C + c] = t2;
+        if (c == 0) stats[2 * C] = count;
+    }
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gb,
@@ -198,8 +228,8 @@ extern "C" int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_fc = (size_t)(a->spk_dim + a->noise_dim) * sizeof(float);
     hipLaunchKernelGGL(cond_fc_kernel, dim3(a->B, a->n_stages), dim3(128), lds_fc, st, *a);
-    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(256), (size_t)2 * maxR * sizeof(float), st, *a);
-    hipLaunchKernelGGL(cond_linear_kernel, dim3(a->B, a->n_stages), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), st, *a);
+    hipLaunchKernelGGL(cond_linear_kernel, dim3(a->B, a->n_stages, (maxR + 63) / 64), dim3(256), 0, st, *a);
     return v2w_launch_status();
 }
 
@@ -210,6 +240,12 @@ extern "C" int v2w_bn_stats(const float* x, double* stats, double* partial_ws, i
     slice = (slice + 63) & ~63;   // keep wave-wide row reads aligned
     hipLaunchKernelGGL(bn_stats_kernel, dim3(V2W_BN_SPLITS, C), dim3(256), 0, st, x, partial_ws, B, C, L, slice);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial_ws, stats, C, (double)B * (double)L);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_bn_reduce_partials(const float* part, int ntiles, int C, double count, double* stats, void* stream) {
+    if (!part || !stats || ntiles <= 0 || C <= 0 || count <= 0.0) return V2W_E_ARG;
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, stats, ntiles, C, count);
     return v2w_launch_status();
 }
 

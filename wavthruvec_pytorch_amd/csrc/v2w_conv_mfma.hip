@@ -31,6 +31,7 @@ struct TileArgs {
     const float* wp; const float* bias;
     const float* res; const float* res_a; const float* res_s;
     float* out;
+    float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
     int B, Cin, Cout, L, K, dil;
     int pad;      // convT only: (K-U)/2
     int hl, hr;   // halo (input positions) left / right of the tile
@@ -338,6 +339,47 @@ conv_tile_kernel(const TileArgs p) {
             }
         }
     }
+
+    // ---- fused BatchNorm statistics of the transposed-conv output (modules.py:23): per tile and channel (sum, sumsq),
+    // lanes -> wavefront shuffles -> the WN waves through LDS in fixed order -> one slot per (tile, channel); the slots are
+    // summed in fp64 by bn_reduce_partials_kernel, so the result is bit-reproducible (no atomics).
+    if constexpr (U > 1) {
+        if (p.stats_part) {
+            __syncthreads();                      // everyone is done with the signal tiles: reuse them as scratch
+            float* red = smem;                    // [WN][MT][2]
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int e = 0; e < F::NREG; ++e) {
+                    const int col = wm0 + i * MF + F::row(e, hk);
+                    const float bias = p.bias ? p.bias[m0 + col] : 0.f;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int q = n0 + wn0 + j * MF + lr;
+                        if (q < L) {
+#pragma unroll
+                            for (int r = 0; r < U; ++r) { const float v = acc[r][i][j][e] + bias; s1 += v; s2 = fmaf(v, v, s2); }
+                        }
+                    }
+#pragma unroll
+                    for (int off = MF / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                    if (lr == 0) {
+                        red[((wave % WN) * MT + col) * 2 + 0] = s1;
+                        red[((wave % WN) * MT + col) * 2 + 1] = s2;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < MT; c += NTHREADS) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { t1 += red[(w * MT + c) * 2]; t2 += red[(w * MT + c) * 2 + 1]; }
+                p.stats_part[((size_t)tile * p.Cout + m0 + c) * 2 + 0] = t1;
+                p.stats_part[((size_t)tile * p.Cout + m0 + c) * 2 + 1] = t2;
+            }
+        }
+    }
 }
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK>
@@ -350,8 +392,8 @@ int launch_tile(TileArgs p, hipStream_t stream) {
     static_assert(NTHREADS * NPF < 8192, "slot index range of the magic division");
     if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
     if (p.cfg_out) {
-        const int c[9] = {MF, U, MI, NI, WM, WN, CK, NPF, RING};
-        for (int i = 0; i < 9; ++i) p.cfg_out[i] = c[i];
+        const int c[10] = {MF, U, MI, NI, WM, WN, CK, NPF, RING, p.B * ((p.L + NT - 1) / NT)};
+        for (int i = 0; i < 10; ++i) p.cfg_out[i] = c[i];   // [9] = number of position tiles (rows of stats_part)
         return 0;
     }
     p.hla = (p.hl + 3) & ~3;
@@ -418,6 +460,74 @@ pack_mfma_kernel(const float* __restrict__ wf, float* __restrict__ wp, int K, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched weight-norm fold + pack: every MFMA layer of the generator in two launches (scale, pack) driven by a device
+// array of descriptors, instead of three tiny launches per layer.
+__device__ __forceinline__ int find_layer(const int32_t* __restrict__ starts, int n, int blk) {
+    int lo = 0, hi = n;                       // starts[li] <= blk < starts[li+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= blk) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// scale[row] = g[row] / ||v[row,:]||  (1 when g == NULL); one block per (layer, row)
+__global__ void __launch_bounds__(256)
+fold_scale_batch_kernel(const v2w_fold_desc* __restrict__ descs, const int32_t* __restrict__ starts, int n) {
+    __shared__ double red[16];
+    const int li = find_layer(starts, n, blockIdx.x);
+    const v2w_fold_desc d = descs[li];
+    const int row = blockIdx.x - starts[li];
+    const int inner = (d.transposed ? d.c_out : d.c_in) * d.k;
+    const float* src = d.v + (size_t)row * inner;
+    double acc = 0.0;
+    if (d.g)
+        for (int i = threadIdx.x; i < inner; i += 256) { const double x = (double)src[i]; acc += x * x; }
+    const double n2 = v2w_block_sum(acc, red);
+    if (threadIdx.x == 0) d.scale[row] = d.g ? (float)((double)d.g[row] / sqrt(n2)) : 1.f;
+}
+
+// one block per (layer, row block mb, channel chunk ch): coalesced read of the MF x CK x K sub-block of v into LDS,
+// then the K*GPC fragments of that (mb, ch) are written out contiguously in consumption order
+__global__ void __launch_bounds__(256)
+fold_pack_batch_kernel(const v2w_fold_desc* __restrict__ descs, const int32_t* __restrict__ starts, int n) {
+    extern __shared__ float tile[];
+    const int li = find_layer(starts, n, blockIdx.x);
+    const v2w_fold_desc d = descs[li];
+    const int blk = blockIdx.x - starts[li];
+    const int MF = d.mf, CK = d.ck, K = d.k, U = d.u;
+    const int KSTEP = MF == 32 ? 2 : 4, CKG = 4 * KSTEP, GPC = CK / CKG, nch = d.c_in / CK;
+    const int mb = blk / nch, ch = blk % nch;
+    const int nrow = d.transposed ? CK : MF;            // LDS rows
+    const int rlen = (d.transposed ? MF : CK) * K;      // contiguous floats per row in v
+    const int rstride = rlen + 1;
+    for (int idx = threadIdx.x; idx < nrow * rlen; idx += 256) {
+        const int r = idx / rlen, x = idx - r * rlen;
+        const float* src = d.transposed ? d.v + ((size_t)(ch * CK + r) * d.c_out + mb * MF) * K
+                                        : d.v + ((size_t)(mb * MF + r) * d.c_in + ch * CK) * K;
+        const float sc = d.scale[d.transposed ? ch * CK + r : mb * MF + r];
+        tile[r * rstride + x] = src[x] * sc;
+    }
+    __syncthreads();
+    const int pad = (K - U) / 2;
+    float* dst = d.wp + (size_t)(mb * nch + ch) * K * GPC * 256;
+    for (int o = threadIdx.x; o < K * GPC * 256; o += 256) {
+        const int j = o & 3, lane = (o >> 2) & 63;
+        const int rest = o >> 8;
+        const int gg = rest % GPC, ts = rest / GPC;
+        int t = ts;
+        if (U > 1) {
+            int left = ts;
+            for (int r = 0; r < U; ++r) {
+                const int t0 = (r + pad) % U, nt = (K - t0 + U - 1) / U;
+                if (left < nt) { t = t0 + left * U; break; }
+                left -= nt;
+            }
+        }
+        const int c = gg * CKG + j * KSTEP + lane / MF, co = lane % MF;
+        dst[o] = d.transposed ? tile[c * rstride + co * K + t] : tile[co * rstride + c * K + t];
+    }
+}
+
 }  // namespace
 
 // Tile configuration of a layer: MFMA fragment (32 / 16, 0 = none) and channel chunk CK.  Shared by v2w_pack_mfma and
@@ -474,7 +584,7 @@ int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out
     if ((!a->wp && !cfg_out) || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
     p.cfg_out = cfg_out;
-    p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out;
+    p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = 1;
     p.pad = (a->k - a->u) / 2;
     p.slope = a->slope; p.accumulate = 0; p.out_div = 0.f;
@@ -493,4 +603,40 @@ int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out
         case 8: return launch_convt_u<8>(p, stream);
         default: return V2W_E_SHAPE;
     }
+}
+
+// ---- batched fold + pack (see include/vec2wav_hip.h)
+extern "C" int v2w_fold_plan(v2w_fold_desc* descs, int n, int32_t* starts) {
+    if (!descs || !starts || n <= 0) return V2W_E_ARG;
+    int bs = 0, bp = 0, lds = 0;
+    for (int i = 0; i < n; ++i) {
+        v2w_fold_desc& d = descs[i];
+        if (d.c_in <= 0 || d.c_out <= 0 || d.k <= 0 || d.u <= 0) return V2W_E_ARG;
+        const LayerCfg cfg = v2w_layer_cfg(d.c_in, d.c_out, d.transposed ? d.u : 1);
+        if (!cfg.mf) return V2W_E_SHAPE;
+        d.mf = cfg.mf; d.ck = cfg.ck;
+        starts[i] = bs; starts[n + 1 + i] = bp;
+        bs += d.transposed ? d.c_in : d.c_out;
+        bp += (d.c_out / cfg.mf) * (d.c_in / cfg.ck);
+        const int nrow = d.transposed ? cfg.ck : cfg.mf, rlen = (d.transposed ? cfg.mf : cfg.ck) * d.k;
+        const int bytes = nrow * (rlen + 1) * (int)sizeof(float);
+        if (bytes > lds) lds = bytes;
+    }
+    starts[n] = bs; starts[2 * n + 1] = bp;
+    if (lds > 160 * 1024) return V2W_E_SHAPE;
+    return lds;   // dynamic LDS bytes the pack kernel needs (> 0)
+}
+
+extern "C" int v2w_fold_pack_batch(const v2w_fold_desc* descs_dev, const int32_t* starts_dev, int n,
+                                   int nblk_scale, int nblk_pack, int lds_bytes, void* stream) {
+    if (!descs_dev || !starts_dev || n <= 0 || nblk_scale <= 0 || nblk_pack <= 0 || lds_bytes <= 0) return V2W_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_pack_batch_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fold_scale_batch_kernel, dim3(nblk_scale), dim3(256), 0, st, descs_dev, starts_dev, n);
+    hipLaunchKernelGGL(fold_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds_bytes, st, descs_dev, starts_dev + n + 1, n);
+    return v2w_launch_status();
 }

@@ -95,6 +95,45 @@ conv_post_tanh_kernel(const float* __restrict__ in, const float* __restrict__ wf
         if (l0 + o < L) dst[o] = tanhf(acc[o] + bv);
 }
 
+// Vectorised tail for L % 4 == 0 and k <= 9: per channel three aligned float4 loads cover the 4 outputs' window
+// [l0-4, l0+8); every load is a full 16 B/lane coalesced access.
+__global__ void __launch_bounds__(256)
+conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
+                           float* __restrict__ out, int B, int Cin, int L, int k, float slope) {
+    extern __shared__ float w_s[];   // [k][Cin]
+    for (int i = threadIdx.x; i < k * Cin; i += blockDim.x) w_s[i] = wf[i];
+    __syncthreads();
+    const int pad = (k - 1) / 2;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (l0 >= L) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* src = in + ((size_t)b * Cin + ci) * L + l0;
+        const f32x4 lo = l0 >= 4 ? *reinterpret_cast<const f32x4*>(src - 4) : zero4;
+        const f32x4 mid = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi = l0 + 4 < L ? *reinterpret_cast<const f32x4*>(src + 4) : zero4;
+        float win[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { win[e] = v2w_lrelu(lo[e], slope); win[4 + e] = v2w_lrelu(mid[e], slope); win[8 + e] = v2w_lrelu(hi[e], slope); }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < k) {
+                const float w = w_s[t * Cin + ci];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(w, win[4 + o + t - pad], acc[o]);   // pad <= 4
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    f32x4 y;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) y[o] = tanhf(acc[o] + bv);
+    *reinterpret_cast<f32x4*>(out + (size_t)b * L + l0) = y;
+}
+
 }  // namespace
 
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
@@ -116,6 +155,11 @@ extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float*
     dim3 grid((L + 1023) / 1024, B);
     const size_t lds = (size_t)k * C_in * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    const bool aligned = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (aligned && k <= 9) {
+        hipLaunchKernelGGL(conv_post_tanh_vec4_kernel, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+        return v2w_launch_status();
+    }
     if (k <= 7) hipLaunchKernelGGL(conv_post_tanh_kernel<7>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
     else hipLaunchKernelGGL(conv_post_tanh_kernel<15>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
     return v2w_launch_status();

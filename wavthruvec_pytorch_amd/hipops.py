@@ -88,11 +88,12 @@ def conv1d(x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, r
     return out
 
 
-def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None):
+def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats_part=None):
     """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias."""
     B, ci, L = x.shape
     a = _hip.ConvT1dArgs()
     a.in_ = x.data_ptr(); a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias); a.out = out.data_ptr()
+    a.stats_part = _hip.ptr(stats_part)
     a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
     a.slope = slope; a.algo = algo
     _hip.check(_hip.load().v2w_convt1d_fwd(C.byref(a), _stream(x)), 'v2w_convt1d_fwd')
@@ -151,7 +152,7 @@ def conv_post_tanh(x, wf, bias, out, *, k, slope):
 
 def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
     """Name of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel)."""
-    cfg = (C.c_int32 * 9)()
+    cfg = (C.c_int32 * 10)()
     if u == 1:
         a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
         rc = _hip.load().v2w_conv1d_tile_config(C.byref(a), cfg)
@@ -160,4 +161,49 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
         rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
     if rc != 0:
         return None
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg) + '>'
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + '>'
+
+
+def convt_stats_tiles(B, c_in, c_out, L, k, u):
+    """Rows of the `stats_part` array the MFMA transposed conv fills for this problem (0: direct kernel, no fused stats)."""
+    cfg = (C.c_int32 * 10)()
+    a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
+    return int(cfg[9]) if _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg) == 0 else 0
+
+
+def bn_reduce_partials(part, ntiles, Cc, count, stats):
+    _hip.check(_hip.load().v2w_bn_reduce_partials(part.data_ptr(), ntiles, Cc, float(count), stats.data_ptr(), _stream(part)),
+               'v2w_bn_reduce_partials')
+    return stats
+
+
+class FoldPlan:
+    """Device-resident descriptor table for v2w_fold_pack_batch: every MFMA layer folded + packed in two launches."""
+
+    def __init__(self, layers, device):
+        """layers: list of (v, g|None, wp, c_in, c_out, k, u, transposed) with tensors already on `device`."""
+        n = len(layers)
+        self.n = n
+        rows = [(ci if tr else co) for (_, _, _, ci, co, _, _, tr) in layers]
+        self.scale = torch.empty((sum(rows),), device=device, dtype=torch.float32)
+        descs = (_hip.FoldDesc * n)()
+        off = 0
+        for d, (v, g, wp, ci, co, k, u, tr), r in zip(descs, layers, rows):
+            d.v = v.data_ptr(); d.g = _hip.ptr(g); d.wp = wp.data_ptr()
+            d.scale = self.scale.data_ptr() + 4 * off
+            d.c_in, d.c_out, d.k, d.u, d.transposed = ci, co, k, u, int(tr)
+            off += r
+        starts = (C.c_int32 * (2 * (n + 1)))()
+        lds = _hip.load().v2w_fold_plan(descs, n, starts)
+        _hip.check(0 if lds > 0 else (lds or -1), 'v2w_fold_plan')
+        self.lds = lds
+        self.nblk_scale, self.nblk_pack = starts[n], starts[2 * n + 1]
+        self.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+        self.starts_dev = torch.tensor(list(starts), dtype=torch.int32, device=device)
+        self.key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), wp.data_ptr()) for (v, g, wp, *_r) in layers)
+
+    def run(self):
+        _hip.check(_hip.load().v2w_fold_pack_batch(self.descs_dev.data_ptr(), self.starts_dev.data_ptr(), self.n,
+                                                   self.nblk_scale, self.nblk_pack, self.lds,
+                                                   torch.cuda.current_stream(self.scale.device).cuda_stream),
+                   'v2w_fold_pack_batch')

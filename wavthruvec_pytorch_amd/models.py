@@ -231,34 +231,43 @@ class Generator(nn.Module):
         yield 'conv_post', self.conv_post
 
     def _fold_weights(self, device):
-        """K0: weight-norm fold + relayout of every conv into [k][C_in][C_out] (`wf`) and into MFMA A-fragment order
-        (`wp`, None for a layer without an MFMA tile configuration); skipped for a layer whose parameters are
-        unchanged (storage pointer and in-place version counter) unless `always_refold` in train mode."""
-        out, packed = {}, {}
+        """K0: weight-norm fold of every conv.  Layers with an MFMA tile configuration are folded AND packed into their
+        fragment stream `wp` by one batched call (two launches for the whole generator); the others (conv_post, odd
+        shapes, or everything under ALGO_DIRECT) are folded one by one into `wf` [k][C_in][C_out].  Skipped while the
+        parameters are unchanged (storage pointers + in-place version counters) unless `always_refold` in train mode."""
+        layers = list(self._conv_layers())
+        vers = []
+        for name, m in layers:
+            ps = (m.weight_v, m.weight_g) if m.weight_normed else (m.weight,)
+            vers.append(tuple((p.data_ptr(), p._version) for p in ps))
+        state = (tuple(vers), self.algo, str(device))
         force = self.training and self.always_refold
-        for name, m in self._conv_layers():
-            if m.weight_normed:
-                v, g = m.weight_v, m.weight_g
-                key = (v.data_ptr(), v._version, g.data_ptr(), g._version)
+        if not force and self._fold_key.get('state') == state:
+            return self._fold_key['wf'], self._fold_key['wp']
+        wf, wp, batch = {}, {}, []
+        for name, m in layers:
+            v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+            u = m.stride if m.transposed else 1
+            mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
+                       hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size, 1, u) is not None)
+            if mfma_ok:
+                wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
+                batch.append((v, g, wpb, m.in_channels, m.out_channels, m.kernel_size, u, m.transposed))
+                wf[name], wp[name] = None, wpb
             else:
-                v, g = m.weight, None
-                key = (v.data_ptr(), v._version)
-            wf = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
-            if force or self._fold_key.get(name) != key or self._fold_key.get(name + '.ptr') != wf.data_ptr():
+                wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
                 scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
-                vd = v.detach()
-                gd = None if g is None else g.detach()
-                if m.transposed:
-                    hipops.fold_convt_weight(vd, gd, wf, scratch)
-                else:
-                    hipops.fold_conv_weight(vd, gd, wf, scratch)
-                wp = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
-                self._fold_key[name + '.wp'] = hipops.pack_mfma(wf, wp, u=m.stride) if name != 'conv_post' else None
-                self._fold_key[name] = key
-                self._fold_key[name + '.ptr'] = wf.data_ptr()
-            out[name] = wf
-            packed[name] = self._fold_key[name + '.wp']
-        return out, packed
+                (hipops.fold_convt_weight if m.transposed else hipops.fold_conv_weight)(v, g, wfb, scratch)
+                wf[name], wp[name] = wfb, None
+        if batch:
+            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, *_r) in batch)
+            plan = self._fold_key.get('plan')
+            if plan is None or plan.key != key:
+                plan = hipops.FoldPlan(batch, device)
+                self._fold_key['plan'] = plan
+            plan.run()
+        self._fold_key.update(state=state, wf=wf, wp=wp)
+        return wf, wp
 
     # -------------------------------------------------------------------------------------------
     def forward(self, x, spk_emb=None, noise=None):
@@ -312,16 +321,26 @@ class Generator(nn.Module):
                 Lo = L * up.stride
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
                 xr = self._buf(f'act.up{i}', (B, C, Lo), device=dev)
-                self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
-                            u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'])
-                # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 cbn = self.cbns[i]
                 bn = cbn.batch_nrom
-                stats = None
+                stats = part = None
+                nt_stats = 0
                 if training:
                     stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
-                    part = self._buf('bn.partial', (2 * max(C, 256) * 64,), dtype=torch.float64, device=dev)
-                    hipops.bn_stats(xr, stats, part)
+                    # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
+                    if algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
+                        nt_stats = hipops.convt_stats_tiles(B, up.in_channels, C, L, up.kernel_size, up.stride)
+                    if nt_stats:
+                        part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
+                self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
+                            u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
+                # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
+                if training:
+                    if nt_stats:
+                        hipops.bn_reduce_partials(part, nt_stats, C, B * Lo, stats)
+                    else:
+                        pws = self._buf('bn.partial', (2 * max(C, 256) * 64,), dtype=torch.float64, device=dev)
+                        hipops.bn_stats(xr, stats, pws)
                     if self.stat_sync is not None:
                         self.stat_sync(stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
