@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 2
+#define V2W_ABI_VERSION 3
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -94,6 +94,9 @@ typedef struct {
     const float* wp;   /* v2w_pack_mfma() form: read by the MFMA kernel; NULL -> direct kernel under V2W_ALGO_AUTO */
     const float* bias;
     const float* res;  const float* res_a; const float* res_s;
+    const float* add0; const float* add1;   /* optional extra addends (B, C_out, L): out = (add0 [+ add1]) + value, then / out_div;
+                                             * the explicit form of `xs += ...` (models.py:137-141) when the branches ran
+                                             * concurrently into separate buffers; exclusive with `accumulate` */
     float*       out;
     int32_t B, C_in, C_out, L, k, dil;
     float   slope;
@@ -102,6 +105,9 @@ typedef struct {
     int32_t algo;
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
+/* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
+ * the residual branches of one generator stage, heaviest first. */
+int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
 
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */

@@ -302,3 +302,43 @@ def test_fold_pack_batch_equals_per_layer_path(dev):
     plan.run()
     for (v, g, wp, *_), w in zip(layers, want):
         assert (wp - w).abs().max().item() <= 2e-7 * w.abs().max().item()
+
+
+def test_conv1d_multi_equals_sequential(dev):
+    """Three branches (k = 3, 7, 11) in one launch, and the explicit-addend form of the running sum."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(10)
+    B, C, L = 2, 64, 700
+    x = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    ia = _t((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), dev)
+    is_ = _t((0.3 * r.standard_normal((B, C))).astype(np.float32), dev)
+    ws, bs = {}, {}
+    for k in (3, 7, 11):
+        w = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        ws[k] = (_t(_relayout(w).numpy(), dev), w)
+        bs[k] = _t(r.standard_normal(C).astype(np.float32), dev)
+    seq, multi = {}, {}
+    probs = []
+    for k in (11, 7, 3):
+        wf = ws[k][0]
+        wp = hipops.pack_mfma(wf)
+        seq[k] = torch.empty((B, C, L), device=dev)
+        multi[k] = torch.full((B, C, L), float('nan'), device=dev)
+        kw = dict(k=k, dil=3 if k > 3 else 1, slope=0.1, in_affine=(ia, is_), res=x, res_affine=(ia, is_), wp=wp)
+        hipops.conv1d(x, wf, bs[k], seq[k], **kw)
+        probs.append((x, wf, bs[k], multi[k], kw))
+    hipops.conv1d_multi(probs)
+    for k in (3, 7, 11):
+        assert torch.equal(seq[k], multi[k]), k
+    # ((o0 + o1) + value) / 3 with explicit addends == the accumulate chain
+    wf = ws[11][0]; wp = hipops.pack_mfma(wf)
+    chain = seq[3].clone()
+    chain += seq[7]
+    hipops.conv1d(x, wf, bs[11], chain, k=11, dil=1, slope=0.1, res=x, accumulate=True, out_div=3.0, wp=wp)
+    fused = torch.empty_like(chain)
+    hipops.conv1d(x, wf, bs[11], fused, k=11, dil=1, slope=0.1, res=x, add=[seq[3], seq[7]], out_div=3.0, wp=wp)
+    assert torch.equal(chain, fused)
+    direct = torch.empty_like(chain)
+    hipops.conv1d(x, wf, bs[11], direct, k=11, dil=1, slope=0.1, res=x, add=[seq[3], seq[7]], out_div=3.0,
+                  algo=hipops.ALGO_DIRECT)
+    assert (direct - fused).abs().max().item() <= 2e-5

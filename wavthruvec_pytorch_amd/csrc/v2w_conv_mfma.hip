@@ -30,6 +30,7 @@ struct TileArgs {
     const float* in; const float* in_a; const float* in_s;
     const float* wp; const float* bias;
     const float* res; const float* res_a; const float* res_s;
+    const float* add0; const float* add1;   // conv only, optional extra addends: out = ((add0 [+ add1]) + value)
     float* out;
     float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
     int B, Cin, Cout, L, K, dil;
@@ -46,6 +47,14 @@ struct TileArgs {
     int accumulate;
     float out_div;
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
+};
+
+#define V2W_MAX_MULTI 4
+// Up to V2W_MAX_MULTI problems of identical tile configuration in one launch (the residual branches of a stage):
+// blocks [start[q], start[q+1]) belong to problem q; heaviest problem first so the tail of the launch is made of light tiles.
+struct MultiArgs {
+    TileArgs p[V2W_MAX_MULTI];
+    int start[V2W_MAX_MULTI + 1];
 };
 
 template <int MF> struct Frag;
@@ -70,7 +79,7 @@ template <> struct Frag<16> {
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING>
 __global__ void __launch_bounds__(64 * WM * WN)
-conv_tile_kernel(const TileArgs p) {
+conv_tile_kernel(const MultiArgs m) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
     constexpr int NTHREADS = 64 * WM * WN;
@@ -86,8 +95,12 @@ conv_tile_kernel(const TileArgs p) {
 
     // ---- which tile: ids that differ by a multiple of 8 tend to share an XCD (and its L2), so the M-tiles that
     // re-read the same input tile are placed 8 apart (speed only, never correctness).
+    int pq = 0;
+#pragma unroll
+    for (int i = 1; i < V2W_MAX_MULTI; ++i) pq += (int)blockIdx.x >= m.start[i] ? 1 : 0;
+    const TileArgs& p = m.p[pq];
     const int mtiles = p.Cout / MT;
-    const int id = blockIdx.x;
+    const int id = blockIdx.x - m.start[pq];
     const int grp = id / (8 * mtiles), rem = id % (8 * mtiles);
     const int mt = rem >> 3;
     const int tile = grp * 8 + (rem & 7);
@@ -108,7 +121,8 @@ conv_tile_kernel(const TileArgs p) {
     const float slope = p.slope;
     const int nch = p.Cin / CK;
     const int pos0 = n0 - p.hla;           // position of LDS column 0
-    float* const atab = smem + p.atab_off;    // folded CondBN affine of this batch item: a[Cin] then s[Cin]
+    float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias[MT], res_a[MT], res_s[MT]
+    float* const atab = etab + 3 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
 
     acc_t acc[U][MI][NI];
 #pragma unroll
@@ -208,7 +222,12 @@ conv_tile_kernel(const TileArgs p) {
         }
     };
 
-    // ---- prologue: affine table, chunk 0, first fragments
+    // ---- prologue: epilogue constants, affine table, chunk 0, first fragments
+    for (int c = tid; c < MT; c += NTHREADS) {
+        etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
+        etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
+        etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
+    }
     if (p.in_a) {
         for (int c = tid; c < p.Cin; c += NTHREADS) {
             atab[c] = p.in_a[b * p.Cin + c];
@@ -278,10 +297,10 @@ conv_tile_kernel(const TileArgs p) {
         if constexpr (U == 1) {
             // gather the residual / running-sum values of EG accumulator rows first (all loads in flight together), then
             // combine and store; EG bounds the registers this takes
-            constexpr int EG = 4;
+            constexpr int EG = (MI == 1 && F::NREG >= 8) ? 8 : 4;
 #pragma unroll
             for (int e0 = 0; e0 < F::NREG; e0 += EG) {
-                float rv[EG][NI], ov[EG][NI];
+                float rv[EG][NI], ov[EG][NI], o2[EG][NI];
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
                     const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
@@ -290,24 +309,24 @@ conv_tile_kernel(const TileArgs p) {
                     for (int j = 0; j < NI; ++j) {
                         const int q = n0 + wn0 + j * MF + lr;
                         rv[ee][j] = (p.res && q < L) ? p.res[orow + q] : 0.f;
-                        ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : 0.f;
+                        ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : ((p.add0 && q < L) ? p.add0[orow + q] : 0.f);
+                        o2[ee][j] = (p.add1 && q < L) ? p.add1[orow + q] : 0.f;
                     }
                 }
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
                     const int e = e0 + ee;
-                    const int co = m0 + wm0 + i * MF + F::row(e, hk);
-                    const float bias = p.bias ? p.bias[co] : 0.f;
-                    const size_t orow = ((size_t)b * p.Cout + co) * Lout;
-                    float ra = 1.f, rs = 0.f;
-                    if (p.res_a) { ra = p.res_a[b * p.Cout + co]; rs = p.res_s[b * p.Cout + co]; }
+                    const int col = wm0 + i * MF + F::row(e, hk);
+                    const size_t orow = ((size_t)b * p.Cout + m0 + col) * Lout;
+                    const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int q = n0 + wn0 + j * MF + lr;
                         if (q >= L) continue;
                         float v = acc[0][i][j][e] + bias;
                         if (p.res) v += fmaf(ra, rv[ee][j], rs);
-                        if (p.accumulate) v += ov[ee][j];
+                        if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
+                        else if (p.accumulate || p.add0) v += ov[ee][j];
                         if (p.out_div != 0.f) v = v / p.out_div;
                         p.out[orow + q] = v;
                     }
@@ -317,7 +336,7 @@ conv_tile_kernel(const TileArgs p) {
 #pragma unroll
             for (int e = 0; e < F::NREG; ++e) {
                 const int co = m0 + wm0 + i * MF + F::row(e, hk);
-                const float bias = p.bias ? p.bias[co] : 0.f;
+                const float bias = etab[co - m0];
                 const size_t orow = ((size_t)b * p.Cout + co) * Lout;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
@@ -352,7 +371,7 @@ conv_tile_kernel(const TileArgs p) {
 #pragma unroll
                 for (int e = 0; e < F::NREG; ++e) {
                     const int col = wm0 + i * MF + F::row(e, hk);
-                    const float bias = p.bias ? p.bias[m0 + col] : 0.f;
+                    const float bias = etab[col];
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
@@ -383,48 +402,60 @@ conv_tile_kernel(const TileArgs p) {
 }
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK>
-int launch_tile(TileArgs p, hipStream_t stream) {
+int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * WM * WN;
     constexpr int HMAX = 32;                                       // largest halo (each side) the staging slots cover
     constexpr int NPF = (CK * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
     constexpr int KSTEP = MF == 32 ? 2 : 4;
     constexpr int RING = (U == 1 && CK / (4 * KSTEP) == 4) ? 4 : 2;
     static_assert(NTHREADS * NPF < 8192, "slot index range of the magic division");
-    if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
-    if (p.cfg_out) {
-        const int c[10] = {MF, U, MI, NI, WM, WN, CK, NPF, RING, p.B * ((p.L + NT - 1) / NT)};
-        for (int i = 0; i < 10; ++i) p.cfg_out[i] = c[i];   // [9] = number of position tiles (rows of stats_part)
-        return 0;
+    if (nprob < 1 || nprob > V2W_MAX_MULTI) return V2W_E_ARG;
+    MultiArgs m{};
+    size_t lds = 0;
+    int grid = 0;
+    for (int i = 0; i < nprob; ++i) {
+        TileArgs p = ps[i];
+        if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
+        if (p.cfg_out) {
+            const int c[10] = {MF, U, MI, NI, WM, WN, CK, NPF, RING, p.B * ((p.L + NT - 1) / NT)};
+            for (int k = 0; k < 10; ++k) p.cfg_out[k] = c[k];   // [9] = number of position tiles (rows of stats_part)
+            return 0;
+        }
+        p.hla = (p.hl + 3) & ~3;
+        if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
+        p.ntl = (p.L + NT - 1) / NT;
+        p.ntiles = p.B * p.ntl;
+        p.xcols = (p.hla + NT + p.hr + 3) & ~3;
+        int xw = p.xcols;
+        if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
+        p.xw = xw;
+        p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+        const int nbuf = p.Cin / CK > 1 ? 2 : 1;
+        p.atab_off = nbuf * CK * xw;
+        const size_t l = ((size_t)p.atab_off + 3 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        if (l > lds) lds = l;
+        m.p[i] = p;
+        m.start[i] = grid;
+        grid += ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
     }
-    p.hla = (p.hl + 3) & ~3;
-    if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
-    p.ntl = (p.L + NT - 1) / NT;
-    p.ntiles = p.B * p.ntl;
-    p.xcols = (p.hla + NT + p.hr + 3) & ~3;
-    int xw = p.xcols;
-    if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
-    p.xw = xw;
-    p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
-    const int nbuf = p.Cin / CK > 1 ? 2 : 1;
-    p.atab_off = nbuf * CK * xw;
-    const size_t lds = ((size_t)p.atab_off + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+    for (int i = nprob; i <= V2W_MAX_MULTI; ++i) m.start[i] = i == nprob ? grid : 0x7fffffff;
+    m.start[nprob] = grid;
+    for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const int mtiles = p.Cout / MT;
-    const int grid = ((p.ntiles + 7) / 8) * 8 * mtiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
     return v2w_launch_status();
 }
 
 template <int U>
 int launch_convt_u(TileArgs p, hipStream_t stream) {
-    if (p.Cout % 64 == 0) return launch_tile<32, U, 1, 1, 2, 2, 16>(p, stream);
-    if (p.Cout == 32) return launch_tile<32, U, 1, 1, 1, 4, 16>(p, stream);
-    if (p.Cout == 16) return launch_tile<16, U, 1, 2, 1, 4, 16>(p, stream);
+    if (p.Cout % 64 == 0) return launch_tile<32, U, 1, 1, 2, 2, 16>(&p, 1, stream);
+    if (p.Cout == 32) return launch_tile<32, U, 1, 1, 1, 4, 16>(&p, 1, stream);
+    if (p.Cout == 16) return launch_tile<16, U, 1, 2, 1, 4, 16>(&p, 1, stream);
     return V2W_E_SHAPE;
 }
 
@@ -557,25 +588,36 @@ extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_
 }
 
 // Called by v2w_api.hip.  Returns V2W_E_SHAPE when no tile configuration fits (caller falls back to the direct kernel).
-int v2w_conv1d_mfma(const v2w_conv1d_args* a, hipStream_t stream, int* cfg_out) {
+// n problems (1 <= n <= V2W_MAX_MULTI) that share B, C_in, C_out, L - hence the tile configuration - in ONE launch.
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out) {
+    if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
     const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, 1);
-    if ((!a->wp && !cfg_out) || !cfg.mf) return V2W_E_SHAPE;
-    TileArgs p{};
-    p.cfg_out = cfg_out;
-    p.in = a->in; p.in_a = a->in_a; p.in_s = a->in_s; p.wp = a->wp; p.bias = a->bias;
-    p.res = a->res; p.res_a = a->res_a; p.res_s = a->res_s; p.out = a->out;
-    p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = a->dil;
-    p.pad = 0; p.hl = p.hr = a->dil * (a->k - 1) / 2;
-    p.slope = a->slope; p.accumulate = a->accumulate; p.out_div = a->out_div;
-    if (cfg.mf == 32 && p.Cout % 128 == 0) {
-        // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
-        const long tiles128 = (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
-        if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(p, stream);
-        return launch_tile<32, 1, 2, 1, 2, 2, 32>(p, stream);
+    if (!cfg.mf) return V2W_E_SHAPE;
+    TileArgs ps[V2W_MAX_MULTI];
+    long tiles128 = 0;
+    for (int i = 0; i < n; ++i) {
+        const v2w_conv1d_args* q = a + i;
+        if (q->B != a->B || q->C_in != a->C_in || q->C_out != a->C_out || q->L != a->L) return V2W_E_SHAPE;
+        if (!q->wp && !cfg_out) return V2W_E_SHAPE;
+        TileArgs p{};
+        p.cfg_out = cfg_out;
+        p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wp = q->wp; p.bias = q->bias;
+        p.res = q->res; p.res_a = q->res_a; p.res_s = q->res_s; p.out = q->out;
+        p.add0 = q->add0; p.add1 = q->add1;
+        p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
+        p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
+        p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
+        ps[i] = p;
+        tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
     }
-    if (cfg.mf == 32 && p.Cout % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(p, stream);
-    if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(p, stream);
-    if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(p, stream);
+    if (cfg.mf == 32 && a->C_out % 128 == 0) {
+        // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
+        if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(ps, n, stream);
+        return launch_tile<32, 1, 2, 1, 2, 2, 32>(ps, n, stream);
+    }
+    if (cfg.mf == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
+    if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(ps, n, stream);
+    if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(ps, n, stream);
     return V2W_E_SHAPE;
 }
 

@@ -30,7 +30,9 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
         const float rs = a.res_s ? a.res_s[b * a.C_out + co] : 0.f;
         v += fmaf(ra, a.res[o], rs);
     }
-    if (a.accumulate) v += a.out[o];
+    if (a.add1) v += a.add0[o] + a.add1[o];
+    else if (a.add0) v += a.add0[o];
+    else if (a.accumulate) v += a.out[o];
     if (a.out_div != 0.f) v = v / a.out_div;
     a.out[o] = v;
 }

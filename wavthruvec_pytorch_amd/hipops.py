@@ -70,22 +70,45 @@ def pack_mfma(wf, out=None, u=1):
     return out
 
 
-def conv1d(x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
-           accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None):
-    """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out] [/ out_div]; see the header."""
+def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
+                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None):
     B, ci, L = x.shape
-    co = out.shape[1]
-    a = _hip.Conv1dArgs()
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
     a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
     a.res = _hip.ptr(res)
     a.res_a, a.res_s = (_hip.ptr(res_affine[0]), _hip.ptr(res_affine[1])) if res_affine is not None else (None, None)
+    add = list(add or [])
+    a.add0 = _hip.ptr(add[0]) if len(add) > 0 else None
+    a.add1 = _hip.ptr(add[1]) if len(add) > 1 else None
     a.out = out.data_ptr()
-    a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, co, L, k, dil
+    a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, out.shape[1], L, k, dil
     a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
+
+
+def conv1d(x, wf, bias, out, **kw):
+    """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out | + add0 (+ add1)] [/ out_div]; see the header."""
+    a = _hip.Conv1dArgs()
+    _conv1d_args(a, x, wf, bias, out, **kw)
     _hip.check(_hip.load().v2w_conv1d_fwd(C.byref(a), _stream(x)), 'v2w_conv1d_fwd')
     return out
+
+
+def conv1d_multi(problems):
+    """`problems`: list of (x, wf, bias, out, kwargs) sharing B, C_in, C_out, L.  One launch when the MFMA path takes them
+    (heaviest first), otherwise one launch each."""
+    n = len(problems)
+    if 1 < n <= 4:
+        arr = (_hip.Conv1dArgs * n)()
+        for a, (x, wf, bias, out, kw) in zip(arr, problems):
+            _conv1d_args(a, x, wf, bias, out, **kw)
+        rc = _hip.load().v2w_conv1d_fwd_multi(arr, n, _stream(problems[0][0]))
+        if rc == 0:
+            return
+        if rc != -2:
+            _hip.check(rc, 'v2w_conv1d_fwd_multi')
+    for x, wf, bias, out, kw in problems:
+        conv1d(x, wf, bias, out, **kw)
 
 
 def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats_part=None):

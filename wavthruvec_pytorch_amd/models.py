@@ -348,36 +348,90 @@ class Generator(nn.Module):
                 hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                    training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
-                # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input
+                # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input.
+                # The branches are independent until the final sum, so conv n of ALL branches goes out as one launch
+                # (heaviest kernel size first); the first nk-1 branches end in their own buffers o_j and the last branch's
+                # final conv adds them in the reference's order ((r0 + r1) + r2) / nk  (models.py:135-141).
                 xs = self._buf(f'act.rb{i}', (B, C, Lo), device=dev)
-                t1 = self._buf(f'act.t1_{i}', (B, C, Lo), device=dev)
-                for j in range(nk):
-                    rb = self.resblocks[i * nk + j]
-                    name = f'resblocks.{i * nk + j}'
-                    k = rb.kernel_size
-                    last = dict(accumulate=(j > 0), out_div=(float(nk) if j == nk - 1 else 0.0))
-                    if isinstance(rb, ResBlock2):
-                        c1, c2 = rb.convs[0], rb.convs[1]
-                        self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
-                                    dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo,
-                                    wp=wp[name + '.convs.0'])
-                        self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
-                                    dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, wp=wp[name + '.convs.1'], **last)
+                rbs = [self.resblocks[i * nk + j] for j in range(nk)]
+                names = [f'resblocks.{i * nk + j}' for j in range(nk)]
+                merged = algo != hipops.ALGO_DIRECT and nk <= 3
+                if merged:
+                    t1s = [self._buf(f'act.t1_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                    outs = [self._buf(f'act.o_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk - 1)] + [xs]
+                    heavy_first = sorted(range(nk), key=lambda j: -rbs[j].kernel_size)
+
+                    def launch(tag_sfx, probs):
+                        probs = [probs[j] for j in heavy_first if j in probs]
+                        tag = '+'.join(f'{names[j]}.{tag_sfx}' for j, _ in probs)
+                        self._timed(tag, hipops.conv1d_multi, [pr for _, pr in probs])
+
+                    def final_kw(j):
+                        if j < nk - 1:
+                            return {}
+                        return dict(add=outs[:nk - 1], out_div=float(nk))
+
+                    if isinstance(rbs[0], ResBlock2):
+                        launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
+                                             dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
+                                                  in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                                  wp=wp[names[j] + '.convs.0']))) for j in range(nk)})
+                        conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
+                                         dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
+                                              res=t1s[j], algo=algo, wp=wp[names[j] + '.convs.1'], **final_kw(j))))
+                                 for j in range(nk)}
+                        if nk > 1:
+                            launch('1', {j: conv2[j] for j in range(nk - 1)})
+                        launch('1', {nk - 1: conv2[nk - 1]})
                     else:
-                        xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
-                        xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
-                        src, src_aff = xr, aff
-                        dsts = [xa, xb, xs]
+                        xas = [self._buf(f'act.xa_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                        xbs = [self._buf(f'act.xb_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                        srcs, src_aff = [xr] * nk, aff
                         for n in range(3):
-                            c1, c2 = rb.convs1[n], rb.convs2[n]
-                            self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
-                                        k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
-                                        wp=wp[f'{name}.convs1.{n}'])
-                            extra = last if n == 2 else {}
-                            self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
-                                        dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo,
-                                        wp=wp[f'{name}.convs2.{n}'], **extra)
-                            src, src_aff = dsts[n], None
+                            dsts = [xas, xbs, outs][n]
+                            launch(str(2 * n), {j: (j, (srcs[j], wf[f'{names[j]}.convs1.{n}'], rbs[j].convs1[n].bias.detach(),
+                                                        t1s[j], dict(k=rbs[j].kernel_size, dil=rbs[j].convs1[n].dilation,
+                                                                     slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                                                     wp=wp[f'{names[j]}.convs1.{n}']))) for j in range(nk)})
+                            conv2 = {j: (j, (t1s[j], wf[f'{names[j]}.convs2.{n}'], rbs[j].convs2[n].bias.detach(), dsts[j],
+                                             dict(k=rbs[j].kernel_size, dil=1, slope=LRELU_SLOPE, res=srcs[j],
+                                                  res_affine=src_aff, algo=algo, wp=wp[f'{names[j]}.convs2.{n}'],
+                                                  **(final_kw(j) if n == 2 else {})))) for j in range(nk)}
+                            if n < 2:
+                                launch(str(2 * n + 1), conv2)
+                            else:
+                                if nk > 1:
+                                    launch('5', {j: conv2[j] for j in range(nk - 1)})
+                                launch('5', {nk - 1: conv2[nk - 1]})
+                            srcs, src_aff = dsts, None
+                else:
+                    t1 = self._buf(f'act.t1_{i}', (B, C, Lo), device=dev)
+                    for j in range(nk):
+                        rb, name = rbs[j], names[j]
+                        k = rb.kernel_size
+                        last = dict(accumulate=(j > 0), out_div=(float(nk) if j == nk - 1 else 0.0))
+                        if isinstance(rb, ResBlock2):
+                            c1, c2 = rb.convs[0], rb.convs[1]
+                            self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
+                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                        wp=wp[name + '.convs.0'])
+                            self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
+                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, wp=wp[name + '.convs.1'], **last)
+                        else:
+                            xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
+                            xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
+                            src, src_aff = xr, aff
+                            dsts = [xa, xb, xs]
+                            for n in range(3):
+                                c1, c2 = rb.convs1[n], rb.convs2[n]
+                                self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
+                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                            wp=wp[f'{name}.convs1.{n}'])
+                                extra = last if n == 2 else {}
+                                self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
+                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo,
+                                            wp=wp[f'{name}.convs2.{n}'], **extra)
+                                src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
             # ---- K8: leaky_relu(0.01) -> conv_post -> tanh
