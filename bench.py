@@ -144,38 +144,44 @@ def main():
                 for tag, e0, e1 in g._profile:
                     per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
             g._profile = None
-        # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints)
+        # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
+        # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
+        def kernel_of(l):
+            if l['name'] == 'conv_post':
+                return 'conv_post_tanh_vec4_kernel'
+            direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
+            if args.algo == 'direct':
+                return direct
+            return hipops.conv_tile_config(B, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
+
+        launches = {}      # tag -> dict(kernel, flops, bytes, t)
+        for tag, ts in per.items():
+            ls = [layers[n] for n in tag.split('+')]
+            launches[tag] = dict(kernel=kernel_of(ls[0]), flops=sum(l['flops'] for l in ls), bytes=sum(l['bytes'] for l in ls),
+                                 t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
         groups = {}
-        for n, l in layers.items():
-            if n == 'conv_post':
-                kname = 'conv_post_tanh_kernel<7>'
-            elif args.algo == 'direct':
-                kname = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
-            else:
-                kname = hipops.conv_tile_config(B, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) \
-                    or ('conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel')
-            groups.setdefault(kname, []).append(n)
-        gtime = {k: sum(mean(per[n]) for n in v) for k, v in groups.items()}
+        for tag, d in launches.items():
+            groups.setdefault(d['kernel'], []).append(tag)
+        gtime = {k: sum(launches[n]['t'] for n in v) for k, v in groups.items()}
+        gflops = {k: sum(launches[n]['flops'] for n in v) for k, v in groups.items()}
         dom = max(gtime, key=gtime.get)
-        dom_layers = groups[dom]
-        dom_t, dom_f = gtime[dom], sum(layers[n]['flops'] for n in dom_layers)
-        conv_names = [n for n in layers if n != 'conv_post']
-        conv_t = sum(mean(per[n]) for n in conv_names)
-        conv_f = sum(layers[n]['flops'] for n in conv_names)
-        all_t = sum(mean(v) for v in per.values())
+        dom_tags = groups[dom]
+        dom_t, dom_f = gtime[dom], gflops[dom]
+        conv_t = sum(d['t'] for d in launches.values() if d['conv'])
+        conv_f = sum(d['flops'] for d in launches.values() if d['conv'])
+        all_t = sum(d['t'] for d in launches.values())
         tot_f, tot_b = workmodel.totals(h, B, T)
         step_s = elapsed / args.steps
-        roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_layers,
+        roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_tags,
                     achieved=dom_f / dom_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                    launches_per_step=len(dom_layers), avg_launch_us=dom_t / len(dom_layers) * 1e6,
-                    flops_per_launch_avg=dom_f / len(dom_layers),
-                    per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4),
-                                        tflops=round(sum(layers[n]['flops'] for n in v) / gtime[k] / 1e12, 2),
-                                        algorithmic_gbs=round(sum(layers[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
+                    launches_per_step=len(dom_tags), avg_launch_us=dom_t / len(dom_tags) * 1e6,
+                    flops_per_launch_avg=dom_f / len(dom_tags),
+                    per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4), tflops=round(gflops[k] / gtime[k] / 1e12, 2),
+                                        algorithmic_gbs=round(sum(launches[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
                                 for k, v in sorted(groups.items(), key=lambda kv: -gtime[kv[0]])},
                     all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                           launches_per_step=len(conv_names)),
+                                           launches_per_step=sum(1 for d in launches.values() if d['conv'])),
                     whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
                                        mfma_frac=tot_f / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                        hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))

@@ -17,7 +17,17 @@ def main(path, B=32, T=256, which=-2):
     idx = [i for i, n in enumerate(names) if 'cond_fc' in n]
     s, e = idx[which - 1], idx[which]
     h = synthetic.make_hparams(num_wv_feat=768)
-    layers = workmodel.conv_layers(h, B, T)
+    by_name = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
+    # launch groups as Generator.forward issues them: the residual branches of a stage share launches (heaviest first)
+    groups = [['conv_pre']]
+    nk = len(h.resblock_kernel_sizes)
+    for i in range(len(h.upsample_rates)):
+        js = sorted(range(nk), key=lambda j: -h.resblock_kernel_sizes[j])
+        groups.append([f'ups.{i}'])
+        groups.append([f'resblocks.{i * nk + j}.0' for j in js])
+        groups.append([f'resblocks.{i * nk + j}.1' for j in js if j < nk - 1])
+        groups.append([f'resblocks.{i * nk + nk - 1}.1'])
+    groups.append(['conv_post'])
     li = 0
     tot = 0.0
     other = {}
@@ -26,7 +36,9 @@ def main(path, B=32, T=256, which=-2):
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += d
         if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n:
-            l = layers[li]; li += 1
+            grp = groups[li]; li += 1
+            l = dict(name='+'.join(g.replace('resblocks.', 'rb') for g in grp), flops=sum(by_name[g]['flops'] for g in grp),
+                     bytes=sum(by_name[g]['bytes'] for g in grp))
             short = n.split('::')[-1].split('(')[0][:44]
             print(f"{l['name']:20s} {short:46s} {d:8.1f} us {l['flops'] / d / 1e6:7.1f} TF {l['bytes'] / d / 1e3:7.0f} GB/s "
                   f"grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']} agpr={r['Accum_VGPR_Count']}")
