@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 3
+#define V2W_ABI_VERSION 4
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -108,6 +108,24 @@ int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST p
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
  * the residual branches of one generator stage, heaviest first. */
 int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
+
+/* ---- K6 fused pair for the narrow stages (C == 32 or 16; MFMA path): two chained convs of one residual block in ONE kernel,
+ * the intermediate stays in LDS (these layers are HBM-bound as separate launches).
+ *   res_mode 0 (ResBlock2, models.py:65-70): t1 = x + conv_{k,dil1}(lrelu(x)) + b1 ; out = t1 + conv_{k,dil2}(lrelu(t1)) + b2
+ *   res_mode 1 (ResBlock1 pair, models.py:37-44): t1 = conv_{k,dil1}(lrelu(x)) + b1 ; out = x + conv_{k,dil2}(lrelu(t1)) + b2
+ *   x = in_a*in + in_s when the affine is given; then out = ((add0 [+ add1]) + out) [/ out_div] as in v2w_conv1d_args.
+ *   wp1 / wp2: v2w_pack_mfma(k, C, C, 1) streams.  a[0..n) (n <= 4) share B, C, L and go out as one launch.
+ * Returns V2W_E_SHAPE when C or the receptive field does not fit: run the two convs with v2w_conv1d_fwd instead. */
+typedef struct {
+    const float* in; const float* in_a; const float* in_s;
+    const float* wp1; const float* bias1; const float* wp2; const float* bias2;
+    const float* add0; const float* add1;
+    float* out;
+    int32_t B, C, L, k, dil1, dil2;
+    int32_t res_mode;
+    float slope, out_div;
+} v2w_pair_args;
+int v2w_resblock_pair_fwd(const v2w_pair_args* a, int n, void* stream);
 
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */

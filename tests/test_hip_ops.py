@@ -342,3 +342,43 @@ def test_conv1d_multi_equals_sequential(dev):
     hipops.conv1d(x, wf, bs[11], direct, k=11, dil=1, slope=0.1, res=x, add=[seq[3], seq[7]], out_div=3.0,
                   algo=hipops.ALGO_DIRECT)
     assert (direct - fused).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize('C,L,k,d1,d2,mode', [(32, 1000, 11, 1, 3, 0), (32, 900, 3, 1, 3, 0), (16, 3000, 7, 1, 3, 0),
+                                               (16, 250, 11, 5, 1, 1), (32, 40, 7, 3, 1, 1), (16, 4, 3, 1, 3, 0)])
+def test_resblock_pair_fused_equals_two_convs(dev, C, L, k, d1, d2, mode):
+    """The fused pair kernel (intermediate in LDS) vs the same two convs as separate launches, and vs torch."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(11)
+    B = 2
+    x = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    ia = _t((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), dev)
+    is_ = _t((0.3 * r.standard_normal((B, C))).astype(np.float32), dev)
+    w1 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+    w2 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+    b1 = _t(r.standard_normal(C).astype(np.float32), dev); b2 = _t(r.standard_normal(C).astype(np.float32), dev)
+    a0 = _t(r.standard_normal((B, C, L), dtype=np.float32), dev); a1 = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    wf1, wf2 = _t(_relayout(w1).numpy(), dev), _t(_relayout(w2).numpy(), dev)
+    wp1, wp2 = hipops.pack_mfma(wf1), hipops.pack_mfma(wf2)
+    aff = (ia, is_)
+    # separate launches
+    t1 = torch.empty((B, C, L), device=dev); ref = torch.empty((B, C, L), device=dev)
+    if mode == 0:
+        hipops.conv1d(x, None, b1, t1, k=k, dil=d1, slope=0.1, in_affine=aff, res=x, res_affine=aff, wp=wp1)
+        hipops.conv1d(t1, None, b2, ref, k=k, dil=d2, slope=0.1, res=t1, add=[a0, a1], out_div=3.0, wp=wp2)
+    else:
+        hipops.conv1d(x, None, b1, t1, k=k, dil=d1, slope=0.1, in_affine=aff, wp=wp1)
+        hipops.conv1d(t1, None, b2, ref, k=k, dil=d2, slope=0.1, res=x, res_affine=aff, add=[a0, a1], out_div=3.0, wp=wp2)
+    out = torch.full((B, C, L), float('nan'), device=dev)
+    ok = hipops.resblock_pair_multi([dict(x=x, in_affine=aff, wp1=wp1, b1=b1, wp2=wp2, b2=b2, out=out, k=k, dil1=d1, dil2=d2,
+                                          res_mode=mode, slope=0.1, add=[a0, a1], out_div=3.0)])
+    assert ok
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 1e-6
+    # against stock torch on the CPU
+    xin = (ia[:, :, None] * x + is_[:, :, None]).cpu()
+    c1 = F.conv1d(F.leaky_relu(xin, 0.1), w1, b1.cpu(), padding=d1 * (k - 1) // 2, dilation=d1)
+    tt = c1 + xin if mode == 0 else c1
+    c2 = F.conv1d(F.leaky_relu(tt, 0.1), w2, b2.cpu(), padding=d2 * (k - 1) // 2, dilation=d2)
+    want = ((a0.cpu() + a1.cpu()) + (c2 + (tt if mode == 0 else xin))) / 3.0
+    assert (out.cpu() - want).abs().max().item() <= 3e-5

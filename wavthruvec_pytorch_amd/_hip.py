@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
@@ -32,6 +32,13 @@ class ConvT1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32)]
+
+
+class PairArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wp1', _fp), ('bias1', _fp), ('wp2', _fp), ('bias2', _fp),
+                ('add0', _fp), ('add1', _fp), ('out', _fp),
+                ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32), ('k', C.c_int32), ('dil1', C.c_int32), ('dil2', C.c_int32),
+                ('res_mode', C.c_int32), ('slope', C.c_float), ('out_div', C.c_float)]
 
 
 class FoldDesc(C.Structure):
@@ -62,6 +69,7 @@ SIGNATURES = {
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
+    'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
     'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),

@@ -42,3 +42,26 @@ __device__ __forceinline__ T v2w_block_sum(T v, T* red) {
     for (int i = 0; i < nw; ++i) t += red[i];  // fixed order: deterministic
     return t;
 }
+
+// ---- f32 MFMA fragments shared by the tile kernels.  A/B operands are ONE float per lane; for the 32x32x2 shape lane l
+// holds A[row l&31][k l>>5] / B[k l>>5][col l&31], for 16x16x4 A[l&15][l>>4] / B[l>>4][l&15].
+template <int MF> struct Frag;
+template <> struct Frag<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NREG = 16, KSTEP = 2;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    __device__ static __forceinline__ int row(int reg, int hk) { return (reg & 3) + 8 * (reg >> 2) + 4 * hk; }
+};
+template <> struct Frag<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NREG = 4, KSTEP = 4;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane&15, row = (lane>>4)*4 + reg
+    __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
+};
+

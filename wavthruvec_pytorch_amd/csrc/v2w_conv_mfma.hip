@@ -57,26 +57,6 @@ struct MultiArgs {
     int start[V2W_MAX_MULTI + 1];
 };
 
-template <int MF> struct Frag;
-template <> struct Frag<32> {
-    typedef f32x16 acc_t;
-    static constexpr int NREG = 16, KSTEP = 2;
-    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-    // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    __device__ static __forceinline__ int row(int reg, int hk) { return (reg & 3) + 8 * (reg >> 2) + 4 * hk; }
-};
-template <> struct Frag<16> {
-    typedef f32x4 acc_t;
-    static constexpr int NREG = 4, KSTEP = 4;
-    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    // C/D map: col = lane&15, row = (lane>>4)*4 + reg
-    __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
-};
-
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_tile_kernel(const MultiArgs m) {

@@ -230,3 +230,28 @@ class FoldPlan:
                                                    self.nblk_scale, self.nblk_pack, self.lds,
                                                    torch.cuda.current_stream(self.scale.device).cuda_stream),
                    'v2w_fold_pack_batch')
+
+
+def resblock_pair_multi(problems):
+    """`problems`: list of dicts(x, in_affine, wp1, b1, wp2, b2, out, k, dil1, dil2, res_mode, slope, add, out_div) sharing B, C, L.
+    Returns False (nothing launched) when the fused pair kernel does not take the shape."""
+    n = len(problems)
+    arr = (_hip.PairArgs * n)()
+    for a, q in zip(arr, problems):
+        x = q['x']
+        B, Cc, L = x.shape
+        a.in_ = x.data_ptr()
+        aff = q.get('in_affine')
+        a.in_a, a.in_s = (aff[0].data_ptr(), aff[1].data_ptr()) if aff is not None else (None, None)
+        a.wp1 = q['wp1'].data_ptr(); a.bias1 = _hip.ptr(q['b1']); a.wp2 = q['wp2'].data_ptr(); a.bias2 = _hip.ptr(q['b2'])
+        add = list(q.get('add') or [])
+        a.add0 = _hip.ptr(add[0]) if len(add) > 0 else None
+        a.add1 = _hip.ptr(add[1]) if len(add) > 1 else None
+        a.out = q['out'].data_ptr()
+        a.B, a.C, a.L, a.k, a.dil1, a.dil2 = B, Cc, L, q['k'], q['dil1'], q['dil2']
+        a.res_mode = q['res_mode']; a.slope = q['slope']; a.out_div = q.get('out_div', 0.0)
+    rc = _hip.load().v2w_resblock_pair_fwd(arr, n, _stream(problems[0]['x']))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_resblock_pair_fwd')
+    return True

@@ -175,6 +175,7 @@ class Generator(nn.Module):
         self.algo = hipops.ALGO_AUTO          # hipops.ALGO_DIRECT forces the scalar cross-check kernels
         self.stat_sync = None                 # callable(stats fp64 tensor) -> all-reduced in place (distributed.BNStatSync)
         self.always_refold = True             # train mode: fold weight norm every forward, as the reference's hook does
+        self.fuse_pairs = True                # narrow stages: run each conv pair of a residual block as one fused kernel
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._warned_grad = False
@@ -371,38 +372,69 @@ class Generator(nn.Module):
                             return {}
                         return dict(add=outs[:nk - 1], out_div=float(nk))
 
+                    # narrow stages (C = 32 / 16): both convs of a pair in ONE kernel, the intermediate stays in LDS
+                    fused_pair = self.fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
+                                                                          for c in (('convs.0', 'convs.1') if isinstance(rbs[0], ResBlock2)
+                                                                                    else ('convs1.0', 'convs2.0')))
+
+                    def launch_pairs(tag_sfx, probs):
+                        """probs: {j: dict}; first nk-1 branches in one launch, the summing branch after them."""
+                        done = True
+                        for js in ([j for j in heavy_first if j in probs and j < nk - 1], [nk - 1] if nk - 1 in probs else []):
+                            if js and done:
+                                tag = '+'.join(f'{names[j]}.{tag_sfx}' for j in js)
+                                done = self._timed(tag, hipops.resblock_pair_multi, [probs[j] for j in js])
+                        return done
+
                     if isinstance(rbs[0], ResBlock2):
-                        launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
-                                             dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
-                                                  in_affine=aff, res=xr, res_affine=aff, algo=algo,
-                                                  wp=wp[names[j] + '.convs.0']))) for j in range(nk)})
-                        conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
-                                         dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
-                                              res=t1s[j], algo=algo, wp=wp[names[j] + '.convs.1'], **final_kw(j))))
-                                 for j in range(nk)}
-                        if nk > 1:
-                            launch('1', {j: conv2[j] for j in range(nk - 1)})
-                        launch('1', {nk - 1: conv2[nk - 1]})
+                        ok = False
+                        if fused_pair:
+                            ok = launch_pairs('0&1', {j: dict(x=xr, in_affine=aff, wp1=wp[names[j] + '.convs.0'],
+                                                              b1=rbs[j].convs[0].bias.detach(), wp2=wp[names[j] + '.convs.1'],
+                                                              b2=rbs[j].convs[1].bias.detach(), out=outs[j], k=rbs[j].kernel_size,
+                                                              dil1=rbs[j].convs[0].dilation, dil2=rbs[j].convs[1].dilation,
+                                                              res_mode=0, slope=LRELU_SLOPE, **final_kw(j)) for j in range(nk)})
+                        if not ok:
+                            launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
+                                                 dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
+                                                      in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                                      wp=wp[names[j] + '.convs.0']))) for j in range(nk)})
+                            conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
+                                             dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
+                                                  res=t1s[j], algo=algo, wp=wp[names[j] + '.convs.1'], **final_kw(j))))
+                                     for j in range(nk)}
+                            if nk > 1:
+                                launch('1', {j: conv2[j] for j in range(nk - 1)})
+                            launch('1', {nk - 1: conv2[nk - 1]})
                     else:
                         xas = [self._buf(f'act.xa_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
                         xbs = [self._buf(f'act.xb_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
                         srcs, src_aff = [xr] * nk, aff
                         for n in range(3):
                             dsts = [xas, xbs, outs][n]
-                            launch(str(2 * n), {j: (j, (srcs[j], wf[f'{names[j]}.convs1.{n}'], rbs[j].convs1[n].bias.detach(),
-                                                        t1s[j], dict(k=rbs[j].kernel_size, dil=rbs[j].convs1[n].dilation,
-                                                                     slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
-                                                                     wp=wp[f'{names[j]}.convs1.{n}']))) for j in range(nk)})
-                            conv2 = {j: (j, (t1s[j], wf[f'{names[j]}.convs2.{n}'], rbs[j].convs2[n].bias.detach(), dsts[j],
-                                             dict(k=rbs[j].kernel_size, dil=1, slope=LRELU_SLOPE, res=srcs[j],
-                                                  res_affine=src_aff, algo=algo, wp=wp[f'{names[j]}.convs2.{n}'],
-                                                  **(final_kw(j) if n == 2 else {})))) for j in range(nk)}
-                            if n < 2:
-                                launch(str(2 * n + 1), conv2)
-                            else:
-                                if nk > 1:
-                                    launch('5', {j: conv2[j] for j in range(nk - 1)})
-                                launch('5', {nk - 1: conv2[nk - 1]})
+                            ok = False
+                            if fused_pair:
+                                ok = launch_pairs(f'{2 * n}&{2 * n + 1}',
+                                                  {j: dict(x=srcs[j], in_affine=src_aff, wp1=wp[f'{names[j]}.convs1.{n}'],
+                                                           b1=rbs[j].convs1[n].bias.detach(), wp2=wp[f'{names[j]}.convs2.{n}'],
+                                                           b2=rbs[j].convs2[n].bias.detach(), out=dsts[j], k=rbs[j].kernel_size,
+                                                           dil1=rbs[j].convs1[n].dilation, dil2=1, res_mode=1, slope=LRELU_SLOPE,
+                                                           **(final_kw(j) if n == 2 else {})) for j in range(nk)})
+                            if not ok:
+                                launch(str(2 * n), {j: (j, (srcs[j], wf[f'{names[j]}.convs1.{n}'], rbs[j].convs1[n].bias.detach(),
+                                                            t1s[j], dict(k=rbs[j].kernel_size, dil=rbs[j].convs1[n].dilation,
+                                                                         slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                                                         wp=wp[f'{names[j]}.convs1.{n}']))) for j in range(nk)})
+                                conv2 = {j: (j, (t1s[j], wf[f'{names[j]}.convs2.{n}'], rbs[j].convs2[n].bias.detach(), dsts[j],
+                                                 dict(k=rbs[j].kernel_size, dil=1, slope=LRELU_SLOPE, res=srcs[j],
+                                                      res_affine=src_aff, algo=algo, wp=wp[f'{names[j]}.convs2.{n}'],
+                                                      **(final_kw(j) if n == 2 else {})))) for j in range(nk)}
+                                if n < 2:
+                                    launch(str(2 * n + 1), conv2)
+                                else:
+                                    if nk > 1:
+                                        launch('5', {j: conv2[j] for j in range(nk - 1)})
+                                    launch('5', {nk - 1: conv2[nk - 1]})
                             srcs, src_aff = dsts, None
                 else:
                     t1 = self._buf(f'act.t1_{i}', (B, C, Lo), device=dev)
