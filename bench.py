@@ -156,8 +156,22 @@ def main():
 
         launches = {}      # tag -> dict(kernel, flops, bytes, t)
         for tag, ts in per.items():
-            ls = [layers[n] for n in tag.split('+')]
-            launches[tag] = dict(kernel=kernel_of(ls[0]), flops=sum(l['flops'] for l in ls), bytes=sum(l['bytes'] for l in ls),
+            names, fused = [], False
+            for part in tag.split('+'):            # 'resblocks.J.a&b' = convs a and b of block J in one fused-pair kernel
+                if '&' in part:
+                    base, ab = part.rsplit('.', 1)
+                    names += [f'{base}.{x}' for x in ab.split('&')]
+                    fused = True
+                else:
+                    names.append(part)
+            ls = [layers[n] for n in names]
+            kname = kernel_of(ls[0])
+            if fused:
+                kname = 'resblock_pair_kernel<32, 2, 4>' if ls[0]['cout'] == 32 else 'resblock_pair_kernel<16, 4, 4>'
+            nbytes = sum(l['bytes'] for l in ls)
+            if fused:                              # the intermediate is neither written nor re-read
+                nbytes -= sum(2 * B * l['cout'] * l['L'] * 4 for l in ls[::2])
+            launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
                                  t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
         groups = {}
         for tag, d in launches.items():

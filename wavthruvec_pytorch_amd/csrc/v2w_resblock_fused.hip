@@ -32,6 +32,7 @@ struct PairArgs {
     int ntl, ntiles;
     int vec4;
     int res_mode;     // 0: ResBlock2 (t1 += x, out += t1)   1: ResBlock1 (out += x)
+    int toff, eoff;   // LDS offsets (floats) of T1 and of the bias table
     float slope, out_div;
 };
 
@@ -69,8 +70,8 @@ resblock_pair_kernel(const PairMulti m) {
     const int L = p.L, K = p.K, xw = p.xw, tw = p.tw;
     const float slope = p.slope;
     float* const Xs = smem;                 // [C][xw]
-    float* const Ts = smem + C * xw;        // [C][tw]
-    float* const etab = Ts + C * tw;        // bias1[C], bias2[C]
+    float* const Ts = smem + p.toff;        // [C][tw]; ResBlock2 (res_mode 0) overlays it on X: x is dead once t1 exists
+    float* const etab = smem + p.eoff;      // bias1[C], bias2[C]
 
     // ---- stage x = a*in + s (0 outside the sequence); X column 0 <-> position pos0 (a multiple of 4)
     const int pos0 = n0 - p.h2 - p.h1 - p.xoff;
@@ -153,8 +154,15 @@ resblock_pair_kernel(const PairMulti m) {
             const int pos = n0 - p.h2 + col;
             float v = acc[j][e] + bias;
             if (p.res_mode == 0) v += Xs[co * xw + col + p.xoff + p.h1];
-            Ts[co * tw + col] = (pos >= 0 && pos < L) ? v : 0.f;
+            acc[j][e] = (pos >= 0 && pos < L) ? v : 0.f;
         }
+    }
+    if (p.toff == 0) __syncthreads();       // T1 overlays X: every wave must be done reading x (operands and residual)
+#pragma unroll
+    for (int e = 0; e < F::NREG; ++e) {
+        const int co = F::row(e, hk);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Ts[co * tw + wn0 + j * MF + lr] = acc[j][e];
     }
     __syncthreads();
 
@@ -213,7 +221,9 @@ int launch_pair(const v2w_pair_args* a, int n, hipStream_t stream) {
         p.ntiles = q.B * p.ntl;
         p.vec4 = (q.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q.in) & 15) == 0);
         p.res_mode = q.res_mode; p.slope = q.slope; p.out_div = q.out_div;
-        const size_t l = ((size_t)MF * (xw + tw) + 2 * MF) * sizeof(float);
+        p.toff = q.res_mode == 0 ? 0 : MF * xw;
+        p.eoff = q.res_mode == 0 ? MF * (xw > tw ? xw : tw) : MF * (xw + tw);
+        const size_t l = ((size_t)p.eoff + 2 * MF) * sizeof(float);
         if (l > lds) lds = l;
         m.p[i] = p;
         m.start[i] = grid;

@@ -175,7 +175,8 @@ class Generator(nn.Module):
         self.algo = hipops.ALGO_AUTO          # hipops.ALGO_DIRECT forces the scalar cross-check kernels
         self.stat_sync = None                 # callable(stats fp64 tensor) -> all-reduced in place (distributed.BNStatSync)
         self.always_refold = True             # train mode: fold weight norm every forward, as the reference's hook does
-        self.fuse_pairs = True                # narrow stages: run each conv pair of a residual block as one fused kernel
+        self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
+                                              # ties at C=32 where the per-layer tiles are already MFMA-bound)
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._warned_grad = False
@@ -373,7 +374,7 @@ class Generator(nn.Module):
                         return dict(add=outs[:nk - 1], out_div=float(nk))
 
                     # narrow stages (C = 32 / 16): both convs of a pair in ONE kernel, the intermediate stays in LDS
-                    fused_pair = self.fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
+                    fused_pair = C in self.fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
                                                                           for c in (('convs.0', 'convs.1') if isinstance(rbs[0], ResBlock2)
                                                                                     else ('convs1.0', 'convs2.0')))
 
