@@ -146,13 +146,14 @@ def main():
             g._profile = None
         # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
         # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
-        def kernel_of(l):
+        def kernel_of(l, nprob=1):
             if l['name'] == 'conv_post':
                 return 'conv_post_tanh_vec4_kernel'
             direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
             if args.algo == 'direct':
                 return direct
-            return hipops.conv_tile_config(B, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
+            # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
+            return hipops.conv_tile_config(B * nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
 
         launches = {}      # tag -> dict(kernel, flops, bytes, t)
         for tag, ts in per.items():
@@ -165,7 +166,7 @@ def main():
                 else:
                     names.append(part)
             ls = [layers[n] for n in names]
-            kname = kernel_of(ls[0])
+            kname = kernel_of(ls[0], len(tag.split('+')))
             if fused:
                 kname = 'resblock_pair_kernel<32, 2, 4>' if ls[0]['cout'] == 32 else 'resblock_pair_kernel<16, 4, 4>'
             nbytes = sum(l['bytes'] for l in ls)
@@ -186,9 +187,21 @@ def main():
         all_t = sum(d['t'] for d in launches.values())
         tot_f, tot_b = workmodel.totals(h, B, T)
         step_s = elapsed / args.steps
+        # HBM bytes per launch of that kernel from the PMC passes (tools/pmc_traffic.py; FETCH_SIZE x2 + WRITE_SIZE, KiB ->
+        # bytes as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process: the committed summary
+        # of the same command is used when its kernel name matches, else null.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_cfg2_hbm_traffic.json')
+        if os.path.exists(tpath) and (B, T) == (32, 256):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if dom in tj:
+                traffic = tj[dom]['hbm_bytes_per_launch']
+                traffic_src = 'profiles/r01_cfg2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
         roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_tags,
                     achieved=dom_f / dom_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                    frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch_avg=sum(launches[n]['bytes'] for n in dom_tags) / len(dom_tags),
                     launches_per_step=len(dom_tags), avg_launch_us=dom_t / len(dom_tags) * 1e6,
                     flops_per_launch_avg=dom_f / len(dom_tags),
                     per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4), tflops=round(gflops[k] / gtime[k] / 1e12, 2),

@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:
             continue
-        name = r['Kernel_Name'].split('::')[-1].split('(')[0]
+        name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
         d = acc.setdefault(name, [0, 0.0])
         d[0] += 1
         d[1] += float(r['Counter_Value'])

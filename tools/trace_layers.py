@@ -44,11 +44,11 @@ def main(path, B=32, T=256, which=-2):
             grp = groups[li]; li += 1
             l = dict(name='+'.join(g.replace('resblocks.', 'rb') for g in grp), flops=sum(by_name[g]['flops'] for g in grp),
                      bytes=sum(by_name[g]['bytes'] for g in grp))
-            short = n.split('::')[-1].split('(')[0][:44]
+            short = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:46]
             print(f"{l['name']:20s} {short:46s} {d:8.1f} us {l['flops'] / d / 1e6:7.1f} TF {l['bytes'] / d / 1e3:7.0f} GB/s "
                   f"grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']} agpr={r['Accum_VGPR_Count']}")
         else:
-            k = n.split('::')[-1].split('(')[0]
+            k = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
             other[k] = other.get(k, 0) + d
     for k, v in sorted(other.items(), key=lambda kv: -kv[1]):
         print(f'  other {k:40s} {v:8.1f} us')
