@@ -113,7 +113,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     with torch.no_grad():
         for _ in range(args.warmup):

@@ -595,6 +595,7 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(ps, n, stream);
         return launch_tile<32, 1, 2, 1, 2, 2, 32>(ps, n, stream);
     }
+    // (64 x 256 and 64 x 128 single-row-block variants measured slower on MI355X: 52-92 / 61-90 vs 64-93 TF)
     if (cfg.mf == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
     if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(ps, n, stream);
     if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(ps, n, stream);

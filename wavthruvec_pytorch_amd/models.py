@@ -189,6 +189,34 @@ class Generator(nn.Module):
         self.stat_sync = BNStatSync(group)
         return self
 
+    def capture_graph(self, x, spk_emb, noise, warmup: int = 2):
+        """Capture one forward (current train/eval mode, these shapes) into a HIP graph and return `run(x, spk_emb, noise)`.
+
+        The forward is ~40-60 kernel launches; at inference sizes (B=1, T~50) it is launch-bound, and replaying one graph
+        removes the per-launch host cost.  Inputs are copied into static buffers, the returned tensor is the graph's static
+        output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured."""
+        if self.stat_sync is not None:
+            raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
+        sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=sx.device)
+            side.wait_stream(torch.cuda.current_stream(sx.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):     # builds every workspace buffer and the fold plan outside the capture
+                    self.forward(sx, ss, sn)
+            torch.cuda.current_stream(sx.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                sy = self.forward(sx, ss, sn)
+
+        def run(x, spk_emb, noise):
+            sx.copy_(x); ss.copy_(spk_emb); sn.copy_(noise)
+            graph.replay()
+            return sy
+
+        run.graph = graph
+        return run
+
     def remove_weight_norm(self):
         print('Removing weight norm...')
         for l in self.ups:
