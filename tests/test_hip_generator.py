@@ -264,9 +264,33 @@ def test_graph_capture_matches_eager(dev):
     gt = build_generator(h, sd, dev, training=True)
     ge = build_generator(h, sd, dev, training=True)
     with torch.no_grad():
-        run_t = gt.capture_graph(*inp, warmup=1)     # warm-up + capture = 2 train steps on gt
-        ge(*inp); ge(*inp)
+        run_t = gt.capture_graph(*inp, warmup=1)     # the warm-up executes one train step; the capture only records
+        ge(*inp)
         y_g = run_t(*inp2).clone()
         y_e = ge(*inp2)
     assert torch.equal(y_g, y_e)
-    assert gt.cbns[0].batch_nrom.num_batches_tracked.item() == ge.cbns[0].batch_nrom.num_batches_tracked.item() == 3
+    assert gt.cbns[0].batch_nrom.num_batches_tracked.item() == ge.cbns[0].batch_nrom.num_batches_tracked.item() == 2
+
+
+def test_synthesize_entry_end_to_end(dev, tmp_path):
+    """Checkpoint file + text2vec-format latents + speaker-embedding file -> wav, equal to the oracle's eval forward."""
+    import os
+    import wave
+    from wavthruvec_pytorch_amd import synthesize as S, utils
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    x, spk, nz = synthetic.make_inputs(h, 1, 20, seed=3)
+    O.calibrate_running_stats(sd, h, x, spk, nz)                      # a "trained" checkpoint: sensible running stats
+    d = str(tmp_path)
+    utils.save_checkpoint(os.path.join(d, 'g_00000042'), {'generator': sd})
+    np.save(os.path.join(d, 'utt_feat_postnet.npy'), x.permute(0, 2, 1).numpy())     # (1, T, C) as text2vec/eval.py writes
+    torch.save(spk.reshape(1, 1, -1), os.path.join(d, 'spk.pth'))
+    rc = S.main(['--checkpoint', d, '--feat', os.path.join(d, 'utt_feat_postnet.npy'), '--spk-emb', os.path.join(d, 'spk.pth'),
+                 '--out', os.path.join(d, 'o.wav'), '--seed', '7'])
+    assert rc == 0
+    noise = torch.randn(1, 192, generator=torch.Generator().manual_seed(7))
+    want, _ = O.generator_forward(sd, h, x, spk, noise, training=False)
+    with wave.open(os.path.join(d, 'o.wav')) as w:
+        assert w.getframerate() == 16000 and w.getnframes() == 20 * 320
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2').astype(np.float32) / 32767.0
+    assert np.abs(pcm - want.reshape(-1).clamp(-1, 1).numpy()).max() <= 1e-4 + 1.0 / 32767

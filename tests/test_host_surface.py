@@ -99,3 +99,26 @@ def test_checkpoint_helpers(tmp_path):
     sd = utils.load_checkpoint(p, 'cpu')['generator']
     Generator(h).load_state_dict(sd)
     assert utils.get_padding(11, 3) == 15 and utils.get_padding(7) == 3
+
+
+def test_synthesize_wire_formats(tmp_path):
+    """text2vec `.npy` (1,T,C) -> (1,C,T); `{spk}.pth` (1,1,192) -> (1,192); 16-bit PCM wav writer."""
+    import wave
+    import numpy as np
+    from wavthruvec_pytorch_amd import synthesize as S
+    a = np.random.default_rng(0).standard_normal((1, 13, 768)).astype(np.float32)
+    np.save(os.path.join(str(tmp_path), 'u_feat_postnet.npy'), a)
+    x = S.load_latents(os.path.join(str(tmp_path), 'u_feat_postnet.npy'))
+    assert x.shape == (1, 768, 13) and x.is_contiguous()
+    assert torch.equal(x[0, :, 3], torch.from_numpy(a[0, 3]))
+    torch.save(torch.randn(1, 1, 192), os.path.join(str(tmp_path), 'SSB0005.pth'))
+    assert S.load_speaker_embedding(os.path.join(str(tmp_path), 'SSB0005.pth')).shape == (1, 192)
+    y = torch.tensor([[[0.0, 0.5, -1.0, 1.0, 2.0]]])
+    S.write_wav(os.path.join(str(tmp_path), 'o.wav'), y, 16000)
+    with wave.open(os.path.join(str(tmp_path), 'o.wav')) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 5)
+        pcm = np.frombuffer(w.readframes(5), dtype='<i2')
+    assert list(pcm) == [0, 16384, -32767, 32767, 32767]
+    with pytest.raises(ValueError):
+        np.save(os.path.join(str(tmp_path), 'bad.npy'), np.zeros((2, 3, 4), np.float32))
+        S.load_latents(os.path.join(str(tmp_path), 'bad.npy'))
