@@ -158,7 +158,8 @@ def main():
         launches = {}      # tag -> dict(kernel, flops, bytes, t)
         for tag, ts in per.items():
             names, fused = [], False
-            for part in tag.split('+'):            # 'resblocks.J.a&b' = convs a and b of block J in one fused-pair kernel
+            staged = tag.startswith('stage:')       # whole residual section of a narrow stage in one kernel
+            for part in tag.replace('stage:', '').split('+'):   # 'resblocks.J.a&b' = convs a and b of block J fused
                 if '&' in part:
                     base, ab = part.rsplit('.', 1)
                     names += [f'{base}.{x}' for x in ab.split('&')]
@@ -168,10 +169,14 @@ def main():
             ls = [layers[n] for n in names]
             kname = kernel_of(ls[0], len(tag.split('+')))
             if fused:
-                kname = 'resblock_pair_kernel<32, 2, 4>' if ls[0]['cout'] == 32 else 'resblock_pair_kernel<16, 4, 4>'
+                kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
+                        ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
             nbytes = sum(l['bytes'] for l in ls)
             if fused:                              # the intermediate is neither written nor re-read
                 nbytes -= sum(2 * B * l['cout'] * l['L'] * 4 for l in ls[::2])
+            if staged:                             # x read once, no per-branch outputs / running-sum traffic
+                act = B * ls[0]['cout'] * ls[0]['L'] * 4
+                nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
             launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
                                  t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
         groups = {}

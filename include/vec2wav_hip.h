@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 4
+#define V2W_ABI_VERSION 5
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -126,6 +126,20 @@ typedef struct {
     float slope, out_div;
 } v2w_pair_args;
 int v2w_resblock_pair_fwd(const v2w_pair_args* a, int n, void* stream);
+
+/* ---- K6+K7 fused for a narrow ResBlock2 stage (C == 32 or 16): the whole residual section of models.py:135-141,
+ *   out = ( sum_j [ t1_j + conv_{k_j,dil2_j}(lrelu(t1_j)) + b2_j ] ) / out_div,  t1_j = x + conv_{k_j,dil1_j}(lrelu(x)) + b1_j,
+ * x = in_a*in + in_s, in ONE kernel: x is read once, every t1_j stays in LDS, the branch sum stays in registers and is
+ * added in the reference's order.  nk <= 4 branches.  V2W_E_SHAPE -> use the per-branch entry points. */
+typedef struct {
+    const float* in; const float* in_a; const float* in_s;
+    const float* wp1[4]; const float* bias1[4]; const float* wp2[4]; const float* bias2[4];
+    int32_t k[4], dil1[4], dil2[4];
+    float* out;
+    int32_t nk, B, C, L;
+    float slope, out_div;
+} v2w_stage_args;
+int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
 
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */

@@ -382,3 +382,38 @@ def test_resblock_pair_fused_equals_two_convs(dev, C, L, k, d1, d2, mode):
     c2 = F.conv1d(F.leaky_relu(tt, 0.1), w2, b2.cpu(), padding=d2 * (k - 1) // 2, dilation=d2)
     want = ((a0.cpu() + a1.cpu()) + (c2 + (tt if mode == 0 else xin))) / 3.0
     assert (out.cpu() - want).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize('C,L', [(32, 1000), (16, 3000), (16, 4), (32, 252)])
+def test_resblock2_stage_fused_equals_branchwise(dev, C, L):
+    """One kernel for the whole ResBlock2 residual section of a stage vs the per-branch launches (bit-identical sum order)."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(12)
+    B = 2
+    x = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    aff = (_t((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), dev), _t((0.3 * r.standard_normal((B, C))).astype(np.float32), dev))
+    branches, outs = [], []
+    for k in (3, 7, 11):
+        w1 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        w2 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        branches.append(dict(wp1=hipops.pack_mfma(_t(_relayout(w1).numpy(), dev)), b1=_t(r.standard_normal(C).astype(np.float32), dev),
+                             wp2=hipops.pack_mfma(_t(_relayout(w2).numpy(), dev)), b2=_t(r.standard_normal(C).astype(np.float32), dev),
+                             k=k, dil1=1, dil2=3, w1=w1, w2=w2))
+    # per-branch path: two convs each, the last one adds the other two and divides
+    for j, br in enumerate(branches):
+        t1 = torch.empty((B, C, L), device=dev); o = torch.empty((B, C, L), device=dev)
+        hipops.conv1d(x, None, br['b1'], t1, k=br['k'], dil=1, slope=0.1, in_affine=aff, res=x, res_affine=aff, wp=br['wp1'])
+        extra = dict(add=outs[:2], out_div=3.0) if j == 2 else {}
+        hipops.conv1d(t1, None, br['b2'], o, k=br['k'], dil=3, slope=0.1, res=t1, wp=br['wp2'], **extra)
+        outs.append(o)
+    got = torch.full((B, C, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage(x, aff, branches, got, slope=0.1, out_div=3.0)
+    assert torch.isfinite(got).all()
+    assert (got - outs[2]).abs().max().item() <= 1e-6
+    xin = (aff[0][:, :, None] * x + aff[1][:, :, None]).cpu()
+    want = None
+    for br in branches:
+        t1 = xin + F.conv1d(F.leaky_relu(xin, 0.1), br['w1'], br['b1'].cpu(), padding=(br['k'] - 1) // 2)
+        rj = t1 + F.conv1d(F.leaky_relu(t1, 0.1), br['w2'], br['b2'].cpu(), padding=3 * (br['k'] - 1) // 2, dilation=3)
+        want = rj if want is None else want + rj
+    assert (got.cpu() - want / 3.0).abs().max().item() <= 3e-5

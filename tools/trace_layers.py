@@ -25,9 +25,8 @@ def main(path, B=32, T=256, which=-2):
         js = sorted(range(nk), key=lambda j: -h.resblock_kernel_sizes[j])
         groups.append([f'ups.{i}'])
         C = h.upsample_initial_channel // 2 ** (i + 1)
-        if C in (16,):   # fused pair kernel (Generator.fuse_pairs default): both convs of a block in one launch
-            groups.append([f'resblocks.{i * nk + j}.{c}' for j in js if j < nk - 1 for c in (0, 1)])
-            groups.append([f'resblocks.{i * nk + nk - 1}.{c}' for c in (0, 1)])
+        if C in (16, 32):   # Generator.fuse_stage default: the whole residual section of the stage is ONE launch
+            groups.append([f'resblocks.{i * nk + j}.{c}' for j in range(nk) for c in (0, 1)])
         else:
             groups.append([f'resblocks.{i * nk + j}.0' for j in js])
             groups.append([f'resblocks.{i * nk + j}.1' for j in js if j < nk - 1])
@@ -40,7 +39,7 @@ def main(path, B=32, T=256, which=-2):
         n = r['Kernel_Name']
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += d
-        if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n:
+        if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n or 'resblock2_stage' in n:
             grp = groups[li]; li += 1
             l = dict(name='+'.join(g.replace('resblocks.', 'rb') for g in grp), flops=sum(by_name[g]['flops'] for g in grp),
                      bytes=sum(by_name[g]['bytes'] for g in grp))

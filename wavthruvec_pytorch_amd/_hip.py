@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
@@ -39,6 +39,14 @@ class PairArgs(C.Structure):
                 ('add0', _fp), ('add1', _fp), ('out', _fp),
                 ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32), ('k', C.c_int32), ('dil1', C.c_int32), ('dil2', C.c_int32),
                 ('res_mode', C.c_int32), ('slope', C.c_float), ('out_div', C.c_float)]
+
+
+class StageArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp),
+                ('wp1', _fp * 4), ('bias1', _fp * 4), ('wp2', _fp * 4), ('bias2', _fp * 4),
+                ('k', C.c_int32 * 4), ('dil1', C.c_int32 * 4), ('dil2', C.c_int32 * 4),
+                ('out', _fp), ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
+                ('slope', C.c_float), ('out_div', C.c_float)]
 
 
 class FoldDesc(C.Structure):
@@ -70,6 +78,7 @@ SIGNATURES = {
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
+    'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
     'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),

@@ -255,3 +255,24 @@ def resblock_pair_multi(problems):
         return False
     _hip.check(rc, 'v2w_resblock_pair_fwd')
     return True
+
+
+def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
+    """Whole ResBlock2 residual section of a narrow stage in one kernel.  `branches`: list of dicts(wp1, b1, wp2, b2, k, dil1, dil2).
+    Returns False (nothing launched) when the shape is not taken."""
+    B, Cc, L = x.shape
+    a = _hip.StageArgs()
+    a.in_ = x.data_ptr()
+    a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
+    for j, br in enumerate(branches):
+        a.wp1[j] = br['wp1'].data_ptr(); a.bias1[j] = _hip.ptr(br['b1'])
+        a.wp2[j] = br['wp2'].data_ptr(); a.bias2[j] = _hip.ptr(br['b2'])
+        a.k[j], a.dil1[j], a.dil2[j] = br['k'], br['dil1'], br['dil2']
+    a.out = out.data_ptr()
+    a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
+    a.slope = slope; a.out_div = out_div
+    rc = _hip.load().v2w_resblock2_stage_fwd(C.byref(a), _stream(x))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_resblock2_stage_fwd')
+    return True

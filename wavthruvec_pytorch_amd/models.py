@@ -177,6 +177,7 @@ class Generator(nn.Module):
         self.always_refold = True             # train mode: fold weight norm every forward, as the reference's hook does
         self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
                                               # ties at C=32 where the per-layer tiles are already MFMA-bound)
+        self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._warned_grad = False
@@ -417,7 +418,14 @@ class Generator(nn.Module):
 
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
-                        if fused_pair:
+                        if C in self.fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
+                            # the whole residual section of the stage in ONE kernel: x read once, t1_j in LDS, sum in registers
+                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
+                                             [dict(wp1=wp[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                   wp2=wp[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk))
+                        if not ok and fused_pair:
                             ok = launch_pairs('0&1', {j: dict(x=xr, in_affine=aff, wp1=wp[names[j] + '.convs.0'],
                                                               b1=rbs[j].convs[0].bias.detach(), wp2=wp[names[j] + '.convs.1'],
                                                               b2=rbs[j].convs[1].bias.detach(), out=outs[j], k=rbs[j].kernel_size,
