@@ -15,7 +15,10 @@ def main():
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).eval()
-    for B, T in [(1, 50), (1, 256), (4, 256)]:
+    shapes = [(1, 50), (1, 256), (4, 256)]
+    if len(sys.argv) > 2:
+        shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
+    for B, T in shapes:
         inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
         with torch.no_grad():
             for _ in range(5):
