@@ -133,17 +133,18 @@ def main():
 
     # ---- roofline of the dominant kernel: events around every conv launch, on the launching stream, live
     roof = None
-    if rank == 0:
-        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
-        per = {}
-        with torch.no_grad():
-            for _ in range(3):
-                g._profile = []
-                g(x, spk, nz)
-                torch.cuda.synchronize()
+    per = {}
+    with torch.no_grad():          # every rank runs these forwards (they contain the statistics all-reduce); rank 0 records
+        for _ in range(3):
+            g._profile = [] if rank == 0 else None
+            g(x, spk, nz)
+            torch.cuda.synchronize()
+            if rank == 0:
                 for tag, e0, e1 in g._profile:
                     per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
-            g._profile = None
+        g._profile = None
+    if rank == 0:
+        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
         # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
         # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
         def kernel_of(l, nprob=1):
