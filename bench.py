@@ -92,11 +92,17 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the Vec2Wav HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # test hooks for a 1-GPU box: V2W_BENCH_DEVICE pins every rank to one device, V2W_BENCH_BACKEND=gloo replaces RCCL
+    dev_index = int(os.environ.get('V2W_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('V2W_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from wavthruvec_pytorch_amd import Generator, synthetic, workmodel, hipops
 
@@ -113,7 +119,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == 'nccl':
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -127,7 +136,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
