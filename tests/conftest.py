@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _hip_library_built():
+    """The shared library is a build artefact (git-ignored): compile it for gfx950 when it is missing or stale.
+    hipcc cross-compiles without a GPU, so this also is the CPU suite's "does it build" check."""
+    from wavthruvec_pytorch_amd import build
+    if build.needs_build():
+        build.build()
+    return build.LIB_PATH
