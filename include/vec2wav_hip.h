@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 5
+#define V2W_ABI_VERSION 6
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -53,6 +53,10 @@ int v2w_wn_fold_conv (const float* v, const float* g, float* wf, float* scratch,
                       int c_out, int c_in, int k, void* stream);
 int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
                       int c_in, int c_out, int k, void* stream);
+
+/* dgrad weights: out[t][C_out][C_in] = wf[k-1-t][C_in][C_out]; the conv that back-propagates through Conv1d(w, dilation d)
+ * is a Conv1d of the output gradient with these weights and the same dilation (then v2w_pack_mfma(out, k, C_out, C_in)). */
+int v2w_wf_transpose_flip(const float* wf, float* out, int k, int c_in, int c_out, void* stream);
 
 /* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same k*C_in*C_out weights as a stream of 1 KiB MFMA A-fragments
  * (64 lanes x float4 = four consecutive MFMA k-steps) in exactly the order the tile kernel of that layer consumes them:
@@ -97,12 +101,16 @@ typedef struct {
     const float* add0; const float* add1;   /* optional extra addends (B, C_out, L): out = (add0 [+ add1]) + value, then / out_div;
                                              * the explicit form of `xs += ...` (models.py:137-141) when the branches ran
                                              * concurrently into separate buffers; exclusive with `accumulate` */
+    const float* mask_src; const float* mask_a; const float* mask_s;   /* optional (backward use): the conv result is
+                                             * multiplied by lrelu'(mask_a*mask_src + mask_s) = 1 or mask_slope BEFORE bias /
+                                             * residual / addends; mask_src (B, C_out, L), mask_a/_s (B, C_out) or NULL */
     float*       out;
     int32_t B, C_in, C_out, L, k, dil;
     float   slope;
     int32_t accumulate;
     float   out_div;
     int32_t algo;
+    float   mask_slope;
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):

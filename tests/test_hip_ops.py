@@ -417,3 +417,33 @@ def test_resblock2_stage_fused_equals_branchwise(dev, C, L):
         rj = t1 + F.conv1d(F.leaky_relu(t1, 0.1), br['w2'], br['b2'].cpu(), padding=3 * (br['k'] - 1) // 2, dilation=3)
         want = rj if want is None else want + rj
     assert (got.cpu() - want / 3.0).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize('B,C,L,k,dil', [(2, 256, 300, 11, 3), (2, 64, 700, 7, 1), (3, 32, 1000, 3, 3), (2, 16, 3000, 11, 1)])
+def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
+    """Backward through one ResBlock2 step  y = x + conv_{k,d}(lrelu(x)),  x = a*in + s  (first piece):
+    dx = dy + lrelu'(x) * conv_{k,d}(dy; W^T flipped) is the SAME fused conv kernel run on dy with transposed-flipped weights,
+    the leaky_relu derivative applied as an epilogue mask and dy as the residual.  Checked against torch autograd."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(13)
+    xin = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    a = torch.from_numpy((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32))
+    s = torch.from_numpy((0.3 * r.standard_normal((B, C))).astype(np.float32))
+    w = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+    dy = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    x = (a[:, :, None] * xin + s[:, :, None]).requires_grad_(True)
+    y = x + F.conv1d(F.leaky_relu(x, 0.1), w, None, padding=dil * (k - 1) // 2, dilation=dil)
+    y.backward(dy)
+    want = x.grad
+    wf = _t(_relayout(w).numpy(), dev)
+    wpT = hipops.pack_mfma(hipops.transpose_flip(wf))
+    dyd = _t(dy.numpy(), dev)
+    got = torch.full((B, C, L), float('nan'), device=dev)
+    hipops.conv1d(dyd, None, None, got, k=k, dil=dil, slope=1.0, res=dyd, wp=wpT,
+                  mask=(_t(xin.numpy(), dev), (_t(a.numpy(), dev), _t(s.numpy(), dev))), mask_slope=0.1)
+    assert (got.cpu() - want).abs().max().item() <= 3e-5
+    # direct kernel agrees
+    got2 = torch.empty_like(got)
+    hipops.conv1d(dyd, hipops.transpose_flip(wf), None, got2, k=k, dil=dil, slope=1.0, res=dyd, algo=hipops.ALGO_DIRECT,
+                  mask=(_t(xin.numpy(), dev), (_t(a.numpy(), dev), _t(s.numpy(), dev))), mask_slope=0.1)
+    assert (got2.cpu() - want).abs().max().item() <= 3e-5

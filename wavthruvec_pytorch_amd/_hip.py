@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
@@ -22,10 +22,11 @@ _fp = C.c_void_p  # device pointers travel as integers
 
 class Conv1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp),
-                ('res', _fp), ('res_a', _fp), ('res_s', _fp), ('add0', _fp), ('add1', _fp), ('out', _fp),
+                ('res', _fp), ('res_a', _fp), ('res_s', _fp), ('add0', _fp), ('add1', _fp),
+                ('mask_src', _fp), ('mask_a', _fp), ('mask_s', _fp), ('out', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
-                ('out_div', C.c_float), ('algo', C.c_int32)]
+                ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float)]
 
 
 class ConvT1dArgs(C.Structure):
@@ -72,6 +73,7 @@ SIGNATURES = {
     'v2w_build_arch': (C.c_char_p, []),
     'v2w_wn_fold_conv': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wn_fold_convt': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_wf_transpose_flip': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -18,6 +18,8 @@ static int check_conv1d(const v2w_conv1d_args* a) {
     if (a->res_a && !a->res) return V2W_E_ARG;
     if (a->add1 && !a->add0) return V2W_E_ARG;
     if (a->add0 && a->accumulate) return V2W_E_ARG;               // either the running sum in `out` or explicit addends
+    if ((a->mask_a == nullptr) != (a->mask_s == nullptr)) return V2W_E_ARG;
+    if (a->mask_a && !a->mask_src) return V2W_E_ARG;
     return 0;
 }
 

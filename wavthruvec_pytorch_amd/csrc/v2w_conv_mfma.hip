@@ -31,6 +31,8 @@ struct TileArgs {
     const float* wp; const float* bias;
     const float* res; const float* res_a; const float* res_s;
     const float* add0; const float* add1;   // conv only, optional extra addends: out = ((add0 [+ add1]) + value)
+    const float* mask_src; const float* mask_a; const float* mask_s;   // conv only: acc *= lrelu'(mask_a*mask_src + mask_s)
+    float mask_slope;
     float* out;
     float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
     int B, Cin, Cout, L, K, dil;
@@ -101,8 +103,8 @@ conv_tile_kernel(const MultiArgs m) {
     const float slope = p.slope;
     const int nch = p.Cin / CK;
     const int pos0 = n0 - p.hla;           // position of LDS column 0
-    float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias[MT], res_a[MT], res_s[MT]
-    float* const atab = etab + 3 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
+    float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias, res_a, res_s, mask_a, mask_s [MT] each
+    float* const atab = etab + 5 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
 
     acc_t acc[U][MI][NI];
 #pragma unroll
@@ -207,6 +209,8 @@ conv_tile_kernel(const MultiArgs m) {
         etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
         etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
         etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
+        etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
+        etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
     }
     if (p.in_a) {
         for (int c = tid; c < p.Cin; c += NTHREADS) {
@@ -280,7 +284,7 @@ conv_tile_kernel(const MultiArgs m) {
             constexpr int EG = (MI == 1 && F::NREG >= 8) ? 8 : 4;
 #pragma unroll
             for (int e0 = 0; e0 < F::NREG; e0 += EG) {
-                float rv[EG][NI], ov[EG][NI], o2[EG][NI];
+                float rv[EG][NI], ov[EG][NI], o2[EG][NI], mv[EG][NI];
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
                     const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
@@ -291,6 +295,7 @@ conv_tile_kernel(const MultiArgs m) {
                         rv[ee][j] = (p.res && q < L) ? p.res[orow + q] : 0.f;
                         ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : ((p.add0 && q < L) ? p.add0[orow + q] : 0.f);
                         o2[ee][j] = (p.add1 && q < L) ? p.add1[orow + q] : 0.f;
+                        mv[ee][j] = (p.mask_src && q < L) ? p.mask_src[orow + q] : 1.f;
                     }
                 }
 #pragma unroll
@@ -303,7 +308,10 @@ conv_tile_kernel(const MultiArgs m) {
                     for (int j = 0; j < NI; ++j) {
                         const int q = n0 + wn0 + j * MF + lr;
                         if (q >= L) continue;
-                        float v = acc[0][i][j][e] + bias;
+                        float v = acc[0][i][j][e];
+                        if (p.mask_src)   // backward through the leaky_relu in front of the forward conv: d/dx lrelu = 1 or slope
+                            v = fmaf(etab[3 * MT + col], mv[ee][j], etab[4 * MT + col]) > 0.f ? v : v * p.mask_slope;
+                        v += bias;
                         if (p.res) v += fmaf(ra, rv[ee][j], rs);
                         if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
                         else if (p.accumulate || p.add0) v += ov[ee][j];
@@ -412,7 +420,7 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
         const int nbuf = p.Cin / CK > 1 ? 2 : 1;
         p.atab_off = nbuf * CK * xw;
-        const size_t l = ((size_t)p.atab_off + 3 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        const size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
         if (l > lds) lds = l;
         m.p[i] = p;
         m.start[i] = grid;
@@ -584,6 +592,7 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wp = q->wp; p.bias = q->bias;
         p.res = q->res; p.res_a = q->res_a; p.res_s = q->res_s; p.out = q->out;
         p.add0 = q->add0; p.add1 = q->add1;
+        p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
         p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;

@@ -24,7 +24,12 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
         }
     }
     const size_t o = ((size_t)b * a.C_out + co) * a.L + l;
-    float v = acc + (a.bias ? a.bias[co] : 0.f);
+    float v = acc;
+    if (a.mask_src) {
+        const float ma = a.mask_a ? a.mask_a[b * a.C_out + co] : 1.f, ms = a.mask_a ? a.mask_s[b * a.C_out + co] : 0.f;
+        v = fmaf(ma, a.mask_src[o], ms) > 0.f ? v : v * a.mask_slope;
+    }
+    v += a.bias ? a.bias[co] : 0.f;
     if (a.res) {
         const float ra = a.res_a ? a.res_a[b * a.C_out + co] : 1.f;
         const float rs = a.res_s ? a.res_s[b * a.C_out + co] : 0.f;

@@ -57,6 +57,15 @@ def fold_convt_weight(v, g, out=None, scratch=None):
     return out
 
 
+def transpose_flip(wf, out=None):
+    """wf [k][C_in][C_out] -> dgrad weights [k][C_out][C_in] (taps reversed)."""
+    k, ci, co = wf.shape
+    if out is None:
+        out = torch.empty((k, co, ci), device=wf.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_wf_transpose_flip(wf.data_ptr(), out.data_ptr(), k, ci, co, _stream(wf)), 'v2w_wf_transpose_flip')
+    return out
+
+
 def pack_mfma(wf, out=None, u=1):
     """wf [k][C_in][C_out] -> the same weights as the MFMA A-fragment stream of that layer (u = 1 conv, stride for convT),
     or None when the layer has no MFMA tile configuration."""
@@ -71,7 +80,7 @@ def pack_mfma(wf, out=None, u=1):
 
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
-                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None):
+                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0):
     B, ci, L = x.shape
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
@@ -81,6 +90,10 @@ def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, re
     add = list(add or [])
     a.add0 = _hip.ptr(add[0]) if len(add) > 0 else None
     a.add1 = _hip.ptr(add[1]) if len(add) > 1 else None
+    if mask is not None:          # (mask_src, (mask_a, mask_s) | None)
+        a.mask_src = mask[0].data_ptr()
+        a.mask_a, a.mask_s = (mask[1][0].data_ptr(), mask[1][1].data_ptr()) if mask[1] is not None else (None, None)
+    a.mask_slope = mask_slope
     a.out = out.data_ptr()
     a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, out.shape[1], L, k, dil
     a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
