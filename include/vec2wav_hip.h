@@ -216,6 +216,15 @@ int v2w_bn_finalize(const double* stats, const float* gb,
  * consumers' loads instead. */
 int v2w_affine_apply(const float* x, const float* a, const float* s, float* out, int B, int C, int L, void* stream);
 
+/* ---- backward building blocks (the forward entry points above run dgrad: see v2w_wf_transpose_flip).
+ * v2w_wgrad: dwf [k][C_in][C_out] = sum_{b,q} lrelu(x_a*x + x_s)[b,ci,q + off_t] * dy[b,co,u*q + r_t]
+ *   Conv1d(k, dil): u = 1 ; ConvTranspose1d(k, stride u, pad (k-u)/2): `dil` ignored, dy is (B, C_out, u*Lq).
+ *   x (B, C_in, Lq); slab_ws: v2w_wgrad_slabs(...) * k*C_in*C_out floats (per-split partials, summed in fixed order).
+ *   V2W_E_SHAPE unless C_in and C_out are multiples of 16. */
+int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq);
+int v2w_wgrad(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
+              int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, void* stream);
+
 /* ---- K8: leaky_relu(slope) -> Conv1d(C_in -> 1, k, pad (k-1)/2) -> +bias -> tanh  (models.py:143-145).
  * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
 int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,

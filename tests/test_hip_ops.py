@@ -447,3 +447,30 @@ def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
     hipops.conv1d(dyd, hipops.transpose_flip(wf), None, got2, k=k, dil=dil, slope=1.0, res=dyd, algo=hipops.ALGO_DIRECT,
                   mask=(_t(xin.numpy(), dev), (_t(a.numpy(), dev), _t(s.numpy(), dev))), mask_slope=0.1)
     assert (got2.cpu() - want).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,dil,u', [(2, 256, 256, 300, 11, 3, 1), (2, 64, 64, 1000, 7, 1, 1), (3, 32, 32, 777, 3, 5, 1),
+                                                   (2, 16, 16, 3000, 11, 1, 1), (2, 768, 512, 50, 7, 1, 1),
+                                                   (2, 512, 256, 50, 11, 1, 5), (2, 128, 64, 333, 8, 1, 4), (2, 64, 32, 500, 4, 1, 2),
+                                                   (2, 32, 16, 1000, 4, 1, 2), (1, 512, 256, 17, 16, 1, 8)])
+def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
+    """dW of the fused [affine] -> lrelu -> Conv1d / ConvTranspose1d against torch autograd (weights in [k][C_in][C_out] layout)."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(14)
+    x = torch.from_numpy(r.standard_normal((B, cin, L), dtype=np.float32))
+    a = torch.from_numpy((1 + 0.2 * r.standard_normal((B, cin))).astype(np.float32))
+    s = torch.from_numpy((0.3 * r.standard_normal((B, cin))).astype(np.float32))
+    act = F.leaky_relu(a[:, :, None] * x + s[:, :, None], 0.1)
+    if u == 1:
+        w = torch.from_numpy((r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)).requires_grad_(True)
+        y = F.conv1d(act, w, None, padding=dil * (k - 1) // 2, dilation=dil)
+    else:
+        w = torch.from_numpy((r.standard_normal((cin, cout, k)) / np.sqrt(cin * k)).astype(np.float32)).requires_grad_(True)
+        y = F.conv_transpose1d(act, w, None, stride=u, padding=(k - u) // 2)
+    dy = torch.from_numpy(r.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(dy)
+    want = w.grad.permute(2, 1, 0) if u == 1 else w.grad.permute(2, 0, 1)      # -> [k][C_in][C_out]
+    got = hipops.wgrad(_t(x.numpy(), dev), _t(dy.numpy(), dev), k=k, dil=dil, u=u, slope=0.1,
+                       x_affine=(_t(a.numpy(), dev), _t(s.numpy(), dev))).cpu()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, scale) * 10

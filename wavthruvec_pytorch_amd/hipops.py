@@ -289,3 +289,21 @@ def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
         return False
     _hip.check(rc, 'v2w_resblock2_stage_fwd')
     return True
+
+
+def wgrad(x, dy, *, k, dil=1, u=1, slope=1.0, x_affine=None, out=None):
+    """Weight gradient dwf [k][C_in][C_out] of a fused lrelu -> Conv1d (u = 1) or lrelu -> ConvTranspose1d (stride u).
+    x (B, C_in, Lq) is the forward conv's input (before the affine / activation), dy (B, C_out, u*Lq) the output gradient."""
+    B, ci, Lq = x.shape
+    co = dy.shape[1]
+    lib = _hip.load()
+    ns = lib.v2w_wgrad_slabs(B, ci, co, Lq)
+    if ns == 0:
+        raise _hip.HipLibraryError(f'v2w_wgrad: no configuration for C_in={ci}, C_out={co}')
+    if out is None:
+        out = torch.empty((k, ci, co), device=x.device, dtype=torch.float32)
+    slab = torch.empty((ns * k * ci * co,), device=x.device, dtype=torch.float32)
+    xa, xs = (x_affine[0].data_ptr(), x_affine[1].data_ptr()) if x_affine is not None else (None, None)
+    _hip.check(lib.v2w_wgrad(x.data_ptr(), xa, xs, dy.data_ptr(), out.data_ptr(), slab.data_ptr(), B, ci, co, Lq, k, dil, u, slope,
+                             _stream(x)), 'v2w_wgrad')
+    return out
