@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 6
+#define V2W_ABI_VERSION 7
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -57,6 +57,9 @@ int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
 /* dgrad weights: out[t][C_out][C_in] = wf[k-1-t][C_in][C_out]; the conv that back-propagates through Conv1d(w, dilation d)
  * is a Conv1d of the output gradient with these weights and the same dilation (then v2w_pack_mfma(out, k, C_out, C_in)). */
 int v2w_wf_transpose_flip(const float* wf, float* out, int k, int c_in, int c_out, void* stream);
+/* general form: out[m][C_out][C_in] = wf[t_start + m*t_step][C_in][C_out], m < n.  Phase r of ConvTranspose1d(k, u, pad):
+ * t_start = (r+pad)%u, t_step = u, n = taps of the phase; run as Conv1d over dy's phase r with pad_left = (r+pad)/u. */
+int v2w_wf_gather_transpose(const float* wf, float* out, int k, int c_in, int c_out, int t_start, int t_step, int n, void* stream);
 
 /* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same k*C_in*C_out weights as a stream of 1 KiB MFMA A-fragments
  * (64 lanes x float4 = four consecutive MFMA k-steps) in exactly the order the tile kernel of that layer consumes them:
@@ -111,6 +114,9 @@ typedef struct {
     float   out_div;
     int32_t algo;
     float   mask_slope;
+    int32_t in_stride, in_phase;  /* 0/1, 0: plain.  > 1: the conv reads the de-interleaved phase in[.., in_stride*l + in_phase] of a
+                                   * (B, C_in, in_stride*L) tensor (dgrad of a transposed conv, one launch per phase) */
+    int32_t pad_left;             /* -1: symmetric padding dil*(k-1)/2.  >= 0: taps sit at offsets -pad_left + t*dil (k may be even) */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):

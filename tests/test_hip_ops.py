@@ -474,3 +474,20 @@ def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
                        x_affine=(_t(a.numpy(), dev), _t(s.numpy(), dev))).cpu()
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * max(1.0, scale) * 10
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 512, 256, 50, 11, 5), (2, 128, 64, 333, 8, 4), (2, 64, 32, 500, 4, 2),
+                                             (2, 32, 16, 1000, 4, 2), (1, 512, 256, 17, 16, 8)])
+def test_convt1d_dgrad_matches_autograd(dev, B, cin, cout, L, k, u):
+    """dx of  y = ConvTranspose1d(lrelu(x)): one small Conv1d per output phase on the strided phase of dy, lrelu' as epilogue mask."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(15)
+    x = torch.from_numpy(r.standard_normal((B, cin, L), dtype=np.float32)).requires_grad_(True)
+    w = torch.from_numpy((r.standard_normal((cin, cout, k)) / np.sqrt(cin * k)).astype(np.float32))
+    y = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, None, stride=u, padding=(k - u) // 2)
+    dy = torch.from_numpy(r.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(dy)
+    wf = _t(w.permute(2, 0, 1).contiguous().numpy(), dev)
+    out = torch.full((B, cin, L), float('nan'), device=dev)
+    hipops.convt1d_dgrad(_t(dy.numpy(), dev), wf, out, k=k, u=u, mask=(_t(x.detach().numpy(), dev), None), mask_slope=0.1)
+    assert (out.cpu() - x.grad).abs().max().item() <= 3e-5

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
@@ -26,7 +26,8 @@ class Conv1dArgs(C.Structure):
                 ('mask_src', _fp), ('mask_a', _fp), ('mask_s', _fp), ('out', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
-                ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float)]
+                ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
+                ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32)]
 
 
 class ConvT1dArgs(C.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     'v2w_wn_fold_conv': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wn_fold_convt': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wf_transpose_flip': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_wf_gather_transpose': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

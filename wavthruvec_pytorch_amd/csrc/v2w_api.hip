@@ -12,7 +12,9 @@ extern "C" const char* v2w_build_arch(void) { return "gfx950"; }
 static int check_conv1d(const v2w_conv1d_args* a) {
     if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->dil <= 0) return V2W_E_ARG;
-    if ((a->k & 1) == 0) return V2W_E_SHAPE;                       // padding d*(k-1)/2 keeps the length only for odd k
+    if ((a->k & 1) == 0 && a->pad_left < 0) return V2W_E_SHAPE;    // symmetric padding d*(k-1)/2 keeps the length only for odd k
+    if (a->pad_left > a->dil * (a->k - 1) || a->in_stride < 0 || a->in_phase < 0 || (a->in_stride > 0 && a->in_phase >= a->in_stride))
+        return V2W_E_ARG;
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
     if ((a->res_a == nullptr) != (a->res_s == nullptr)) return V2W_E_ARG;
     if (a->res_a && !a->res) return V2W_E_ARG;

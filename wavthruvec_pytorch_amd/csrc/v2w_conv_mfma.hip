@@ -33,6 +33,7 @@ struct TileArgs {
     const float* add0; const float* add1;   // conv only, optional extra addends: out = ((add0 [+ add1]) + value)
     const float* mask_src; const float* mask_a; const float* mask_s;   // conv only: acc *= lrelu'(mask_a*mask_src + mask_s)
     float mask_slope;
+    int in_stride, in_phase;   // the conv reads in[.., in_stride*pos + in_phase] (de-interleaved phase of a longer sequence)
     float* out;
     float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
     int B, Cin, Cout, L, K, dil;
@@ -160,16 +161,16 @@ conv_tile_kernel(const MultiArgs m) {
             *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
         }
     };
-    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment: dword loads straight into LDS
+    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment / input stride: dword loads straight into LDS
         for (int c = wave; c < CK; c += WM * WN) {
             const int ch = b * p.Cin + ci0 + c;
-            const float* src = p.in + (size_t)ch * L;
+            const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
             const float av = p.in_a ? p.in_a[ch] : 1.f;
             const float sv = p.in_s ? p.in_s[ch] : 0.f;
             for (int j = lane; j < p.xcols; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
-                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[l], sv), slope);
+                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[(size_t)l * p.in_stride], sv), slope);
                 Xs[c * xw + j] = v;
             }
         }
@@ -417,7 +418,8 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         int xw = p.xcols;
         if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
         p.xw = xw;
-        p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+        if (p.in_stride < 1) p.in_stride = 1;
+        p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) && p.in_stride == 1;
         const int nbuf = p.Cin / CK > 1 ? 2 : 1;
         p.atab_off = nbuf * CK * xw;
         const size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
@@ -595,6 +597,8 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
         p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
+        if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
+        p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);

@@ -10,16 +10,17 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int co = blockIdx.y, b = blockIdx.z;
     if (l >= a.L) return;
-    const int pad = a.dil * (a.k - 1) / 2;
+    const int pad = a.pad_left >= 0 ? a.pad_left : a.dil * (a.k - 1) / 2;
+    const int istr = a.in_stride > 0 ? a.in_stride : 1;
     float acc = 0.f;
     for (int ci = 0; ci < a.C_in; ++ci) {
-        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L;
+        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L * istr + a.in_phase;
         const float av = a.in_a ? a.in_a[b * a.C_in + ci] : 1.f;
         const float sv = a.in_s ? a.in_s[b * a.C_in + ci] : 0.f;
         for (int t = 0; t < a.k; ++t) {
             const int li = l + t * a.dil - pad;
             if (li < 0 || li >= a.L) continue;
-            const float x = v2w_lrelu(fmaf(av, src[li], sv), a.slope);
+            const float x = v2w_lrelu(fmaf(av, src[(size_t)li * istr], sv), a.slope);
             acc = fmaf(a.wf[((size_t)t * a.C_in + ci) * a.C_out + co], x, acc);
         }
     }

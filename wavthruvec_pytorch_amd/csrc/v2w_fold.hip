@@ -59,14 +59,15 @@ fold_convt_kernel(const float* __restrict__ v, const float* __restrict__ g, floa
     }
 }
 
-// out[t][co][ci] = wf[K-1-t][ci][co]: the weights of the conv that back-propagates through a forward conv (its dgrad)
+// out[m][co][ci] = wf[t_start + m*t_step][ci][co], m < n: the weights of the conv that back-propagates through a forward
+// conv (t_start = K-1, t_step = -1: flipped taps) or through one phase of a transposed conv (t_start = t0_r, t_step = u)
 __global__ void __launch_bounds__(256)
-transpose_flip_kernel(const float* __restrict__ wf, float* __restrict__ out, int K, int Cin, int Cout) {
+transpose_flip_kernel(const float* __restrict__ wf, float* __restrict__ out, int t_start, int t_step, int Cin, int Cout) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float* src = wf + (size_t)(K - 1 - t) * Cin * Cout;
+    const float* src = wf + (size_t)(t_start + t * t_step) * Cin * Cout;
     for (int y = ty; y < 32; y += 8) {
         const int ci = ci0 + y, co = co0 + tx;
         tile[y][tx] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
@@ -84,7 +85,16 @@ transpose_flip_kernel(const float* __restrict__ wf, float* __restrict__ out, int
 extern "C" int v2w_wf_transpose_flip(const float* wf, float* out, int k, int c_in, int c_out, void* stream) {
     if (!wf || !out || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
     hipLaunchKernelGGL(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, k), dim3(256), 0, (hipStream_t)stream,
-                       wf, out, k, c_in, c_out);
+                       wf, out, k - 1, -1, c_in, c_out);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_wf_gather_transpose(const float* wf, float* out, int k, int c_in, int c_out, int t_start, int t_step, int n,
+                                       void* stream) {
+    if (!wf || !out || k <= 0 || c_in <= 0 || c_out <= 0 || n <= 0) return V2W_E_ARG;
+    if (t_start < 0 || t_start >= k || t_start + (n - 1) * t_step < 0 || t_start + (n - 1) * t_step >= k) return V2W_E_ARG;
+    hipLaunchKernelGGL(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, n), dim3(256), 0, (hipStream_t)stream,
+                       wf, out, t_start, t_step, c_in, c_out);
     return v2w_launch_status();
 }
 

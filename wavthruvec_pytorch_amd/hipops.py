@@ -66,6 +66,16 @@ def transpose_flip(wf, out=None):
     return out
 
 
+def gather_transpose(wf, t_start, t_step, n, out=None):
+    """out[m][C_out][C_in] = wf[t_start + m*t_step][C_in][C_out], m < n (dgrad weights of one transposed-conv phase)."""
+    k, ci, co = wf.shape
+    if out is None:
+        out = torch.empty((n, co, ci), device=wf.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_wf_gather_transpose(wf.data_ptr(), out.data_ptr(), k, ci, co, t_start, t_step, n, _stream(wf)),
+               'v2w_wf_gather_transpose')
+    return out
+
+
 def pack_mfma(wf, out=None, u=1):
     """wf [k][C_in][C_out] -> the same weights as the MFMA A-fragment stream of that layer (u = 1 conv, stride for convT),
     or None when the layer has no MFMA tile configuration."""
@@ -80,8 +90,11 @@ def pack_mfma(wf, out=None, u=1):
 
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
-                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0):
-    B, ci, L = x.shape
+                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
+                 in_stride=0, in_phase=0, pad_left=-1, L=None):
+    B, ci, Lx = x.shape
+    L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
+    a.in_stride, a.in_phase, a.pad_left = in_stride, in_phase, pad_left
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
     a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
@@ -191,6 +204,7 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
     cfg = (C.c_int32 * 10)()
     if u == 1:
         a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
+        a.pad_left = -1
         rc = _hip.load().v2w_conv1d_tile_config(C.byref(a), cfg)
     else:
         a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
@@ -306,4 +320,18 @@ def wgrad(x, dy, *, k, dil=1, u=1, slope=1.0, x_affine=None, out=None):
     xa, xs = (x_affine[0].data_ptr(), x_affine[1].data_ptr()) if x_affine is not None else (None, None)
     _hip.check(lib.v2w_wgrad(x.data_ptr(), xa, xs, dy.data_ptr(), out.data_ptr(), slab.data_ptr(), B, ci, co, Lq, k, dil, u, slope,
                              _stream(x)), 'v2w_wgrad')
+    return out
+
+
+def convt1d_dgrad(dy, wf, out, *, k, u, mask=None, mask_slope=1.0, algo=ALGO_AUTO):
+    """Input gradient of the fused lrelu -> ConvTranspose1d(k, stride u, pad (k-u)/2): dx = lrelu'(x) * sum over the u
+    output phases of a small Conv1d on that phase of dy.  dy (B, C_out, u*L), wf [k][C_in][C_out], out (B, C_in, L)."""
+    pad = (k - u) // 2
+    L = out.shape[2]
+    for r in range(u):
+        t0, c = (r + pad) % u, (r + pad) // u
+        nt = (k - t0 + u - 1) // u
+        wr = gather_transpose(wf, t0, u, nt)                   # [nt][C_out][C_in]
+        conv1d(dy, wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask, mask_slope=mask_slope,
+               in_stride=u, in_phase=r, pad_left=c, L=L, algo=algo)
     return out
