@@ -231,6 +231,30 @@ int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq);
 int v2w_wgrad(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
               int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, void* stream);
 
+/* Conditional BatchNorm backward (modules.py:20-30).  Given dx = dL/d(gamma*xhat+beta) and xr (the BN input):
+ *   v2w_cbn_bwd_sums : dgb (B, 2C) = [dgamma | dbeta] and csum[2C] fp64 = [sum_b gamma*dbeta | sum_b gamma*dgamma]
+ *                      (a data-parallel run all-reduces csum between the two calls); s12_ws: 2*B*C floats.
+ *   v2w_cbn_bwd_apply: dxr = A*dx + Bc*xr + Cc  (train: full BatchNorm backward with batch statistics `stats` = the
+ *                      forward's [sum|sumsq|count]; eval: dxr = gamma*rstd*dx); tab_ws: B*C + 2C floats. */
+int v2w_cbn_bwd_sums(const float* dx, const float* xr, const float* gb, const double* stats,
+                     const float* running_mean, const float* running_var, float* s12_ws, float* dgb, double* csum,
+                     int B, int C, int L, int training, float eps, void* stream);
+int v2w_cbn_bwd_apply(const float* dx, const float* xr, const float* gb, const double* stats, const double* csum,
+                      const float* running_mean, const float* running_var, float* tab_ws, float* dxr,
+                      int B, int C, int L, int training, float eps, void* stream);
+/* tanh + conv_post backward (models.py:143-145): dp = dy*(1-y^2) (dp_ws: B*L floats; its sum is d conv_post.bias),
+ * dx = lrelu'(x) * conv_post^T(dp), dwf [k][C_in][1]; part_ws: C_in*k*64 doubles. */
+int v2w_tail_bwd(const float* dy, const float* y, const float* x, const float* wf, float* dp_ws, double* part_ws,
+                 float* dx, float* dwf, int B, int C_in, int L, int k, float slope, void* stream);
+/* weight-norm backward: (dwf [k][C_in][C_out], v, g) -> dv (v's layout), dg; g == NULL: dv = dw relayouted, dg untouched. */
+int v2w_wn_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg,
+               int c_in, int c_out, int k, int transposed, void* stream);
+/* conditioning backward of one stage: dgb (B,2C) -> d weight_orig (2C,128), d layer.bias (2C), d fcs.weight (128,D), d fcs.bias;
+ * z (B,128) and sigma are the forward's; dz_ws: B*128 + 1 floats. */
+int v2w_cond_bwd(const float* dgb, const float* z, const float* sn_w, const float* sn_u, const float* sn_v, const float* sigma,
+                 const float* spk, const float* noise, float* d_sn_w, float* d_sn_b, float* d_fc_w, float* d_fc_b,
+                 float* dz_ws, int B, int C, int spk_dim, int noise_dim, void* stream);
+
 /* ---- K8: leaky_relu(slope) -> Conv1d(C_in -> 1, k, pad (k-1)/2) -> +bias -> tanh  (models.py:143-145).
  * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
 int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,

@@ -64,8 +64,9 @@ def spectral_norm_weight(w_orig, u, v, training: bool, eps: float = SN_EPS):
     Returns (W / sigma, u_new, v_new); in eval mode u, v are returned unchanged.
     """
     if training:
-        v = F.normalize(torch.mv(w_orig.t(), u), dim=0, eps=eps)
-        u = F.normalize(torch.mv(w_orig, v), dim=0, eps=eps)
+        with torch.no_grad():     # the hook iterates under no_grad and then treats u, v as constants
+            v = F.normalize(torch.mv(w_orig.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(w_orig, v), dim=0, eps=eps)
     sigma = torch.dot(u, torch.mv(w_orig, v))
     return w_orig / sigma, u, v
 
@@ -106,9 +107,14 @@ def _resblock(sd, prefix, x, k, dil, resblock1: bool, dtype):
     return x
 
 
-@torch.no_grad()
-def generator_forward(sd: Dict[str, torch.Tensor], h, x, spk_emb, noise, training: bool = True,
-                      dtype=torch.float32, probes: Optional[dict] = None, sync_stats=None):
+def generator_forward(sd, h, x, spk_emb, noise, training: bool = True, dtype=torch.float32, probes=None, sync_stats=None):
+    """Reference ``Generator.forward`` over a state_dict, without autograd (see ``generator_forward_impl``)."""
+    with torch.no_grad():
+        return generator_forward_impl(sd, h, x, spk_emb, noise, training, dtype, probes, sync_stats)
+
+
+def generator_forward_impl(sd: Dict[str, torch.Tensor], h, x, spk_emb, noise, training: bool = True,
+                           dtype=torch.float32, probes: Optional[dict] = None, sync_stats=None):
     """Reference ``Generator.forward`` over a state_dict.
 
     Returns ``(y, new_buffers)``; ``new_buffers`` holds the post-forward values of every buffer
@@ -174,6 +180,19 @@ def generator_forward(sd: Dict[str, torch.Tensor], h, x, spk_emb, noise, trainin
     if probes is not None:
         probes['conv_post'] = x
     return torch.tanh(x), new_buffers
+
+
+def generator_gradients(sd, h, x, spk_emb, noise, dy, training: bool = True, dtype=torch.float32):
+    """Reference gradients of sum(y * dy) w.r.t. every floating-point parameter of the state_dict (torch autograd through
+    the restated forward): what `loss_gen_all.backward()` (vec2wav/train.py:214) sends into the generator."""
+    leaves = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and not any(t in k for t in ('running_', 'weight_u', 'layer.weight_v')):
+            leaves[k] = v.detach().clone().to(dtype).requires_grad_(True)
+    sd2 = {k: leaves.get(k, v) for k, v in sd.items()}
+    y, nb = generator_forward_impl(sd2, h, x, spk_emb, noise, training, dtype)
+    (y * dy.to(dtype)).sum().backward()
+    return y.detach(), {k: v.grad for k, v in leaves.items()}, nb
 
 
 def apply_buffers(sd: Dict[str, torch.Tensor], new_buffers: Dict[str, torch.Tensor]) -> None:

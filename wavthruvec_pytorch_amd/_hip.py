@@ -95,6 +95,11 @@ SIGNATURES = {
     'v2w_wgrad_slabs': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'v2w_wgrad': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_float, _fp]),
+    'v2w_cbn_bwd_sums': (C.c_int, [_fp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    'v2w_cbn_bwd_apply': (C.c_int, [_fp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    'v2w_tail_bwd': (C.c_int, [_fp] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    'v2w_wn_bwd': (C.c_int, [_fp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_cond_bwd': (C.c_int, [_fp] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv_post_tanh': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
 }
 

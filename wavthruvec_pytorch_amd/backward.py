@@ -1,0 +1,132 @@
+"""Backward pass of the Vec2Wav generator on the HIP path (`loss_gen_all.backward()` of
+vec2wav/train.py:214 back-propagates through `generator(wv_feat, spk_emb, noise)`).
+
+`GeneratorFunction` wraps `Generator._forward_hip(save=...)` for autograd.  The backward mirrors the forward schedule in
+reverse and runs entirely through the C ABI:
+
+  conv / transposed-conv input gradients  the forward tile kernel itself (v2w_conv1d_fwd) on the output gradient with
+                                          transposed(-flipped) weights, the leaky_relu derivative as an epilogue mask
+  weight gradients                        v2w_wgrad (MFMA, reduction over positions, deterministic slab reduce)
+  bias gradients                          v2w_bn_stats (per-channel sums)
+  Conditional BatchNorm                   v2w_cbn_bwd_sums / v2w_cbn_bwd_apply (+ one all-reduce of 2C sums when data-parallel)
+  tanh + conv_post                        v2w_tail_bwd
+  weight norm, spectral-norm Linear, fcs  v2w_wn_bwd, v2w_cond_bwd
+
+Scope: ResBlock2 generators (the reference default).  ResBlock1 raises NotImplementedError in grad mode.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hipops
+
+LRELU_SLOPE = 0.1
+
+
+class GeneratorFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gen, names, x, spk, nz, *params):
+        from .models import ResBlock2
+        if not all(isinstance(rb, ResBlock2) for rb in gen.resblocks):
+            raise NotImplementedError('Generator (HIP) backward covers ResBlock2 generators (the reference default); '
+                                      "run resblock='1' models under torch.no_grad()")
+        if gen.num_kernels > 3:
+            raise NotImplementedError('Generator (HIP) backward supports up to 3 residual branches per stage')
+        save = {}
+        y = gen._forward_hip(x, spk, nz, save)
+        ctx.gen, ctx.names, ctx.saved = gen, names, save
+        ctx.needs = [p.requires_grad for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = generator_backward(ctx.gen, ctx.saved, dy.contiguous().float())
+        ctx.saved = None
+        out = [grads.get(n) if need else None for n, need in zip(ctx.names, ctx.needs)]
+        return (None, None, None, None, None, *out)
+
+
+def _wn_grads(grads, name, m, dwf):
+    """dW in the [k][C_in][C_out] layout -> gradients of the layer's weight_v / weight_g (or plain weight)."""
+    if m.weight_normed:
+        dv, dg = hipops.wn_backward(dwf, m.weight_v.detach(), m.weight_g.detach(), m.transposed)
+        grads[name + '.weight_v'], grads[name + '.weight_g'] = dv, dg
+    else:
+        dv, _ = hipops.wn_backward(dwf, m.weight.detach(), None, m.transposed)
+        grads[name + '.weight'] = dv
+
+
+@torch.no_grad()
+def generator_backward(gen, sv, dy):
+    """dy (B, 1, L_out) -> {parameter name: gradient}.  `sv` is the dict filled by `Generator._forward_hip(save=...)`."""
+    ws, wf = sv['ws'], sv['wf']
+    x, spk, nz, y, training = sv['x'], sv['spk'], sv['nz'], sv['y'], sv['training']
+    B = sv['B']
+    dev = x.device
+    ns, nk = gen.num_upsamples, gen.num_kernels
+    grads = {}
+
+    # ---- tanh + conv_post (models.py:143-145)
+    xs_last = ws[f'act.rb{ns - 1}']
+    dxs, dwf_post, dp = hipops.tail_backward(dy, y, xs_last, wf['conv_post'], k=7, slope=0.01)
+    grads['conv_post.bias'] = hipops.channel_sum(dp)
+    _wn_grads(grads, 'conv_post', gen.conv_post, dwf_post)
+
+    z_all = ws['z_ws'].view(ns, B, 128)
+    for i in reversed(range(ns)):
+        up = gen.ups[i]
+        C = up.out_channels
+        xr = ws[f'act.up{i}']
+        aff = (ws[f'bn.a{i}'], ws[f'bn.s{i}'])
+        cur_in = ws['act.pre'] if i == 0 else ws[f'act.rb{i - 1}']
+        Lo = xr.shape[2]
+
+        # ---- mean over the nk residual branches: every branch receives dr = dxs / nk
+        inv = torch.full((B, C), 1.0 / nk, device=dev)
+        zero = torch.zeros((B, C), device=dev)
+        dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
+        db2 = hipops.channel_sum(dr)
+        dx = torch.empty_like(dr)
+        for j in range(nk):
+            rb = gen.resblocks[i * nk + j]
+            name = f'resblocks.{i * nk + j}'
+            k = rb.kernel_size
+            c1, c2 = rb.convs[0], rb.convs[1]
+            t1 = ws[f'act.t1_{i}_{j}']
+            # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
+            w2T = hipops.transpose_flip(wf[name + '.convs.1'])
+            dt1 = torch.empty_like(dr)
+            hipops.conv1d(dr, w2T, None, dt1, k=k, dil=c2.dilation, slope=1.0, res=dr, wp=hipops.pack_mfma(w2T),
+                          mask=(t1, None), mask_slope=LRELU_SLOPE)
+            _wn_grads(grads, name + '.convs.1', c2, hipops.wgrad(t1, dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
+            grads[name + '.convs.1.bias'] = db2
+            # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx += dt1 + lrelu'(x) * conv(dt1; W1^T flipped)
+            w1T = hipops.transpose_flip(wf[name + '.convs.0'])
+            hipops.conv1d(dt1, w1T, None, dx, k=k, dil=c1.dilation, slope=1.0, res=dt1, wp=hipops.pack_mfma(w1T),
+                          mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
+            _wn_grads(grads, name + '.convs.0', c1,
+                      hipops.wgrad(xr, dt1, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+            grads[name + '.convs.0.bias'] = hipops.channel_sum(dt1)
+
+        # ---- Conditional BatchNorm (modules.py:20-30): through the affine, the batch statistics and into gamma / beta
+        cbn = gen.cbns[i]
+        bn = cbn.batch_nrom
+        dxr, dgb = hipops.cbn_backward(dx, xr, ws[f'gb.{i}'], ws.get(f'bn.stats{i}'), bn.running_mean, bn.running_var,
+                                       training=training, eps=bn.eps, sync=gen.stat_sync)
+        ly, fc = cbn.layer, gen.fcs[i]
+        d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), ly.weight_u, ly.weight_v,
+                                                    ws['sigma_ws'][i:i + 1], spk, nz)
+        grads[f'cbns.{i}.layer.weight_orig'], grads[f'cbns.{i}.layer.bias'] = d_w, d_b
+        grads[f'fcs.{i}.weight'], grads[f'fcs.{i}.bias'] = d_fw, d_fb
+
+        # ---- leaky_relu -> ConvTranspose1d (models.py:128-129)
+        grads[f'ups.{i}.bias'] = hipops.channel_sum(dxr)
+        _wn_grads(grads, f'ups.{i}', up,
+                  hipops.wgrad(cur_in, dxr, k=up.kernel_size, u=up.stride, slope=LRELU_SLOPE))
+        dxs = torch.empty_like(cur_in)
+        hipops.convt1d_dgrad(dxr, wf[f'ups.{i}'], dxs, k=up.kernel_size, u=up.stride, mask=(cur_in, None), mask_slope=LRELU_SLOPE)
+
+    # ---- conv_pre (models.py:123): no activation in front of it, no input gradient requested
+    grads['conv_pre.bias'] = hipops.channel_sum(dxs)
+    _wn_grads(grads, 'conv_pre', gen.conv_pre, hipops.wgrad(x, dxs, k=7, dil=1, slope=1.0))
+    return grads

@@ -335,3 +335,74 @@ def convt1d_dgrad(dy, wf, out, *, k, u, mask=None, mask_slope=1.0, algo=ALGO_AUT
         conv1d(dy, wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask, mask_slope=mask_slope,
                in_stride=u, in_phase=r, pad_left=c, L=L, algo=algo)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward building blocks
+def cbn_backward(dx, xr, gb, stats, running_mean, running_var, *, training, eps=1e-5, sync=None):
+    """CondBN backward: returns (dxr, dgb).  `sync(csum)` all-reduces the per-channel sums in data-parallel runs."""
+    B, Cc, L = dx.shape
+    dev = dx.device
+    lib = _hip.load()
+    s12 = torch.empty((2 * B * Cc,), device=dev)
+    dgb = torch.empty((B, 2 * Cc), device=dev)
+    csum = torch.empty((2 * Cc,), device=dev, dtype=torch.float64)
+    st = _stream(dx)
+    _hip.check(lib.v2w_cbn_bwd_sums(dx.data_ptr(), xr.data_ptr(), gb.data_ptr(), _hip.ptr(stats), running_mean.data_ptr(),
+                                    running_var.data_ptr(), s12.data_ptr(), dgb.data_ptr(), csum.data_ptr(), B, Cc, L,
+                                    int(training), eps, st), 'v2w_cbn_bwd_sums')
+    if sync is not None and training:
+        sync(csum)
+    tab = torch.empty((B * Cc + 2 * Cc,), device=dev)
+    dxr = torch.empty_like(dx)
+    _hip.check(lib.v2w_cbn_bwd_apply(dx.data_ptr(), xr.data_ptr(), gb.data_ptr(), _hip.ptr(stats), csum.data_ptr(),
+                                     running_mean.data_ptr(), running_var.data_ptr(), tab.data_ptr(), dxr.data_ptr(), B, Cc, L,
+                                     int(training), eps, st), 'v2w_cbn_bwd_apply')
+    return dxr, dgb
+
+
+def tail_backward(dy, y, x, wf, *, k, slope):
+    """tanh + conv_post backward: returns (dx, dwf [k][C_in][1], dp) - d bias = dp.sum()."""
+    B, ci, L = x.shape
+    dev = x.device
+    dp = torch.empty((B, 1, L), device=dev)
+    part = torch.empty((ci * k * 64,), device=dev, dtype=torch.float64)
+    dx = torch.empty_like(x)
+    dwf = torch.empty((k, ci, 1), device=dev)
+    _hip.check(_hip.load().v2w_tail_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), wf.data_ptr(), dp.data_ptr(), part.data_ptr(),
+                                        dx.data_ptr(), dwf.data_ptr(), B, ci, L, k, slope, _stream(x)), 'v2w_tail_bwd')
+    return dx, dwf, dp
+
+
+def wn_backward(dwf, v, g, transposed):
+    """(dwf [k][C_in][C_out], weight_v, weight_g | None) -> (dv, dg | None)."""
+    k, ci, co = dwf.shape
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g) if g is not None else None
+    _hip.check(_hip.load().v2w_wn_bwd(dwf.data_ptr(), v.data_ptr(), _hip.ptr(g), dv.data_ptr(), _hip.ptr(dg), ci, co, k,
+                                      int(transposed), _stream(dwf)), 'v2w_wn_bwd')
+    return dv, dg
+
+
+def cond_backward(dgb, z, sn_w, sn_u, sn_v, sigma, spk, noise):
+    """One stage's conditioning backward -> (d weight_orig, d layer.bias, d fcs.weight, d fcs.bias)."""
+    B, R = dgb.shape
+    dev = dgb.device
+    d_w = torch.empty_like(sn_w); d_b = torch.empty((R,), device=dev)
+    D = spk.shape[1] + noise.shape[1]
+    d_fw = torch.empty((128, D), device=dev); d_fb = torch.empty((128,), device=dev)
+    ws = torch.empty((B * 128 + 1,), device=dev)
+    _hip.check(_hip.load().v2w_cond_bwd(dgb.data_ptr(), z.data_ptr(), sn_w.data_ptr(), sn_u.data_ptr(), sn_v.data_ptr(),
+                                        sigma.data_ptr(), spk.data_ptr(), noise.data_ptr(), d_w.data_ptr(), d_b.data_ptr(),
+                                        d_fw.data_ptr(), d_fb.data_ptr(), ws.data_ptr(), B, R // 2, spk.shape[1], noise.shape[1],
+                                        _stream(dgb)), 'v2w_cond_bwd')
+    return d_w, d_b, d_fw, d_fb
+
+
+def channel_sum(x):
+    """sum over (B, L) per channel of x (B, C, L) -> (C,) fp32: bias gradients (fp64 accumulation inside)."""
+    B, Cc, L = x.shape
+    stats = torch.empty((2 * Cc + 1,), device=x.device, dtype=torch.float64)
+    part = torch.empty((2 * Cc * _hip.V2W_BN_SPLITS,), device=x.device, dtype=torch.float64)
+    bn_stats(x, stats, part)
+    return stats[:Cc].float()

@@ -261,7 +261,7 @@ class Generator(nn.Module):
                     yield f'resblocks.{i}.convs.{n}', m
         yield 'conv_post', self.conv_post
 
-    def _fold_weights(self, device):
+    def _fold_weights(self, device, need_wf=False):
         """K0: weight-norm fold of every conv.  Layers with an MFMA tile configuration are folded AND packed into their
         fragment stream `wp` by one batched call (two launches for the whole generator); the others (conv_post, odd
         shapes, or everything under ALGO_DIRECT) are folded one by one into `wf` [k][C_in][C_out].  Skipped while the
@@ -271,8 +271,8 @@ class Generator(nn.Module):
         for name, m in layers:
             ps = (m.weight_v, m.weight_g) if m.weight_normed else (m.weight,)
             vers.append(tuple((p.data_ptr(), p._version) for p in ps))
-        state = (tuple(vers), self.algo, str(device))
-        force = self.training and self.always_refold
+        state = (tuple(vers), self.algo, str(device), need_wf)
+        force = (self.training and self.always_refold) or need_wf
         if not force and self._fold_key.get('state') == state:
             return self._fold_key['wf'], self._fold_key['wp']
         wf, wp, batch = {}, {}, []
@@ -281,7 +281,13 @@ class Generator(nn.Module):
             u = m.stride if m.transposed else 1
             mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
                        hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size, 1, u) is not None)
-            if mfma_ok:
+            if mfma_ok and need_wf:     # a forward that will be back-propagated: dgrad / wgrad also read the plain layout
+                wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
+                (hipops.fold_convt_weight if m.transposed else hipops.fold_conv_weight)(v, g, wfb, scratch)
+                wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
+                wf[name], wp[name] = wfb, hipops.pack_mfma(wfb, wpb, u=u)
+            elif mfma_ok:
                 wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
                 batch.append((v, g, wpb, m.in_channels, m.out_channels, m.kernel_size, u, m.transposed))
                 wf[name], wp[name] = None, wpb
@@ -314,20 +320,38 @@ class Generator(nn.Module):
             raise RuntimeError(f'Generator parameters live on {self.conv_pre.bias.device}, inputs on {dev}')
         if x.dim() != 3 or x.shape[1] != self.h.num_wv_feat:
             raise RuntimeError(f'expected x of shape (B, {self.h.num_wv_feat}, T), got {tuple(x.shape)}')
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError('Generator (HIP): gradients w.r.t. the latent input x are not provided (the reference '
+                                      'training loop never asks for them, vec2wav/train.py:154-167)')
         x = x.detach().contiguous().float()
         spk = spk_emb.detach().contiguous().float()
         nz = noise.detach().contiguous().float()
-        B, _, T = x.shape
-        if spk.shape != (B, self.h.spk_dim) or nz.shape != (B, self.h.noise_dim):
+        if spk.shape != (x.shape[0], self.h.spk_dim) or nz.shape != (x.shape[0], self.h.noise_dim):
             raise RuntimeError('spk_emb / noise must be (B, spk_dim) / (B, noise_dim)')
+        if needs_grad:
+            from .backward import GeneratorFunction
+            names, params = zip(*[(n, q) for n, q in self.named_parameters()])
+            return GeneratorFunction.apply(self, names, x, spk, nz, *params)
+        return self._forward_hip(x, spk, nz, None)
+
+    def _forward_hip(self, x, spk, nz, save):
+        """The launch schedule of one forward.  `save` (a dict) switches to the back-propagatable form: every intermediate in
+        its own fresh buffer (handed over in save['ws']), no stage / pair fusion, plain-layout weights kept next to the packed ones."""
+        dev = x.device
+        B, _, T = x.shape
         training = self.training
         algo = self.algo
         nk = self.num_kernels
         c0 = self.h.upsample_initial_channel
+        keep_ws = None
+        if save is not None:
+            keep_ws, self._ws = self._ws, {}
+        fuse_stage = () if save is not None else self.fuse_stage
+        fuse_pairs = () if save is not None else self.fuse_pairs
 
         with torch.no_grad():
-            wf, wp = self._fold_weights(dev)
+            wf, wp = self._fold_weights(dev, need_wf=save is not None)
 
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
             ns = self.num_upsamples
@@ -403,7 +427,7 @@ class Generator(nn.Module):
                         return dict(add=outs[:nk - 1], out_div=float(nk))
 
                     # narrow stages (C = 32 / 16): both convs of a pair in ONE kernel, the intermediate stays in LDS
-                    fused_pair = C in self.fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
+                    fused_pair = C in fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
                                                                           for c in (('convs.0', 'convs.1') if isinstance(rbs[0], ResBlock2)
                                                                                     else ('convs1.0', 'convs2.0')))
 
@@ -418,7 +442,7 @@ class Generator(nn.Module):
 
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
-                        if C in self.fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
+                        if C in fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
                             # the whole residual section of the stage in ONE kernel: x read once, t1_j in LDS, sum in registers
                             ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
                                              [dict(wp1=wp[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
@@ -508,9 +532,8 @@ class Generator(nn.Module):
             self._timed('conv_post', hipops.conv_post_tanh, cur, wf['conv_post'], self.conv_post.bias.detach(), y, k=7,
                         slope=0.01)
 
-        if needs_grad:
-            if not self._warned_grad:
-                warnings.warn('Generator (HIP): forward is not differentiable yet; calling backward on its output raises')
-                self._warned_grad = True
-            y = _NoBackward.apply(y, torch.zeros((), device=dev, requires_grad=True))
+        if save is not None:
+            save.update(ws=self._ws, wf=wf, wp=wp, y=y, x=x, spk=spk, nz=nz, training=training, B=B, T=T)
+            self._ws = keep_ws
+            self._fold_key.pop('state', None)     # the cached fold pointed into the handed-over buffers
         return y
