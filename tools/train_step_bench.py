@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Forward + backward time of the generator at cfg2 (the generator half of a vec2wav/train.py step), with a per-kernel summary."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from wavthruvec_pytorch_amd import Generator, synthetic  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    dev = torch.device('cuda:0')
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = Generator(h)
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+    g = g.to(dev).train()
+    opt = torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99))
+    inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
+    dy = torch.randn(B, 1, T * 320, device=dev)
+    for it in range(steps + 2):
+        if it == 2:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        y = g(*inp)
+        (y * dy).sum().backward()
+        opt.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(steps):
+            g(*inp)
+        torch.cuda.synchronize()
+        df = (time.perf_counter() - t1) / steps
+    print(f'B={B} T={T}: forward+backward+AdamW {dt * 1e3:.2f} ms/step ; inference-schedule forward {df * 1e3:.2f} ms ; '
+          f'{B * T * 320 / dt / 1e6:.1f} M samples/s trained')
+
+
+if __name__ == '__main__':
+    main()
