@@ -559,6 +559,7 @@ static LayerCfg v2w_layer_cfg(int c_in, int c_out, int u) {
     if (c_in % 16 != 0) return c;
     if (u == 1) {
         if (c_out % 32 == 0 && c_in % 32 == 0) c = {32, 32};
+        else if (c_out % 32 == 0) c = {32, 16};      // C_in = 16 (+32k): backward of the narrowest upsampler
         else if (c_out == 16) c = {16, 16};
     } else if (u == 2 || u == 4 || u == 5 || u == 8) {
         if (c_out % 64 == 0 || c_out == 32) c = {32, 16};
@@ -603,13 +604,14 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
     }
-    if (cfg.mf == 32 && a->C_out % 128 == 0) {
+    if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 128 == 0) {
         // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
         if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(ps, n, stream);
         return launch_tile<32, 1, 2, 1, 2, 2, 32>(ps, n, stream);
     }
     // (64 x 256 and 64 x 128 single-row-block variants measured slower on MI355X: 52-92 / 61-90 vs 64-93 TF)
-    if (cfg.mf == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
+    if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
+    if (cfg.mf == 32 && cfg.ck == 16) return launch_tile<32, 1, 1, 2, 1, 4, 16>(ps, n, stream);
     if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(ps, n, stream);
     if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(ps, n, stream);
     return V2W_E_SHAPE;
