@@ -120,21 +120,6 @@ class ResBlock2(nn.Module):
             l.remove_weight_norm()
 
 
-class _NoBackward(torch.autograd.Function):
-    """Marks the HIP forward in the autograd graph so that a backward attempt fails loudly instead of silently
-    producing no gradients (native backward kernels are the next scope row)."""
-
-    @staticmethod
-    def forward(ctx, y, *deps):
-        return y.view_as(y)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(
-            'wavthruvec_pytorch_amd.Generator: the HIP forward has no backward yet; run it under torch.no_grad() '
-            '(inference / validation / the discriminator step on y_g_hat.detach())')
-
-
 class Generator(nn.Module):
     """HiFi-GAN-style Vec2Wav generator (reference: vec2wav/models.py:77-156)."""
 
@@ -180,7 +165,6 @@ class Generator(nn.Module):
         self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
-        self._warned_grad = False
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
 
     # -------------------------------------------------------------------------------------------
