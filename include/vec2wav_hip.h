@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 7
+#define V2W_ABI_VERSION 8
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -39,6 +39,9 @@ extern "C" {
 #define V2W_ALGO_AUTO   0    /* MFMA tile kernel when the shape allows, else the direct kernel */
 #define V2W_ALGO_DIRECT 1    /* one-thread-per-output scalar FMA kernel: any shape; cross-check */
 #define V2W_ALGO_MFMA   2    /* f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) implicit GEMM; V2W_E_SHAPE if unsupported */
+#define V2W_ALGO_SPLIT  3    /* split-f16 MFMA: x = hi + lo halves, x_hi*w_hi + x_hi*w_lo + x_lo*w_hi accumulated in fp32 (~22-bit
+                              * products; v_mfma_f32_32x32x16_f16); needs wps / winv from v2w_pack_split; Conv1d with
+                              * C_in % 32 == 0 and C_out % 64 == 0, else V2W_E_SHAPE */
 
 int         v2w_abi_version(void);
 const char* v2w_build_arch(void);       /* "gfx950" */
@@ -117,11 +120,21 @@ typedef struct {
     int32_t in_stride, in_phase;  /* 0/1, 0: plain.  > 1: the conv reads the de-interleaved phase in[.., in_stride*l + in_phase] of a
                                    * (B, C_in, in_stride*L) tensor (dgrad of a transposed conv, one launch per phase) */
     int32_t pad_left;             /* -1: symmetric padding dil*(k-1)/2.  >= 0: taps sit at offsets -pad_left + t*dil (k may be even) */
+    const void*  wps;             /* V2W_ALGO_SPLIT: v2w_pack_split() fragments of this layer; else ignored */
+    const float* winv;            /* V2W_ALGO_SPLIT: device pointer to 1/scale of the layer (sc[0] of v2w_pack_split) */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
  * the residual branches of one generator stage, heaviest first. */
 int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
+
+/* ---- split-f16 weights (V2W_ALGO_SPLIT).  wf [k][C_in][C_out] (folded fp32) -> wps: k*C_in*C_out*4 bytes holding, per 32-row
+ * block, chunk of 32 input channels and tap, the (hi, lo) half-precision MFMA A fragments of scale*w in consumption order;
+ * scale = the power of two that puts max|w| of the layer into [8192, 16384) (both halves stay in the normal f16 range).
+ * sc: 4 floats of device memory: [0] = 1/scale (the `winv` of v2w_conv1d_args), [1] = scale, [2] = scratch.
+ * Activations are split on the fly by the conv kernel and must satisfy |x| <= 65504 (they are clamped there). */
+int v2w_split_supported(int c_in, int c_out, int u);   /* 1 when V2W_ALGO_SPLIT serves this layer shape */
+int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);
 
 /* ---- K6 fused pair for the narrow stages (C == 32 or 16; MFMA path): two chained convs of one residual block in ONE kernel,
  * the intermediate stays in LDS (these layers are HBM-bound as separate launches).

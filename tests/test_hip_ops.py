@@ -101,6 +101,71 @@ def test_conv1d_fused(dev, algo, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+SPLIT_CASES = [
+    # B, Cin, Cout, L, k, dil
+    (2, 768, 512, 52, 7, 1),      # conv_pre (float4 staging: L % 4 == 0)
+    (2, 256, 256, 252, 3, 1),     # 128 x 128 tiles, ragged last tile
+    (2, 256, 256, 1280, 11, 3),
+    (1, 128, 128, 5120, 7, 5),
+    (4, 128, 128, 5120, 11, 1),   # 128 x 256 tiles
+    (2, 64, 64, 700, 11, 3),      # 64 x 256 tiles
+    (2, 64, 64, 701, 3, 1),       # L % 4 != 0: scalar staging
+    (1, 64, 128, 9, 7, 3),        # shorter than the receptive field
+]
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', SPLIT_CASES)
+def test_conv1d_split_f16(dev, B, cin, cout, L, k, dil):
+    """V2W_ALGO_SPLIT (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on the f16 matrix pipe) against an fp64 convolution: the error must
+    stay at the fp32 kernel's level (both are compared with the same fp64 reference), all epilogue flags on."""
+    from wavthruvec_pytorch_amd import hipops
+    assert hipops.split_supported(cin, cout)
+    r = _rng(11)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    w[0, 0, 0] = 1e-6                                        # a weight 6 orders below the layer maximum
+    x[0, 0, : min(L, 4)] = [3e-5, -2e-7, 1e3, 0.0][: min(L, 4)]    # activations in the f16 subnormal range and a large one
+    bias = r.standard_normal(cout).astype(np.float32)
+    ia, is_ = (1 + 0.2 * r.standard_normal((B, cin))).astype(np.float32), (0.3 * r.standard_normal((B, cin))).astype(np.float32)
+    res = r.standard_normal((B, cout, L), dtype=np.float32)
+    prev = r.standard_normal((B, cout, L), dtype=np.float32)
+    tx, tw = torch.from_numpy(x).double(), torch.from_numpy(w).double()
+    xin = (torch.from_numpy(ia).double()[:, :, None] * tx + torch.from_numpy(is_).double()[:, :, None]).float().double()
+    want = F.conv1d(F.leaky_relu(xin, 0.1), tw, torch.from_numpy(bias).double(), padding=dil * (k - 1) // 2, dilation=dil)
+    want = (want + torch.from_numpy(res).double() + torch.from_numpy(prev).double()) / 3.0
+    wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+    kw = dict(k=k, dil=dil, slope=0.1, in_affine=(_t(ia, dev), _t(is_, dev)), res=_t(res, dev), accumulate=True, out_div=3.0)
+    o_split = _t(prev, dev).clone()
+    hipops.conv1d(_t(x, dev), None, _t(bias, dev), o_split, algo=hipops.ALGO_SPLIT, wps=hipops.pack_split(wf), **kw)
+    o_f32 = _t(prev, dev).clone()
+    hipops.conv1d(_t(x, dev), wf, _t(bias, dev), o_f32, algo=hipops.ALGO_MFMA, wp=hipops.pack_mfma(wf), **kw)
+    e_split = (o_split.cpu().double() - want).abs().max().item()
+    e_f32 = (o_f32.cpu().double() - want).abs().max().item()
+    # the bar is the exact-fp32 kernel itself (both against fp64): the split products may not be worse than 2x its rounding noise
+    assert e_split <= 2 * e_f32 + 1e-6, f'split max err {e_split} vs f32 kernel {e_f32}'
+
+
+def test_conv1d_split_multi_and_rejects(dev):
+    from wavthruvec_pytorch_amd import hipops
+    assert not hipops.split_supported(16, 16) and not hipops.split_supported(32, 32) and not hipops.split_supported(64, 64, 2)
+    r = _rng(12)
+    B, C, L = 2, 128, 640
+    x = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    probs, wants = [], []
+    for k, d in ((11, 1), (7, 3), (3, 1)):
+        w = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+        wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+        out = torch.full((B, C, L), float('nan'), device=dev)
+        probs.append((x, None, None, out, dict(k=k, dil=d, slope=0.1, res=x, algo=hipops.ALGO_SPLIT, wps=hipops.pack_split(wf))))
+        wants.append(x.cpu() + F.conv1d(F.leaky_relu(x.cpu(), 0.1), torch.from_numpy(w), None, padding=d * (k - 1) // 2, dilation=d))
+    hipops.conv1d_multi(probs)
+    for (_, _, _, out, _), want in zip(probs, wants):
+        assert (out.cpu() - want).abs().max().item() <= 2e-5
+    from wavthruvec_pytorch_amd._hip import HipLibraryError
+    with pytest.raises(HipLibraryError):          # missing fragments
+        hipops.conv1d(x, None, None, probs[0][3], k=3, algo=hipops.ALGO_SPLIT)
+
+
 @pytest.mark.parametrize('B,cin,cout,L,k,dil', CONV_CASES[:7])
 def test_conv1d_plain_and_mfma_forced(dev, B, cin, cout, L, k, dil):
     """No optional inputs; V2W_ALGO_MFMA must accept every generator shape and agree with the direct kernel."""

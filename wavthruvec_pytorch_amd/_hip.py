@@ -12,10 +12,10 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT = 0, 1, 2, 3
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -27,7 +27,8 @@ class Conv1dArgs(C.Structure):
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
                 ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
-                ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32)]
+                ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32),
+                ('wps', _fp), ('winv', _fp)]
 
 
 class ConvT1dArgs(C.Structure):
@@ -77,6 +78,8 @@ SIGNATURES = {
     'v2w_wf_transpose_flip': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wf_gather_transpose': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
@@ -111,7 +114,8 @@ class HipLibraryError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # V2W_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
+    return os.environ.get('V2W_LIB') or _build.LIB_PATH
 
 
 def load():

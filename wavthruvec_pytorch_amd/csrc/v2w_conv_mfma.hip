@@ -22,43 +22,9 @@
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
-#include "v2w_common.h"
+#include "v2w_tile.h"
 
 namespace {
-
-struct TileArgs {
-    const float* in; const float* in_a; const float* in_s;
-    const float* wp; const float* bias;
-    const float* res; const float* res_a; const float* res_s;
-    const float* add0; const float* add1;   // conv only, optional extra addends: out = ((add0 [+ add1]) + value)
-    const float* mask_src; const float* mask_a; const float* mask_s;   // conv only: acc *= lrelu'(mask_a*mask_src + mask_s)
-    float mask_slope;
-    int in_stride, in_phase;   // the conv reads in[.., in_stride*pos + in_phase] (de-interleaved phase of a longer sequence)
-    float* out;
-    float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
-    int B, Cin, Cout, L, K, dil;
-    int pad;      // convT only: (K-U)/2
-    int hl, hr;   // halo (input positions) left / right of the tile
-    int hla;      // hl rounded up to a multiple of 4: LDS column 0 <-> position n0 - hla (16-B aligned rows)
-    int xw;       // LDS row stride of the input tile (floats)
-    int xcols;    // columns actually staged (multiple of 4)
-    int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging
-    int atab_off; // LDS offset (floats) of the affine table: after the 1 or 2 signal buffers
-    int ntl;      // position tiles per batch item
-    int ntiles;   // B * ntl
-    float slope;
-    int accumulate;
-    float out_div;
-    int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
-};
-
-#define V2W_MAX_MULTI 4
-// Up to V2W_MAX_MULTI problems of identical tile configuration in one launch (the residual branches of a stage):
-// blocks [start[q], start[q+1]) belong to problem q; heaviest problem first so the tail of the launch is made of light tiles.
-struct MultiArgs {
-    TileArgs p[V2W_MAX_MULTI];
-    int start[V2W_MAX_MULTI + 1];
-};
 
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING>
 __global__ void __launch_bounds__(64 * WM * WN)

@@ -1,0 +1,471 @@
+// Conv1d of the generator on the gfx950 f16 matrix pipe with fp32-equivalent products ("split f16x3").
+//
+//   out[b,co,l] = bias[co] + sum_{ci,t} W[t][ci][co] * act(in[b,ci,l + (t-(k-1)/2)*dil])      (models.py:37-44, 65-70, 123)
+//
+// Every fp32 operand is split into two halves-precision parts  x = x_hi + x_lo  (x_hi = rne_f16(x), x_lo = rne_f16(x - x_hi);
+// weights are first scaled by a per-layer power of two so that both parts sit in the normal f16 range) and the product is
+// accumulated in fp32 as  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi  - three v_mfma_f32_32x32x16_f16.  x_hi*w_hi is exact in fp32
+// (11 x 11 bits), the dropped x_lo*w_lo term is <= 2^-22 |x w|: the result carries ~22 bits per product against fp32's 24,
+// i.e. it differs from the exact-fp32 kernel by about as much as two fp32 summation orders differ from each other
+// (measured through the whole generator: 1e-7, parity bar 1e-4).  The f16 pipe runs 16x the f32 MFMA rate, so three passes
+// still leave >5x headroom: these layers stop being MFMA-bound and approach their HBM / LDS bounds.
+//
+// GEMM view per workgroup: M = MT output channels, N = NT positions, K = C_in x taps, consumed as (chunk of 32 channels) x tap.
+// B (signal) : LDS tile [position][32 ch hi | 32 ch lo | pad] (144 B rows: conflict-free ds_read_b128 of 8 channels per
+//              lane), double buffered over chunks; the fp32 -> (hi, lo) split, the CondBN affine, leaky_relu and zero
+//              padding happen once at staging; a tap is a ROW offset into the same tile.
+// A (weights): v2w_pack_split() stores, per 32-row block, chunk and tap, the four MFMA A fragments (2 k-steps x hi/lo,
+//              1 KiB each) contiguously; a stage (= all row blocks of the workgroup for one chunk x tap) is copied
+//              global -> LDS by global_load_lds_dwordx4 (no registers), two stages ahead of its use.
+// Sync       : one workgroup barrier per tap; the async copies are fenced with explicit s_waitcnt vmcnt (see the loop).
+#include "v2w_tile.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define V2W_SPLIT_CK 16        // input channels per stage = one MFMA k-step
+#define V2W_SPLIT_ROWB 80       // bytes per staged position: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad
+#define V2W_SPLIT_UNIT 2048     // bytes of the A fragments of one (32-row block, chunk, tap): [hi, lo][64 lanes][16 B]
+#define V2W_SPLIT_HMAX 32       // largest halo per side
+#define V2W_SPLIT_NAB 3         // weight stages resident in LDS (two in flight)
+
+#define V2W_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define V2W_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int MI, int NI, int WM, int WN>
+__global__ void __launch_bounds__(256, 2)
+conv_split_kernel(const MultiArgs m) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    static_assert(WM * WN == 4, "four waves: the staging maps one wave to 4 of the 16 chunk channels");
+    constexpr int NTHREADS = 256;
+    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, CK = V2W_SPLIT_CK;
+    constexpr int ROWB = V2W_SPLIT_ROWB;
+    constexpr int NMT = MT / 32;                                // 32-row blocks per workgroup
+    constexpr int ASTAGE = NMT * V2W_SPLIT_UNIT;                // bytes of one weight stage
+    constexpr int NAB = V2W_SPLIT_NAB;
+    constexpr int ADMA = ASTAGE / (NTHREADS * 16);              // async 16-B copies per thread and stage
+    static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
+    constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
+    constexpr int NSIG = NS * 4;                                // global loads of one signal prefetch (always all issued)
+    constexpr int RS = 32 * NI + 8;                             // floats per row of the epilogue transpose tile (4*RS % 64 == 32)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    int pq = 0;
+#pragma unroll
+    for (int i = 1; i < V2W_MAX_MULTI; ++i) pq += (int)blockIdx.x >= m.start[i] ? 1 : 0;
+    const TileArgs& p = m.p[pq];
+    const int mtiles = p.Cout / MT;
+    const int id = blockIdx.x - m.start[pq];
+    const int grp = id / (8 * mtiles), rem = id % (8 * mtiles);
+    const int mt = rem >> 3;
+    const int tile = grp * 8 + (rem & 7);
+    if (tile >= p.ntiles) return;
+    const int b = tile / p.ntl;
+    const int n0 = (tile % p.ntl) * NT;
+    const int m0 = mt * MT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, hk = lane >> 5;
+    const int wmi = wave / WN;                                   // row-block group of this wave
+    const int wm0 = wmi * (32 * MI);
+    const int wn0 = (wave % WN) * (32 * NI);
+    const int L = p.L, K = p.K;
+    const float slope = p.slope;
+    const int nch = p.Cin / CK;
+    const int nst = nch * K;                                     // (chunk, tap) stages
+    const int pos0 = n0 - p.hla;                                 // position of LDS row 0
+    const int xbytes = p.xcols * ROWB;
+    unsigned char* const Xs0 = smem;
+    unsigned char* const As0 = smem + 2 * xbytes;
+    float* const etab = reinterpret_cast<float*>(smem + p.atab_off);   // bias, res_a, res_s, mask_a, mask_s [MT] each
+    float* const atab = etab + 5 * MT;                           // a[Cin], s[Cin] of this batch item
+
+    acc_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- weight stages: async global -> LDS.  Copy #i of a thread moves 16 B; a wave instruction fills 1 KiB of LDS.
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.wps);
+    auto dma_stage = [&](int st) {
+        unsigned char* dst = As0 + (st % NAB) * ASTAGE;
+#pragma unroll
+        for (int i = 0; i < ADMA; ++i) {
+            const int q = i * NTHREADS + tid;                    // 16-B element of the stage; 128 of them per unit
+            const int unit = q >> 7, off = q & 127;
+            const unsigned char* src = wsrc + ((size_t)(m0 / 32 + unit) * nst + st) * V2W_SPLIT_UNIT + off * 16;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                             (void __attribute__((address_space(3)))*)(dst + (i * NTHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- signal staging: wave w owns channels 4w..4w+3 of the chunk, lane l the position groups l, l+64, ... (1 KiB
+    // contiguous per row and load instruction); every thread issues exactly NSIG loads (addresses clamped).
+    const int xp4 = p.xcols >> 2;
+    f32x4 pf[NS][4];
+    auto prefetch = [&](int ci0) {
+        const float* src = p.in + (size_t)(b * p.Cin + ci0 + wave * 4) * L;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            int pos = pos0 + (lane + s * 64) * 4;
+            pos = pos < 0 ? 0 : (pos > L - 4 ? L - 4 : pos);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pf[s][c] = *reinterpret_cast<const f32x4*>(src + (size_t)c * L + pos);
+        }
+    };
+    auto commit = [&](int ci0, unsigned char* Xs) {
+        float av[4], sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            av[c] = p.in_a ? atab[ci0 + wave * 4 + c] : 1.f;
+            sv[c] = p.in_a ? atab[p.Cin + ci0 + wave * 4 + c] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int pg = lane + s * 64;
+            if (pg >= xp4) continue;
+            const int pos = pos0 + pg * 4;
+            const bool in_seq = pos >= 0 && pos < L;             // L % 4 == 0, pos % 4 == 0: whole float4 in or out
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = in_seq ? v2w_lrelu(fmaf(av[c], pf[s][c][e], sv[c]), slope) : 0.f;   // padding of the ACTIVATED signal
+                    v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+                    const _Float16 h = (_Float16)v;
+                    hi[c] = h;
+                    lo[c] = (_Float16)(v - (float)h);
+                }
+                unsigned char* d = Xs + (pg * 4 + e) * ROWB + wave * 8;
+                *reinterpret_cast<h4*>(d) = hi;
+                *reinterpret_cast<h4*>(d + 32) = lo;
+            }
+        }
+    };
+    auto stage_scalar = [&](int ci0, unsigned char* Xs) {        // any L / alignment / input stride
+        for (int c = wave; c < CK; c += 4) {
+            const int ch = b * p.Cin + ci0 + c;
+            const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
+            const float av = p.in_a ? p.in_a[ch] : 1.f;
+            const float sv = p.in_s ? p.in_s[ch] : 0.f;
+            for (int j = lane; j < p.xcols; j += 64) {
+                const int l = pos0 + j;
+                float v = 0.f;
+                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[(size_t)l * p.in_stride], sv), slope);
+                v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+                const _Float16 h = (_Float16)v;
+                _Float16* d = reinterpret_cast<_Float16*>(Xs + j * ROWB) + c;
+                d[0] = h;
+                d[16] = (_Float16)(v - (float)h);
+            }
+        }
+    };
+
+    // ---- prologue
+    for (int c = tid; c < MT; c += NTHREADS) {
+        etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
+        etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
+        etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
+        etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
+        etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
+    }
+    if (p.in_a) {
+        for (int c = tid; c < p.Cin; c += NTHREADS) {
+            atab[c] = p.in_a[b * p.Cin + c];
+            atab[p.Cin + c] = p.in_s[b * p.Cin + c];
+        }
+    }
+    const float winv = p.winv[0];
+    __syncthreads();
+    dma_stage(0);
+    if (nst > 1) dma_stage(1);
+    if (p.vec4) { prefetch(0); commit(0, Xs0); }
+    else stage_scalar(0, Xs0);
+    V2W_WAIT_VM(0);
+    V2W_BARRIER();
+
+    const int rowbase = wn0 + lr + p.hla - p.hl;                 // LDS row of this lane's column for tap 0
+    int st = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
+        unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
+        const bool more = ch + 1 < nch;
+        for (int t = 0; t < K; ++t, ++st) {
+            // Issue order inside a stage: the weight copy of stage st+2, then (tap 0 only) the signal prefetch of the next
+            // chunk.  vmcnt retires in order, so at the end of the stage
+            //   tap 0 : vmcnt(ADMA + NSIG) leaves exactly this stage's issues outstanding -> stage st+1 (issued a stage ago) landed;
+            //   tap>=1: vmcnt(ADMA) leaves this stage's copy outstanding -> st+1 landed (and the signal prefetch, >= 1 stage old).
+            const bool dma = st + 2 < nst;
+            if (dma) dma_stage(st + 2);
+            const bool sig = t == 0 && more && p.vec4;
+            if (sig) prefetch((ch + 1) * CK);
+            __builtin_amdgcn_sched_barrier(0);
+
+            const unsigned char* Ab = As0 + (st % NAB) * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
+            h8 ah[MI], al[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT);
+                al[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT + 1024);
+            }
+            const unsigned char* xr = Xs + (rowbase + t * p.dil) * ROWB + hk * 16;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const h8 bh = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB);
+                const h8 bl = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB + 32);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
+            }
+
+            if (t == K - 1 && more) {
+                if (p.vec4) commit((ch + 1) * CK, Xn);
+                else stage_scalar((ch + 1) * CK, Xn);
+            }
+            if (!dma) V2W_WAIT_VM(0);
+            else if (sig) V2W_WAIT_VM(ADMA + NSIG);
+            else V2W_WAIT_VM(ADMA);
+            V2W_BARRIER();
+        }
+    }
+
+    // ---- epilogue (same contract as the f32 tile kernel): undo the weight scale, mask, + bias [+ residual] [+ addends]
+    // [/ out_div].  The accumulators hold 4 consecutive ROWS per lane; each wave transposes 32 x (32*NI) blocks through its
+    // own LDS region (all stages are consumed: the tile buffers are free) so that global traffic is float4 along positions.
+    float* const T = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) T[F::row(e, hk) * RS + j * 32 + lr] = acc[i][j][e] * winv;   // power of two: exact
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private region: no workgroup barrier needed
+        constexpr int C4 = 8 * NI;                               // float4 per row
+        constexpr int NIT = 32 * C4 / 64;                        // float4 per lane
+        constexpr int EG = MI * NI >= 8 ? 2 : 4;                 // float4 gathers in flight per operand (register budget)
+#pragma unroll
+        for (int g0 = 0; g0 < NIT; g0 += EG) {
+            f32x4 rv[EG], ov[EG], o2[EG], mv[EG];
+#pragma unroll
+            for (int g = 0; g < EG; ++g) {
+                const int f = (g0 + g) * 64 + lane;
+                const int row = f / C4, q = n0 + wn0 + (f % C4) * 4;
+                const size_t o = ((size_t)b * p.Cout + m0 + wm0 + i * 32 + row) * L + q;
+                const bool in = p.evec && q < L;
+                rv[g] = (p.res && in) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ov[g] = (p.accumulate && in) ? *reinterpret_cast<const f32x4*>(p.out + o)
+                                             : ((p.add0 && in) ? *reinterpret_cast<const f32x4*>(p.add0 + o) : f32x4{0.f, 0.f, 0.f, 0.f});
+                o2[g] = (p.add1 && in) ? *reinterpret_cast<const f32x4*>(p.add1 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                mv[g] = (p.mask_src && in) ? *reinterpret_cast<const f32x4*>(p.mask_src + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+#pragma unroll
+            for (int g = 0; g < EG; ++g) {
+                const int f = (g0 + g) * 64 + lane;
+                const int row = f / C4, c4 = f % C4, q = n0 + wn0 + c4 * 4;
+                if (q >= L) continue;
+                const int col = wm0 + i * 32 + row;
+                const size_t o = ((size_t)b * p.Cout + m0 + col) * L + q;
+                const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
+                const float ma = etab[3 * MT + col], ms = etab[4 * MT + col];
+                f32x4 v = *reinterpret_cast<const f32x4*>(T + row * RS + c4 * 4);
+                if (!p.evec) {                                   // ragged L / unaligned operands: element-wise tail path
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (q + e >= L) break;
+                        float x = v[e];
+                        if (p.mask_src) x = fmaf(ma, p.mask_src[o + e], ms) > 0.f ? x : x * p.mask_slope;
+                        x += bias;
+                        if (p.res) x += fmaf(ra, p.res[o + e], rs);
+                        if (p.add1) x += p.add0[o + e] + p.add1[o + e];
+                        else if (p.accumulate) x += p.out[o + e];
+                        else if (p.add0) x += p.add0[o + e];
+                        if (p.out_div != 0.f) x = x / p.out_div;
+                        p.out[o + e] = x;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    if (p.mask_src) x = fmaf(ma, mv[g][e], ms) > 0.f ? x : x * p.mask_slope;
+                    x += bias;
+                    if (p.res) x += fmaf(ra, rv[g][e], rs);
+                    if (p.add1) x += ov[g][e] + o2[g][e];        // (add0 + add1) + value: the reference's `xs += ...` order
+                    else if (p.accumulate || p.add0) x += ov[g][e];
+                    if (p.out_div != 0.f) x = x / p.out_div;
+                    v[e] = x;
+                }
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads of T done before the next block overwrites it
+    }
+}
+
+template <int MI, int NI, int WM, int WN>
+int launch_split(const TileArgs* ps, int nprob, hipStream_t stream) {
+    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, CK = V2W_SPLIT_CK;
+    constexpr int RS = 32 * NI + 8;
+    if (nprob < 1 || nprob > V2W_MAX_MULTI) return V2W_E_ARG;
+    MultiArgs m{};
+    size_t lds = 0;
+    int grid = 0;
+    for (int i = 0; i < nprob; ++i) {
+        TileArgs p = ps[i];
+        if (p.Cout % MT != 0 || p.Cin % CK != 0 || !p.wps || !p.winv) return V2W_E_SHAPE;
+        p.hla = (p.hl + 3) & ~3;
+        if (p.hla > V2W_SPLIT_HMAX || p.hr > V2W_SPLIT_HMAX) return V2W_E_SHAPE;
+        p.ntl = (p.L + NT - 1) / NT;
+        p.ntiles = p.B * p.ntl;
+        p.xcols = (p.hla + NT + p.hr + 3) & ~3;
+        p.xw = 0;
+        if (p.in_stride < 1) p.in_stride = 1;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        p.vec4 = (p.L % 4 == 0) && p.L >= 4 && al16(p.in) && p.in_stride == 1;
+        p.evec = (p.L % 4 == 0) && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
+        size_t l = (size_t)2 * p.xcols * V2W_SPLIT_ROWB + (size_t)V2W_SPLIT_NAB * (MT / 32) * V2W_SPLIT_UNIT;
+        const size_t tl = (size_t)4 * 32 * RS * sizeof(float);       // epilogue transpose tiles overlay the stage buffers
+        if (tl > l) l = tl;
+        p.atab_off = (int)l;
+        l += ((size_t)5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        if (l > lds) lds = l;
+        m.p[i] = p;
+        m.start[i] = grid;
+        grid += ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
+    }
+    m.start[nprob] = grid;
+    for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
+    // every problem of the launch shares one etab/atab offset (the largest), so that the kernel reads it from its own args
+    auto kern = conv_split_kernel<MI, NI, WM, WN>;
+    if (lds > 160 * 1024) return V2W_E_SHAPE;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    return v2w_launch_status();
+}
+
+// ---- weight preparation: max |w| of the layer -> power-of-two scale -> (hi, lo) half fragments in consumption order
+__global__ void __launch_bounds__(256)
+split_absmax_kernel(const float* __restrict__ wf, size_t n, unsigned int* __restrict__ amax_bits) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(wf[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(amax_bits, __float_as_uint(mx));              // non-negative floats order like their bit patterns: deterministic
+    }
+}
+
+// scale = 2^(13 - exponent(max |w|)): the largest weight lands in [8192, 16384); sc[0] = 1/scale (epilogue), sc[1] = scale
+__device__ __forceinline__ float split_scale_from_bits(unsigned int bits) {
+    const float mx = __uint_as_float(bits);
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+    int ex;
+    frexpf(mx, &ex);                                            // mx = f * 2^ex, f in [0.5, 1)
+    return ldexpf(1.f, 14 - ex);
+}
+
+// wps 16-B element o = (((mb*nch + ch)*K + t)*2 + hl)*64 + lane  (nch = C_in / 16 chunks) holds, for j = 0..7,
+//   part_hl( scale * wf[t][ch*16 + 8*(lane>>5) + j][mb*32 + (lane&31)] )
+__global__ void __launch_bounds__(256)
+pack_split_kernel(const float* __restrict__ wf, h8* __restrict__ wps, const unsigned int* __restrict__ amax_bits,
+                  float* __restrict__ sc, int K, int Cin, int Cout) {
+    const float scale = split_scale_from_bits(amax_bits[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = 1.f / scale; sc[1] = scale; }
+    const int nch = Cin / V2W_SPLIT_CK;
+    const size_t total = (size_t)(Cout / 32) * nch * K * 64;            // lanes; each writes its hi and lo fragment element
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = o & 63;
+        size_t rest = o >> 6;
+        const int t = rest % K; rest /= K;
+        const int ch = rest % nch;
+        const int mb = rest / nch;
+        const int co = mb * 32 + (lane & 31);
+        const int c0 = ch * V2W_SPLIT_CK + 8 * (lane >> 5);
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wf[((size_t)t * Cin + c0 + j) * Cout + co] * scale;
+            const _Float16 h = (_Float16)v;
+            hi[j] = h;
+            lo[j] = (_Float16)(v - (float)h);
+        }
+        const size_t base = (((size_t)(mb * nch + ch) * K + t) * 2) * 64 + lane;
+        wps[base] = hi;
+        wps[base + 64] = lo;
+    }
+}
+
+}  // namespace
+
+extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
+    return (u == 1 && c_in % V2W_SPLIT_CK == 0 && c_out % 64 == 0) ? 1 : 0;
+}
+
+// wps: k*c_in*c_out*4 bytes (two halves per weight); sc: 4 floats of device scratch/output: [0] = 1/scale (pass as `winv`),
+// [1] = scale, [2] = max |w| bits (zeroed here).  Three tiny launches on `stream`.
+extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
+    if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
+    if (!v2w_split_supported(c_in, c_out, 1)) return V2W_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned int* amax = reinterpret_cast<unsigned int*>(sc + 2);
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return (int)e;
+    const size_t n = (size_t)k * c_in * c_out;
+    int g1 = (int)((n + 255) / 256); if (g1 > 256) g1 = 256;
+    hipLaunchKernelGGL(split_absmax_kernel, dim3(g1), dim3(256), 0, st, wf, n, amax);
+    const size_t total = n / 8;                                      // one thread per 8 weights
+    int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(pack_split_kernel, dim3(g2), dim3(256), 0, st, wf, reinterpret_cast<h8*>(wps), amax, sc, k, c_in, c_out);
+    return v2w_launch_status();
+}
+
+// Called by v2w_api.hip for algo == V2W_ALGO_SPLIT.  n problems sharing B, C_in, C_out, L in one launch.
+int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream) {
+    if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
+    if (!v2w_split_supported(a->C_in, a->C_out, 1)) return V2W_E_SHAPE;
+    TileArgs ps[V2W_MAX_MULTI];
+    long tiles256 = 0;
+    for (int i = 0; i < n; ++i) {
+        const v2w_conv1d_args* q = a + i;
+        if (q->B != a->B || q->C_in != a->C_in || q->C_out != a->C_out || q->L != a->L) return V2W_E_SHAPE;
+        if (!q->wps || !q->winv) return V2W_E_ARG;
+        TileArgs p{};
+        p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wps = q->wps; p.winv = q->winv; p.bias = q->bias;
+        p.res = q->res; p.res_a = q->res_a; p.res_s = q->res_s; p.out = q->out;
+        p.add0 = q->add0; p.add1 = q->add1;
+        p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
+        p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
+        p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
+        if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
+        p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
+        p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
+        ps[i] = p;
+        tiles256 += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 128);
+    }
+    // two workgroups per CU are resident: prefer the largest tile that still gives every slot ~1 workgroup
+    if (a->C_out % 128 == 0) {
+        if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream);       // 128 x 128
+        return launch_split<1, 2, 2, 2>(ps, n, stream);                                // 64 x 128
+    }
+    return launch_split<2, 2, 1, 4>(ps, n, stream);                                    // 64 x 256
+}

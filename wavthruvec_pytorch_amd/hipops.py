@@ -13,7 +13,7 @@ import torch
 
 from . import _hip
 
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA, _hip.ALGO_SPLIT
 
 
 def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
@@ -89,15 +89,34 @@ def pack_mfma(wf, out=None, u=1):
     return out
 
 
+def split_supported(c_in, c_out, u=1):
+    """True when the split-f16 kernel (ALGO_SPLIT) serves this layer shape."""
+    return bool(_hip.load().v2w_split_supported(c_in, c_out, u))
+
+
+def pack_split(wf, out=None, sc=None):
+    """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
+    scale record (sc[0] = 1/scale is the kernel's `winv`)."""
+    k, ci, co = wf.shape
+    if out is None:
+        out = torch.empty((k * ci * co * 2,), device=wf.device, dtype=torch.float16)
+    if sc is None:
+        sc = torch.empty((4,), device=wf.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_pack_split(wf.data_ptr(), out.data_ptr(), sc.data_ptr(), k, ci, co, _stream(wf)), 'v2w_pack_split')
+    return out, sc
+
+
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
                  accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None):
+                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None):
     B, ci, Lx = x.shape
     L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
     a.in_stride, a.in_phase, a.pad_left = in_stride, in_phase, pad_left
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
     a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
+    if wps is not None:           # (fragments, scale record) of pack_split
+        a.wps, a.winv = wps[0].data_ptr(), wps[1].data_ptr()
     a.res = _hip.ptr(res)
     a.res_a, a.res_s = (_hip.ptr(res_affine[0]), _hip.ptr(res_affine[1])) if res_affine is not None else (None, None)
     add = list(add or [])
