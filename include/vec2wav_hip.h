@@ -128,7 +128,7 @@ int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST p
  * the residual branches of one generator stage, heaviest first. */
 int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
 
-/* ---- split-f16 weights (V2W_ALGO_SPLIT).  wf [k][C_in][C_out] (folded fp32) -> wps: k*C_in*C_out*4 bytes holding, per 32-row
+/* ---- split-f16 weights (V2W_ALGO_SPLIT).  wf [k][C_in][C_out] (folded fp32) -> wps: k*C_in*C_out*4 + 2048 bytes (the tail is padding) holding, per 32-row
  * block, chunk of 32 input channels and tap, the (hi, lo) half-precision MFMA A fragments of scale*w in consumption order;
  * scale = the power of two that puts max|w| of the layer into [8192, 16384) (both halves stay in the normal f16 range).
  * sc: 4 floats of device memory: [0] = 1/scale (the `winv` of v2w_conv1d_args), [1] = scale, [2] = scratch.

@@ -8,6 +8,8 @@ from wavthruvec_pytorch_amd import hipops
 dev = torch.device('cuda:0')
 CASES = [(32, 768, 512, 256, 7, 1), (32, 256, 256, 1280, 11, 1), (32, 256, 256, 1280, 3, 3), (32, 128, 128, 5120, 7, 1),
          (32, 128, 128, 5120, 11, 3), (32, 64, 64, 20480, 7, 1), (32, 64, 64, 20480, 3, 1)]
+if len(sys.argv) > 1:
+    CASES = [CASES[int(a)] for a in sys.argv[1:]]
 for B, ci, co, L, k, d in CASES:
     x = torch.randn(B, ci, L, device=dev)
     wf = torch.randn(k, ci, co, device=dev) / (ci * k) ** 0.5

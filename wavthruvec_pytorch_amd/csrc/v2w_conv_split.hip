@@ -20,6 +20,14 @@
 // Sync       : one workgroup barrier per tap; the async copies are fenced with explicit s_waitcnt vmcnt (see the loop).
 #include "v2w_tile.h"
 
+#ifdef V2W_EXP_TIMELINE
+__device__ unsigned long long v2w_dbg[8192];
+extern "C" int v2w_debug_read(void* dst, int bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2w_dbg), bytes); }
+#define V2W_TICK(k) do { if (dbg_on && st < 64) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) v2w_dbg[(wave * 64 + st) * 8 + (k)] = t_; } } while (0)
+#else
+#define V2W_TICK(k) do {} while (0)
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -29,13 +37,21 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define V2W_SPLIT_ROWB 80       // bytes per staged position: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad
 #define V2W_SPLIT_UNIT 2048     // bytes of the A fragments of one (32-row block, chunk, tap): [hi, lo][64 lanes][16 B]
 #define V2W_SPLIT_HMAX 32       // largest halo per side
-#define V2W_SPLIT_NAB 3         // weight stages resident in LDS (two in flight)
+#ifndef V2W_SPLIT_NAB
+#define V2W_SPLIT_NAB 3         // weight stages resident in LDS (NAB - 1 in flight)
+#endif
+#ifndef V2W_SPLIT_WPE
+#define V2W_SPLIT_WPE 2         // waves per SIMD the register allocation targets (= workgroups per CU)
+#endif
+#ifndef V2W_SPLIT_FORCE
+#define V2W_SPLIT_FORCE 0       // experiments: 1 = 64 x 128 tiles, 2 = 128 x 128 tiles for every C_out % 128 == 0 layer
+#endif
 
 #define V2W_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define V2W_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int MI, int NI, int WM, int WN>
-__global__ void __launch_bounds__(256, 2)
+template <int MI, int NI, int WM, int WN, bool VEC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V2W_SPLIT_WPE, V2W_SPLIT_WPE)))
 conv_split_kernel(const MultiArgs m) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -50,7 +66,8 @@ conv_split_kernel(const MultiArgs m) {
     static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
     constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
     constexpr int NSIG = NS * 4;                                // global loads of one signal prefetch (always all issued)
-    constexpr int RS = 32 * NI + 8;                             // floats per row of the epilogue transpose tile (4*RS % 64 == 32)
+    constexpr int RS = 72;                                      // floats per row of the epilogue transpose tile (32 x 64 per pass; 4*RS % 64 == 32)
+    static_assert(NI % 2 == 0, "the epilogue works on pairs of 32-column blocks");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -78,7 +95,7 @@ conv_split_kernel(const MultiArgs m) {
     const int L = p.L, K = p.K;
     const float slope = p.slope;
     const int nch = p.Cin / CK;
-    const int nst = nch * K;                                     // (chunk, tap) stages
+    const int nst = nch * K;                                     // (chunk, tap) stages = units per row block, contiguous in wps
     const int pos0 = n0 - p.hla;                                 // position of LDS row 0
     const int xbytes = p.xcols * ROWB;
     unsigned char* const Xs0 = smem;
@@ -94,25 +111,39 @@ conv_split_kernel(const MultiArgs m) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- weight stages: async global -> LDS.  Copy #i of a thread moves 16 B; a wave instruction fills 1 KiB of LDS.
-    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.wps);
-    auto dma_stage = [&](int st) {
-        unsigned char* dst = As0 + (st % NAB) * ASTAGE;
+    // ---- weight stages: async global -> LDS.  Copy #i of a thread moves 16 B, a wave instruction fills 1 KiB of LDS; the
+    // (chunk, tap) units of a row block are contiguous, so the source of the next stage is simply + one unit, and the ring
+    // slot advances by one: all bookkeeping is a few scalar adds per stage.
+    const unsigned char* dsrc[ADMA];
+#pragma unroll
+    for (int i = 0; i < ADMA; ++i) {
+        const int q = i * NTHREADS + tid;                        // 16-B element of the stage; 128 of them per unit
+        dsrc[i] = reinterpret_cast<const unsigned char*>(p.wps) + (size_t)(m0 / 32 + (q >> 7)) * nst * V2W_SPLIT_UNIT + (q & 127) * 16;
+    }
+    const unsigned a_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(As0 + wave * 1024));
+    int dma_slot = 0;                                            // ring slot the next copy fills
+    auto dma_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < ADMA; ++i) {
-            const int q = i * NTHREADS + tid;                    // 16-B element of the stage; 128 of them per unit
-            const int unit = q >> 7, off = q & 127;
-            const unsigned char* src = wsrc + ((size_t)(m0 / 32 + unit) * nst + st) * V2W_SPLIT_UNIT + off * 16;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                             (void __attribute__((address_space(3)))*)(dst + (i * NTHREADS + wave * 64) * 16), 16, 0, 0);
+            // Issued through inline asm ON PURPOSE: hipcc orders every later LDS read behind a builtin LDS-DMA with
+            // s_waitcnt vmcnt(0) (it cannot prove the buffers distinct), which would serialise copy and compute.  Hidden
+            // from its bookkeeping, the copy only makes the compiler's own vmcnt waits more conservative (vmcnt retires in
+            // order); the waits THIS data needs are the explicit V2W_WAIT_VM below.  M0 = LDS byte address of lane 0.
+            const unsigned lds = a_lds + dma_slot * ASTAGE + i * (NTHREADS * 16);
+            unsigned m0_save;                                    // M0 is a reserved register: hand it back as found
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_save) : "s"(lds), "v"(dsrc[i]) : "memory");
+            dsrc[i] += V2W_SPLIT_UNIT;
         }
+        dma_slot = dma_slot + 1 == NAB ? 0 : dma_slot + 1;
     };
 
     // ---- signal staging: wave w owns channels 4w..4w+3 of the chunk, lane l the position groups l, l+64, ... (1 KiB
     // contiguous per row and load instruction); every thread issues exactly NSIG loads (addresses clamped).
     const int xp4 = p.xcols >> 2;
     f32x4 pf[NS][4];
-    auto prefetch = [&](int ci0) {
+    auto prefetch = [&](int ci0) __attribute__((always_inline)) {
         const float* src = p.in + (size_t)(b * p.Cin + ci0 + wave * 4) * L;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -122,7 +153,11 @@ conv_split_kernel(const MultiArgs m) {
             for (int c = 0; c < 4; ++c) pf[s][c] = *reinterpret_cast<const f32x4*>(src + (size_t)c * L + pos);
         }
     };
-    auto commit = [&](int ci0, unsigned char* Xs) {
+    auto act = [&](float v) __attribute__((always_inline)) {     // leaky_relu, then into the f16 range (see the header)
+        v = slope <= 1.f ? fmaxf(v, v * slope) : v2w_lrelu(v, slope);
+        return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    };
+    auto commit = [&](int ci0, unsigned char* Xs) __attribute__((always_inline)) {
         float av[4], sv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -135,13 +170,13 @@ conv_split_kernel(const MultiArgs m) {
             if (pg >= xp4) continue;
             const int pos = pos0 + pg * 4;
             const bool in_seq = pos >= 0 && pos < L;             // L % 4 == 0, pos % 4 == 0: whole float4 in or out
+            // rows 4 apart alias 4-way in LDS (320 B = 16 banks mod 64): 8 stores per chunk and wave, not worth a rotation
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 h4 hi, lo;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float v = in_seq ? v2w_lrelu(fmaf(av[c], pf[s][c][e], sv[c]), slope) : 0.f;   // padding of the ACTIVATED signal
-                    v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+                    const float v = in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f;   // padding of the ACTIVATED signal
                     const _Float16 h = (_Float16)v;
                     hi[c] = h;
                     lo[c] = (_Float16)(v - (float)h);
@@ -152,7 +187,7 @@ conv_split_kernel(const MultiArgs m) {
             }
         }
     };
-    auto stage_scalar = [&](int ci0, unsigned char* Xs) {        // any L / alignment / input stride
+    auto stage_scalar = [&](int ci0, unsigned char* Xs) __attribute__((always_inline)) {        // any L / alignment / input stride
         for (int c = wave; c < CK; c += 4) {
             const int ch = b * p.Cin + ci0 + c;
             const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
@@ -161,8 +196,7 @@ conv_split_kernel(const MultiArgs m) {
             for (int j = lane; j < p.xcols; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
-                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[(size_t)l * p.in_stride], sv), slope);
-                v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+                if (l >= 0 && l < L) v = act(fmaf(av, src[(size_t)l * p.in_stride], sv));
                 const _Float16 h = (_Float16)v;
                 _Float16* d = reinterpret_cast<_Float16*>(Xs + j * ROWB) + c;
                 d[0] = h;
@@ -187,59 +221,90 @@ conv_split_kernel(const MultiArgs m) {
     }
     const float winv = p.winv[0];
     __syncthreads();
-    dma_stage(0);
-    if (nst > 1) dma_stage(1);
-    if (p.vec4) { prefetch(0); commit(0, Xs0); }
+    for (int s0 = 0; s0 < NAB - 1; ++s0)
+        if (s0 < nst) dma_next();
+    if constexpr (VEC) { prefetch(0); commit(0, Xs0); }
     else stage_scalar(0, Xs0);
     V2W_WAIT_VM(0);
     V2W_BARRIER();
 
     const int rowbase = wn0 + lr + p.hla - p.hl;                 // LDS row of this lane's column for tap 0
     int st = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
-        unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
-        const bool more = ch + 1 < nch;
-        for (int t = 0; t < K; ++t, ++st) {
-            // Issue order inside a stage: the weight copy of stage st+2, then (tap 0 only) the signal prefetch of the next
-            // chunk.  vmcnt retires in order, so at the end of the stage
-            //   tap 0 : vmcnt(ADMA + NSIG) leaves exactly this stage's issues outstanding -> stage st+1 (issued a stage ago) landed;
-            //   tap>=1: vmcnt(ADMA) leaves this stage's copy outstanding -> st+1 landed (and the signal prefetch, >= 1 stage old).
-            const bool dma = st + 2 < nst;
-            if (dma) dma_stage(st + 2);
-            const bool sig = t == 0 && more && p.vec4;
-            if (sig) prefetch((ch + 1) * CK);
-            __builtin_amdgcn_sched_barrier(0);
-
-            const unsigned char* Ab = As0 + (st % NAB) * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
-            h8 ah[MI], al[MI];
+    // One stage = one (chunk, tap): 3 * MI * NI MFMAs per wave between two workgroup barriers.
+    // Issue order inside a stage: the weight copy of stage st+NAB-1, then (first tap of a chunk) the signal prefetch of the
+    // next chunk.  vmcnt retires in order; stage st+1 was issued NAB-2 stages ago, so at the end of the stage
+    //   SIG stage : vmcnt((NAB-2)*ADMA + NSIG) leaves the NAB-2 younger copies and this stage's prefetch outstanding;
+    //   otherwise : vmcnt((NAB-2)*ADMA) leaves the NAB-2 younger copies outstanding (a prefetch older than that has landed);
+    //   tail      : once no copy is issued any more the counts no longer hold -> vmcnt(0).
+    // SIG / COMMIT are compile-time so that hipcc's own (path-insensitive) vmcnt bookkeeping sees prefetch -> commit as a
+    // straight line and adds no waits of its own inside the tap loop.
+    // B (signal) fragments of a stage come from the chunk's tile, which does not change between the taps of a chunk: they
+    // are read for tap t+1 BEFORE the barrier that ends tap t (their LDS latency hides under this tap's MFMAs); only the
+    // A fragments, which the barrier publishes, are read after it.
+    h8 bh[NI], bl[NI];
+    auto read_b = [&](const unsigned char* Xs, int t) __attribute__((always_inline)) {
+        const unsigned char* xr = Xs + (rowbase + t * p.dil) * ROWB + hk * 16;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT);
-                al[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT + 1024);
-            }
-            const unsigned char* xr = Xs + (rowbase + t * p.dil) * ROWB + hk * 16;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const h8 bh = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB);
-                const h8 bl = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB + 32);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][j], 0, 0, 0);
-            }
-
-            if (t == K - 1 && more) {
-                if (p.vec4) commit((ch + 1) * CK, Xn);
-                else stage_scalar((ch + 1) * CK, Xn);
-            }
-            if (!dma) V2W_WAIT_VM(0);
-            else if (sig) V2W_WAIT_VM(ADMA + NSIG);
-            else V2W_WAIT_VM(ADMA);
-            V2W_BARRIER();
+        for (int j = 0; j < NI; ++j) {
+            bh[j] = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB);
+            bl[j] = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB + 32);
         }
+    };
+    int ring = 0;                                                // ring slot of the stage being computed
+    auto stage = [&](const bool SIG, const bool COMMIT, int ch, int t) __attribute__((always_inline)) {
+        const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
+        const bool more = ch + 1 < nch;
+        const bool dma = st + (NAB - 1) < nst;
+        if (dma) dma_next();
+        const bool sig = SIG && VEC && more;
+        if (sig) prefetch((ch + 1) * CK);
+        __builtin_amdgcn_sched_barrier(0);
+
+        const unsigned char* Ab = As0 + ring * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
+        ring = ring + 1 == NAB ? 0 : ring + 1;
+        h8 ah[MI], al[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            ah[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT);
+            al[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT + 1024);
+        }
+        if (SIG) read_b(Xs, t);                                  // first tap of a chunk: its tile was committed just before the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        h8 ch_[NI], cl_[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { ch_[j] = bh[j]; cl_[j] = bl[j]; }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ch_[j], acc[i][j], 0, 0, 0);
+        if (!COMMIT) read_b(Xs, t + 1);                          // next tap's signal fragments: in flight across the barrier
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cl_[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], ch_[j], acc[i][j], 0, 0, 0);
+
+        if (COMMIT && more) {
+            unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
+            if constexpr (VEC) commit((ch + 1) * CK, Xn);
+            else stage_scalar((ch + 1) * CK, Xn);
+        }
+        if (!dma) V2W_WAIT_VM(0);
+        else if (sig) V2W_WAIT_VM((NAB - 2) * ADMA + NSIG);
+        else V2W_WAIT_VM((NAB - 2) * ADMA);
+        // the barrier publishes the landed weight stage and the committed tile; LDS reads already in flight (next tap's B
+        // fragments) need not drain first, so only the LDS WRITES of the commit are waited for (COMMIT stages)
+        if (COMMIT) V2W_BARRIER(); else asm volatile("s_barrier" ::: "memory");
+        ++st;
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        if (K == 1) { stage(true, true, ch, 0); continue; }
+        stage(true, false, ch, 0);
+        for (int t = 1; t < K - 1; ++t) stage(false, false, ch, t);
+        stage(false, true, ch, K - 1);
     }
 
     // ---- epilogue (same contract as the f32 tile kernel): undo the weight scale, mask, + bias [+ residual] [+ addends]
@@ -249,76 +314,79 @@ conv_split_kernel(const MultiArgs m) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j0 = 0; j0 < NI; j0 += 2) {                     // 32 rows x 64 positions per pass: bounded registers for any NI
 #pragma unroll
-            for (int e = 0; e < 16; ++e) T[F::row(e, hk) * RS + j * 32 + lr] = acc[i][j][e] * winv;   // power of two: exact
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private region: no workgroup barrier needed
-        constexpr int C4 = 8 * NI;                               // float4 per row
-        constexpr int NIT = 32 * C4 / 64;                        // float4 per lane
-        constexpr int EG = MI * NI >= 8 ? 2 : 4;                 // float4 gathers in flight per operand (register budget)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int g0 = 0; g0 < NIT; g0 += EG) {
-            f32x4 rv[EG], ov[EG], o2[EG], mv[EG];
+                for (int e = 0; e < 16; ++e) T[F::row(e, hk) * RS + jj * 32 + lr] = acc[i][j0 + jj][e] * winv;   // power of two: exact
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: no workgroup barrier needed
+            constexpr int C4 = 16;                               // float4 per row of the pass
+            constexpr int NIT = 32 * C4 / 64;                    // float4 per lane
+            constexpr int EG = 4;
 #pragma unroll
-            for (int g = 0; g < EG; ++g) {
-                const int f = (g0 + g) * 64 + lane;
-                const int row = f / C4, q = n0 + wn0 + (f % C4) * 4;
-                const size_t o = ((size_t)b * p.Cout + m0 + wm0 + i * 32 + row) * L + q;
-                const bool in = p.evec && q < L;
-                rv[g] = (p.res && in) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-                ov[g] = (p.accumulate && in) ? *reinterpret_cast<const f32x4*>(p.out + o)
-                                             : ((p.add0 && in) ? *reinterpret_cast<const f32x4*>(p.add0 + o) : f32x4{0.f, 0.f, 0.f, 0.f});
-                o2[g] = (p.add1 && in) ? *reinterpret_cast<const f32x4*>(p.add1 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-                mv[g] = (p.mask_src && in) ? *reinterpret_cast<const f32x4*>(p.mask_src + o) : f32x4{1.f, 1.f, 1.f, 1.f};
-            }
+            for (int g0 = 0; g0 < NIT; g0 += EG) {
+                f32x4 rv[EG], ov[EG], o2[EG], mv[EG];
 #pragma unroll
-            for (int g = 0; g < EG; ++g) {
-                const int f = (g0 + g) * 64 + lane;
-                const int row = f / C4, c4 = f % C4, q = n0 + wn0 + c4 * 4;
-                if (q >= L) continue;
-                const int col = wm0 + i * 32 + row;
-                const size_t o = ((size_t)b * p.Cout + m0 + col) * L + q;
-                const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
-                const float ma = etab[3 * MT + col], ms = etab[4 * MT + col];
-                f32x4 v = *reinterpret_cast<const f32x4*>(T + row * RS + c4 * 4);
-                if (!p.evec) {                                   // ragged L / unaligned operands: element-wise tail path
+                for (int g = 0; g < EG; ++g) {
+                    const int f = (g0 + g) * 64 + lane;
+                    const int row = f / C4, q = n0 + wn0 + j0 * 32 + (f % C4) * 4;
+                    const size_t o = ((size_t)b * p.Cout + m0 + wm0 + i * 32 + row) * L + q;
+                    const bool in = p.evec && q < L;
+                    rv[g] = (p.res && in) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    ov[g] = (p.accumulate && in) ? *reinterpret_cast<const f32x4*>(p.out + o)
+                                                 : ((p.add0 && in) ? *reinterpret_cast<const f32x4*>(p.add0 + o) : f32x4{0.f, 0.f, 0.f, 0.f});
+                    o2[g] = (p.add1 && in) ? *reinterpret_cast<const f32x4*>(p.add1 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    mv[g] = (p.mask_src && in) ? *reinterpret_cast<const f32x4*>(p.mask_src + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+#pragma unroll
+                for (int g = 0; g < EG; ++g) {
+                    const int f = (g0 + g) * 64 + lane;
+                    const int row = f / C4, c4 = f % C4, q = n0 + wn0 + j0 * 32 + c4 * 4;
+                    if (q >= L) continue;
+                    const int col = wm0 + i * 32 + row;
+                    const size_t o = ((size_t)b * p.Cout + m0 + col) * L + q;
+                    const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
+                    const float ma = etab[3 * MT + col], ms = etab[4 * MT + col];
+                    f32x4 v = *reinterpret_cast<const f32x4*>(T + row * RS + c4 * 4);
+                    if (!p.evec) {                               // ragged L / unaligned operands: element-wise tail path
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (q + e >= L) break;
+                            float x = v[e];
+                            if (p.mask_src) x = fmaf(ma, p.mask_src[o + e], ms) > 0.f ? x : x * p.mask_slope;
+                            x += bias;
+                            if (p.res) x += fmaf(ra, p.res[o + e], rs);
+                            if (p.add1) x += p.add0[o + e] + p.add1[o + e];
+                            else if (p.accumulate) x += p.out[o + e];
+                            else if (p.add0) x += p.add0[o + e];
+                            if (p.out_div != 0.f) x = x / p.out_div;
+                            p.out[o + e] = x;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (q + e >= L) break;
                         float x = v[e];
-                        if (p.mask_src) x = fmaf(ma, p.mask_src[o + e], ms) > 0.f ? x : x * p.mask_slope;
+                        if (p.mask_src) x = fmaf(ma, mv[g][e], ms) > 0.f ? x : x * p.mask_slope;
                         x += bias;
-                        if (p.res) x += fmaf(ra, p.res[o + e], rs);
-                        if (p.add1) x += p.add0[o + e] + p.add1[o + e];
-                        else if (p.accumulate) x += p.out[o + e];
-                        else if (p.add0) x += p.add0[o + e];
+                        if (p.res) x += fmaf(ra, rv[g][e], rs);
+                        if (p.add1) x += ov[g][e] + o2[g][e];    // (add0 + add1) + value: the reference's `xs += ...` order
+                        else if (p.accumulate || p.add0) x += ov[g][e];
                         if (p.out_div != 0.f) x = x / p.out_div;
-                        p.out[o + e] = x;
+                        v[e] = x;
                     }
-                    continue;
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e];
-                    if (p.mask_src) x = fmaf(ma, mv[g][e], ms) > 0.f ? x : x * p.mask_slope;
-                    x += bias;
-                    if (p.res) x += fmaf(ra, rv[g][e], rs);
-                    if (p.add1) x += ov[g][e] + o2[g][e];        // (add0 + add1) + value: the reference's `xs += ...` order
-                    else if (p.accumulate || p.add0) x += ov[g][e];
-                    if (p.out_div != 0.f) x = x / p.out_div;
-                    v[e] = x;
-                }
-                *reinterpret_cast<f32x4*>(p.out + o) = v;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of T done before the next pass overwrites it
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads of T done before the next block overwrites it
     }
 }
 
 template <int MI, int NI, int WM, int WN>
 int launch_split(const TileArgs* ps, int nprob, hipStream_t stream) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, CK = V2W_SPLIT_CK;
-    constexpr int RS = 32 * NI + 8;
+    constexpr int RS = 72;
     if (nprob < 1 || nprob > V2W_MAX_MULTI) return V2W_E_ARG;
     MultiArgs m{};
     size_t lds = 0;
@@ -349,7 +417,10 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream) {
     m.start[nprob] = grid;
     for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     // every problem of the launch shares one etab/atab offset (the largest), so that the kernel reads it from its own args
-    auto kern = conv_split_kernel<MI, NI, WM, WN>;
+    bool vec = true;                                               // one staging flavour per launch: float4 only if every problem allows it
+    for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
+    for (int i = 0; i < nprob; ++i) m.p[i].vec4 = vec;
+    auto kern = vec ? conv_split_kernel<MI, NI, WM, WN, true> : conv_split_kernel<MI, NI, WM, WN, false>;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -421,7 +492,7 @@ extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
     return (u == 1 && c_in % V2W_SPLIT_CK == 0 && c_out % 64 == 0) ? 1 : 0;
 }
 
-// wps: k*c_in*c_out*4 bytes (two halves per weight); sc: 4 floats of device scratch/output: [0] = 1/scale (pass as `winv`),
+// wps: k*c_in*c_out*4 + 2048 bytes (two halves per weight + one unit of padding: stage copies move whole tap pairs); sc: 4 floats of device scratch/output: [0] = 1/scale (pass as `winv`),
 // [1] = scale, [2] = max |w| bits (zeroed here).  Three tiny launches on `stream`.
 extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
     if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
@@ -464,6 +535,8 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream) {
     }
     // two workgroups per CU are resident: prefer the largest tile that still gives every slot ~1 workgroup
     if (a->C_out % 128 == 0) {
+        if (V2W_SPLIT_FORCE == 1) return launch_split<1, 2, 2, 2>(ps, n, stream);
+        if (V2W_SPLIT_FORCE == 2) return launch_split<2, 2, 2, 2>(ps, n, stream);
         if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream);       // 128 x 128
         return launch_split<1, 2, 2, 2>(ps, n, stream);                                // 64 x 128
     }

@@ -94,12 +94,18 @@ def split_supported(c_in, c_out, u=1):
     return bool(_hip.load().v2w_split_supported(c_in, c_out, u))
 
 
+def split_halves(k, c_in, c_out):
+    """Elements (f16) of the wps buffer of one layer: two halves per weight + one 2 KiB unit of padding (the kernel's
+    stage copies always move whole tap pairs)."""
+    return k * c_in * c_out * 2 + 1024
+
+
 def pack_split(wf, out=None, sc=None):
     """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
     scale record (sc[0] = 1/scale is the kernel's `winv`)."""
     k, ci, co = wf.shape
     if out is None:
-        out = torch.empty((k * ci * co * 2,), device=wf.device, dtype=torch.float16)
+        out = torch.empty((split_halves(k, ci, co),), device=wf.device, dtype=torch.float16)
     if sc is None:
         sc = torch.empty((4,), device=wf.device, dtype=torch.float32)
     _hip.check(_hip.load().v2w_pack_split(wf.data_ptr(), out.data_ptr(), sc.data_ptr(), k, ci, co, _stream(wf)), 'v2w_pack_split')

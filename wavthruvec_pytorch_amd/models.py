@@ -163,6 +163,10 @@ class Generator(nn.Module):
         self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
                                               # ties at C=32 where the per-layer tiles are already MFMA-bound)
         self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
+        self.precision = 'f32'                # 'f32': exact fp32 MFMA everywhere (default).  'f16x3': Conv1d layers with
+                                              # C_out >= split_min_channels run on the f16 matrix pipe with split operands
+                                              # (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulate; hipops.ALGO_SPLIT)
+        self.split_min_channels = 64
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
@@ -287,8 +291,35 @@ class Generator(nn.Module):
                 plan = hipops.FoldPlan(batch, device)
                 self._fold_key['plan'] = plan
             plan.run()
-        self._fold_key.update(state=state, wf=wf, wp=wp)
+        self._fold_key.update(state=state, wf=wf, wp=wp, gen=self._fold_key.get('gen', 0) + 1)
         return wf, wp
+
+    def _split_weights(self, device):
+        """precision == 'f16x3': (hi, lo) half-precision fragments + scale record of every Conv1d layer the split kernel
+        serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward)."""
+        if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
+            return {}
+        if self.precision != 'f16x3':
+            raise ValueError(f"Generator.precision must be 'f32' or 'f16x3', got {self.precision!r}")
+        gen = self._fold_key.get('gen', 0)
+        cached = self._fold_key.get('wps')
+        if cached is not None and cached[0] == gen:
+            return cached[1]
+        out = {}
+        for name, m in self._conv_layers():
+            if m.transposed or name == 'conv_post' or m.out_channels < self.split_min_channels:
+                continue
+            if not hipops.split_supported(m.in_channels, m.out_channels):
+                continue
+            v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+            wfb = self._buf('wfs.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
+            scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
+            hipops.fold_conv_weight(v, g, wfb, scratch)
+            wpsb = self._buf('wps.' + name, (hipops.split_halves(m.kernel_size, m.in_channels, m.out_channels),), dtype=torch.float16, device=device)
+            scb = self._buf('wsc.' + name, (4,), device=device)
+            out[name] = hipops.pack_split(wfb, wpsb, scb)
+        self._fold_key['wps'] = (gen, out)
+        return out
 
     # -------------------------------------------------------------------------------------------
     def forward(self, x, spk_emb=None, noise=None):
@@ -336,6 +367,10 @@ class Generator(nn.Module):
 
         with torch.no_grad():
             wf, wp = self._fold_weights(dev, need_wf=save is not None)
+            wps = self._split_weights(dev) if save is None else {}
+
+            def ck(nm):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
+                return dict(algo=hipops.ALGO_SPLIT, wps=wps[nm]) if nm in wps else dict(algo=algo, wp=wp[nm])
 
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
             ns = self.num_upsamples
@@ -352,7 +387,7 @@ class Generator(nn.Module):
             # ---- K1: conv_pre (no activation in front of it)
             cur = self._buf('act.pre', (B, c0, T), device=dev)
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
-                        slope=1.0, algo=algo, wp=wp['conv_pre'])
+                        slope=1.0, **ck('conv_pre'))
             L = T
             for i in range(ns):
                 up = self.ups[i]
@@ -442,11 +477,10 @@ class Generator(nn.Module):
                         if not ok:
                             launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
                                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
-                                                      in_affine=aff, res=xr, res_affine=aff, algo=algo,
-                                                      wp=wp[names[j] + '.convs.0']))) for j in range(nk)})
+                                                      in_affine=aff, res=xr, res_affine=aff, **ck(names[j] + '.convs.0')))) for j in range(nk)})
                             conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
                                              dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
-                                                  res=t1s[j], algo=algo, wp=wp[names[j] + '.convs.1'], **final_kw(j))))
+                                                  res=t1s[j], **ck(names[j] + '.convs.1'), **final_kw(j))))
                                      for j in range(nk)}
                             if nk > 1:
                                 launch('1', {j: conv2[j] for j in range(nk - 1)})
@@ -468,11 +502,10 @@ class Generator(nn.Module):
                             if not ok:
                                 launch(str(2 * n), {j: (j, (srcs[j], wf[f'{names[j]}.convs1.{n}'], rbs[j].convs1[n].bias.detach(),
                                                             t1s[j], dict(k=rbs[j].kernel_size, dil=rbs[j].convs1[n].dilation,
-                                                                         slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
-                                                                         wp=wp[f'{names[j]}.convs1.{n}']))) for j in range(nk)})
+                                                                         slope=LRELU_SLOPE, in_affine=src_aff, **ck(f'{names[j]}.convs1.{n}')))) for j in range(nk)})
                                 conv2 = {j: (j, (t1s[j], wf[f'{names[j]}.convs2.{n}'], rbs[j].convs2[n].bias.detach(), dsts[j],
                                                  dict(k=rbs[j].kernel_size, dil=1, slope=LRELU_SLOPE, res=srcs[j],
-                                                      res_affine=src_aff, algo=algo, wp=wp[f'{names[j]}.convs2.{n}'],
+                                                      res_affine=src_aff, **ck(f'{names[j]}.convs2.{n}'),
                                                       **(final_kw(j) if n == 2 else {})))) for j in range(nk)}
                                 if n < 2:
                                     launch(str(2 * n + 1), conv2)
@@ -490,10 +523,9 @@ class Generator(nn.Module):
                         if isinstance(rb, ResBlock2):
                             c1, c2 = rb.convs[0], rb.convs[1]
                             self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
-                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo,
-                                        wp=wp[name + '.convs.0'])
+                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, **ck(name + '.convs.0'))
                             self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
-                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, wp=wp[name + '.convs.1'], **last)
+                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, **ck(name + '.convs.1'), **last)
                         else:
                             xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
                             xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
@@ -502,12 +534,10 @@ class Generator(nn.Module):
                             for n in range(3):
                                 c1, c2 = rb.convs1[n], rb.convs2[n]
                                 self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
-                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
-                                            wp=wp[f'{name}.convs1.{n}'])
+                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, **ck(f'{name}.convs1.{n}'))
                                 extra = last if n == 2 else {}
                                 self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
-                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo,
-                                            wp=wp[f'{name}.convs2.{n}'], **extra)
+                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, **ck(f'{name}.convs2.{n}'), **extra)
                                 src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
