@@ -135,6 +135,17 @@ int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
  * Activations are split on the fly by the conv kernel and must satisfy |x| <= 65504 (they are clamped there). */
 int v2w_split_supported(int c_in, int c_out, int u);   /* 1 when V2W_ALGO_SPLIT serves this layer shape */
 int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);
+/* Batched weight-norm fold + split pack of n Conv1d layers straight from the parameters (weight_v (C_out, C_in, k), weight_g or
+ * NULL): three launches for all of them.  descs / starts are DEVICE arrays; starts[0..n] = prefix sums of c_out,
+ * starts[n+1..2n+1] = prefix sums of (c_out/32)*(c_in/16); nblk_* = their totals; k_max = largest kernel size. */
+typedef struct {
+    const float* v; const float* g;   /* weight_v, weight_g (NULL: plain weight) */
+    void* wps; float* sc;             /* outputs: as v2w_pack_split */
+    float* rowscale;                  /* c_out floats of workspace */
+    int32_t c_in, c_out, k, _pad;
+} v2w_split_desc;
+int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32_t* starts_dev, int n, int nblk_rows, int nblk_pack,
+                         int k_max, void* stream);
 
 /* ---- K6 fused pair for the narrow stages (C == 32 or 16; MFMA path): two chained convs of one residual block in ONE kernel,
  * the intermediate stays in LDS (these layers are HBM-bound as separate launches).

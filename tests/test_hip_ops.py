@@ -166,6 +166,25 @@ def test_conv1d_split_multi_and_rejects(dev):
         hipops.conv1d(x, None, None, probs[0][3], k=3, algo=hipops.ALGO_SPLIT)
 
 
+def test_split_pack_batch_equals_per_layer(dev):
+    """v2w_split_pack_batch (weight-norm fold + split pack of many layers, three launches) == fold_conv_weight + pack_split."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(13)
+    layers, want = [], []
+    for cout, cin, k, wn in ((512, 768, 7, True), (256, 256, 11, True), (128, 128, 3, True), (64, 64, 7, False)):
+        v = _t(r.standard_normal((cout, cin, k), dtype=np.float32), dev)
+        g = _t((1 + 0.1 * r.standard_normal((cout, 1, 1))).astype(np.float32), dev) if wn else None
+        wps = torch.zeros((hipops.split_halves(k, cin, cout),), device=dev, dtype=torch.float16)
+        sc = torch.zeros((4,), device=dev)
+        layers.append((v, g, wps, sc))
+        want.append(hipops.pack_split(hipops.fold_conv_weight(v, g)))
+    hipops.SplitPlan(layers, dev).run()
+    for (v, g, wps, sc), (wps0, sc0) in zip(layers, want):
+        n = wps.numel() - 1024                                   # the tail unit is padding
+        assert torch.equal(sc[:2].cpu(), sc0[:2].cpu())
+        assert torch.equal(wps[:n].view(torch.int16).cpu(), wps0[:n].view(torch.int16).cpu())
+
+
 @pytest.mark.parametrize('B,cin,cout,L,k,dil', CONV_CASES[:7])
 def test_conv1d_plain_and_mfma_forced(dev, B, cin, cout, L, k, dil):
     """No optional inputs; V2W_ALGO_MFMA must accept every generator shape and agree with the direct kernel."""

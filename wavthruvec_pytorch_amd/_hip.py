@@ -58,6 +58,11 @@ class FoldDesc(C.Structure):
                 ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32)]
 
 
+class SplitDesc(C.Structure):
+    _fields_ = [('v', _fp), ('g', _fp), ('wps', _fp), ('sc', _fp), ('rowscale', _fp),
+                ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('_pad', C.c_int32)]
+
+
 _PA = _fp * V2W_MAX_STAGES
 
 
@@ -80,6 +85,7 @@ SIGNATURES = {
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),

@@ -486,6 +486,80 @@ pack_split_kernel(const float* __restrict__ wf, h8* __restrict__ wps, const unsi
     }
 }
 
+// ---- batched weight-norm fold + split pack: every split layer of the generator in three launches driven by a device
+// descriptor table (mirrors v2w_fold_pack_batch of the f32 path).
+__device__ __forceinline__ int split_find_layer(const int32_t* __restrict__ starts, int n, int blk) {
+    int lo = 0, hi = n;                       // starts[li] <= blk < starts[li+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= blk) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ void split_zero_batch_kernel(const v2w_split_desc* __restrict__ descs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<unsigned int*>(descs[i].sc)[2] = 0u;
+}
+
+// one block per (layer, output row): rowscale[row] = g[row] / ||v[row,:]|| (1 when g == NULL) and the layer's max |w|
+__global__ void __launch_bounds__(256)
+split_rowscale_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t* __restrict__ starts, int n) {
+    __shared__ double red[16];
+    __shared__ float redm[4];
+    const int li = split_find_layer(starts, n, blockIdx.x);
+    const v2w_split_desc d = descs[li];
+    const int row = blockIdx.x - starts[li];
+    const int inner = d.c_in * d.k;
+    const float* src = d.v + (size_t)row * inner;
+    double acc = 0.0;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < inner; i += 256) { const float x = src[i]; acc += (double)x * x; mx = fmaxf(mx, fabsf(x)); }
+    const double n2 = v2w_block_sum(acc, red);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sc = d.g ? (float)((double)d.g[row] / sqrt(n2)) : 1.f;
+        d.rowscale[row] = sc;
+        mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])) * fabsf(sc);
+        atomicMax(reinterpret_cast<unsigned int*>(d.sc) + 2, __float_as_uint(mx));   // order of non-negative floats = order of their bits
+    }
+}
+
+// one block per (layer, 32-row block mb, 16-channel chunk ch): the 32 x 16 x K sub-block of v goes through LDS (coalesced
+// rows), then the K units of that (mb, ch) are written contiguously as (hi, lo) fragments
+__global__ void __launch_bounds__(256)
+split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t* __restrict__ starts, int n) {
+    extern __shared__ float tile[];
+    const int li = split_find_layer(starts, n, blockIdx.x);
+    const v2w_split_desc d = descs[li];
+    const int blk = blockIdx.x - starts[li];
+    const int K = d.k, nch = d.c_in / V2W_SPLIT_CK;
+    const int mb = blk / nch, ch = blk % nch;
+    const float scale = split_scale_from_bits(reinterpret_cast<const unsigned int*>(d.sc)[2]);
+    if (blk == 0 && threadIdx.x == 0) { d.sc[0] = 1.f / scale; d.sc[1] = scale; }
+    const int rlen = V2W_SPLIT_CK * K, rstride = rlen + 1;
+    for (int idx = threadIdx.x; idx < 32 * rlen; idx += 256) {
+        const int r = idx / rlen, x = idx - r * rlen;
+        tile[r * rstride + x] = d.v[((size_t)(mb * 32 + r) * d.c_in + ch * V2W_SPLIT_CK) * K + x] * d.rowscale[mb * 32 + r] * scale;
+    }
+    __syncthreads();
+    h8* dst = reinterpret_cast<h8*>(d.wps) + (size_t)(mb * nch + ch) * K * 128;
+    for (int o = threadIdx.x; o < K * 64; o += 256) {
+        const int lane = o & 63, t = o >> 6;
+        const int r = lane & 31, c0 = 8 * (lane >> 5);
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[r * rstride + (c0 + j) * K + t];
+            const _Float16 h = (_Float16)v;
+            hi[j] = h;
+            lo[j] = (_Float16)(v - (float)h);
+        }
+        dst[t * 128 + lane] = hi;
+        dst[t * 128 + 64 + lane] = lo;
+    }
+}
+
 }  // namespace
 
 extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
@@ -541,4 +615,18 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream) {
         return launch_split<1, 2, 2, 2>(ps, n, stream);                                // 64 x 128
     }
     return launch_split<2, 2, 1, 4>(ps, n, stream);                                    // 64 x 256
+}
+
+// Batched form of (v2w_wn_fold_conv + v2w_pack_split) for n Conv1d layers: descs / starts live in DEVICE memory;
+// starts[0..n] = prefix sums of c_out (rows), starts[n+1 .. 2n+1] = prefix sums of (c_out/32)*(c_in/16) (pack blocks).
+extern "C" int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32_t* starts_dev, int n, int nblk_rows, int nblk_pack,
+                                    int k_max, void* stream) {
+    if (!descs_dev || !starts_dev || n <= 0 || nblk_rows <= 0 || nblk_pack <= 0 || k_max <= 0) return V2W_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int lds = 32 * (V2W_SPLIT_CK * k_max + 1) * (int)sizeof(float);
+    if (lds > 64 * 1024) return V2W_E_SHAPE;
+    hipLaunchKernelGGL(split_zero_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, st, descs_dev, n);
+    hipLaunchKernelGGL(split_rowscale_batch_kernel, dim3(nblk_rows), dim3(256), 0, st, descs_dev, starts_dev, n);
+    hipLaunchKernelGGL(split_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds, st, descs_dev, starts_dev + n + 1, n);
+    return v2w_launch_status();
 }

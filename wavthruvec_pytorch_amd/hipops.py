@@ -284,6 +284,40 @@ class FoldPlan:
                    'v2w_fold_pack_batch')
 
 
+class SplitPlan:
+    """Device-resident descriptor table for v2w_split_pack_batch: every split-f16 layer folded (weight norm) and packed into
+    its (hi, lo) fragment stream in three launches."""
+
+    def __init__(self, layers, device):
+        """layers: list of (v (C_out, C_in, k), g|None, wps, sc) with tensors already on `device`."""
+        n = len(layers)
+        self.n = n
+        self.rowscale = torch.empty((sum(v.shape[0] for v, *_ in layers),), device=device, dtype=torch.float32)
+        descs = (_hip.SplitDesc * n)()
+        starts = [0] * (2 * (n + 1))
+        off = blocks = 0
+        for i, (d, (v, g, wps, sc)) in enumerate(zip(descs, layers)):
+            co, ci, k = v.shape
+            d.v = v.data_ptr(); d.g = _hip.ptr(g); d.wps = wps.data_ptr(); d.sc = sc.data_ptr()
+            d.rowscale = self.rowscale.data_ptr() + 4 * off
+            d.c_in, d.c_out, d.k = ci, co, k
+            starts[i], starts[n + 1 + i] = off, blocks
+            off += co
+            blocks += (co // 32) * (ci // 16)
+        starts[n], starts[2 * n + 1] = off, blocks
+        self.nblk_rows, self.nblk_pack = off, blocks
+        self.k_max = max(v.shape[2] for v, *_ in layers)
+        self.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+        self.starts_dev = torch.tensor(starts, dtype=torch.int32, device=device)
+        self.key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in layers)
+
+    def run(self):
+        _hip.check(_hip.load().v2w_split_pack_batch(self.descs_dev.data_ptr(), self.starts_dev.data_ptr(), self.n,
+                                                    self.nblk_rows, self.nblk_pack, self.k_max,
+                                                    torch.cuda.current_stream(self.rowscale.device).cuda_stream),
+                   'v2w_split_pack_batch')
+
+
 def resblock_pair_multi(problems):
     """`problems`: list of dicts(x, in_affine, wp1, b1, wp2, b2, out, k, dil1, dil2, res_mode, slope, add, out_div) sharing B, C, L.
     Returns False (nothing launched) when the fused pair kernel does not take the shape."""

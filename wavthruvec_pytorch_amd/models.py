@@ -305,19 +305,24 @@ class Generator(nn.Module):
         cached = self._fold_key.get('wps')
         if cached is not None and cached[0] == gen:
             return cached[1]
-        out = {}
+        out, batch = {}, []
         for name, m in self._conv_layers():
             if m.transposed or name == 'conv_post' or m.out_channels < self.split_min_channels:
                 continue
             if not hipops.split_supported(m.in_channels, m.out_channels):
                 continue
             v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
-            wfb = self._buf('wfs.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
-            scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
-            hipops.fold_conv_weight(v, g, wfb, scratch)
             wpsb = self._buf('wps.' + name, (hipops.split_halves(m.kernel_size, m.in_channels, m.out_channels),), dtype=torch.float16, device=device)
             scb = self._buf('wsc.' + name, (4,), device=device)
-            out[name] = hipops.pack_split(wfb, wpsb, scb)
+            batch.append((v.contiguous(), g, wpsb, scb))
+            out[name] = (wpsb, scb)
+        if batch:
+            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in batch)
+            plan = self._fold_key.get('split_plan')
+            if plan is None or plan.key != key:
+                plan = hipops.SplitPlan(batch, device)
+                self._fold_key['split_plan'] = plan
+            plan.run()
         self._fold_key['wps'] = (gen, out)
         return out
 
