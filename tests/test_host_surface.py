@@ -75,7 +75,7 @@ def test_struct_layouts_match_header_field_order():
     header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
     body = header[header.index('typedef struct {', header.index('K1/K5/K6/K7')):header.index('} v2w_conv1d_args;')]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
-    names = re.findall(r'\b(?:const\s+)?(?:float|int32_t)\s*\*?\s*([a-zA-Z_0-9]+(?:\s*,\s*[a-zA-Z_0-9]+)*)\s*;', body)
+    names = re.findall(r'\b(?:const\s+)?(?:float|int32_t|void)\s*\*?\s*([a-zA-Z_0-9]+(?:\s*,\s*[a-zA-Z_0-9]+)*)\s*;', body)
     flat = [n.strip() for grp in names for n in grp.split(',')]
     want = [f[0].rstrip('_') for f in _hip.Conv1dArgs._fields_]
     assert flat == want, (flat, want)

@@ -83,7 +83,6 @@ def main():
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--algo', default='auto', choices=['auto', 'direct'])
-    ap.add_argument('--no-alt', action='store_true', help="skip the additional precision='f16x3' measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -93,17 +92,11 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the Vec2Wav HIP path has no CPU fallback)')
-    # test hooks for a 1-GPU box: V2W_BENCH_DEVICE pins every rank to one device, V2W_BENCH_BACKEND=gloo replaces RCCL
-    dev_index = int(os.environ.get('V2W_BENCH_DEVICE', local_rank))
-    backend = os.environ.get('V2W_BENCH_BACKEND', 'nccl')
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from wavthruvec_pytorch_amd import Generator, synthetic, workmodel, hipops
 
@@ -120,10 +113,7 @@ def main():
 
     def barrier():
         if world > 1:
-            if backend == 'nccl':
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -136,54 +126,24 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
-    def max_over_ranks(v):
-        if world > 1:
-            t = torch.tensor([v], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t.item()
-        return v
-
-    elapsed = max_over_ranks(elapsed)
-
-    # ---- the same step with Generator.precision = 'f16x3' (wide Conv1d layers on the f16 matrix pipe with split operands,
-    # fp32 accumulation; same parity bar).  Reported BESIDE the exact-fp32 `value`, never instead of it.
-    alt = None
-    if args.algo == 'auto' and not args.no_alt:
-        with torch.no_grad():
-            y32 = g(x, spk, nz).clone()
-            g.precision = 'f16x3'
-            for _ in range(args.warmup):
-                ysp = g(x, spk, nz)
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                ysp = g(x, spk, nz)
-            torch.cuda.synchronize()
-            barrier()
-            alt_elapsed = max_over_ranks(time.perf_counter() - t0)
-            diff = max_over_ranks((ysp - y32).abs().max().item())
-            g.precision = 'f32'
-            g(x, spk, nz)                   # back on the fp32 fragments for the profiling pass below
-        alt = dict(precision='f16x3', value=samples_per_step * args.steps / alt_elapsed, unit='samples/s',
-                   ms_per_step=alt_elapsed / args.steps * 1e3, max_abs_diff_vs_f32_path=diff, parity_bar=1e-4,
-                   arithmetic='Conv1d layers with C_out >= 64: x = x_hi + x_lo (f16), x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on '
-                              'v_mfma_f32_32x32x16_f16, fp32 accumulate; all other kernels exact fp32')
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
 
     # ---- roofline of the dominant kernel: events around every conv launch, on the launching stream, live
     roof = None
-    per = {}
-    with torch.no_grad():          # every rank runs these forwards (they contain the statistics all-reduce); rank 0 records
-        for _ in range(3):
-            g._profile = [] if rank == 0 else None
-            g(x, spk, nz)
-            torch.cuda.synchronize()
-            if rank == 0:
-                for tag, e0, e1 in g._profile:
-                    per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
-        g._profile = None
     if rank == 0:
         layers = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
+        per = {}
+        with torch.no_grad():
+            for _ in range(3):
+                g._profile = []
+                g(x, spk, nz)
+                torch.cuda.synchronize()
+                for tag, e0, e1 in g._profile:
+                    per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
+            g._profile = None
         # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
         # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
         def kernel_of(l, nprob=1):
@@ -274,7 +234,7 @@ def main():
             'config': {'workload': f'BASELINE configs[1]: B={B}/GPU x T={T} frames, 768-d latents, upsample (5,4,4,2,2) x320, '
                                    'ResBlock2, train-mode CondBN, fp32', 'global_batch': B * world, 'frames': T,
                        'parallelism': f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt,
+            'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,219 @@
+/*
+ * vec2wav_hip.h - C ABI of libvec2wav_hip.so: the Vec2Wav generator forward path as
+ * hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * The reference (p1an-lin-jung/WavThruVec_pytorch) has no FFI/operator layer: its boundary is
+ * the Python nn.Module surface (vec2wav/models.py:77-156, vec2wav/modules.py:5-30) and everything
+ * underneath is stock torch ops.  Each entry point below therefore cites the reference statement
+ * (file:line under /root/reference) whose arithmetic it replaces; the Python mirror of the
+ * reference surface (wavthruvec_pytorch_amd/models.py) is the only caller.  INTEGRATION.md shows
+ * the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch types; every pointer is a DEVICE pointer unless said
+ *     otherwise; activations are fp32, channels-first, contiguous (B, C, L);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are asynchronous,
+ *     nothing allocates, nothing synchronises, no ownership is transferred;
+ *   - return value: 0 = enqueued; < 0 = bad argument (V2W_E_*); > 0 = a hipError_t from the launch;
+ *   - no global mutable state: safe to call concurrently on distinct streams.
+ *
+ * Folded weight layout ("wf"): fp32 [k][C_in][C_out] (C_out fastest) for both Conv1d and
+ * ConvTranspose1d, produced by v2w_wn_fold_* from the reference's weight_g/weight_v parameters.
+ */
+#ifndef VEC2WAV_HIP_H
+#define VEC2WAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2W_ABI_VERSION 5
+
+#define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
+#define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
+#define V2W_E_ALGO     (-3)  /* unknown algorithm id */
+
+/* algorithm selector of the conv entry points */
+#define V2W_ALGO_AUTO   0    /* MFMA tile kernel when the shape allows, else the direct kernel */
+#define V2W_ALGO_DIRECT 1    /* one-thread-per-output scalar FMA kernel: any shape; cross-check */
+#define V2W_ALGO_MFMA   2    /* f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) implicit GEMM; V2W_E_SHAPE if unsupported */
+
+int         v2w_abi_version(void);
+const char* v2w_build_arch(void);       /* "gfx950" */
+
+/* ---- K0: weight-norm fold (torch.nn.utils.weight_norm pre-forward hook, dim=0; triggered by
+ * models.py:18-33,58-61,83,90-92,100).  w = g * v / ||v||, norm over all dims but 0.
+ * conv : v (C_out, C_in, k), g (C_out)  -> wf [k][C_in][C_out]      (norm per C_out)
+ * convt: v (C_in, C_out, k), g (C_in)   -> wf [k][C_in][C_out]      (norm per C_in)
+ * g == NULL means "weight norm already removed" (models.py:149-156): v is the plain weight, relayout only.
+ * scratch: >= rows floats (rows = C_out for conv, C_in for convt). */
+int v2w_wn_fold_conv (const float* v, const float* g, float* wf, float* scratch,
+                      int c_out, int c_in, int k, void* stream);
+int v2w_wn_fold_convt(const float* v, const float* g, float* wf, float* scratch,
+                      int c_in, int c_out, int k, void* stream);
+
+/* MFMA operand packing: wf [k][C_in][C_out] -> wp, the same k*C_in*C_out weights as a stream of 1 KiB MFMA A-fragments
+ * (64 lanes x float4 = four consecutive MFMA k-steps) in exactly the order the tile kernel of that layer consumes them:
+ * [row block mb][C_in chunk][tap, phase-major for a transposed conv][fragment]; the kernel reads it strictly
+ * sequentially.  u = 1 for Conv1d, the stride for ConvTranspose1d.  Returns V2W_E_SHAPE when the layer has no MFMA
+ * tile configuration (C_in % 16 != 0, C_out neither 16 nor a multiple of 32, unsupported stride): such layers run on
+ * the direct kernel with wp = NULL. */
+int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream);
+
+/* Batched form of fold + pack for every MFMA layer of a generator: two launches instead of three per layer.
+ *   v2w_fold_plan       (host only) fills mf/ck of each descriptor and starts[2*(n+1)] (block prefix sums of the scale
+ *                       and of the pack kernel); returns the dynamic-LDS byte count (> 0) the pack kernel needs, or
+ *                       V2W_E_SHAPE when a layer has no MFMA tile configuration (fold such layers one by one).
+ *   v2w_fold_pack_batch descs_dev / starts_dev are DEVICE copies of the planned arrays; nblk_scale = starts[n],
+ *                       nblk_pack = starts[2n+1].
+ * v: weight_v (conv (C_out,C_in,k); transposed (C_in,C_out,k)); g: weight_g or NULL; scale: >= rows floats scratch. */
+typedef struct {
+    const float* v; const float* g; float* wp; float* scale;
+    int32_t c_in, c_out, k, u, transposed;
+    int32_t mf, ck;     /* filled by v2w_fold_plan */
+    int32_t _pad;
+} v2w_fold_desc;
+int v2w_fold_plan(v2w_fold_desc* descs, int n, int32_t* starts);
+int v2w_fold_pack_batch(const v2w_fold_desc* descs_dev, const int32_t* starts_dev, int n,
+                        int nblk_scale, int nblk_pack, int lds_bytes, void* stream);
+
+/* ---- K1/K5/K6/K7: fused [per-(b,c) affine] -> leaky_relu -> dilated Conv1d -> +bias [-> +residual]
+ * [-> += out] [-> / out_div].  Replaces F.leaky_relu + Conv1d (+ `xt + x`, `xs += ...`, `xs / num_kernels`)
+ * of models.py:37-44 (ResBlock1), 65-70 (ResBlock2), 123 (conv_pre), 135-141 (mean over kernels).
+ *   in   (B, C_in, L)     in_a/in_s   (B, C_in)  or NULL : x = in_a*in + in_s before the activation
+ *                                                          (the CondBN affine of modules.py:25-28 folded into the load)
+ *   res  (B, C_out, L) or NULL; res_a/res_s (B, C_out) or NULL : residual = res_a*res + res_s
+ *   out  (B, C_out, L);   padding = dil*(k-1)/2 (utils.py:35-36), k odd
+ *   slope: leaky_relu negative slope applied to the conv operand (1.0f = none)
+ *   accumulate != 0: out = out_old + value ; out_div != 0: out = value / out_div (applied last) */
+typedef struct {
+    const float* in;   const float* in_a;  const float* in_s;
+    const float* wf;   /* [k][C_in][C_out]: read by the direct kernel; may be NULL when algo == V2W_ALGO_MFMA */
+    const float* wp;   /* v2w_pack_mfma() form: read by the MFMA kernel; NULL -> direct kernel under V2W_ALGO_AUTO */
+    const float* bias;
+    const float* res;  const float* res_a; const float* res_s;
+    const float* add0; const float* add1;   /* optional extra addends (B, C_out, L): out = (add0 [+ add1]) + value, then / out_div;
+                                             * the explicit form of `xs += ...` (models.py:137-141) when the branches ran
+                                             * concurrently into separate buffers; exclusive with `accumulate` */
+    float*       out;
+    int32_t B, C_in, C_out, L, k, dil;
+    float   slope;
+    int32_t accumulate;
+    float   out_div;
+    int32_t algo;
+} v2w_conv1d_args;
+int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
+/* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
+ * the residual branches of one generator stage, heaviest first. */
+int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
+
+/* ---- K6 fused pair for the narrow stages (C == 32 or 16; MFMA path): two chained convs of one residual block in ONE kernel,
+ * the intermediate stays in LDS (these layers are HBM-bound as separate launches).
+ *   res_mode 0 (ResBlock2, models.py:65-70): t1 = x + conv_{k,dil1}(lrelu(x)) + b1 ; out = t1 + conv_{k,dil2}(lrelu(t1)) + b2
+ *   res_mode 1 (ResBlock1 pair, models.py:37-44): t1 = conv_{k,dil1}(lrelu(x)) + b1 ; out = x + conv_{k,dil2}(lrelu(t1)) + b2
+ *   x = in_a*in + in_s when the affine is given; then out = ((add0 [+ add1]) + out) [/ out_div] as in v2w_conv1d_args.
+ *   wp1 / wp2: v2w_pack_mfma(k, C, C, 1) streams.  a[0..n) (n <= 4) share B, C, L and go out as one launch.
+ * Returns V2W_E_SHAPE when C or the receptive field does not fit: run the two convs with v2w_conv1d_fwd instead. */
+typedef struct {
+    const float* in; const float* in_a; const float* in_s;
+    const float* wp1; const float* bias1; const float* wp2; const float* bias2;
+    const float* add0; const float* add1;
+    float* out;
+    int32_t B, C, L, k, dil1, dil2;
+    int32_t res_mode;
+    float slope, out_div;
+} v2w_pair_args;
+int v2w_resblock_pair_fwd(const v2w_pair_args* a, int n, void* stream);
+
+/* ---- K6+K7 fused for a narrow ResBlock2 stage (C == 32 or 16): the whole residual section of models.py:135-141,
+ *   out = ( sum_j [ t1_j + conv_{k_j,dil2_j}(lrelu(t1_j)) + b2_j ] ) / out_div,  t1_j = x + conv_{k_j,dil1_j}(lrelu(x)) + b1_j,
+ * x = in_a*in + in_s, in ONE kernel: x is read once, every t1_j stays in LDS, the branch sum stays in registers and is
+ * added in the reference's order.  nk <= 4 branches.  V2W_E_SHAPE -> use the per-branch entry points. */
+typedef struct {
+    const float* in; const float* in_a; const float* in_s;
+    const float* wp1[4]; const float* bias1[4]; const float* wp2[4]; const float* bias2[4];
+    int32_t k[4], dil1[4], dil2[4];
+    float* out;
+    int32_t nk, B, C, L;
+    float slope, out_div;
+} v2w_stage_args;
+int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
+
+/* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
+ * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */
+typedef struct {
+    const float* in; const float* wf; const float* wp; const float* bias; float* out;
+    float* stats_part;  /* optional (MFMA path only): [ntiles][C_out][2] per-tile (sum, sumsq) of the output, the fused form of
+                         * v2w_bn_stats; ntiles = cfg[9] of v2w_convt1d_tile_config; reduce with v2w_bn_reduce_partials */
+    int32_t B, C_in, C_out, L, k, u;
+    float   slope;
+    int32_t algo;
+} v2w_convt1d_args;
+int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
+
+/* Introspection for profiling: which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation the MFMA path uses for
+ * this problem (only the sizes of `a` are read).  0 and cfg[10] filled (cfg[9] = number of position tiles), or V2W_E_SHAPE
+ * when the direct kernel would run. */
+int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg);
+int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg);
+
+/* ---- K3: per-stage conditioning  z = fcs[i](cat(spk, noise))  (models.py:120,131), legacy
+ * spectral_norm power iteration on cbns[i].layer (modules.py:16,24) and [gamma|beta] = (W/sigma) z + b.
+ * One call serves every stage (they depend on spk/noise only).  Arrays of n_stages DEVICE pointers are
+ * passed by value inside the struct (HOST struct).
+ *   spk (B, spk_dim), noise (B, noise_dim); fc_w[i] (128, spk_dim+noise_dim), fc_b[i] (128)
+ *   sn_w[i] (2C_i, 128) = weight_orig, sn_b[i] (2C_i), sn_u[i] (2C_i), sn_v[i] (128)
+ *   training != 0: one power iteration, u and v are UPDATED IN PLACE (as the reference's hook does)
+ *   gb[i] (B, 2C_i): gamma = gb[:, :C], beta = gb[:, C:]   (chunk(2,1), modules.py:24)
+ *   z_ws: workspace of n_stages*B*128 floats; sigma_ws: n_stages floats
+ *   fc_w[i] == fc_b[i] == NULL: no fcs layer, z = cat(spk, noise) itself (needs spk_dim+noise_dim == 128;
+ *   noise may be NULL with noise_dim == 0) - ConditionalBatchNorm1d.forward(inputs, noise) used on its own. */
+#define V2W_MAX_STAGES 8
+typedef struct {
+    const float* spk; const float* noise;
+    const float* fc_w[V2W_MAX_STAGES]; const float* fc_b[V2W_MAX_STAGES];
+    const float* sn_w[V2W_MAX_STAGES]; const float* sn_b[V2W_MAX_STAGES];
+    float* sn_u[V2W_MAX_STAGES]; float* sn_v[V2W_MAX_STAGES];
+    float* gb[V2W_MAX_STAGES];
+    int32_t C[V2W_MAX_STAGES];
+    float* z_ws; float* sigma_ws;
+    int32_t n_stages, B, spk_dim, noise_dim, training;
+} v2w_cond_args;
+int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream);
+
+/* ---- K4: BatchNorm1d(affine=False) statistics and finalisation (modules.py:14,23).
+ * v2w_bn_stats   : x (B,C,L) -> stats[2C] doubles = [sum_c | sumsq_c] over (B,L); deterministic two-level
+ *                  reduction; partial_ws >= 2*C*V2W_BN_SPLITS doubles.
+ *                  In data-parallel runs the host all-reduces `stats` (RCCL, sum) between the two calls.
+ * v2w_bn_finalize: training: mean/biased var from stats (count = stats[2C]), running_mean/var
+ *                  momentum update with the unbiased var, num_batches_tracked += 1 (int64);
+ *                  eval: running stats are used, nothing is written.
+ *                  Then the folded per-sample affine  a[b,c] = gamma*rstd, s[b,c] = beta - gamma*mean*rstd
+ *                  (so that CondBN(x) = a*x + s, modules.py:23-28) from gb (B, 2C). */
+#define V2W_BN_SPLITS 64
+/* stats: 2C+1 doubles = [sum_c | sumsq_c | count]; count = B*L is written by the kernel so that one
+ * all-reduce(sum) of the whole array yields the global sums AND the global element count. */
+int v2w_bn_stats(const float* x, double* stats, double* partial_ws, int B, int C, int L, void* stream);
+/* Fixed-order fp64 reduction of the per-tile partials written by v2w_convt1d_fwd(stats_part) -> stats[2C+1]. */
+int v2w_bn_reduce_partials(const float* part, int ntiles, int C, double count, double* stats, void* stream);
+int v2w_bn_finalize(const double* stats, const float* gb,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* a_out, float* s_out, int B, int C, int training,
+                    float momentum, float eps, void* stream);
+
+/* ---- K5 (standalone form): out = a[b,c]*x + s[b,c] over (B,C,L).  Only ConditionalBatchNorm1d.forward used on
+ * its own (modules.py:20-30) materialises the normalised tensor; Generator.forward folds the affine into its
+ * consumers' loads instead. */
+int v2w_affine_apply(const float* x, const float* a, const float* s, float* out, int B, int C, int L, void* stream);
+
+/* ---- K8: leaky_relu(slope) -> Conv1d(C_in -> 1, k, pad (k-1)/2) -> +bias -> tanh  (models.py:143-145).
+ * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
+int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
+                       int B, int C_in, int L, int k, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEC2WAV_HIP_H */

@@ -1,0 +1,146 @@
+"""ctypes binding of libvec2wav_hip.so (the C ABI of include/vec2wav_hip.h).
+
+There is no fallback: if the library is missing, or an entry point reports an error, the caller
+gets an exception.  ``torch`` must be imported before the library is loaded so that both share the
+process's one HIP runtime (same ``libamdhip64.so.7``), which makes torch's stream handles and
+device pointers directly usable by the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+ABI_VERSION = 5
+V2W_MAX_STAGES = 8
+V2W_BN_SPLITS = 64
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class Conv1dArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp),
+                ('res', _fp), ('res_a', _fp), ('res_s', _fp), ('add0', _fp), ('add1', _fp), ('out', _fp),
+                ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
+                ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
+                ('out_div', C.c_float), ('algo', C.c_int32)]
+
+
+class ConvT1dArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
+                ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
+                ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32)]
+
+
+class PairArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp), ('wp1', _fp), ('bias1', _fp), ('wp2', _fp), ('bias2', _fp),
+                ('add0', _fp), ('add1', _fp), ('out', _fp),
+                ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32), ('k', C.c_int32), ('dil1', C.c_int32), ('dil2', C.c_int32),
+                ('res_mode', C.c_int32), ('slope', C.c_float), ('out_div', C.c_float)]
+
+
+class StageArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp),
+                ('wp1', _fp * 4), ('bias1', _fp * 4), ('wp2', _fp * 4), ('bias2', _fp * 4),
+                ('k', C.c_int32 * 4), ('dil1', C.c_int32 * 4), ('dil2', C.c_int32 * 4),
+                ('out', _fp), ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
+                ('slope', C.c_float), ('out_div', C.c_float)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [('v', _fp), ('g', _fp), ('wp', _fp), ('scale', _fp),
+                ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('u', C.c_int32), ('transposed', C.c_int32),
+                ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32)]
+
+
+_PA = _fp * V2W_MAX_STAGES
+
+
+class CondArgs(C.Structure):
+    _fields_ = [('spk', _fp), ('noise', _fp),
+                ('fc_w', _PA), ('fc_b', _PA), ('sn_w', _PA), ('sn_b', _PA), ('sn_u', _PA), ('sn_v', _PA),
+                ('gb', _PA), ('C', C.c_int32 * V2W_MAX_STAGES), ('z_ws', _fp), ('sigma_ws', _fp),
+                ('n_stages', C.c_int32), ('B', C.c_int32), ('spk_dim', C.c_int32), ('noise_dim', C.c_int32),
+                ('training', C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/vec2wav_hip.h declares
+SIGNATURES = {
+    'v2w_abi_version': (C.c_int, []),
+    'v2w_build_arch': (C.c_char_p, []),
+    'v2w_wn_fold_conv': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_wn_fold_convt': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
+    'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
+    'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
+    'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
+    'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
+    'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
+    'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
+    'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
+    'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
+    'v2w_bn_stats': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),
+    'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
+                                  C.c_float, C.c_float, _fp]),
+    'v2w_affine_apply': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_conv_post_tanh': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) and return the library handle; raises HipLibraryError when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            f'{path} not found: build it with `python -m wavthruvec_pytorch_amd.build` '
+            '(or __graft_entry__.build()); there is no CPU/PyTorch fallback for the Vec2Wav hot path')
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f'{path} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.v2w_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f'ABI version mismatch: library {lib.v2w_abi_version()}, binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        msg = {-1: 'bad argument', -2: 'unsupported shape for the requested algorithm', -3: 'unknown algorithm'}.get(rc, '?')
+        raise HipLibraryError(f'{what}: V2W error {rc} ({msg})')
+    raise HipLibraryError(f'{what}: hipError_t {rc}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,76 @@
+// extern "C" dispatch of the conv entry points declared in include/vec2wav_hip.h.
+#include "v2w_common.h"
+
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out);
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out);
+int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream);
+int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream);
+
+extern "C" int v2w_abi_version(void) { return V2W_ABI_VERSION; }
+extern "C" const char* v2w_build_arch(void) { return "gfx950"; }
+
+static int check_conv1d(const v2w_conv1d_args* a) {
+    if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
+    if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->dil <= 0) return V2W_E_ARG;
+    if ((a->k & 1) == 0) return V2W_E_SHAPE;                       // padding d*(k-1)/2 keeps the length only for odd k
+    if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
+    if ((a->res_a == nullptr) != (a->res_s == nullptr)) return V2W_E_ARG;
+    if (a->res_a && !a->res) return V2W_E_ARG;
+    if (a->add1 && !a->add0) return V2W_E_ARG;
+    if (a->add0 && a->accumulate) return V2W_E_ARG;               // either the running sum in `out` or explicit addends
+    return 0;
+}
+
+extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
+    if (const int rc = check_conv1d(a)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->algo) {
+        case V2W_ALGO_DIRECT: return a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG;
+        case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, 1, st, nullptr);
+        case V2W_ALGO_AUTO: {
+            const int rc = v2w_conv1d_mfma(a, 1, st, nullptr);
+            return rc == V2W_E_SHAPE ? (a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG) : rc;
+        }
+        default: return V2W_E_ALGO;
+    }
+}
+
+extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
+    if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
+    if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 0) return V2W_E_ARG;
+    if (a->k < a->u || ((a->k - a->u) & 1)) return V2W_E_SHAPE;    // L_out = u*L needs k-u even
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->algo) {
+        case V2W_ALGO_DIRECT: return (a->wf && !a->stats_part) ? v2w_convt1d_direct(a, st) : V2W_E_ARG;
+        case V2W_ALGO_MFMA: return v2w_convt1d_mfma(a, st, nullptr);
+        case V2W_ALGO_AUTO: {
+            const int rc = v2w_convt1d_mfma(a, st, nullptr);
+            return rc == V2W_E_SHAPE ? ((a->wf && !a->stats_part) ? v2w_convt1d_direct(a, st) : V2W_E_ARG) : rc;
+        }
+        default: return V2W_E_ALGO;
+    }
+}
+
+// Which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation V2W_ALGO_AUTO/MFMA picks for this problem
+// (pointers in `a` are not dereferenced).  Returns 0 and fills cfg[9], or V2W_E_SHAPE when the direct kernel is used.
+// cfg[10]: MF,U,MI,NI,WM,WN,CK,NPF,RING and cfg[9] = number of position tiles
+extern "C" int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    return v2w_conv1d_mfma(a, 1, nullptr, cfg);
+}
+extern "C" int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    return v2w_convt1d_mfma(a, nullptr, cfg);
+}
+
+// n (<= 4) fused convs that share B, C_in, C_out and L in ONE launch: the residual branches of a generator stage read the
+// same input / write independent outputs, so their tiles are mixed (heaviest first) instead of paying one launch tail each.
+// MFMA path only; V2W_E_SHAPE tells the caller to issue them one by one.
+extern "C" int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream) {
+    if (!a || n < 1 || n > 4) return V2W_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (const int rc = check_conv1d(a + i)) return rc;
+        if (a[i].algo == V2W_ALGO_DIRECT) return V2W_E_SHAPE;
+    }
+    return v2w_conv1d_mfma(a, n, (hipStream_t)stream, nullptr);
+}

@@ -1,0 +1,262 @@
+// Conditional BatchNorm pieces of the Vec2Wav generator (vec2wav/modules.py:5-30, models.py:120,131-134):
+//   cond_*      : z = fcs[i](cat(spk, noise)); legacy spectral-norm power iteration; [gamma|beta] = (W/sigma) z + b
+//   bn_stats    : per-channel sum / sum-of-squares over (B, L): wavefront shuffles -> block -> fixed-order fp64
+//   bn_finalize : mean / var / running-stat update and the folded per-sample affine a[b,c], s[b,c]
+// The normalised tensor itself is never written: consumers apply a*x + s while staging their tiles.
+#include "v2w_common.h"
+
+namespace {
+
+// ---- z[s][b][j] = fc_b[j] + sum_i fc_w[j][i] * cat(spk,noise)[b][i];  grid (B, n_stages), 128 threads (one per j)
+__global__ void __launch_bounds__(128)
+cond_fc_kernel(const v2w_cond_args a) {
+    extern __shared__ float sn[];   // cat(spk[b], noise[b])
+    const int b = blockIdx.x, s = blockIdx.y, j = threadIdx.x;
+    const int D = a.spk_dim + a.noise_dim;
+    for (int i = threadIdx.x; i < D; i += blockDim.x)
+        sn[i] = i < a.spk_dim ? a.spk[(size_t)b * a.spk_dim + i] : a.noise[(size_t)b * a.noise_dim + (i - a.spk_dim)];
+    __syncthreads();
+    if (!a.fc_w[s]) {   // no fcs layer in front (ConditionalBatchNorm1d used on its own): z is the input itself
+        a.z_ws[((size_t)s * a.B + b) * 128 + j] = sn[j];
+        return;
+    }
+    const float* w = a.fc_w[s] + (size_t)j * D;
+    float acc = 0.f;
+    for (int i = 0; i < D; ++i) acc = fmaf(w[i], sn[i], acc);
+    a.z_ws[((size_t)s * a.B + b) * 128 + j] = acc + a.fc_b[s][j];
+}
+
+// ---- legacy torch.nn.utils.spectral_norm hook (n_power_iterations = 1, eps = 1e-12); one 1024-thread block per stage.
+//   training: v <- normalize(W^T u); u <- normalize(W v)   (written back in place)
+//   sigma = u . (W v)
+__global__ void __launch_bounds__(1024)
+cond_sn_kernel(const v2w_cond_args a) {
+    __shared__ float v_s[128];
+    __shared__ float part[8][128];
+    __shared__ float red[16];
+    extern __shared__ float u_s[];   // [R] then wv[R]
+    const int s = blockIdx.x, R = 2 * a.C[s];
+    float* wv_s = u_s + R;
+    const float* W = a.sn_w[s];
+    const int tid = threadIdx.x;
+    for (int r = tid; r < R; r += 1024) u_s[r] = a.sn_u[s][r];
+    if (tid < 128) v_s[tid] = a.sn_v[s][tid];
+    __syncthreads();
+    const float eps = 1e-12f;
+    if (a.training) {
+        // v = W^T u : column j = tid % 128, rows r = tid/128 (mod 8): each row read is one coalesced 512-B line
+        const int j = tid & 127, q = tid >> 7;
+        float acc = 0.f;
+        for (int r = q; r < R; r += 8) acc = fmaf(W[(size_t)r * 128 + j], u_s[r], acc);
+        part[q][j] = acc;
+        __syncthreads();
+        float col = 0.f;
+        if (tid < 128) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) col += part[k][tid];   // fixed order
+        }
+        const float n2 = v2w_block_sum(tid < 128 ? col * col : 0.f, red);
+        const float inv = 1.f / fmaxf(sqrtf(n2), eps);
+        if (tid < 128) v_s[tid] = col * inv;
+        __syncthreads();
+    }
+    // wv = W v : one wave per row, lanes over the 128 columns
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < R; r += 16) {
+        float p = W[(size_t)r * 128 + lane] * v_s[lane] + W[(size_t)r * 128 + 64 + lane] * v_s[64 + lane];
+        p = v2w_wave_sum(p);
+        if (lane == 0) wv_s[r] = p;
+    }
+    __syncthreads();
+    if (a.training) {
+        float pp = 0.f;
+        for (int r = tid; r < R; r += 1024) pp += wv_s[r] * wv_s[r];
+        const float n2 = v2w_block_sum(pp, red);
+        const float inv = 1.f / fmaxf(sqrtf(n2), eps);
+        for (int r = tid; r < R; r += 1024) u_s[r] = wv_s[r] * inv;
+        __syncthreads();
+        for (int r = tid; r < R; r += 1024) a.sn_u[s][r] = u_s[r];
+        if (tid < 128) a.sn_v[s][tid] = v_s[tid];
+    }
+    float pp = 0.f;
+    for (int r = tid; r < R; r += 1024) pp += u_s[r] * wv_s[r];
+    const float sigma = v2w_block_sum(pp, red);
+    if (tid == 0) a.sigma_ws[s] = sigma;
+}
+
+// ---- gb[s][b][r] = sn_b[r] + (sum_j W[r][j] z[j]) / sigma ; grid (B, n_stages, row groups of 64), one wave per row
+__global__ void __launch_bounds__(256)
+cond_linear_kernel(const v2w_cond_args a) {
+    __shared__ float z_s[128];
+    const int b = blockIdx.x, s = blockIdx.y, R = 2 * a.C[s];
+    const int r0 = blockIdx.z * 64;
+    if (r0 >= R) return;
+    if (threadIdx.x < 128) z_s[threadIdx.x] = a.z_ws[((size_t)s * a.B + b) * 128 + threadIdx.x];
+    __syncthreads();
+    const float sigma = a.sigma_ws[s];
+    const float* W = a.sn_w[s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float z0 = z_s[lane], z1 = z_s[64 + lane];
+    for (int r = r0 + wave; r < min(R, r0 + 64); r += 4) {
+        // (W / sigma) z == (W z) / sigma up to one rounding of the row sum
+        float p = W[(size_t)r * 128 + lane] * z0 + W[(size_t)r * 128 + 64 + lane] * z1;
+        p = v2w_wave_sum(p);
+        if (lane == 0) a.gb[s][(size_t)b * R + r] = p / sigma + a.sn_b[s][r];
+    }
+}
+
+// ---- per-channel partial sums; grid (V2W_BN_SPLITS, C); each block covers a slice of L for every batch item
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int B, int C, int L, int slice) {
+    __shared__ double red[16];
+    const int sp = blockIdx.x, c = blockIdx.y;
+    const int lo = sp * slice, hi = min(L, lo + slice);
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* row = x + ((size_t)b * C + c) * L;
+        for (int l = lo + threadIdx.x; l < hi; l += 256) {
+            const float v = row[l];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+        }
+        // spill the fp32 running sums into fp64 once per batch item: bounds the fp32 chain length to slice/256
+        d1 += (double)s1; d2 += (double)s2; s1 = 0.f; s2 = 0.f;
+    }
+    const double t1 = v2w_block_sum(d1, red);
+    const double t2 = v2w_block_sum(d2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * V2W_BN_SPLITS + sp) * 2 + 0] = t1;
+        partial[((size_t)c * V2W_BN_SPLITS + sp) * 2 + 1] = t2;
+    }
+}
+
+__global__ void bn_reduce_kernel(const double* __restrict__ partial, double* __restrict__ stats, int C, double count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (c == 0) stats[2 * C] = count;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < V2W_BN_SPLITS; ++i) {   // fixed order -> run-to-run deterministic
+        s1 += partial[((size_t)c * V2W_BN_SPLITS + i) * 2 + 0];
+        s2 += partial[((size_t)c * V2W_BN_SPLITS + i) * 2 + 1];
+    }
+    stats[c] = s1;
+    stats[C + c] = s2;
+}
+
+// stats[c] = sum over tiles of part[tile][c][0..1] in fp64, fixed order; one block per channel
+__global__ void __launch_bounds__(256)
+bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ stats, int ntiles, int C, double count) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        s1 += (double)part[((size_t)t * C + c) * 2 + 0];
+        s2 += (double)part[((size_t)t * C + c) * 2 + 1];
+    }
+    const double t1 = v2w_block_sum(s1, red);
+    const double t2 = v2w_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        stats[c] = t1;
+        stats[C + c] = t2;
+        if (c == 0) stats[2 * C] = count;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gb,
+                                   float* running_mean, float* running_var, int64_t* nbt,
+                                   float* __restrict__ a_out, float* __restrict__ s_out,
+                                   int B, int C, int training, float momentum, float eps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx % C;
+    double mean, var, count = 1.0;
+    if (training) {
+        count = stats[2 * C];
+        mean = stats[c] / count;
+        var = stats[C + c] / count - mean * mean;   // biased (normalisation) variance
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gamma = gb[(size_t)b * 2 * C + c], beta = gb[(size_t)b * 2 * C + C + c];
+    const float av = gamma * rstd;
+    a_out[idx] = av;
+    s_out[idx] = fmaf(-av, (float)mean, beta);
+    if (training && b == 0) {
+        // F.batch_norm: running = (1-m)*running + m*stat, running_var with the UNBIASED batch variance
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        if (c == 0 && nbt) *nbt += 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ s,
+                    float* __restrict__ out, int L) {
+    const int row = blockIdx.y;   // b*C + c
+    const float av = a[row], sv = s[row];
+    const float* src = x + (size_t)row * L;
+    float* dst = out + (size_t)row * L;
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) dst[l] = fmaf(av, src[l], sv);
+}
+
+}  // namespace
+
+extern "C" int v2w_affine_apply(const float* x, const float* a, const float* s, float* out, int B, int C, int L, void* stream) {
+    if (!x || !a || !s || !out || B <= 0 || C <= 0 || L <= 0) return V2W_E_ARG;
+    int gx = (L + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, a, s, out, L);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream) {
+    if (!a || !a->spk || (!a->noise && a->noise_dim > 0) || !a->z_ws || !a->sigma_ws) return V2W_E_ARG;
+    if (a->spk_dim <= 0 || a->noise_dim < 0) return V2W_E_ARG;
+    if (a->n_stages <= 0 || a->n_stages > V2W_MAX_STAGES || a->B <= 0) return V2W_E_ARG;
+    int maxR = 0;
+    for (int s = 0; s < a->n_stages; ++s) {
+        if ((a->fc_w[s] == nullptr) != (a->fc_b[s] == nullptr)) return V2W_E_ARG;
+        if (!a->fc_w[s] && a->spk_dim + a->noise_dim != 128) return V2W_E_SHAPE;
+        if (!a->sn_w[s] || !a->sn_b[s] || !a->sn_u[s] || !a->sn_v[s] || !a->gb[s] || a->C[s] <= 0)
+            return V2W_E_ARG;
+        if (2 * a->C[s] > maxR) maxR = 2 * a->C[s];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_fc = (size_t)(a->spk_dim + a->noise_dim) * sizeof(float);
+    hipLaunchKernelGGL(cond_fc_kernel, dim3(a->B, a->n_stages), dim3(128), lds_fc, st, *a);
+    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), st, *a);
+    hipLaunchKernelGGL(cond_linear_kernel, dim3(a->B, a->n_stages, (maxR + 63) / 64), dim3(256), 0, st, *a);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_bn_stats(const float* x, double* stats, double* partial_ws, int B, int C, int L, void* stream) {
+    if (!x || !stats || !partial_ws || B <= 0 || C <= 0 || L <= 0) return V2W_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int slice = (L + V2W_BN_SPLITS - 1) / V2W_BN_SPLITS;
+    slice = (slice + 63) & ~63;   // keep wave-wide row reads aligned
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(V2W_BN_SPLITS, C), dim3(256), 0, st, x, partial_ws, B, C, L, slice);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial_ws, stats, C, (double)B * (double)L);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_bn_reduce_partials(const float* part, int ntiles, int C, double count, double* stats, void* stream) {
+    if (!part || !stats || ntiles <= 0 || C <= 0 || count <= 0.0) return V2W_E_ARG;
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, stats, ntiles, C, count);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* a_out, float* s_out, int B, int C, int training,
+                               float momentum, float eps, void* stream) {
+    if (!gb || !a_out || !s_out || !running_mean || !running_var || B <= 0 || C <= 0) return V2W_E_ARG;
+    if (training && !stats) return V2W_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps);
+    return v2w_launch_status();
+}

@@ -1,0 +1,67 @@
+// Shared device helpers for the Vec2Wav gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vec2wav_hip.h"
+
+#define V2W_WAVE 64  // CDNA wavefront width (hard-coded: warpSize folds to 64 on gfx950)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static inline int v2w_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+__device__ __forceinline__ float v2w_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// Sum over the 64 lanes of a wave (all lanes receive the total).
+__device__ __forceinline__ double v2w_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float v2w_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum for blocks of up to 1024 threads; `red` is >= 16 elements of LDS scratch.
+template <typename T>
+__device__ __forceinline__ T v2w_block_sum(T v, T* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    v = v2w_wave_sum(v);
+    __syncthreads();  // protect `red` against a previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    T t = 0;
+    for (int i = 0; i < nw; ++i) t += red[i];  // fixed order: deterministic
+    return t;
+}
+
+// ---- f32 MFMA fragments shared by the tile kernels.  A/B operands are ONE float per lane; for the 32x32x2 shape lane l
+// holds A[row l&31][k l>>5] / B[k l>>5][col l&31], for 16x16x4 A[l&15][l>>4] / B[l>>4][l&15].
+template <int MF> struct Frag;
+template <> struct Frag<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NREG = 16, KSTEP = 2;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    __device__ static __forceinline__ int row(int reg, int hk) { return (reg & 3) + 8 * (reg >> 2) + 4 * hk; }
+};
+template <> struct Frag<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NREG = 4, KSTEP = 4;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane&15, row = (lane>>4)*4 + reg
+    __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
+};
+

@@ -22,13 +22,42 @@
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
-#include "v2w_tile.h"
+#include "v2w_common.h"
 
 namespace {
 
-// MASK: the backward-only epilogue (leaky_relu-derivative mask) is compiled in.  It costs 8 VGPRs (one occupancy step on
-// the 128 x 128 tile), so forward launches use the MASK = false instantiation.
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, bool MASK>
+struct TileArgs {
+    const float* in; const float* in_a; const float* in_s;
+    const float* wp; const float* bias;
+    const float* res; const float* res_a; const float* res_s;
+    const float* add0; const float* add1;   // conv only, optional extra addends: out = ((add0 [+ add1]) + value)
+    float* out;
+    float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
+    int B, Cin, Cout, L, K, dil;
+    int pad;      // convT only: (K-U)/2
+    int hl, hr;   // halo (input positions) left / right of the tile
+    int hla;      // hl rounded up to a multiple of 4: LDS column 0 <-> position n0 - hla (16-B aligned rows)
+    int xw;       // LDS row stride of the input tile (floats)
+    int xcols;    // columns actually staged (multiple of 4)
+    int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging
+    int atab_off; // LDS offset (floats) of the affine table: after the 1 or 2 signal buffers
+    int ntl;      // position tiles per batch item
+    int ntiles;   // B * ntl
+    float slope;
+    int accumulate;
+    float out_div;
+    int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
+};
+
+#define V2W_MAX_MULTI 4
+// Up to V2W_MAX_MULTI problems of identical tile configuration in one launch (the residual branches of a stage):
+// blocks [start[q], start[q+1]) belong to problem q; heaviest problem first so the tail of the launch is made of light tiles.
+struct MultiArgs {
+    TileArgs p[V2W_MAX_MULTI];
+    int start[V2W_MAX_MULTI + 1];
+};
+
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_tile_kernel(const MultiArgs m) {
     typedef Frag<MF> F;
@@ -72,8 +101,8 @@ conv_tile_kernel(const MultiArgs m) {
     const float slope = p.slope;
     const int nch = p.Cin / CK;
     const int pos0 = n0 - p.hla;           // position of LDS column 0
-    float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias, res_a, res_s, mask_a, mask_s [MT] each
-    float* const atab = etab + 5 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
+    float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias[MT], res_a[MT], res_s[MT]
+    float* const atab = etab + 3 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
 
     acc_t acc[U][MI][NI];
 #pragma unroll
@@ -129,16 +158,16 @@ conv_tile_kernel(const MultiArgs m) {
             *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
         }
     };
-    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment / input stride: dword loads straight into LDS
+    auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment: dword loads straight into LDS
         for (int c = wave; c < CK; c += WM * WN) {
             const int ch = b * p.Cin + ci0 + c;
-            const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
+            const float* src = p.in + (size_t)ch * L;
             const float av = p.in_a ? p.in_a[ch] : 1.f;
             const float sv = p.in_s ? p.in_s[ch] : 0.f;
             for (int j = lane; j < p.xcols; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
-                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[(size_t)l * p.in_stride], sv), slope);
+                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[l], sv), slope);
                 Xs[c * xw + j] = v;
             }
         }
@@ -178,8 +207,6 @@ conv_tile_kernel(const MultiArgs m) {
         etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
         etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
         etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
-        etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
-        etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
     }
     if (p.in_a) {
         for (int c = tid; c < p.Cin; c += NTHREADS) {
@@ -253,7 +280,7 @@ conv_tile_kernel(const MultiArgs m) {
             constexpr int EG = (MI == 1 && F::NREG >= 8) ? 8 : 4;
 #pragma unroll
             for (int e0 = 0; e0 < F::NREG; e0 += EG) {
-                float rv[EG][NI], ov[EG][NI], o2[EG][NI], mv[MASK ? EG : 1][MASK ? NI : 1];
+                float rv[EG][NI], ov[EG][NI], o2[EG][NI];
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
                     const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
@@ -264,7 +291,6 @@ conv_tile_kernel(const MultiArgs m) {
                         rv[ee][j] = (p.res && q < L) ? p.res[orow + q] : 0.f;
                         ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : ((p.add0 && q < L) ? p.add0[orow + q] : 0.f);
                         o2[ee][j] = (p.add1 && q < L) ? p.add1[orow + q] : 0.f;
-                        if constexpr (MASK) mv[ee][j] = (p.mask_src && q < L) ? p.mask_src[orow + q] : 1.f;
                     }
                 }
 #pragma unroll
@@ -277,10 +303,7 @@ conv_tile_kernel(const MultiArgs m) {
                     for (int j = 0; j < NI; ++j) {
                         const int q = n0 + wn0 + j * MF + lr;
                         if (q >= L) continue;
-                        float v = acc[0][i][j][e];
-                        if constexpr (MASK)   // backward through the leaky_relu in front of the forward conv: d/dx lrelu = 1 or slope
-                            if (p.mask_src) v = fmaf(etab[3 * MT + col], mv[ee][j], etab[4 * MT + col]) > 0.f ? v : v * p.mask_slope;
-                        v += bias;
+                        float v = acc[0][i][j][e] + bias;
                         if (p.res) v += fmaf(ra, rv[ee][j], rs);
                         if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
                         else if (p.accumulate || p.add0) v += ov[ee][j];
@@ -386,11 +409,10 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         int xw = p.xcols;
         if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
         p.xw = xw;
-        if (p.in_stride < 1) p.in_stride = 1;
-        p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) && p.in_stride == 1;
+        p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
         const int nbuf = p.Cin / CK > 1 ? 2 : 1;
         p.atab_off = nbuf * CK * xw;
-        const size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        const size_t l = ((size_t)p.atab_off + 3 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
         if (l > lds) lds = l;
         m.p[i] = p;
         m.start[i] = grid;
@@ -399,9 +421,7 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     for (int i = nprob; i <= V2W_MAX_MULTI; ++i) m.start[i] = i == nprob ? grid : 0x7fffffff;
     m.start[nprob] = grid;
     for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
-    bool mask = false;
-    for (int i = 0; i < nprob; ++i) mask = mask || m.p[i].mask_src != nullptr;
-    auto kern = mask ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, false>;
+    auto kern = conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -529,7 +549,6 @@ static LayerCfg v2w_layer_cfg(int c_in, int c_out, int u) {
     if (c_in % 16 != 0) return c;
     if (u == 1) {
         if (c_out % 32 == 0 && c_in % 32 == 0) c = {32, 32};
-        else if (c_out % 32 == 0) c = {32, 16};      // C_in = 16 (+32k): backward of the narrowest upsampler
         else if (c_out == 16) c = {16, 16};
     } else if (u == 2 || u == 4 || u == 5 || u == 8) {
         if (c_out % 64 == 0 || c_out == 32) c = {32, 16};
@@ -565,23 +584,19 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wp = q->wp; p.bias = q->bias;
         p.res = q->res; p.res_a = q->res_a; p.res_s = q->res_s; p.out = q->out;
         p.add0 = q->add0; p.add1 = q->add1;
-        p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
         p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
-        if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
-        p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
     }
-    if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 128 == 0) {
+    if (cfg.mf == 32 && a->C_out % 128 == 0) {
         // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
         if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(ps, n, stream);
         return launch_tile<32, 1, 2, 1, 2, 2, 32>(ps, n, stream);
     }
     // (64 x 256 and 64 x 128 single-row-block variants measured slower on MI355X: 52-92 / 61-90 vs 64-93 TF)
-    if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
-    if (cfg.mf == 32 && cfg.ck == 16) return launch_tile<32, 1, 1, 2, 1, 4, 16>(ps, n, stream);
+    if (cfg.mf == 32 && a->C_out % 64 == 0) return launch_tile<32, 1, 1, 2, 2, 2, 32>(ps, n, stream);
     if (cfg.mf == 32) return launch_tile<32, 1, 1, 2, 1, 4, 32>(ps, n, stream);
     if (cfg.mf == 16) return launch_tile<16, 1, 1, 4, 1, 4, 16>(ps, n, stream);
     return V2W_E_SHAPE;

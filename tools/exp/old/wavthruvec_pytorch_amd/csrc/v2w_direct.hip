@@ -1,0 +1,168 @@
+// Scalar-FMA kernels: the any-shape path of the conv entry points (V2W_ALGO_DIRECT) and the fused tail
+// leaky_relu -> conv_post -> tanh (models.py:143-145).  One thread per output sample, lanes along the
+// frame axis so every global access is coalesced.
+#include "v2w_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+conv1d_direct_kernel(const v2w_conv1d_args a) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int co = blockIdx.y, b = blockIdx.z;
+    if (l >= a.L) return;
+    const int pad = a.dil * (a.k - 1) / 2;
+    float acc = 0.f;
+    for (int ci = 0; ci < a.C_in; ++ci) {
+        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L;
+        const float av = a.in_a ? a.in_a[b * a.C_in + ci] : 1.f;
+        const float sv = a.in_s ? a.in_s[b * a.C_in + ci] : 0.f;
+        for (int t = 0; t < a.k; ++t) {
+            const int li = l + t * a.dil - pad;
+            if (li < 0 || li >= a.L) continue;
+            const float x = v2w_lrelu(fmaf(av, src[li], sv), a.slope);
+            acc = fmaf(a.wf[((size_t)t * a.C_in + ci) * a.C_out + co], x, acc);
+        }
+    }
+    const size_t o = ((size_t)b * a.C_out + co) * a.L + l;
+    float v = acc + (a.bias ? a.bias[co] : 0.f);
+    if (a.res) {
+        const float ra = a.res_a ? a.res_a[b * a.C_out + co] : 1.f;
+        const float rs = a.res_s ? a.res_s[b * a.C_out + co] : 0.f;
+        v += fmaf(ra, a.res[o], rs);
+    }
+    if (a.add1) v += a.add0[o] + a.add1[o];
+    else if (a.add0) v += a.add0[o];
+    else if (a.accumulate) v += a.out[o];
+    if (a.out_div != 0.f) v = v / a.out_div;
+    a.out[o] = v;
+}
+
+__global__ void __launch_bounds__(256)
+convt1d_direct_kernel(const v2w_convt1d_args a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;   // output position
+    const int co = blockIdx.y, b = blockIdx.z;
+    const int Lout = a.L * a.u;
+    if (n >= Lout) return;
+    const int pad = (a.k - a.u) / 2;
+    // out[n] = sum_{i,t : i*u - pad + t = n} in[i] * w[t]   (torch ConvTranspose1d)
+    const int t0 = (n + pad) % a.u;
+    float acc = 0.f;
+    for (int ci = 0; ci < a.C_in; ++ci) {
+        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L;
+        for (int t = t0; t < a.k; t += a.u) {
+            const int i = (n + pad - t) / a.u;
+            if (n + pad - t < 0 || i >= a.L) continue;
+            const float x = v2w_lrelu(src[i], a.slope);
+            acc = fmaf(a.wf[((size_t)t * a.C_in + ci) * a.C_out + co], x, acc);
+        }
+    }
+    a.out[((size_t)b * a.C_out + co) * Lout + n] = acc + (a.bias ? a.bias[co] : 0.f);
+}
+
+// Tail: each thread produces 4 consecutive samples from a register window of 4 + (k-1) inputs per channel.
+// HBM-bound (3.3 FLOP/B): the input is read once (neighbour overlap is served by L1/L2), the output written once.
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+conv_post_tanh_kernel(const float* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
+                      float* __restrict__ out, int B, int Cin, int L, int k, float slope) {
+    extern __shared__ float w_s[];   // [k][Cin]
+    for (int i = threadIdx.x; i < k * Cin; i += blockDim.x) w_s[i] = wf[i];
+    __syncthreads();
+    const int pad = (k - 1) / 2;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (l0 >= L) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* src = in + ((size_t)b * Cin + ci) * L;
+        float win[4 + KMAX - 1];
+#pragma unroll
+        for (int j = 0; j < 4 + KMAX - 1; ++j) {
+            const int li = l0 - pad + j;
+            win[j] = (j < 4 + k - 1 && li >= 0 && li < L) ? v2w_lrelu(src[li], slope) : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t < k) {
+                const float w = w_s[t * Cin + ci];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(w, win[o + t], acc[o]);
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float* dst = out + (size_t)b * L + l0;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (l0 + o < L) dst[o] = tanhf(acc[o] + bv);
+}
+
+// Vectorised tail for L % 4 == 0 and k <= 9: per channel three aligned float4 loads cover the 4 outputs' window
+// [l0-4, l0+8); every load is a full 16 B/lane coalesced access.
+__global__ void __launch_bounds__(256)
+conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
+                           float* __restrict__ out, int B, int Cin, int L, int k, float slope) {
+    extern __shared__ float w_s[];   // [k][Cin]
+    for (int i = threadIdx.x; i < k * Cin; i += blockDim.x) w_s[i] = wf[i];
+    __syncthreads();
+    const int pad = (k - 1) / 2;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (l0 >= L) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* src = in + ((size_t)b * Cin + ci) * L + l0;
+        const f32x4 lo = l0 >= 4 ? *reinterpret_cast<const f32x4*>(src - 4) : zero4;
+        const f32x4 mid = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi = l0 + 4 < L ? *reinterpret_cast<const f32x4*>(src + 4) : zero4;
+        float win[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { win[e] = v2w_lrelu(lo[e], slope); win[4 + e] = v2w_lrelu(mid[e], slope); win[8 + e] = v2w_lrelu(hi[e], slope); }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < k) {
+                const float w = w_s[t * Cin + ci];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(w, win[4 + o + t - pad], acc[o]);   // pad <= 4
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    f32x4 y;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) y[o] = tanhf(acc[o] + bv);
+    *reinterpret_cast<f32x4*>(out + (size_t)b * L + l0) = y;
+}
+
+}  // namespace
+
+int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
+    dim3 grid((a->L + 255) / 256, a->C_out, a->B);
+    hipLaunchKernelGGL(conv1d_direct_kernel, grid, dim3(256), 0, stream, *a);
+    return v2w_launch_status();
+}
+
+int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream) {
+    dim3 grid((a->L * a->u + 255) / 256, a->C_out, a->B);
+    hipLaunchKernelGGL(convt1d_direct_kernel, grid, dim3(256), 0, stream, *a);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
+                                  int B, int C_in, int L, int k, float slope, void* stream) {
+    if (!in || !wf || !out || B <= 0 || C_in <= 0 || L <= 0 || k <= 0 || (k & 1) == 0) return V2W_E_ARG;
+    if (k > 15) return V2W_E_SHAPE;
+    dim3 grid((L + 1023) / 1024, B);
+    const size_t lds = (size_t)k * C_in * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (aligned && k <= 9) {
+        hipLaunchKernelGGL(conv_post_tanh_vec4_kernel, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+        return v2w_launch_status();
+    }
+    if (k <= 7) hipLaunchKernelGGL(conv_post_tanh_kernel<7>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    else hipLaunchKernelGGL(conv_post_tanh_kernel<15>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    return v2w_launch_status();
+}

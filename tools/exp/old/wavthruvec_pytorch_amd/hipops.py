@@ -13,7 +13,7 @@ import torch
 
 from . import _hip
 
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA, _hip.ALGO_SPLIT
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA
 
 
 def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
@@ -57,25 +57,6 @@ def fold_convt_weight(v, g, out=None, scratch=None):
     return out
 
 
-def transpose_flip(wf, out=None):
-    """wf [k][C_in][C_out] -> dgrad weights [k][C_out][C_in] (taps reversed)."""
-    k, ci, co = wf.shape
-    if out is None:
-        out = torch.empty((k, co, ci), device=wf.device, dtype=torch.float32)
-    _hip.check(_hip.load().v2w_wf_transpose_flip(wf.data_ptr(), out.data_ptr(), k, ci, co, _stream(wf)), 'v2w_wf_transpose_flip')
-    return out
-
-
-def gather_transpose(wf, t_start, t_step, n, out=None):
-    """out[m][C_out][C_in] = wf[t_start + m*t_step][C_in][C_out], m < n (dgrad weights of one transposed-conv phase)."""
-    k, ci, co = wf.shape
-    if out is None:
-        out = torch.empty((n, co, ci), device=wf.device, dtype=torch.float32)
-    _hip.check(_hip.load().v2w_wf_gather_transpose(wf.data_ptr(), out.data_ptr(), k, ci, co, t_start, t_step, n, _stream(wf)),
-               'v2w_wf_gather_transpose')
-    return out
-
-
 def pack_mfma(wf, out=None, u=1):
     """wf [k][C_in][C_out] -> the same weights as the MFMA A-fragment stream of that layer (u = 1 conv, stride for convT),
     or None when the layer has no MFMA tile configuration."""
@@ -89,49 +70,17 @@ def pack_mfma(wf, out=None, u=1):
     return out
 
 
-def split_supported(c_in, c_out, u=1):
-    """True when the split-f16 kernel (ALGO_SPLIT) serves this layer shape."""
-    return bool(_hip.load().v2w_split_supported(c_in, c_out, u))
-
-
-def split_halves(k, c_in, c_out):
-    """Elements (f16) of the wps buffer of one layer: two halves per weight + one 2 KiB unit of padding (the kernel's
-    stage copies always move whole tap pairs)."""
-    return k * c_in * c_out * 2 + 1024
-
-
-def pack_split(wf, out=None, sc=None):
-    """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
-    scale record (sc[0] = 1/scale is the kernel's `winv`)."""
-    k, ci, co = wf.shape
-    if out is None:
-        out = torch.empty((split_halves(k, ci, co),), device=wf.device, dtype=torch.float16)
-    if sc is None:
-        sc = torch.empty((4,), device=wf.device, dtype=torch.float32)
-    _hip.check(_hip.load().v2w_pack_split(wf.data_ptr(), out.data_ptr(), sc.data_ptr(), k, ci, co, _stream(wf)), 'v2w_pack_split')
-    return out, sc
-
-
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
-                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None):
-    B, ci, Lx = x.shape
-    L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
-    a.in_stride, a.in_phase, a.pad_left = in_stride, in_phase, pad_left
+                 accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None):
+    B, ci, L = x.shape
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
     a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
-    if wps is not None:           # (fragments, scale record) of pack_split
-        a.wps, a.winv = wps[0].data_ptr(), wps[1].data_ptr()
     a.res = _hip.ptr(res)
     a.res_a, a.res_s = (_hip.ptr(res_affine[0]), _hip.ptr(res_affine[1])) if res_affine is not None else (None, None)
     add = list(add or [])
     a.add0 = _hip.ptr(add[0]) if len(add) > 0 else None
     a.add1 = _hip.ptr(add[1]) if len(add) > 1 else None
-    if mask is not None:          # (mask_src, (mask_a, mask_s) | None)
-        a.mask_src = mask[0].data_ptr()
-        a.mask_a, a.mask_s = (mask[1][0].data_ptr(), mask[1][1].data_ptr()) if mask[1] is not None else (None, None)
-    a.mask_slope = mask_slope
     a.out = out.data_ptr()
     a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, out.shape[1], L, k, dil
     a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
@@ -229,14 +178,13 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
     cfg = (C.c_int32 * 10)()
     if u == 1:
         a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
-        a.pad_left = -1
         rc = _hip.load().v2w_conv1d_tile_config(C.byref(a), cfg)
     else:
         a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
         rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
     if rc != 0:
         return None
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', false>'   # forward instantiation (MASK = false)
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + '>'
 
 
 def convt_stats_tiles(B, c_in, c_out, L, k, u):
@@ -284,40 +232,6 @@ class FoldPlan:
                    'v2w_fold_pack_batch')
 
 
-class SplitPlan:
-    """Device-resident descriptor table for v2w_split_pack_batch: every split-f16 layer folded (weight norm) and packed into
-    its (hi, lo) fragment stream in three launches."""
-
-    def __init__(self, layers, device):
-        """layers: list of (v (C_out, C_in, k), g|None, wps, sc) with tensors already on `device`."""
-        n = len(layers)
-        self.n = n
-        self.rowscale = torch.empty((sum(v.shape[0] for v, *_ in layers),), device=device, dtype=torch.float32)
-        descs = (_hip.SplitDesc * n)()
-        starts = [0] * (2 * (n + 1))
-        off = blocks = 0
-        for i, (d, (v, g, wps, sc)) in enumerate(zip(descs, layers)):
-            co, ci, k = v.shape
-            d.v = v.data_ptr(); d.g = _hip.ptr(g); d.wps = wps.data_ptr(); d.sc = sc.data_ptr()
-            d.rowscale = self.rowscale.data_ptr() + 4 * off
-            d.c_in, d.c_out, d.k = ci, co, k
-            starts[i], starts[n + 1 + i] = off, blocks
-            off += co
-            blocks += (co // 32) * (ci // 16)
-        starts[n], starts[2 * n + 1] = off, blocks
-        self.nblk_rows, self.nblk_pack = off, blocks
-        self.k_max = max(v.shape[2] for v, *_ in layers)
-        self.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
-        self.starts_dev = torch.tensor(starts, dtype=torch.int32, device=device)
-        self.key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in layers)
-
-    def run(self):
-        _hip.check(_hip.load().v2w_split_pack_batch(self.descs_dev.data_ptr(), self.starts_dev.data_ptr(), self.n,
-                                                    self.nblk_rows, self.nblk_pack, self.k_max,
-                                                    torch.cuda.current_stream(self.rowscale.device).cuda_stream),
-                   'v2w_split_pack_batch')
-
-
 def resblock_pair_multi(problems):
     """`problems`: list of dicts(x, in_affine, wp1, b1, wp2, b2, out, k, dil1, dil2, res_mode, slope, add, out_div) sharing B, C, L.
     Returns False (nothing launched) when the fused pair kernel does not take the shape."""
@@ -362,106 +276,3 @@ def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
         return False
     _hip.check(rc, 'v2w_resblock2_stage_fwd')
     return True
-
-
-def wgrad(x, dy, *, k, dil=1, u=1, slope=1.0, x_affine=None, out=None):
-    """Weight gradient dwf [k][C_in][C_out] of a fused lrelu -> Conv1d (u = 1) or lrelu -> ConvTranspose1d (stride u).
-    x (B, C_in, Lq) is the forward conv's input (before the affine / activation), dy (B, C_out, u*Lq) the output gradient."""
-    B, ci, Lq = x.shape
-    co = dy.shape[1]
-    lib = _hip.load()
-    ns = lib.v2w_wgrad_slabs(B, ci, co, Lq)
-    if ns == 0:
-        raise _hip.HipLibraryError(f'v2w_wgrad: no configuration for C_in={ci}, C_out={co}')
-    if out is None:
-        out = torch.empty((k, ci, co), device=x.device, dtype=torch.float32)
-    slab = torch.empty((ns * k * ci * co,), device=x.device, dtype=torch.float32)
-    xa, xs = (x_affine[0].data_ptr(), x_affine[1].data_ptr()) if x_affine is not None else (None, None)
-    _hip.check(lib.v2w_wgrad(x.data_ptr(), xa, xs, dy.data_ptr(), out.data_ptr(), slab.data_ptr(), B, ci, co, Lq, k, dil, u, slope,
-                             _stream(x)), 'v2w_wgrad')
-    return out
-
-
-def convt1d_dgrad(dy, wf, out, *, k, u, mask=None, mask_slope=1.0, algo=ALGO_AUTO):
-    """Input gradient of the fused lrelu -> ConvTranspose1d(k, stride u, pad (k-u)/2): dx = lrelu'(x) * sum over the u
-    output phases of a small Conv1d on that phase of dy.  dy (B, C_out, u*L), wf [k][C_in][C_out], out (B, C_in, L)."""
-    pad = (k - u) // 2
-    L = out.shape[2]
-    for r in range(u):
-        t0, c = (r + pad) % u, (r + pad) // u
-        nt = (k - t0 + u - 1) // u
-        wr = gather_transpose(wf, t0, u, nt)                   # [nt][C_out][C_in]
-        conv1d(dy, wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask, mask_slope=mask_slope,
-               in_stride=u, in_phase=r, pad_left=c, L=L, algo=algo)
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# backward building blocks
-def cbn_backward(dx, xr, gb, stats, running_mean, running_var, *, training, eps=1e-5, sync=None):
-    """CondBN backward: returns (dxr, dgb).  `sync(csum)` all-reduces the per-channel sums in data-parallel runs."""
-    B, Cc, L = dx.shape
-    dev = dx.device
-    lib = _hip.load()
-    s12 = torch.empty((2 * B * Cc,), device=dev)
-    dgb = torch.empty((B, 2 * Cc), device=dev)
-    csum = torch.empty((2 * Cc,), device=dev, dtype=torch.float64)
-    st = _stream(dx)
-    _hip.check(lib.v2w_cbn_bwd_sums(dx.data_ptr(), xr.data_ptr(), gb.data_ptr(), _hip.ptr(stats), running_mean.data_ptr(),
-                                    running_var.data_ptr(), s12.data_ptr(), dgb.data_ptr(), csum.data_ptr(), B, Cc, L,
-                                    int(training), eps, st), 'v2w_cbn_bwd_sums')
-    if sync is not None and training:
-        sync(csum)
-    tab = torch.empty((B * Cc + 2 * Cc,), device=dev)
-    dxr = torch.empty_like(dx)
-    _hip.check(lib.v2w_cbn_bwd_apply(dx.data_ptr(), xr.data_ptr(), gb.data_ptr(), _hip.ptr(stats), csum.data_ptr(),
-                                     running_mean.data_ptr(), running_var.data_ptr(), tab.data_ptr(), dxr.data_ptr(), B, Cc, L,
-                                     int(training), eps, st), 'v2w_cbn_bwd_apply')
-    return dxr, dgb
-
-
-def tail_backward(dy, y, x, wf, *, k, slope):
-    """tanh + conv_post backward: returns (dx, dwf [k][C_in][1], dp) - d bias = dp.sum()."""
-    B, ci, L = x.shape
-    dev = x.device
-    dp = torch.empty((B, 1, L), device=dev)
-    part = torch.empty((ci * k * 64,), device=dev, dtype=torch.float64)
-    dx = torch.empty_like(x)
-    dwf = torch.empty((k, ci, 1), device=dev)
-    _hip.check(_hip.load().v2w_tail_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), wf.data_ptr(), dp.data_ptr(), part.data_ptr(),
-                                        dx.data_ptr(), dwf.data_ptr(), B, ci, L, k, slope, _stream(x)), 'v2w_tail_bwd')
-    return dx, dwf, dp
-
-
-def wn_backward(dwf, v, g, transposed):
-    """(dwf [k][C_in][C_out], weight_v, weight_g | None) -> (dv, dg | None)."""
-    k, ci, co = dwf.shape
-    dv = torch.empty_like(v)
-    dg = torch.empty_like(g) if g is not None else None
-    _hip.check(_hip.load().v2w_wn_bwd(dwf.data_ptr(), v.data_ptr(), _hip.ptr(g), dv.data_ptr(), _hip.ptr(dg), ci, co, k,
-                                      int(transposed), _stream(dwf)), 'v2w_wn_bwd')
-    return dv, dg
-
-
-def cond_backward(dgb, z, sn_w, sn_u, sn_v, sigma, spk, noise):
-    """One stage's conditioning backward -> (d weight_orig, d layer.bias, d fcs.weight, d fcs.bias)."""
-    B, R = dgb.shape
-    dev = dgb.device
-    d_w = torch.empty_like(sn_w); d_b = torch.empty((R,), device=dev)
-    D = spk.shape[1] + noise.shape[1]
-    d_fw = torch.empty((128, D), device=dev); d_fb = torch.empty((128,), device=dev)
-    ws = torch.empty((B * 128 + 1,), device=dev)
-    _hip.check(_hip.load().v2w_cond_bwd(dgb.data_ptr(), z.data_ptr(), sn_w.data_ptr(), sn_u.data_ptr(), sn_v.data_ptr(),
-                                        sigma.data_ptr(), spk.data_ptr(), noise.data_ptr(), d_w.data_ptr(), d_b.data_ptr(),
-                                        d_fw.data_ptr(), d_fb.data_ptr(), ws.data_ptr(), B, R // 2, spk.shape[1], noise.shape[1],
-                                        _stream(dgb)), 'v2w_cond_bwd')
-    return d_w, d_b, d_fw, d_fb
-
-
-def channel_sum(x):
-    """sum over (B, L) per channel of x (B, C, L) -> (C,) fp32: bias gradients (fp64 accumulation inside)."""
-    B, Cc, L = x.shape
-    stats = torch.empty((2 * Cc + 1,), device=x.device, dtype=torch.float64)
-    part = torch.empty((2 * Cc * _hip.V2W_BN_SPLITS,), device=x.device, dtype=torch.float64)
-    bn_stats(x, stats, part)
-    return stats[:Cc].float()

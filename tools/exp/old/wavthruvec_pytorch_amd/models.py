@@ -1,0 +1,516 @@
+"""Vec2Wav `Generator` with the reference's Python surface and a hand-written HIP forward.
+
+Mirrors /root/reference/vec2wav/models.py:13-156 - `Generator(h)`, `forward(x, spk_emb, noise)`,
+`remove_weight_norm()`, `ResBlock1`, `ResBlock2`, `LRELU_SLOPE`, identical `state_dict` keys and shapes -
+so it drops into `vec2wav/train.py` (`from models import Generator`) and loads `g_%08d` checkpoints.
+The modules below only HOLD parameters; `Generator.forward` runs the whole path through the C ABI of
+libvec2wav_hip.so (include/vec2wav_hip.h).  There is no PyTorch/CPU fallback: CPU tensors or a missing
+library raise.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import hipops
+from .modules import ConditionalBatchNorm1d
+from .utils import get_padding, init_weights  # noqa: F401  (re-exported like the reference's models.py)
+
+LRELU_SLOPE = 0.1  # models.py:10
+_Z_CHANNEL = 128   # models.py:110
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders with the key names torch.nn.utils.weight_norm produces (bias, weight_g, weight_v)
+# ------------------------------------------------------------------------------------------------
+class _WNConvBase(nn.Module):
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation, self.padding = kernel_size, stride, dilation, padding
+        wshape = (in_channels, out_channels, kernel_size) if self.transposed else (out_channels, in_channels, kernel_size)
+        fan_in = wshape[1] * kernel_size
+        bound = 1.0 / math.sqrt(fan_in)
+        v = torch.empty(wshape).uniform_(-bound, bound)  # nn.Conv default (kaiming_uniform a=sqrt(5))
+        self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        # weight_norm(dim=0): g = ||v|| over all dims but 0, so that w == v at construction
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+        self.weight_v = nn.Parameter(v)
+
+    @property
+    def weight_normed(self) -> bool:
+        return 'weight_g' in self._parameters
+
+    def remove_weight_norm(self):
+        """`torch.nn.utils.remove_weight_norm`: fold g, v into a plain `weight` parameter (keys: bias, weight)."""
+        if not self.weight_normed:
+            raise ValueError(f'weight_norm of \'weight\' not found in {self}')
+        with torch.no_grad():
+            v, g = self.weight_v, self.weight_g
+            w = v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        del self._parameters['weight_g']
+        del self._parameters['weight_v']
+        self.weight = nn.Parameter(w.detach())
+
+    def extra_repr(self):
+        s = f'{self.in_channels}, {self.out_channels}, kernel_size=({self.kernel_size},), stride=({self.stride},)'
+        if self.padding:
+            s += f', padding=({self.padding},)'
+        if self.dilation != 1:
+            s += f', dilation=({self.dilation},)'
+        return s
+
+
+class Conv1d(_WNConvBase):
+    """Holder for `weight_norm(nn.Conv1d(cin, cout, k, 1, dilation=d, padding=get_padding(k, d)))`."""
+    transposed = False
+
+
+class ConvTranspose1d(_WNConvBase):
+    """Holder for `weight_norm(nn.ConvTranspose1d(cin, cout, k, u, padding=(k-u)//2))`."""
+    transposed = True
+
+
+class ResBlock1(nn.Module):
+    """models.py:13-50: three (dilated conv, conv) pairs with residuals."""
+
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.h = h
+        self.channels, self.kernel_size, self.dilation = channels, kernel_size, tuple(dilation)
+        self.convs1 = nn.ModuleList([
+            Conv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d))
+            for d in dilation[:3]])
+        self.convs2 = nn.ModuleList([
+            Conv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1))
+            for _ in range(3)])
+
+    def forward(self, x):
+        raise RuntimeError('ResBlock1 only holds parameters here; it runs fused inside Generator.forward (HIP)')
+
+    def remove_weight_norm(self):
+        for l in self.convs1:
+            l.remove_weight_norm()
+        for l in self.convs2:
+            l.remove_weight_norm()
+
+
+class ResBlock2(nn.Module):
+    """models.py:53-74: two dilated convs with residuals (uses dilation[0], dilation[1] only)."""
+
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.h = h
+        self.channels, self.kernel_size, self.dilation = channels, kernel_size, tuple(dilation)
+        self.convs = nn.ModuleList([
+            Conv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d))
+            for d in dilation[:2]])
+
+    def forward(self, x):
+        raise RuntimeError('ResBlock2 only holds parameters here; it runs fused inside Generator.forward (HIP)')
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            l.remove_weight_norm()
+
+
+class _NoBackward(torch.autograd.Function):
+    """Marks the HIP forward in the autograd graph so that a backward attempt fails loudly instead of silently
+    producing no gradients (native backward kernels are the next scope row)."""
+
+    @staticmethod
+    def forward(ctx, y, *deps):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(
+            'wavthruvec_pytorch_amd.Generator: the HIP forward has no backward yet; run it under torch.no_grad() '
+            '(inference / validation / the discriminator step on y_g_hat.detach())')
+
+
+class Generator(nn.Module):
+    """HiFi-GAN-style Vec2Wav generator (reference: vec2wav/models.py:77-156)."""
+
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h.resblock_kernel_sizes)
+        self.num_upsamples = len(h.upsample_rates)
+        if self.num_upsamples > 8:
+            raise ValueError('at most 8 upsample stages are supported')
+        c0 = h.upsample_initial_channel
+        self.conv_pre = Conv1d(h.num_wv_feat, c0, 7, 1, padding=3)
+        resblock = ResBlock1 if h.resblock == '1' else ResBlock2   # models.py:84 (string compare)
+
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            self.ups.append(ConvTranspose1d(c0 // (2 ** i), c0 // (2 ** (i + 1)), k, u, padding=(k - u) // 2))
+
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(len(self.ups)):
+            ch = c0 // (2 ** (i + 1))
+            for j, (k, d) in enumerate(zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes)):
+                self.resblocks.append(resblock(h, ch, k, d))
+
+        self.conv_post = Conv1d(ch, 1, 7, 1, padding=3)
+
+        self.cbns = nn.ModuleList()
+        self.fcs = nn.ModuleList()
+        for i in range(len(self.ups)):
+            self.fcs.append(nn.Linear(h.spk_dim + h.noise_dim, _Z_CHANNEL))
+            self.cbns.append(ConditionalBatchNorm1d(256 // pow(2, i)))   # hard-coded widths, models.py:113
+            if self.cbns[i].num_features != self.ups[i].out_channels:
+                raise ValueError('ConditionalBatchNorm1d widths are 256 // 2**i (models.py:113): '
+                                 'upsample_initial_channel must be 512')
+
+        # ---- HIP-path state (not part of the state_dict)
+        self.algo = hipops.ALGO_AUTO          # hipops.ALGO_DIRECT forces the scalar cross-check kernels
+        self.stat_sync = None                 # callable(stats fp64 tensor) -> all-reduced in place (distributed.BNStatSync)
+        self.always_refold = True             # train mode: fold weight norm every forward, as the reference's hook does
+        self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
+                                              # ties at C=32 where the per-layer tiles are already MFMA-bound)
+        self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._fold_key: Dict[str, tuple] = {}
+        self._warned_grad = False
+        self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
+
+    # -------------------------------------------------------------------------------------------
+    def enable_sync_batchnorm(self, group=None):
+        """Data-parallel CondBN: all-reduce the per-stage batch statistics over `group` (RCCL on GPUs)."""
+        from .distributed import BNStatSync
+        self.stat_sync = BNStatSync(group)
+        return self
+
+    def capture_graph(self, x, spk_emb, noise, warmup: int = 2):
+        """Capture one forward (current train/eval mode, these shapes) into a HIP graph and return `run(x, spk_emb, noise)`.
+
+        The forward is ~40-60 kernel launches; at inference sizes (B=1, T~50) it is launch-bound, and replaying one graph
+        removes the per-launch host cost.  Inputs are copied into static buffers, the returned tensor is the graph's static
+        output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured."""
+        if self.stat_sync is not None:
+            raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
+        sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=sx.device)
+            side.wait_stream(torch.cuda.current_stream(sx.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):     # builds every workspace buffer and the fold plan outside the capture
+                    self.forward(sx, ss, sn)
+            torch.cuda.current_stream(sx.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                sy = self.forward(sx, ss, sn)
+
+        def run(x, spk_emb, noise):
+            sx.copy_(x); ss.copy_(spk_emb); sn.copy_(noise)
+            graph.replay()
+            return sy
+
+        run.graph = graph
+        return run
+
+    def remove_weight_norm(self):
+        print('Removing weight norm...')
+        for l in self.ups:
+            l.remove_weight_norm()
+        for l in self.resblocks:
+            l.remove_weight_norm()
+        self.conv_pre.remove_weight_norm()
+        self.conv_post.remove_weight_norm()
+
+    # -------------------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=torch.float32, device=None):
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, device=device, dtype=dtype)
+            self._ws[name] = t
+        return t
+
+    def _timed(self, tag, fn, *args, **kw):
+        """Launch `fn`; when profiling is on, bracket it with events on the launching (current) stream."""
+        if self._profile is None:
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args, **kw)
+        e1.record()
+        self._profile.append((tag, e0, e1))
+        return r
+
+    def _conv_layers(self):
+        yield 'conv_pre', self.conv_pre
+        for i, m in enumerate(self.ups):
+            yield f'ups.{i}', m
+        for i, rb in enumerate(self.resblocks):
+            if isinstance(rb, ResBlock1):
+                for n, m in enumerate(rb.convs1):
+                    yield f'resblocks.{i}.convs1.{n}', m
+                for n, m in enumerate(rb.convs2):
+                    yield f'resblocks.{i}.convs2.{n}', m
+            else:
+                for n, m in enumerate(rb.convs):
+                    yield f'resblocks.{i}.convs.{n}', m
+        yield 'conv_post', self.conv_post
+
+    def _fold_weights(self, device):
+        """K0: weight-norm fold of every conv.  Layers with an MFMA tile configuration are folded AND packed into their
+        fragment stream `wp` by one batched call (two launches for the whole generator); the others (conv_post, odd
+        shapes, or everything under ALGO_DIRECT) are folded one by one into `wf` [k][C_in][C_out].  Skipped while the
+        parameters are unchanged (storage pointers + in-place version counters) unless `always_refold` in train mode."""
+        layers = list(self._conv_layers())
+        vers = []
+        for name, m in layers:
+            ps = (m.weight_v, m.weight_g) if m.weight_normed else (m.weight,)
+            vers.append(tuple((p.data_ptr(), p._version) for p in ps))
+        state = (tuple(vers), self.algo, str(device))
+        force = self.training and self.always_refold
+        if not force and self._fold_key.get('state') == state:
+            return self._fold_key['wf'], self._fold_key['wp']
+        wf, wp, batch = {}, {}, []
+        for name, m in layers:
+            v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+            u = m.stride if m.transposed else 1
+            mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
+                       hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size, 1, u) is not None)
+            if mfma_ok:
+                wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
+                batch.append((v, g, wpb, m.in_channels, m.out_channels, m.kernel_size, u, m.transposed))
+                wf[name], wp[name] = None, wpb
+            else:
+                wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
+                (hipops.fold_convt_weight if m.transposed else hipops.fold_conv_weight)(v, g, wfb, scratch)
+                wf[name], wp[name] = wfb, None
+        if batch:
+            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, *_r) in batch)
+            plan = self._fold_key.get('plan')
+            if plan is None or plan.key != key:
+                plan = hipops.FoldPlan(batch, device)
+                self._fold_key['plan'] = plan
+            plan.run()
+        self._fold_key.update(state=state, wf=wf, wp=wp)
+        return wf, wp
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, x, spk_emb=None, noise=None):
+        """x (B, num_wv_feat, T) channels-first, spk_emb (B, spk_dim), noise (B, noise_dim) -> (B, 1, T*prod(rates))."""
+        if spk_emb is None or noise is None:
+            # the reference's torch.cat((None, None)) raises TypeError
+            raise TypeError('Generator.forward: spk_emb and noise are required')
+        if not (x.is_cuda and spk_emb.is_cuda and noise.is_cuda):
+            raise RuntimeError('Generator.forward runs on the MI355X HIP path only: move inputs and module to a GPU '
+                               '(there is no CPU/PyTorch fallback)')
+        dev = x.device
+        if self.conv_pre.bias.device != dev:
+            raise RuntimeError(f'Generator parameters live on {self.conv_pre.bias.device}, inputs on {dev}')
+        if x.dim() != 3 or x.shape[1] != self.h.num_wv_feat:
+            raise RuntimeError(f'expected x of shape (B, {self.h.num_wv_feat}, T), got {tuple(x.shape)}')
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        x = x.detach().contiguous().float()
+        spk = spk_emb.detach().contiguous().float()
+        nz = noise.detach().contiguous().float()
+        B, _, T = x.shape
+        if spk.shape != (B, self.h.spk_dim) or nz.shape != (B, self.h.noise_dim):
+            raise RuntimeError('spk_emb / noise must be (B, spk_dim) / (B, noise_dim)')
+        training = self.training
+        algo = self.algo
+        nk = self.num_kernels
+        c0 = self.h.upsample_initial_channel
+
+        with torch.no_grad():
+            wf, wp = self._fold_weights(dev)
+
+            # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
+            ns = self.num_upsamples
+            gbs = [self._buf(f'gb.{i}', (B, 2 * self.cbns[i].num_features), device=dev) for i in range(ns)]
+            z_ws = self._buf('z_ws', (ns * B * _Z_CHANNEL,), device=dev)
+            sigma_ws = self._buf('sigma_ws', (ns,), device=dev)
+            hipops.cond_gamma_beta(
+                spk, nz,
+                [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
+                [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
+                gbs, z_ws, sigma_ws, training)
+
+            # ---- K1: conv_pre (no activation in front of it)
+            cur = self._buf('act.pre', (B, c0, T), device=dev)
+            self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
+                        slope=1.0, algo=algo, wp=wp['conv_pre'])
+            L = T
+            for i in range(ns):
+                up = self.ups[i]
+                C = up.out_channels
+                Lo = L * up.stride
+                # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
+                xr = self._buf(f'act.up{i}', (B, C, Lo), device=dev)
+                cbn = self.cbns[i]
+                bn = cbn.batch_nrom
+                stats = part = None
+                nt_stats = 0
+                if training:
+                    stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
+                    # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
+                    if algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
+                        nt_stats = hipops.convt_stats_tiles(B, up.in_channels, C, L, up.kernel_size, up.stride)
+                    if nt_stats:
+                        part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
+                self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
+                            u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
+                # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
+                if training:
+                    if nt_stats:
+                        hipops.bn_reduce_partials(part, nt_stats, C, B * Lo, stats)
+                    else:
+                        pws = self._buf('bn.partial', (2 * max(C, 256) * 64,), dtype=torch.float64, device=dev)
+                        hipops.bn_stats(xr, stats, pws)
+                    if self.stat_sync is not None:
+                        self.stat_sync(stats)
+                a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
+                s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
+                hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
+                                   training=training, momentum=bn.momentum, eps=bn.eps)
+                aff = (a_t, s_t)
+                # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input.
+                # The branches are independent until the final sum, so conv n of ALL branches goes out as one launch
+                # (heaviest kernel size first); the first nk-1 branches end in their own buffers o_j and the last branch's
+                # final conv adds them in the reference's order ((r0 + r1) + r2) / nk  (models.py:135-141).
+                xs = self._buf(f'act.rb{i}', (B, C, Lo), device=dev)
+                rbs = [self.resblocks[i * nk + j] for j in range(nk)]
+                names = [f'resblocks.{i * nk + j}' for j in range(nk)]
+                merged = algo != hipops.ALGO_DIRECT and nk <= 3
+                if merged:
+                    t1s = [self._buf(f'act.t1_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                    outs = [self._buf(f'act.o_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk - 1)] + [xs]
+                    heavy_first = sorted(range(nk), key=lambda j: -rbs[j].kernel_size)
+
+                    def launch(tag_sfx, probs):
+                        probs = [probs[j] for j in heavy_first if j in probs]
+                        tag = '+'.join(f'{names[j]}.{tag_sfx}' for j, _ in probs)
+                        self._timed(tag, hipops.conv1d_multi, [pr for _, pr in probs])
+
+                    def final_kw(j):
+                        if j < nk - 1:
+                            return {}
+                        return dict(add=outs[:nk - 1], out_div=float(nk))
+
+                    # narrow stages (C = 32 / 16): both convs of a pair in ONE kernel, the intermediate stays in LDS
+                    fused_pair = C in self.fuse_pairs and C in (16, 32) and all(wp[f'{nm}.{c}'] is not None for nm in names
+                                                                          for c in (('convs.0', 'convs.1') if isinstance(rbs[0], ResBlock2)
+                                                                                    else ('convs1.0', 'convs2.0')))
+
+                    def launch_pairs(tag_sfx, probs):
+                        """probs: {j: dict}; first nk-1 branches in one launch, the summing branch after them."""
+                        done = True
+                        for js in ([j for j in heavy_first if j in probs and j < nk - 1], [nk - 1] if nk - 1 in probs else []):
+                            if js and done:
+                                tag = '+'.join(f'{names[j]}.{tag_sfx}' for j in js)
+                                done = self._timed(tag, hipops.resblock_pair_multi, [probs[j] for j in js])
+                        return done
+
+                    if isinstance(rbs[0], ResBlock2):
+                        ok = False
+                        if C in self.fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
+                            # the whole residual section of the stage in ONE kernel: x read once, t1_j in LDS, sum in registers
+                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
+                                             [dict(wp1=wp[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                   wp2=wp[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk))
+                        if not ok and fused_pair:
+                            ok = launch_pairs('0&1', {j: dict(x=xr, in_affine=aff, wp1=wp[names[j] + '.convs.0'],
+                                                              b1=rbs[j].convs[0].bias.detach(), wp2=wp[names[j] + '.convs.1'],
+                                                              b2=rbs[j].convs[1].bias.detach(), out=outs[j], k=rbs[j].kernel_size,
+                                                              dil1=rbs[j].convs[0].dilation, dil2=rbs[j].convs[1].dilation,
+                                                              res_mode=0, slope=LRELU_SLOPE, **final_kw(j)) for j in range(nk)})
+                        if not ok:
+                            launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
+                                                 dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
+                                                      in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                                      wp=wp[names[j] + '.convs.0']))) for j in range(nk)})
+                            conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
+                                             dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
+                                                  res=t1s[j], algo=algo, wp=wp[names[j] + '.convs.1'], **final_kw(j))))
+                                     for j in range(nk)}
+                            if nk > 1:
+                                launch('1', {j: conv2[j] for j in range(nk - 1)})
+                            launch('1', {nk - 1: conv2[nk - 1]})
+                    else:
+                        xas = [self._buf(f'act.xa_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                        xbs = [self._buf(f'act.xb_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                        srcs, src_aff = [xr] * nk, aff
+                        for n in range(3):
+                            dsts = [xas, xbs, outs][n]
+                            ok = False
+                            if fused_pair:
+                                ok = launch_pairs(f'{2 * n}&{2 * n + 1}',
+                                                  {j: dict(x=srcs[j], in_affine=src_aff, wp1=wp[f'{names[j]}.convs1.{n}'],
+                                                           b1=rbs[j].convs1[n].bias.detach(), wp2=wp[f'{names[j]}.convs2.{n}'],
+                                                           b2=rbs[j].convs2[n].bias.detach(), out=dsts[j], k=rbs[j].kernel_size,
+                                                           dil1=rbs[j].convs1[n].dilation, dil2=1, res_mode=1, slope=LRELU_SLOPE,
+                                                           **(final_kw(j) if n == 2 else {})) for j in range(nk)})
+                            if not ok:
+                                launch(str(2 * n), {j: (j, (srcs[j], wf[f'{names[j]}.convs1.{n}'], rbs[j].convs1[n].bias.detach(),
+                                                            t1s[j], dict(k=rbs[j].kernel_size, dil=rbs[j].convs1[n].dilation,
+                                                                         slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                                                         wp=wp[f'{names[j]}.convs1.{n}']))) for j in range(nk)})
+                                conv2 = {j: (j, (t1s[j], wf[f'{names[j]}.convs2.{n}'], rbs[j].convs2[n].bias.detach(), dsts[j],
+                                                 dict(k=rbs[j].kernel_size, dil=1, slope=LRELU_SLOPE, res=srcs[j],
+                                                      res_affine=src_aff, algo=algo, wp=wp[f'{names[j]}.convs2.{n}'],
+                                                      **(final_kw(j) if n == 2 else {})))) for j in range(nk)}
+                                if n < 2:
+                                    launch(str(2 * n + 1), conv2)
+                                else:
+                                    if nk > 1:
+                                        launch('5', {j: conv2[j] for j in range(nk - 1)})
+                                    launch('5', {nk - 1: conv2[nk - 1]})
+                            srcs, src_aff = dsts, None
+                else:
+                    t1 = self._buf(f'act.t1_{i}', (B, C, Lo), device=dev)
+                    for j in range(nk):
+                        rb, name = rbs[j], names[j]
+                        k = rb.kernel_size
+                        last = dict(accumulate=(j > 0), out_div=(float(nk) if j == nk - 1 else 0.0))
+                        if isinstance(rb, ResBlock2):
+                            c1, c2 = rb.convs[0], rb.convs[1]
+                            self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
+                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, algo=algo,
+                                        wp=wp[name + '.convs.0'])
+                            self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
+                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, algo=algo, wp=wp[name + '.convs.1'], **last)
+                        else:
+                            xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
+                            xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
+                            src, src_aff = xr, aff
+                            dsts = [xa, xb, xs]
+                            for n in range(3):
+                                c1, c2 = rb.convs1[n], rb.convs2[n]
+                                self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
+                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, algo=algo,
+                                            wp=wp[f'{name}.convs1.{n}'])
+                                extra = last if n == 2 else {}
+                                self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
+                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, algo=algo,
+                                            wp=wp[f'{name}.convs2.{n}'], **extra)
+                                src, src_aff = dsts[n], None
+                cur = xs
+                L = Lo
+            # ---- K8: leaky_relu(0.01) -> conv_post -> tanh
+            y = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
+            self._timed('conv_post', hipops.conv_post_tanh, cur, wf['conv_post'], self.conv_post.bias.detach(), y, k=7,
+                        slope=0.01)
+
+        if needs_grad:
+            if not self._warned_grad:
+                warnings.warn('Generator (HIP): forward is not differentiable yet; calling backward on its output raises')
+                self._warned_grad = True
+            y = _NoBackward.apply(y, torch.zeros((), device=dev, requires_grad=True))
+        return y
