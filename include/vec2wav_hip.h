@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 8
+#define V2W_ABI_VERSION 9
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -39,6 +39,8 @@ extern "C" {
 #define V2W_ALGO_AUTO   0    /* MFMA tile kernel when the shape allows, else the direct kernel */
 #define V2W_ALGO_DIRECT 1    /* one-thread-per-output scalar FMA kernel: any shape; cross-check */
 #define V2W_ALGO_MFMA   2    /* f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) implicit GEMM; V2W_E_SHAPE if unsupported */
+#define V2W_ALGO_BF16   4    /* bf16 operands (rne), ONE v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate: BASELINE configs[2];
+                              * same kernel, tiles and buffers as V2W_ALGO_SPLIT with fragments from v2w_pack_bf16 */
 #define V2W_ALGO_SPLIT  3    /* split-f16 MFMA: x = hi + lo halves, x_hi*w_hi + x_hi*w_lo + x_lo*w_hi accumulated in fp32 (~22-bit
                               * products; v_mfma_f32_32x32x16_f16); needs wps / winv from v2w_pack_split; Conv1d with
                               * C_in % 32 == 0 and C_out % 64 == 0, else V2W_E_SHAPE */
@@ -135,6 +137,7 @@ int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
  * Activations are split on the fly by the conv kernel and must satisfy |x| <= 65504 (they are clamped there). */
 int v2w_split_supported(int c_in, int c_out, int u);   /* 1 when V2W_ALGO_SPLIT serves this layer shape */
 int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);
+int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);   /* same buffers, V2W_ALGO_BF16 */
 /* Batched weight-norm fold + split pack of n Conv1d layers straight from the parameters (weight_v (C_out, C_in, k), weight_g or
  * NULL): three launches for all of them.  descs / starts are DEVICE arrays; starts[0..n] = prefix sums of c_out,
  * starts[n+1..2n+1] = prefix sums of (c_out/32)*(c_in/16); nblk_* = their totals; k_max = largest kernel size. */
@@ -142,7 +145,8 @@ typedef struct {
     const float* v; const float* g;   /* weight_v, weight_g (NULL: plain weight) */
     void* wps; float* sc;             /* outputs: as v2w_pack_split */
     float* rowscale;                  /* c_out floats of workspace */
-    int32_t c_in, c_out, k, _pad;
+    int32_t c_in, c_out, k;
+    int32_t mode;                     /* 0: split f16 (hi, lo) fragments; 1: bf16 fragments for V2W_ALGO_BF16 */
 } v2w_split_desc;
 int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32_t* starts_dev, int n, int nblk_rows, int nblk_pack,
                          int k_max, void* stream);

@@ -145,6 +145,27 @@ def test_conv1d_split_f16(dev, B, cin, cout, L, k, dil):
     assert e_split <= 2 * e_f32 + 1e-6, f'split max err {e_split} vs f32 kernel {e_f32}'
 
 
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', [SPLIT_CASES[0], SPLIT_CASES[2], SPLIT_CASES[5], SPLIT_CASES[6]])
+def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
+    """V2W_ALGO_BF16 (BASELINE configs[2]: bf16 compute / fp32 accumulate) == an fp64 convolution of the bf16-rounded
+    operands to fp32-accumulation accuracy; the rounding itself is the configuration's stated precision."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(14)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    res = r.standard_normal((B, cout, L), dtype=np.float32)
+    xa = F.leaky_relu(torch.from_numpy(x), 0.1).bfloat16().double()
+    wb = torch.from_numpy(w).bfloat16().double()
+    want = F.conv1d(xa, wb, torch.from_numpy(bias).double(), padding=dil * (k - 1) // 2, dilation=dil) + torch.from_numpy(res).double()
+    wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+    out = torch.full((B, cout, L), float('nan'), device=dev)
+    hipops.conv1d(_t(x, dev), None, _t(bias, dev), out, k=k, dil=dil, slope=0.1, res=_t(res, dev), algo=hipops.ALGO_BF16,
+                  wps=hipops.pack_split(wf, bf16=True))
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5, f'max err {err}'
+
+
 def test_conv1d_split_multi_and_rejects(dev):
     from wavthruvec_pytorch_amd import hipops
     assert not hipops.split_supported(16, 16) and not hipops.split_supported(32, 32) and not hipops.split_supported(64, 64, 2)

@@ -11,7 +11,7 @@ dev = torch.device('cuda:0')
 h = synthetic.make_hparams(num_wv_feat=768)
 inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
 ys = {}
-for prec in ('f32', 'f16x3'):
+for prec in ('f32', 'f16x3', 'bf16'):
     g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train()
     g.precision = prec
     with torch.no_grad():
@@ -23,4 +23,5 @@ for prec in ('f32', 'f16x3'):
     ys[prec] = y.clone()
     ms = e0.elapsed_time(e1) / 10
     print(f'{prec:6s}: {ms:7.3f} ms/forward  {B * T * 320 / ms / 1e3:8.1f} M samples/s')
-print('max|y_f16x3 - y_f32| = %.3g   |y|max = %.3g' % ((ys['f32'] - ys['f16x3']).abs().max().item(), ys['f32'].abs().max().item()))
+print('max|y_f16x3 - y_f32| = %.3g   max|y_bf16 - y_f32| = %.3g   |y|max = %.3g' % (
+    (ys['f32'] - ys['f16x3']).abs().max().item(), (ys['f32'] - ys['bf16']).abs().max().item(), ys['f32'].abs().max().item()))

@@ -12,10 +12,10 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT = 0, 1, 2, 3
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -60,7 +60,7 @@ class FoldDesc(C.Structure):
 
 class SplitDesc(C.Structure):
     _fields_ = [('v', _fp), ('g', _fp), ('wps', _fp), ('sc', _fp), ('rowscale', _fp),
-                ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('_pad', C.c_int32)]
+                ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32)]
 
 
 _PA = _fp * V2W_MAX_STAGES
@@ -85,6 +85,7 @@ SIGNATURES = {
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_bf16': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -3,7 +3,7 @@
 
 int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out);
 int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out);
-int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream);
+int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool bf16);
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream);
 int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream);
 
@@ -12,7 +12,7 @@ extern "C" const char* v2w_build_arch(void) { return "gfx950"; }
 
 static int check_conv1d(const v2w_conv1d_args* a) {
     if (!a || !a->in || !a->out) return V2W_E_ARG;
-    if (a->algo == V2W_ALGO_SPLIT ? (!a->wps || !a->winv) : (!a->wf && !a->wp)) return V2W_E_ARG;
+    if ((a->algo == V2W_ALGO_SPLIT || a->algo == V2W_ALGO_BF16) ? (!a->wps || !a->winv) : (!a->wf && !a->wp)) return V2W_E_ARG;
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->dil <= 0) return V2W_E_ARG;
     if ((a->k & 1) == 0 && a->pad_left < 0) return V2W_E_SHAPE;    // symmetric padding d*(k-1)/2 keeps the length only for odd k
     if (a->pad_left > a->dil * (a->k - 1) || a->in_stride < 0 || a->in_phase < 0 || (a->in_stride > 0 && a->in_phase >= a->in_stride))
@@ -33,7 +33,8 @@ extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
     switch (a->algo) {
         case V2W_ALGO_DIRECT: return a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG;
         case V2W_ALGO_MFMA: return v2w_conv1d_mfma(a, 1, st, nullptr);
-        case V2W_ALGO_SPLIT: return v2w_conv1d_split(a, 1, st);
+        case V2W_ALGO_SPLIT: return v2w_conv1d_split(a, 1, st, false);
+        case V2W_ALGO_BF16: return v2w_conv1d_split(a, 1, st, true);
         case V2W_ALGO_AUTO: {
             const int rc = v2w_conv1d_mfma(a, 1, st, nullptr);
             return rc == V2W_E_SHAPE ? (a->wf ? v2w_conv1d_direct(a, st) : V2W_E_ARG) : rc;
@@ -78,8 +79,9 @@ extern "C" int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* strea
     for (int i = 0; i < n; ++i) {
         if (const int rc = check_conv1d(a + i)) return rc;
         if (a[i].algo == V2W_ALGO_DIRECT) return V2W_E_SHAPE;
-        if ((a[i].algo == V2W_ALGO_SPLIT) != (a[0].algo == V2W_ALGO_SPLIT)) return V2W_E_ARG;   // one kernel per launch
+        if (a[i].algo != a[0].algo && (a[i].algo >= V2W_ALGO_SPLIT || a[0].algo >= V2W_ALGO_SPLIT)) return V2W_E_ARG;   // one kernel per launch
     }
-    if (a[0].algo == V2W_ALGO_SPLIT) return v2w_conv1d_split(a, n, (hipStream_t)stream);
+    if (a[0].algo == V2W_ALGO_SPLIT || a[0].algo == V2W_ALGO_BF16)
+        return v2w_conv1d_split(a, n, (hipStream_t)stream, a[0].algo == V2W_ALGO_BF16);
     return v2w_conv1d_mfma(a, n, (hipStream_t)stream, nullptr);
 }

@@ -32,6 +32,9 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));   // one 16-byte MFMA operand fragment, type-agnostic
 
 #define V2W_SPLIT_CK 16        // input channels per stage = one MFMA k-step
 #define V2W_SPLIT_ROWB 80       // bytes per staged position: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad
@@ -50,7 +53,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define V2W_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define V2W_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int MI, int NI, int WM, int WN, bool VEC>
+// BF = false: split f16x3 (three MFMAs per product).  BF = true: plain bf16 operands, ONE v_mfma_f32_32x32x16_bf16 per product
+// (BASELINE configs[2] 'bf16 compute / fp32 accumulate'): same tiles, same fragment layout with the lo halves unused.
+template <int MI, int NI, int WM, int WN, bool VEC, bool BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V2W_SPLIT_WPE, V2W_SPLIT_WPE)))
 conv_split_kernel(const MultiArgs m) {
     typedef Frag<32> F;
@@ -62,7 +67,8 @@ conv_split_kernel(const MultiArgs m) {
     constexpr int NMT = MT / 32;                                // 32-row blocks per workgroup
     constexpr int ASTAGE = NMT * V2W_SPLIT_UNIT;                // bytes of one weight stage
     constexpr int NAB = V2W_SPLIT_NAB;
-    constexpr int ADMA = ASTAGE / (NTHREADS * 16);              // async 16-B copies per thread and stage
+    // async 16-B copies per thread and stage; bf16 moves only the hi half of every unit (1 KiB = one wave copy per unit)
+    constexpr int ADMA = BF ? (NMT + 3) / 4 : ASTAGE / (NTHREADS * 16);
     static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
     constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
     constexpr int NSIG = NS * 4;                                // global loads of one signal prefetch (always all issued)
@@ -117,11 +123,14 @@ conv_split_kernel(const MultiArgs m) {
     const unsigned char* dsrc[ADMA];
 #pragma unroll
     for (int i = 0; i < ADMA; ++i) {
-        const int q = i * NTHREADS + tid;                        // 16-B element of the stage; 128 of them per unit
-        dsrc[i] = reinterpret_cast<const unsigned char*>(p.wps) + (size_t)(m0 / 32 + (q >> 7)) * nst * V2W_SPLIT_UNIT + (q & 127) * 16;
+        const int q = i * NTHREADS + tid;                        // 16-B element of the stage; 128 of them per unit (bf16: the first 64)
+        const int unit = BF ? (q >> 6) % NMT : q >> 7, off = BF ? (q & 63) : (q & 127);     // bf16, NMT < 4: waves 2, 3 repeat 0, 1
+        dsrc[i] = reinterpret_cast<const unsigned char*>(p.wps) + (size_t)(m0 / 32 + unit) * nst * V2W_SPLIT_UNIT + off * 16;
     }
     const unsigned a_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(As0 + wave * 1024));
+    const unsigned a_lds_bf = __builtin_amdgcn_readfirstlane(    // bf16: wave w fills the hi half of unit (w % NMT)
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(As0 + (wave % NMT) * V2W_SPLIT_UNIT));
     int dma_slot = 0;                                            // ring slot the next copy fills
     auto dma_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -130,7 +139,8 @@ conv_split_kernel(const MultiArgs m) {
             // s_waitcnt vmcnt(0) (it cannot prove the buffers distinct), which would serialise copy and compute.  Hidden
             // from its bookkeeping, the copy only makes the compiler's own vmcnt waits more conservative (vmcnt retires in
             // order); the waits THIS data needs are the explicit V2W_WAIT_VM below.  M0 = LDS byte address of lane 0.
-            const unsigned lds = a_lds + dma_slot * ASTAGE + i * (NTHREADS * 16);
+            const unsigned lds = BF ? a_lds_bf + dma_slot * ASTAGE + i * (4 * V2W_SPLIT_UNIT)
+                                    : a_lds + dma_slot * ASTAGE + i * (NTHREADS * 16);
             unsigned m0_save;                                    // M0 is a reserved register: hand it back as found
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(m0_save) : "s"(lds), "v"(dsrc[i]) : "memory");
@@ -155,7 +165,7 @@ conv_split_kernel(const MultiArgs m) {
     };
     auto act = [&](float v) __attribute__((always_inline)) {     // leaky_relu, then into the f16 range (see the header)
         v = slope <= 1.f ? fmaxf(v, v * slope) : v2w_lrelu(v, slope);
-        return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        return BF ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
     };
     auto commit = [&](int ci0, unsigned char* Xs) __attribute__((always_inline)) {
         float av[4], sv[4];
@@ -173,17 +183,24 @@ conv_split_kernel(const MultiArgs m) {
             // rows 4 apart alias 4-way in LDS (320 B = 16 banks mod 64): 8 stores per chunk and wave, not worth a rotation
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                h4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f;   // padding of the ACTIVATED signal
-                    const _Float16 h = (_Float16)v;
-                    hi[c] = h;
-                    lo[c] = (_Float16)(v - (float)h);
-                }
                 unsigned char* d = Xs + (pg * 4 + e) * ROWB + wave * 8;
-                *reinterpret_cast<h4*>(d) = hi;
-                *reinterpret_cast<h4*>(d + 32) = lo;
+                if constexpr (BF) {
+                    b4 hi;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hi[c] = (__bf16)(in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f);
+                    *reinterpret_cast<b4*>(d) = hi;
+                } else {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f;   // padding of the ACTIVATED signal
+                        const _Float16 h = (_Float16)v;
+                        hi[c] = h;
+                        lo[c] = (_Float16)(v - (float)h);
+                    }
+                    *reinterpret_cast<h4*>(d) = hi;
+                    *reinterpret_cast<h4*>(d + 32) = lo;
+                }
             }
         }
     };
@@ -197,10 +214,14 @@ conv_split_kernel(const MultiArgs m) {
                 const int l = pos0 + j;
                 float v = 0.f;
                 if (l >= 0 && l < L) v = act(fmaf(av, src[(size_t)l * p.in_stride], sv));
-                const _Float16 h = (_Float16)v;
-                _Float16* d = reinterpret_cast<_Float16*>(Xs + j * ROWB) + c;
-                d[0] = h;
-                d[16] = (_Float16)(v - (float)h);
+                if constexpr (BF) {
+                    reinterpret_cast<__bf16*>(Xs + j * ROWB)[c] = (__bf16)v;
+                } else {
+                    const _Float16 h = (_Float16)v;
+                    _Float16* d = reinterpret_cast<_Float16*>(Xs + j * ROWB) + c;
+                    d[0] = h;
+                    d[16] = (_Float16)(v - (float)h);
+                }
             }
         }
     };
@@ -241,13 +262,17 @@ conv_split_kernel(const MultiArgs m) {
     // B (signal) fragments of a stage come from the chunk's tile, which does not change between the taps of a chunk: they
     // are read for tap t+1 BEFORE the barrier that ends tap t (their LDS latency hides under this tap's MFMAs); only the
     // A fragments, which the barrier publishes, are read after it.
-    h8 bh[NI], bl[NI];
+    raw16 bh[NI], bl[BF ? 1 : NI];
+    auto mma = [&](acc_t c, raw16 a, raw16 b) __attribute__((always_inline)) {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    };
     auto read_b = [&](const unsigned char* Xs, int t) __attribute__((always_inline)) {
         const unsigned char* xr = Xs + (rowbase + t * p.dil) * ROWB + hk * 16;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            bh[j] = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB);
-            bl[j] = *reinterpret_cast<const h8*>(xr + j * 32 * ROWB + 32);
+            bh[j] = *reinterpret_cast<const raw16*>(xr + j * 32 * ROWB);
+            if constexpr (!BF) bl[j] = *reinterpret_cast<const raw16*>(xr + j * 32 * ROWB + 32);
         }
     };
     int ring = 0;                                                // ring slot of the stage being computed
@@ -262,30 +287,32 @@ conv_split_kernel(const MultiArgs m) {
 
         const unsigned char* Ab = As0 + ring * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
         ring = ring + 1 == NAB ? 0 : ring + 1;
-        h8 ah[MI], al[MI];
+        raw16 ah[MI], al[BF ? 1 : MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            ah[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT);
-            al[i] = *reinterpret_cast<const h8*>(Ab + i * V2W_SPLIT_UNIT + 1024);
+            ah[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT);
+            if constexpr (!BF) al[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT + 1024);
         }
         if (SIG) read_b(Xs, t);                                  // first tap of a chunk: its tile was committed just before the barrier
         __builtin_amdgcn_sched_barrier(0);
-        h8 ch_[NI], cl_[NI];
+        raw16 ch_[NI], cl_[BF ? 1 : NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) { ch_[j] = bh[j]; cl_[j] = bl[j]; }
+        for (int j = 0; j < NI; ++j) { ch_[j] = bh[j]; if constexpr (!BF) cl_[j] = bl[j]; }
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], ch_[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], ch_[j]);
         if (!COMMIT) read_b(Xs, t + 1);                          // next tap's signal fragments: in flight across the barrier
+        if constexpr (!BF) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cl_[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], cl_[j]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], ch_[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], al[i], ch_[j]);
+        }
 
         if (COMMIT && more) {
             unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
@@ -384,7 +411,7 @@ conv_split_kernel(const MultiArgs m) {
 }
 
 template <int MI, int NI, int WM, int WN>
-int launch_split(const TileArgs* ps, int nprob, hipStream_t stream) {
+int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, CK = V2W_SPLIT_CK;
     constexpr int RS = 72;
     if (nprob < 1 || nprob > V2W_MAX_MULTI) return V2W_E_ARG;
@@ -420,7 +447,8 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream) {
     bool vec = true;                                               // one staging flavour per launch: float4 only if every problem allows it
     for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
     for (int i = 0; i < nprob; ++i) m.p[i].vec4 = vec;
-    auto kern = vec ? conv_split_kernel<MI, NI, WM, WN, true> : conv_split_kernel<MI, NI, WM, WN, false>;
+    auto kern = bf ? (vec ? conv_split_kernel<MI, NI, WM, WN, true, true> : conv_split_kernel<MI, NI, WM, WN, false, true>)
+                   : (vec ? conv_split_kernel<MI, NI, WM, WN, true, false> : conv_split_kernel<MI, NI, WM, WN, false, false>);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -486,6 +514,27 @@ pack_split_kernel(const float* __restrict__ wf, h8* __restrict__ wps, const unsi
     }
 }
 
+// bf16 operands (V2W_ALGO_BF16): same unit layout, hi slot = rne_bf16(w), lo slot unused; no scaling (bf16 has fp32's range)
+__global__ void __launch_bounds__(256)
+pack_bf16_kernel(const float* __restrict__ wf, b8* __restrict__ wps, float* __restrict__ sc, int K, int Cin, int Cout) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = 1.f; sc[1] = 1.f; }
+    const int nch = Cin / V2W_SPLIT_CK;
+    const size_t total = (size_t)(Cout / 32) * nch * K * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = o & 63;
+        size_t rest = o >> 6;
+        const int t = rest % K; rest /= K;
+        const int ch = rest % nch;
+        const int mb = rest / nch;
+        const int co = mb * 32 + (lane & 31);
+        const int c0 = ch * V2W_SPLIT_CK + 8 * (lane >> 5);
+        b8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi[j] = (__bf16)wf[((size_t)t * Cin + c0 + j) * Cout + co];
+        wps[(((size_t)(mb * nch + ch) * K + t) * 2) * 64 + lane] = hi;
+    }
+}
+
 // ---- batched weight-norm fold + split pack: every split layer of the generator in three launches driven by a device
 // descriptor table (mirrors v2w_fold_pack_batch of the f32 path).
 __device__ __forceinline__ int split_find_layer(const int32_t* __restrict__ starts, int n, int blk) {
@@ -535,7 +584,8 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
     const int blk = blockIdx.x - starts[li];
     const int K = d.k, nch = d.c_in / V2W_SPLIT_CK;
     const int mb = blk / nch, ch = blk % nch;
-    const float scale = split_scale_from_bits(reinterpret_cast<const unsigned int*>(d.sc)[2]);
+    const bool bf = d.mode == 1;
+    const float scale = bf ? 1.f : split_scale_from_bits(reinterpret_cast<const unsigned int*>(d.sc)[2]);
     if (blk == 0 && threadIdx.x == 0) { d.sc[0] = 1.f / scale; d.sc[1] = scale; }
     const int rlen = V2W_SPLIT_CK * K, rstride = rlen + 1;
     for (int idx = threadIdx.x; idx < 32 * rlen; idx += 256) {
@@ -547,6 +597,13 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
     for (int o = threadIdx.x; o < K * 64; o += 256) {
         const int lane = o & 63, t = o >> 6;
         const int r = lane & 31, c0 = 8 * (lane >> 5);
+        if (bf) {
+            b8 hb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hb[j] = (__bf16)tile[r * rstride + (c0 + j) * K + t];
+            reinterpret_cast<b8*>(dst)[t * 128 + lane] = hb;
+            continue;
+        }
         h8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -584,8 +641,17 @@ extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int 
     return v2w_launch_status();
 }
 
-// Called by v2w_api.hip for algo == V2W_ALGO_SPLIT.  n problems sharing B, C_in, C_out, L in one launch.
-int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream) {
+extern "C" int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
+    if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
+    if (!v2w_split_supported(c_in, c_out, 1)) return V2W_E_SHAPE;
+    const size_t total = (size_t)k * c_in * c_out / 8;
+    int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), sc, k, c_in, c_out);
+    return v2w_launch_status();
+}
+
+// Called by v2w_api.hip for algo == V2W_ALGO_SPLIT (bf = false) and V2W_ALGO_BF16 (bf = true).  n problems sharing B, C_in, C_out, L in one launch.
+int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool bf) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
     if (!v2w_split_supported(a->C_in, a->C_out, 1)) return V2W_E_SHAPE;
     TileArgs ps[V2W_MAX_MULTI];
@@ -609,12 +675,12 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream) {
     }
     // two workgroups per CU are resident: prefer the largest tile that still gives every slot ~1 workgroup
     if (a->C_out % 128 == 0) {
-        if (V2W_SPLIT_FORCE == 1) return launch_split<1, 2, 2, 2>(ps, n, stream);
-        if (V2W_SPLIT_FORCE == 2) return launch_split<2, 2, 2, 2>(ps, n, stream);
-        if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream);       // 128 x 128
-        return launch_split<1, 2, 2, 2>(ps, n, stream);                                // 64 x 128
+        if (V2W_SPLIT_FORCE == 1) return launch_split<1, 2, 2, 2>(ps, n, stream, bf);
+        if (V2W_SPLIT_FORCE == 2) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);
+        if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);       // 128 x 128
+        return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                // 64 x 128
     }
-    return launch_split<2, 2, 1, 4>(ps, n, stream);                                    // 64 x 256
+    return launch_split<2, 2, 1, 4>(ps, n, stream, bf);                                    // 64 x 256
 }
 
 // Batched form of (v2w_wn_fold_conv + v2w_pack_split) for n Conv1d layers: descs / starts live in DEVICE memory;

@@ -13,7 +13,8 @@ import torch
 
 from . import _hip
 
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT = _hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA, _hip.ALGO_SPLIT
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = (_hip.ALGO_AUTO, _hip.ALGO_DIRECT, _hip.ALGO_MFMA, _hip.ALGO_SPLIT,
+                                                             _hip.ALGO_BF16)
 
 
 def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
@@ -100,7 +101,7 @@ def split_halves(k, c_in, c_out):
     return k * c_in * c_out * 2 + 1024
 
 
-def pack_split(wf, out=None, sc=None):
+def pack_split(wf, out=None, sc=None, bf16=False):
     """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
     scale record (sc[0] = 1/scale is the kernel's `winv`)."""
     k, ci, co = wf.shape
@@ -108,7 +109,8 @@ def pack_split(wf, out=None, sc=None):
         out = torch.empty((split_halves(k, ci, co),), device=wf.device, dtype=torch.float16)
     if sc is None:
         sc = torch.empty((4,), device=wf.device, dtype=torch.float32)
-    _hip.check(_hip.load().v2w_pack_split(wf.data_ptr(), out.data_ptr(), sc.data_ptr(), k, ci, co, _stream(wf)), 'v2w_pack_split')
+    fn = _hip.load().v2w_pack_bf16 if bf16 else _hip.load().v2w_pack_split
+    _hip.check(fn(wf.data_ptr(), out.data_ptr(), sc.data_ptr(), k, ci, co, _stream(wf)), 'v2w_pack_bf16' if bf16 else 'v2w_pack_split')
     return out, sc
 
 
@@ -288,8 +290,8 @@ class SplitPlan:
     """Device-resident descriptor table for v2w_split_pack_batch: every split-f16 layer folded (weight norm) and packed into
     its (hi, lo) fragment stream in three launches."""
 
-    def __init__(self, layers, device):
-        """layers: list of (v (C_out, C_in, k), g|None, wps, sc) with tensors already on `device`."""
+    def __init__(self, layers, device, bf16=False):
+        """layers: list of (v (C_out, C_in, k), g|None, wps, sc) with tensors already on `device`; bf16: fragments for ALGO_BF16."""
         n = len(layers)
         self.n = n
         self.rowscale = torch.empty((sum(v.shape[0] for v, *_ in layers),), device=device, dtype=torch.float32)
@@ -300,7 +302,7 @@ class SplitPlan:
             co, ci, k = v.shape
             d.v = v.data_ptr(); d.g = _hip.ptr(g); d.wps = wps.data_ptr(); d.sc = sc.data_ptr()
             d.rowscale = self.rowscale.data_ptr() + 4 * off
-            d.c_in, d.c_out, d.k = ci, co, k
+            d.c_in, d.c_out, d.k, d.mode = ci, co, k, int(bf16)
             starts[i], starts[n + 1 + i] = off, blocks
             off += co
             blocks += (co // 32) * (ci // 16)

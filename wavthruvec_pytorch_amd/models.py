@@ -163,7 +163,8 @@ class Generator(nn.Module):
         self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
                                               # ties at C=32 where the per-layer tiles are already MFMA-bound)
         self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
-        self.precision = 'f32'                # 'f32': exact fp32 MFMA everywhere (default).  'f16x3': Conv1d layers with
+        self.precision = 'f32'                # 'f32': exact fp32 MFMA everywhere (default).  'bf16': bf16 operands, one MFMA per
+                                              # product (BASELINE configs[2]).  'f16x3': Conv1d layers with
                                               # C_out >= split_min_channels run on the f16 matrix pipe with split operands
                                               # (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulate; hipops.ALGO_SPLIT)
         self.split_min_channels = 64
@@ -299,9 +300,9 @@ class Generator(nn.Module):
         serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward)."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
-        if self.precision != 'f16x3':
-            raise ValueError(f"Generator.precision must be 'f32' or 'f16x3', got {self.precision!r}")
-        gen = self._fold_key.get('gen', 0)
+        if self.precision not in ('f16x3', 'bf16'):
+            raise ValueError(f"Generator.precision must be 'f32', 'f16x3' or 'bf16', got {self.precision!r}")
+        gen = (self._fold_key.get('gen', 0), self.precision)
         cached = self._fold_key.get('wps')
         if cached is not None and cached[0] == gen:
             return cached[1]
@@ -317,10 +318,11 @@ class Generator(nn.Module):
             batch.append((v.contiguous(), g, wpsb, scb))
             out[name] = (wpsb, scb)
         if batch:
-            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in batch)
+            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in batch) + (self.precision,)
             plan = self._fold_key.get('split_plan')
             if plan is None or plan.key != key:
-                plan = hipops.SplitPlan(batch, device)
+                plan = hipops.SplitPlan(batch, device, bf16=self.precision == 'bf16')
+                plan.key = key
                 self._fold_key['split_plan'] = plan
             plan.run()
         self._fold_key['wps'] = (gen, out)
@@ -375,7 +377,9 @@ class Generator(nn.Module):
             wps = self._split_weights(dev) if save is None else {}
 
             def ck(nm):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
-                return dict(algo=hipops.ALGO_SPLIT, wps=wps[nm]) if nm in wps else dict(algo=algo, wp=wp[nm])
+                if nm in wps:
+                    return dict(algo=hipops.ALGO_BF16 if self.precision == 'bf16' else hipops.ALGO_SPLIT, wps=wps[nm])
+                return dict(algo=algo, wp=wp[nm])
 
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
             ns = self.num_upsamples
