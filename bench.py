@@ -84,6 +84,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--algo', default='auto', choices=['auto', 'direct'])
     ap.add_argument('--no-alt', action='store_true', help="skip the additional precision='f16x3' measurement")
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'bf16'],
+                    help="precision mode of the TIMED steps (default: exact fp32; the others are for profiling that mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -113,6 +115,7 @@ def main():
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).train()
     g.algo = hipops.ALGO_DIRECT if args.algo == 'direct' else hipops.ALGO_AUTO
+    g.precision = args.precision
     if world > 1:
         g.enable_sync_batchnorm()
     x, spk, nz = synthetic.make_inputs(h, B, T, seed=1234 + rank, device=dev)
@@ -148,7 +151,7 @@ def main():
     # ---- the same step with Generator.precision = 'f16x3' (wide Conv1d layers on the f16 matrix pipe with split operands,
     # fp32 accumulation; same parity bar).  Reported BESIDE the exact-fp32 `value`, never instead of it.
     alt = None
-    if args.algo == 'auto' and not args.no_alt:
+    if args.algo == 'auto' and not args.no_alt and args.precision == 'f32':
         with torch.no_grad():
             y32 = g(x, spk, nz).clone()
             g.precision = 'f16x3'
@@ -192,6 +195,8 @@ def main():
             direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
             if args.algo == 'direct':
                 return direct
+            if args.precision != 'f32' and l['kind'] == 'conv' and l['cout'] >= g.split_min_channels and l['cout'] % 64 == 0:
+                return 'conv_split_kernel (%s)' % args.precision
             # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
             return hipops.conv_tile_config(B * nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
 
@@ -270,7 +275,8 @@ def main():
             'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': {'f32': 'f32', 'f16x3': 'f32 as f16 hi+lo (3 MFMA per product), f32 accumulate',
+                      'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: B={B}/GPU x T={T} frames, 768-d latents, upsample (5,4,4,2,2) x320, '
                                    'ResBlock2, train-mode CondBN, fp32', 'global_batch': B * world, 'frames': T,
                        'parallelism': f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else 'single GPU'},

@@ -237,8 +237,7 @@ def test_generator_surface_errors(dev):
     with pytest.raises(NotImplementedError):
         g(x.clone().requires_grad_(True), spk, nz)   # no gradient w.r.t. the latents
     g1 = Generator(synthetic.make_hparams(num_wv_feat=768, resblock='1')).to(dev)
-    with pytest.raises(NotImplementedError):
-        g1(x, spk, nz)                         # ResBlock1 backward is not covered: loud, not silent
+    assert g1(x, spk, nz).requires_grad        # ResBlock1 generators are differentiable too
     with torch.no_grad():
         assert g1(x, spk, nz).shape == (1, 1, 4 * 320)
 
@@ -346,11 +345,12 @@ def test_synthesize_entry_end_to_end(dev, tmp_path):
 
 
 
-@pytest.mark.parametrize('training,B,T', [(True, 2, 8), (True, 3, 21), (False, 2, 8)])
-def test_generator_backward_matches_oracle_autograd(dev, training, B, T):
+@pytest.mark.parametrize('training,B,T,resblock', [(True, 2, 8, 1), (True, 3, 21, 1), (False, 2, 8, 1), (True, 2, 9, '1'), (False, 2, 8, '1')])
+def test_generator_backward_matches_oracle_autograd(dev, training, B, T, resblock):
     """`loss.backward()` through the HIP generator (train.py:214): every parameter gradient against torch autograd through the
-    oracle on the CPU.  Bar: |dg| error <= 4e-3 of the largest entry of that gradient (both sides reduce up to 1e5 positions in fp32)."""
-    h = synthetic.make_hparams(num_wv_feat=768)
+    oracle on the CPU.  Bar: |dg| error <= 4e-3 of the largest entry of that gradient (both sides reduce up to 1e5 positions in fp32).
+    resblock 1 (int) = the reference default ResBlock2, '1' = ResBlock1."""
+    h = synthetic.make_hparams(num_wv_feat=768, resblock=resblock)
     sd = synthetic.make_state_dict(h, seed=0)
     inp = synthetic.make_inputs(h, B, T, seed=21)
     dy = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 1, T * 320)).astype(np.float32))

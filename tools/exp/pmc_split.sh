@@ -2,7 +2,7 @@
 # usage: pmc_split.sh <case idx>   (run from repo root on the GPU box)
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_split -o p -- python3 $R/tools/split_microbench.py $1 > $R/gpurun_out/pmc_split.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_split -o p -- python3 $R/tools/split_microbench.py $1 > $R/gpurun_out/pmc_split.log 2>&1
 cd $R
 python3 - <<'PY'
 import csv, glob, collections

@@ -12,7 +12,7 @@ reverse and runs entirely through the C ABI:
   tanh + conv_post                        v2w_tail_bwd
   weight norm, spectral-norm Linear, fcs  v2w_wn_bwd, v2w_cond_bwd
 
-Scope: ResBlock2 generators (the reference default).  ResBlock1 raises NotImplementedError in grad mode.
+Scope: ResBlock2 (the reference default) and ResBlock1 generators with up to 3 residual branches per stage.
 """
 from __future__ import annotations
 
@@ -26,10 +26,6 @@ LRELU_SLOPE = 0.1
 class GeneratorFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gen, names, x, spk, nz, *params):
-        from .models import ResBlock2
-        if not all(isinstance(rb, ResBlock2) for rb in gen.resblocks):
-            raise NotImplementedError('Generator (HIP) backward covers ResBlock2 generators (the reference default); '
-                                      "run resblock='1' models under torch.no_grad()")
         if gen.num_kernels > 3:
             raise NotImplementedError('Generator (HIP) backward supports up to 3 residual branches per stage')
         save = {}
@@ -87,10 +83,39 @@ def generator_backward(gen, sv, dy):
         dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
         db2 = hipops.channel_sum(dr)
         dx = torch.empty_like(dr)
+        from .models import ResBlock1
         for j in range(nk):
             rb = gen.resblocks[i * nk + j]
             name = f'resblocks.{i * nk + j}'
             k = rb.kernel_size
+            if isinstance(rb, ResBlock1):
+                # x_{n+1} = x_n + conv2_n(lrelu(u_n)) + b2,  u_n = conv1_n(lrelu(x_n)) + b1,  x_0 = a*xr + s   (models.py:37-44)
+                xin = [xr, ws[f'act.xa_{i}_{j}'], ws[f'act.xb_{i}_{j}']]
+                dcur = dr
+                for n in (2, 1, 0):
+                    c1, c2 = rb.convs1[n], rb.convs2[n]
+                    u = ws[f'act.t1_{i}_{j}_{n}']
+                    x_aff = aff if n == 0 else None
+                    w2T = hipops.transpose_flip(wf[f'{name}.convs2.{n}'])
+                    du = torch.empty_like(dr)
+                    hipops.conv1d(dcur, w2T, None, du, k=k, dil=1, slope=1.0, wp=hipops.pack_mfma(w2T),
+                                  mask=(u, None), mask_slope=LRELU_SLOPE)
+                    _wn_grads(grads, f'{name}.convs2.{n}', c2, hipops.wgrad(u, dcur, k=k, dil=1, slope=LRELU_SLOPE))
+                    grads[f'{name}.convs2.{n}.bias'] = hipops.channel_sum(dcur) if n < 2 else db2
+                    w1T = hipops.transpose_flip(wf[f'{name}.convs1.{n}'])
+                    if n > 0:
+                        dprev = torch.empty_like(dr)
+                        hipops.conv1d(du, w1T, None, dprev, k=k, dil=c1.dilation, slope=1.0, res=dcur, wp=hipops.pack_mfma(w1T),
+                                      mask=(xin[n], None), mask_slope=LRELU_SLOPE)
+                    else:   # into the stage's dx, summed over the branches
+                        hipops.conv1d(du, w1T, None, dx, k=k, dil=c1.dilation, slope=1.0, res=dcur, wp=hipops.pack_mfma(w1T),
+                                      mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
+                        dprev = None
+                    _wn_grads(grads, f'{name}.convs1.{n}', c1,
+                              hipops.wgrad(xin[n], du, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=x_aff))
+                    grads[f'{name}.convs1.{n}.bias'] = hipops.channel_sum(du)
+                    dcur = dprev
+                continue
             c1, c2 = rb.convs[0], rb.convs[1]
             t1 = ws[f'act.t1_{i}_{j}']
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)

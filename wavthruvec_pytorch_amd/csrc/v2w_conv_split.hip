@@ -250,6 +250,9 @@ conv_split_kernel(const MultiArgs m) {
     V2W_BARRIER();
 
     const int rowbase = wn0 + lr + p.hla - p.hl;                 // LDS row of this lane's column for tap 0
+#ifdef V2W_EXP_STAGGER
+    if ((blockIdx.x >> V2W_EXP_STAGGER_SHIFT) & 1) __builtin_amdgcn_s_sleep(V2W_EXP_STAGGER);
+#endif
     int st = 0;
     // One stage = one (chunk, tap): 3 * MI * NI MFMAs per wave between two workgroup barriers.
     // Issue order inside a stage: the weight copy of stage st+NAB-1, then (first tap of a chunk) the signal prefetch of the

@@ -500,6 +500,8 @@ class Generator(nn.Module):
                         srcs, src_aff = [xr] * nk, aff
                         for n in range(3):
                             dsts = [xas, xbs, outs][n]
+                            if save is not None:   # backward needs every sub-block's conv1 output: one buffer per n
+                                t1s = [self._buf(f'act.t1_{i}_{j}_{n}', (B, C, Lo), device=dev) for j in range(nk)]
                             ok = False
                             if fused_pair:
                                 ok = launch_pairs(f'{2 * n}&{2 * n + 1}',
