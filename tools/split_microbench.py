@@ -14,15 +14,17 @@ for B, ci, co, L, k, d in CASES:
     x = torch.randn(B, ci, L, device=dev)
     wf = torch.randn(k, ci, co, device=dev) / (ci * k) ** 0.5
     out = torch.empty(B, co, L, device=dev)
-    wp, wps = hipops.pack_mfma(wf), hipops.pack_split(wf)
+    BF = os.environ.get('V2W_MB_BF16') == '1'
+    SPL = hipops.ALGO_BF16 if BF else hipops.ALGO_SPLIT
+    wp, wps = hipops.pack_mfma(wf), hipops.pack_split(wf, bf16=BF)
     res = x if ci == co else None
     def run(algo):
         kw = dict(k=k, dil=d, slope=0.1, res=res, algo=algo)
-        if algo == hipops.ALGO_SPLIT: kw['wps'] = wps
+        if algo == SPL: kw['wps'] = wps
         else: kw['wp'] = wp
         hipops.conv1d(x, None, None, out, **kw)
     ts = {}
-    for name, algo in (('f32', hipops.ALGO_MFMA), ('split', hipops.ALGO_SPLIT)):
+    for name, algo in (('f32', hipops.ALGO_MFMA), ('split', SPL)):
         for _ in range(3): run(algo)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

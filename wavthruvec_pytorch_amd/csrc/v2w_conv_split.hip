@@ -23,7 +23,7 @@
 #ifdef V2W_EXP_TIMELINE
 __device__ unsigned long long v2w_dbg[8192];
 extern "C" int v2w_debug_read(void* dst, int bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2w_dbg), bytes); }
-#define V2W_TICK(k) do { if (dbg_on && st < 64) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) v2w_dbg[(wave * 64 + st) * 8 + (k)] = t_; } } while (0)
+#define V2W_TICK(k) do { if (dbg_on && st < 64) { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) v2w_dbg[(wave * 64 + st) * 8 + (k)] = t_; } } while (0)
 #else
 #define V2W_TICK(k) do {} while (0)
 #endif
@@ -71,7 +71,8 @@ conv_split_kernel(const MultiArgs m) {
     constexpr int ADMA = BF ? (NMT + 3) / 4 : ASTAGE / (NTHREADS * 16);
     static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
     constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
-    constexpr int NSIG = NS * 4;                                // global loads of one signal prefetch (always all issued)
+    constexpr int NSIG = (CK * ((NT + 2 * V2W_SPLIT_HMAX) / 4) + NTHREADS - 1) / NTHREADS;   // async copies per thread of one raw signal chunk
+    constexpr int RAWB = NSIG * NTHREADS * 16;                  // bytes of the raw (fp32) chunk image in LDS
     constexpr int RS = 72;                                      // floats per row of the epilogue transpose tile (32 x 64 per pass; 4*RS % 64 == 32)
     static_assert(NI % 2 == 0, "the epilogue works on pairs of 32-column blocks");
 
@@ -106,6 +107,7 @@ conv_split_kernel(const MultiArgs m) {
     const int xbytes = p.xcols * ROWB;
     unsigned char* const Xs0 = smem;
     unsigned char* const As0 = smem + 2 * xbytes;
+    unsigned char* const Rs = As0 + NAB * ASTAGE;                // raw fp32 image of the next chunk: [16 ch][xcols], filled by LDS-DMA
     float* const etab = reinterpret_cast<float*>(smem + p.atab_off);   // bias, res_a, res_s, mask_a, mask_s [MT] each
     float* const atab = etab + 5 * MT;                           // a[Cin], s[Cin] of this batch item
 
@@ -149,18 +151,32 @@ conv_split_kernel(const MultiArgs m) {
         dma_slot = dma_slot + 1 == NAB ? 0 : dma_slot + 1;
     };
 
+    const int xp4 = p.xcols >> 2;
     // ---- signal staging: wave w owns channels 4w..4w+3 of the chunk, lane l the position groups l, l+64, ... (1 KiB
     // contiguous per row and load instruction); every thread issues exactly NSIG loads (addresses clamped).
-    const int xp4 = p.xcols >> 2;
-    f32x4 pf[NS][4];
+    // The next chunk's fp32 signal also travels global -> LDS asynchronously (same hidden-from-hipcc copies as the weights:
+    // with no compiler-visible VMEM load in the loop, hipcc adds no vmcnt waits of its own - a register prefetch made it wait
+    // for the freshly issued weight copies at every commit, ~2900 cycles per chunk).  Float4 #lin of the image [16][xp4]
+    // is copied by thread (lin % 256) in instruction lin / 256; global offsets are fixed per thread, only the chunk base moves.
+    int soff[NSIG];
+#pragma unroll
+    for (int i = 0; i < NSIG; ++i) {
+        const int lin = i * NTHREADS + tid;
+        int row = lin / xp4, c4 = lin - row * xp4;
+        if (row > CK - 1) { row = CK - 1; c4 = 0; }              // beyond the image: a harmless duplicate copy
+        int pos = pos0 + c4 * 4;
+        pos = pos < 0 ? 0 : (pos > L - 4 ? L - 4 : pos);          // out-of-sequence columns are zeroed at commit
+        soff[i] = row * L + pos;
+    }
+    const unsigned r_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(Rs + wave * 1024));
     auto prefetch = [&](int ci0) __attribute__((always_inline)) {
-        const float* src = p.in + (size_t)(b * p.Cin + ci0 + wave * 4) * L;
+        const float* src = p.in + (size_t)(b * p.Cin + ci0) * L;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            int pos = pos0 + (lane + s * 64) * 4;
-            pos = pos < 0 ? 0 : (pos > L - 4 ? L - 4 : pos);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) pf[s][c] = *reinterpret_cast<const f32x4*>(src + (size_t)c * L + pos);
+        for (int i = 0; i < NSIG; ++i) {
+            unsigned m0_save;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_save) : "s"(r_lds + i * (NTHREADS * 16)), "v"(src + soff[i]) : "memory");
         }
     };
     auto act = [&](float v) __attribute__((always_inline)) {     // leaky_relu, then into the f16 range (see the header)
@@ -180,6 +196,9 @@ conv_split_kernel(const MultiArgs m) {
             if (pg >= xp4) continue;
             const int pos = pos0 + pg * 4;
             const bool in_seq = pos >= 0 && pos < L;             // L % 4 == 0, pos % 4 == 0: whole float4 in or out
+            f32x4 pf[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pf[c] = *reinterpret_cast<const f32x4*>(Rs + ((wave * 4 + c) * xp4 + pg) * 16);
             // rows 4 apart alias 4-way in LDS (320 B = 16 banks mod 64): 8 stores per chunk and wave, not worth a rotation
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -187,13 +206,13 @@ conv_split_kernel(const MultiArgs m) {
                 if constexpr (BF) {
                     b4 hi;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) hi[c] = (__bf16)(in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f);
+                    for (int c = 0; c < 4; ++c) hi[c] = (__bf16)(in_seq ? act(fmaf(av[c], pf[c][e], sv[c])) : 0.f);
                     *reinterpret_cast<b4*>(d) = hi;
                 } else {
                     h4 hi, lo;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float v = in_seq ? act(fmaf(av[c], pf[s][c][e], sv[c])) : 0.f;   // padding of the ACTIVATED signal
+                        const float v = in_seq ? act(fmaf(av[c], pf[c][e], sv[c])) : 0.f;   // padding of the ACTIVATED signal
                         const _Float16 h = (_Float16)v;
                         hi[c] = h;
                         lo[c] = (_Float16)(v - (float)h);
@@ -244,9 +263,15 @@ conv_split_kernel(const MultiArgs m) {
     __syncthreads();
     for (int s0 = 0; s0 < NAB - 1; ++s0)
         if (s0 < nst) dma_next();
-    if constexpr (VEC) { prefetch(0); commit(0, Xs0); }
-    else stage_scalar(0, Xs0);
-    V2W_WAIT_VM(0);
+    if constexpr (VEC) {
+        prefetch(0);
+        V2W_WAIT_VM(0);
+        V2W_BARRIER();                                           // raw chunk 0 (and the first weight stages) landed
+        commit(0, Xs0);
+    } else {
+        stage_scalar(0, Xs0);
+        V2W_WAIT_VM(0);
+    }
     V2W_BARRIER();
 
     const int rowbase = wn0 + lr + p.hla - p.hl;                 // LDS row of this lane's column for tap 0
@@ -267,6 +292,9 @@ conv_split_kernel(const MultiArgs m) {
     // A fragments, which the barrier publishes, are read after it.
     raw16 bh[NI], bl[BF ? 1 : NI];
     auto mma = [&](acc_t c, raw16 a, raw16 b) __attribute__((always_inline)) {
+#ifdef V2W_EXP_NOMMA
+        c[0] += __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, b[3]); return c;
+#endif
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
     };
@@ -279,14 +307,27 @@ conv_split_kernel(const MultiArgs m) {
         }
     };
     int ring = 0;                                                // ring slot of the stage being computed
+#ifdef V2W_EXP_TIMELINE
+    const bool dbg_on = blockIdx.x == 300;
+#endif
     auto stage = [&](const bool SIG, const bool COMMIT, int ch, int t) __attribute__((always_inline)) {
+        V2W_TICK(0);
         const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
         const bool more = ch + 1 < nch;
+#ifdef V2W_EXP_NODMA
+        const bool dma = false;
+#else
         const bool dma = st + (NAB - 1) < nst;
+#endif
         if (dma) dma_next();
+#ifdef V2W_EXP_NOSIG
+        const bool sig = false;
+#else
         const bool sig = SIG && VEC && more;
+#endif
         if (sig) prefetch((ch + 1) * CK);
         __builtin_amdgcn_sched_barrier(0);
+        V2W_TICK(1);
 
         const unsigned char* Ab = As0 + ring * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
         ring = ring + 1 == NAB ? 0 : ring + 1;
@@ -298,36 +339,56 @@ conv_split_kernel(const MultiArgs m) {
         }
         if (SIG) read_b(Xs, t);                                  // first tap of a chunk: its tile was committed just before the barrier
         __builtin_amdgcn_sched_barrier(0);
-        raw16 ch_[NI], cl_[BF ? 1 : NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) { ch_[j] = bh[j]; if constexpr (!BF) cl_[j] = bl[j]; }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], ch_[j]);
-        if (!COMMIT) read_b(Xs, t + 1);                          // next tap's signal fragments: in flight across the barrier
+#ifdef V2W_EXP_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        V2W_TICK(2);
+        // term order al*bh, ah*bh, ah*bl: bh has its last use after the second group and bl after the third, so the next tap's
+        // fragments are read into the SAME registers right there (no copies) and their LDS latency hides under the
+        // remaining MFMAs, the wait and the barrier
+        const unsigned char* xn = Xs + (rowbase + (t + 1) * p.dil) * ROWB + hk * 16;
         if constexpr (!BF) {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], cl_[j]);
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], al[i], bh[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], bh[j]);
+        if (!COMMIT) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bh[j] = *reinterpret_cast<const raw16*>(xn + j * 32 * ROWB);
+        }
+        if constexpr (!BF) {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], al[i], ch_[j]);
+                for (int i = 0; i < MI; ++i) acc[i][j] = mma(acc[i][j], ah[i], bl[j]);
+            if (!COMMIT) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bl[j] = *reinterpret_cast<const raw16*>(xn + j * 32 * ROWB + 32);
+            }
         }
 
+#ifndef V2W_EXP_NOSIG
         if (COMMIT && more) {
             unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
+            if (VEC && K < 3) { V2W_WAIT_VM(0); V2W_BARRIER(); }  // K >= 3: the tap-1 wait already covered the raw chunk; every wave's part is needed
             if constexpr (VEC) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
         }
+#endif
+        V2W_TICK(4);
         if (!dma) V2W_WAIT_VM(0);
         else if (sig) V2W_WAIT_VM((NAB - 2) * ADMA + NSIG);
         else V2W_WAIT_VM((NAB - 2) * ADMA);
+        V2W_TICK(5);
         // the barrier publishes the landed weight stage and the committed tile; LDS reads already in flight (next tap's B
         // fragments) need not drain first, so only the LDS WRITES of the commit are waited for (COMMIT stages)
         if (COMMIT) V2W_BARRIER(); else asm volatile("s_barrier" ::: "memory");
+        V2W_TICK(6);
         ++st;
     };
     for (int ch = 0; ch < nch; ++ch) {
@@ -341,18 +402,20 @@ conv_split_kernel(const MultiArgs m) {
     // [/ out_div].  The accumulators hold 4 consecutive ROWS per lane; each wave transposes 32 x (32*NI) blocks through its
     // own LDS region (all stages are consumed: the tile buffers are free) so that global traffic is float4 along positions.
     float* const T = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+    // one pass = 32 rows x 64 positions (two accumulator blocks): bounded registers for any NI.  The passes are spelled out
+    // with STATIC accumulator indices below: left as a loop hipcc does not always unroll it, indexes `acc` dynamically and
+    // parks the whole accumulator array in scratch.
+    auto epass = [&](const acc_t& c0, const acc_t& c1, const int i, const int j0) __attribute__((always_inline)) {
+        {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j0 = 0; j0 < NI; j0 += 2) {                     // 32 rows x 64 positions per pass: bounded registers for any NI
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) T[F::row(e, hk) * RS + jj * 32 + lr] = acc[i][j0 + jj][e] * winv;   // power of two: exact
+            for (int e = 0; e < 16; ++e) {
+                T[F::row(e, hk) * RS + lr] = c0[e] * winv;       // power of two: exact
+                T[F::row(e, hk) * RS + 32 + lr] = c1[e] * winv;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: no workgroup barrier needed
             constexpr int C4 = 16;                               // float4 per row of the pass
             constexpr int NIT = 32 * C4 / 64;                    // float4 per lane
-            constexpr int EG = 4;
+            constexpr int EG = MI * NI >= 8 ? 2 : 4;             // float4 gathers in flight per operand (register budget)
 #pragma unroll
             for (int g0 = 0; g0 < NIT; g0 += EG) {
                 f32x4 rv[EG], ov[EG], o2[EG], mv[EG];
@@ -410,7 +473,14 @@ conv_split_kernel(const MultiArgs m) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of T done before the next pass overwrites it
         }
+    };
+    epass(acc[0][0], acc[0][1], 0, 0);
+    if constexpr (NI >= 4) epass(acc[0][2], acc[0][3], 0, 2);
+    if constexpr (MI >= 2) {
+        epass(acc[1][0], acc[1][1], 1, 0);
+        if constexpr (NI >= 4) epass(acc[1][2], acc[1][3], 1, 2);
     }
+    static_assert(MI <= 2 && NI <= 4, "epilogue passes are spelled out for MI <= 2, NI <= 4");
 }
 
 template <int MI, int NI, int WM, int WN>
@@ -434,7 +504,8 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         p.vec4 = (p.L % 4 == 0) && p.L >= 4 && al16(p.in) && p.in_stride == 1;
         p.evec = (p.L % 4 == 0) && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
-        size_t l = (size_t)2 * p.xcols * V2W_SPLIT_ROWB + (size_t)V2W_SPLIT_NAB * (MT / 32) * V2W_SPLIT_UNIT;
+        constexpr int NSIG = (CK * ((NT + 2 * V2W_SPLIT_HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+        size_t l = (size_t)2 * p.xcols * V2W_SPLIT_ROWB + (size_t)V2W_SPLIT_NAB * (MT / 32) * V2W_SPLIT_UNIT + (size_t)NSIG * NTHREADS * 16;
         const size_t tl = (size_t)4 * 32 * RS * sizeof(float);       // epilogue transpose tiles overlay the stage buffers
         if (tl > l) l = tl;
         p.atab_off = (int)l;
@@ -680,6 +751,7 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
     if (a->C_out % 128 == 0) {
         if (V2W_SPLIT_FORCE == 1) return launch_split<1, 2, 2, 2>(ps, n, stream, bf);
         if (V2W_SPLIT_FORCE == 2) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);
+        // (128 x 256 = <2, 4, 2, 2> halves the weight traffic but needs > 256 VGPRs at two workgroups per CU: spills, 2x slower)
         if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);       // 128 x 128
         return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                // 64 x 128
     }
