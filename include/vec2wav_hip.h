@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 9
+#define V2W_ABI_VERSION 10
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -136,6 +136,7 @@ int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
  * sc: 4 floats of device memory: [0] = 1/scale (the `winv` of v2w_conv1d_args), [1] = scale, [2] = scratch.
  * Activations are split on the fly by the conv kernel and must satisfy |x| <= 65504 (they are clamped there). */
 int v2w_split_supported(int c_in, int c_out, int u);   /* 1 when V2W_ALGO_SPLIT serves this layer shape */
+int v2w_split_packable(int c_in, int c_out);           /* 1 when v2w_pack_split / _bf16 / _batch accept the shape (C_in % 16, C_out % 32) */
 int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);
 int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);   /* same buffers, V2W_ALGO_BF16 */
 /* Batched weight-norm fold + split pack of n Conv1d layers straight from the parameters (weight_v (C_out, C_in, k), weight_g or
@@ -182,6 +183,20 @@ typedef struct {
     float slope, out_div;
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
+
+/* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32: wps / sc from v2w_pack_split or
+ * v2w_pack_bf16 (or the batch) of the (k, 32, 32) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise. */
+typedef struct {
+    const float* in; const float* in_a; const float* in_s;
+    const void*  wps1[4]; const float* sc1[4]; const float* bias1[4];
+    const void*  wps2[4]; const float* sc2[4]; const float* bias2[4];
+    int32_t k[4], dil1[4], dil2[4];
+    float* out;
+    int32_t nk, B, C, L;
+    float slope, out_div;
+    int32_t bf16, _pad;
+} v2w_stage_split_args;
+int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */

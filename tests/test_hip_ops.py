@@ -166,6 +166,33 @@ def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+@pytest.mark.parametrize('B,L,bf16', [(2, 1000, False), (3, 4099, False), (1, 300, False), (2, 1000, True)])
+def test_resblock2_stage_split_c32(dev, B, L, bf16):
+    """Fused C = 32 ResBlock2 stage on the f16 (split) / bf16 matrix pipe against the fp64 math of models.py:65-70,135-141."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(15)
+    C, nk = 32, 3
+    x = r.standard_normal((B, C, L), dtype=np.float32)
+    a, s_ = (1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), (0.3 * r.standard_normal((B, C))).astype(np.float32)
+    xin = (torch.from_numpy(a)[:, :, None] * torch.from_numpy(x) + torch.from_numpy(s_)[:, :, None]).double()
+    branches, want = [], 0
+    for k in (3, 7, 11):
+        ws = [(r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for _ in range(2)]
+        bs = [r.standard_normal(C).astype(np.float32) * 0.1 for _ in range(2)]
+        q = lambda t: t.bfloat16().double() if bf16 else t.double()      # the configuration's stated operand precision
+        t1 = xin + F.conv1d(q(F.leaky_relu(xin, 0.1)), q(torch.from_numpy(ws[0])), torch.from_numpy(bs[0]).double(), padding=(k - 1) // 2)
+        rj = t1 + F.conv1d(q(F.leaky_relu(t1, 0.1)), q(torch.from_numpy(ws[1])), torch.from_numpy(bs[1]).double(), padding=3 * (k - 1) // 2, dilation=3)
+        want = want + rj
+        wfs = [_t(_relayout(torch.from_numpy(w)).numpy(), dev) for w in ws]
+        branches.append(dict(wps1=hipops.pack_split(wfs[0], bf16=bf16), b1=_t(bs[0], dev), wps2=hipops.pack_split(wfs[1], bf16=bf16),
+                             b2=_t(bs[1], dev), k=k, dil1=1, dil2=3))
+    want = want / nk
+    out = torch.full((B, C, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage_split(_t(x, dev), (_t(a, dev), _t(s_, dev)), branches, out, slope=0.1, out_div=float(nk), bf16=bf16)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= (2e-2 if bf16 else 2e-5), f'max err {err}'    # bf16: t1 itself is only carried with 8 bits through the LDS tile
+
+
 def test_conv1d_split_multi_and_rejects(dev):
     from wavthruvec_pytorch_amd import hipops
     assert not hipops.split_supported(16, 16) and not hipops.split_supported(32, 32) and not hipops.split_supported(64, 64, 2)

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -58,6 +58,18 @@ class FoldDesc(C.Structure):
                 ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32)]
 
 
+_P4 = _fp * 4
+_I4 = C.c_int32 * 4
+
+
+class StageSplitArgs(C.Structure):
+    _fields_ = [('in_', _fp), ('in_a', _fp), ('in_s', _fp),
+                ('wps1', _P4), ('sc1', _P4), ('bias1', _P4), ('wps2', _P4), ('sc2', _P4), ('bias2', _P4),
+                ('k', _I4), ('dil1', _I4), ('dil2', _I4), ('out', _fp),
+                ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
+                ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('_pad', C.c_int32)]
+
+
 class SplitDesc(C.Structure):
     _fields_ = [('v', _fp), ('g', _fp), ('wps', _fp), ('sc', _fp), ('rowscale', _fp),
                 ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32)]
@@ -85,6 +97,8 @@ SIGNATURES = {
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_split_packable': (C.c_int, [C.c_int, C.c_int]),
+    'v2w_resblock2_stage_split_fwd': (C.c_int, [C.POINTER(StageSplitArgs), _fp]),
     'v2w_pack_bf16': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),

@@ -693,6 +693,8 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
 
 }  // namespace
 
+extern "C" int v2w_split_packable(int c_in, int c_out) { return (c_in > 0 && c_out > 0 && c_in % V2W_SPLIT_CK == 0 && c_out % 32 == 0) ? 1 : 0; }
+
 extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
     return (u == 1 && c_in % V2W_SPLIT_CK == 0 && c_out % 64 == 0) ? 1 : 0;
 }
@@ -701,7 +703,7 @@ extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
 // [1] = scale, [2] = max |w| bits (zeroed here).  Three tiny launches on `stream`.
 extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
     if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
-    if (!v2w_split_supported(c_in, c_out, 1)) return V2W_E_SHAPE;
+    if (!v2w_split_packable(c_in, c_out)) return V2W_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     unsigned int* amax = reinterpret_cast<unsigned int*>(sc + 2);
     hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned int), st);
@@ -717,7 +719,7 @@ extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int 
 
 extern "C" int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
     if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
-    if (!v2w_split_supported(c_in, c_out, 1)) return V2W_E_SHAPE;
+    if (!v2w_split_packable(c_in, c_out)) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * c_out / 8;
     int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), sc, k, c_in, c_out);

@@ -1,0 +1,343 @@
+// Whole residual section of the C = 32 ResBlock2 stage in ONE kernel on the f16 / bf16 matrix pipe
+// (models.py:135-141 with ResBlock2.forward, models.py:65-70, inlined):
+//   out = ( sum_j [ t1_j + conv_{k_j,d2_j}(lrelu(t1_j)) + b2_j ] ) / nk ,   t1_j = x + conv_{k_j,d1_j}(lrelu(x)) + b1_j ,  x = a*in + s
+//
+// The split-operand counterpart of resblock2_stage_kernel (v2w_resblock_fused.hip): same tiling (x staged once for all nk
+// branches, every t1_j only in LDS, the branch sum in registers in the reference's order ((r0 + r1) + r2)), with the
+// arithmetic of v2w_conv_split.hip: operands x = x_hi + x_lo in f16 (weights pre-scaled by a per-layer power of two),
+// x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (BF: bf16 operands, one MFMA).
+//
+//   LDS  X [position][32 ch hi | 32 ch lo | pad] (144-B rows: conflict-free ds_read_b128 of 8 channels per lane): the
+//          ACTIVATED operand lrelu(x), exactly 0 outside [0, L); a tap is a row offset.
+//        T  same layout: lrelu(t1_j) on the W positions conv2 needs.
+//   Residuals: conv1 adds x itself, re-read from global memory (L2) in accumulator layout and affine-folded on the fly:
+//          exact.  conv2 adds t1, which exists nowhere in fp32: it is rebuilt from its staged halves,
+//          t1 = unlrelu(hi + lo), accurate to 2^-22 |t1| (the precision of the products themselves).
+//   Weights: the (hi, lo) fragment stream of v2w_pack_split for C_out = 32 (row block 0: [chunk 2][tap K][hi | lo][64 lanes][16 B]),
+//          read straight from L2 into registers with a one-unit ping-pong: no weight barrier at all, two barriers per branch.
+#include "v2w_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+
+#define V2W_SS_ROWB 144
+#define V2W_SS_MAXB 4
+
+struct StageSplitArgs {
+    const float* in; const float* in_a; const float* in_s;
+    const unsigned char* w1[V2W_SS_MAXB]; const float* sc1[V2W_SS_MAXB]; const float* bias1[V2W_SS_MAXB];
+    const unsigned char* w2[V2W_SS_MAXB]; const float* sc2[V2W_SS_MAXB]; const float* bias2[V2W_SS_MAXB];
+    int K[V2W_SS_MAXB], d1[V2W_SS_MAXB], d2[V2W_SS_MAXB];
+    float* out;
+    int nk, B, L;
+    int h1max, h2max;
+    int xoff, xrows, nto, ntl;
+    int vec4;
+    float slope, out_div;
+};
+
+template <int NI, int WN, bool BF>
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+stage_split_kernel(const StageSplitArgs p) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int NTHREADS = 64 * WN;
+    constexpr int C = 32;
+    constexpr int W = 32 * NI * WN;                 // positions computed per phase
+    constexpr int ROWB = V2W_SS_ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x;
+    const int b = tile / p.ntl;
+    const int n0 = (tile % p.ntl) * p.nto;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, hk = lane >> 5;
+    const int wn0 = wave * (32 * NI);
+    const int L = p.L;
+    const float slope = p.slope;
+    unsigned char* const Xs = smem;                              // [xrows][ROWB]
+    unsigned char* const Ts = smem + p.xrows * ROWB;             // [W][ROWB]
+    float* const etab = reinterpret_cast<float*>(Ts + W * ROWB); // bias1[nk][C], bias2[nk][C], then a[C], s[C] of this batch item
+
+    auto act = [&](float v) __attribute__((always_inline)) {
+        v = slope <= 1.f ? fmaxf(v, v * slope) : v2w_lrelu(v, slope);
+        return BF ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    };
+    // 4 consecutive channels of one position -> their (hi, lo) halves at `d` (hi) and `d + 64` (lo)
+    auto put4 = [&](unsigned char* d, const float (&v)[4]) __attribute__((always_inline)) {
+        if constexpr (BF) {
+            b4 hi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hi[c] = (__bf16)v[c];
+            *reinterpret_cast<b4*>(d) = hi;
+        } else {
+            h4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const _Float16 h = (_Float16)v[c];
+                hi[c] = h;
+                lo[c] = (_Float16)(v[c] - (float)h);
+            }
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + 64) = lo;
+        }
+    };
+
+    // ---- prologue: biases, the activated x tile (row r <-> position pos0 + r)
+    const int pos0 = n0 - p.h2max - p.h1max - p.xoff;
+    for (int i = tid; i < p.nk * C; i += NTHREADS) {
+        const int j = i / C, c = i - j * C;
+        etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
+        etab[V2W_SS_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
+    }
+    float* const aff = etab + 2 * V2W_SS_MAXB * C;
+    for (int c = tid; c < C; c += NTHREADS) {
+        aff[c] = p.in_a ? p.in_a[b * C + c] : 1.f;
+        aff[C + c] = p.in_a ? p.in_s[b * C + c] : 0.f;
+    }
+    if (p.vec4) {
+        // wave w stages channels 8w .. 8w+7 (two groups of 4), lane l the position groups l, l + 64, ...
+        const int xp4 = p.xrows >> 2;
+        for (int g = 0; g < 2; ++g) {
+            const int c0 = (wave * 2 + g) * 4;
+            float av[4], sv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                av[c] = p.in_a ? p.in_a[b * C + c0 + c] : 1.f;
+                sv[c] = p.in_a ? p.in_s[b * C + c0 + c] : 0.f;
+            }
+            for (int pg = lane; pg < xp4; pg += 64) {
+                const int pos = pos0 + pg * 4;
+                const bool in_seq = pos >= 0 && pos < L;         // L % 4 == 0, pos % 4 == 0: whole float4 in or out
+                f32x4 x4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    x4[c] = in_seq ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(b * C + c0 + c) * L + pos) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = in_seq ? act(fmaf(av[c], x4[c][e], sv[c])) : 0.f;
+                    put4(Xs + (pg * 4 + e) * ROWB + c0 * 2, v);
+                }
+            }
+        }
+    } else {
+        for (int c = wave; c < C; c += WN) {
+            const int ch = b * C + c;
+            const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_a ? p.in_s[ch] : 0.f;
+            for (int r = lane; r < p.xrows; r += 64) {
+                const int pos = pos0 + r;
+                const float v = (pos >= 0 && pos < L) ? act(fmaf(av, p.in[(size_t)ch * L + pos], sv)) : 0.f;
+                if constexpr (BF) {
+                    reinterpret_cast<__bf16*>(Xs + r * ROWB)[c] = (__bf16)v;
+                } else {
+                    const _Float16 h = (_Float16)v;
+                    _Float16* d = reinterpret_cast<_Float16*>(Xs + r * ROWB) + c;
+                    d[0] = h;
+                    d[32] = (_Float16)(v - (float)h);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    auto mma = [&](acc_t c, raw16 a, raw16 bb) __attribute__((always_inline)) {
+        if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, bb), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, bb), c, 0, 0, 0);
+    };
+
+    acc_t acc[NI], oacc[NI];
+    // Weight units (chunk, tap) travel L2 -> registers through a 4-slot ring, THREE units ahead of their use: a unit is only
+    // 3 * NI MFMAs (~200 cycles) of work, one unit of lookahead exposes most of the L2 latency.  The ring runs on across the
+    // conv phases (the tail of a phase prefetches the head of the next stream); a stream has 2K = 6 / 14 / 22 units, so a
+    // phase starts at any slot: the phase body is instantiated per start slot (S0) to keep every slot index static.
+    raw16 rh[4], rl[BF ? 1 : 4];
+    auto ld = [&](auto slot_c, const unsigned char* ptr) __attribute__((always_inline)) {
+        constexpr int sl = decltype(slot_c)::value;
+        rh[sl] = *reinterpret_cast<const raw16*>(ptr);
+        if constexpr (!BF) rl[sl] = *reinterpret_cast<const raw16*>(ptr + 1024);
+    };
+    auto conv_phase = [&](auto s0_c, const unsigned char* wq, const unsigned char* wnext, const unsigned char* src, int rowbase,
+                          int maxrow, int K, int dil) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(s0_c)::value;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        const unsigned char* ap = wq + lane * 16;
+        const unsigned char* an = wnext + lane * 16;
+        const int nu = 2 * K;
+        // signal fragments of unit u+1 are read while the MFMAs of unit u run (bn -> bc hand-over in registers)
+        raw16 bh[NI], bl[BF ? 1 : NI];
+        auto read_b = [&](int u) __attribute__((always_inline)) {
+            const int chk = u >= K ? 1 : 0, t = u - chk * K;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                // columns past the valid outputs of conv2 would read beyond T: clamped (their results are discarded)
+                const unsigned char* xr = src + min(rowbase + j * 32 + t * dil, maxrow) * ROWB + chk * 32 + hk * 16;
+                bh[j] = *reinterpret_cast<const raw16*>(xr);
+                if constexpr (!BF) bl[j] = *reinterpret_cast<const raw16*>(xr + 64);
+            }
+        };
+        read_b(0);
+        auto unit = [&](auto s_c, int u) __attribute__((always_inline)) {
+            constexpr int sl = (S0 + decltype(s_c)::value) & 3, slp = (sl + 3) & 3;
+            const int up = u + 3;
+            ld(std::integral_constant<int, slp>{}, up < nu ? ap + (size_t)up * 2048 : an + (size_t)(up - nu) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            raw16 ch_[NI], cl_[BF ? 1 : NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) { ch_[j] = bh[j]; if constexpr (!BF) cl_[j] = bl[j]; }
+            if (u + 1 < nu) read_b(u + 1);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[j] = mma(acc[j], rh[sl], ch_[j]);
+            if constexpr (!BF) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[j] = mma(acc[j], rh[sl], cl_[j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[j] = mma(acc[j], rl[sl], ch_[j]);
+            }
+        };
+        for (int u0 = 0; u0 < nu; u0 += 4) {                     // nu is even: units come in pairs
+            unit(std::integral_constant<int, 0>{}, u0);
+            unit(std::integral_constant<int, 1>{}, u0 + 1);
+            if (u0 + 2 < nu) {
+                unit(std::integral_constant<int, 2>{}, u0 + 2);
+                unit(std::integral_constant<int, 3>{}, u0 + 3);
+            }
+        }
+    };
+    // a stream has 2K units and K is odd: 2K = 2 (mod 4), so conv1 of every branch starts at ring slot 0 and conv2 at slot 2
+    ld(std::integral_constant<int, 0>{}, p.w1[0] + lane * 16);
+    ld(std::integral_constant<int, 1>{}, p.w1[0] + lane * 16 + 2048);
+    ld(std::integral_constant<int, 2>{}, p.w1[0] + lane * 16 + 4096);
+
+    for (int jb = 0; jb < p.nk; ++jb) {
+        const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
+        const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
+        const float winv1 = p.sc1[jb][0], winv2 = p.sc2[jb][0];
+
+        // ---- conv1_j -> t1_j on positions [n0 - h2max, n0 - h2max + W): X row of output column c, tap 0 = c + xoff + h1max - h1
+        conv_phase(std::integral_constant<int, 0>{}, p.w1[jb], p.w2[jb], Xs, wn0 + lr + p.xoff + (p.h1max - h1), p.xrows - 1, K, d1);
+        if (jb > 0) __syncthreads();              // conv2 of the previous branch has finished reading T
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn0 + j * 32 + lr;
+            const int pos = n0 - p.h2max + col;
+            const bool in_seq = pos >= 0 && pos < L;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int co = 8 * q + 4 * hk + c;            // accumulator register 4*q + c
+                    float t1 = 0.f;
+                    if (in_seq) {
+                        const int ch = b * C + co;
+                        const float x = fmaf(aff[co], p.in[(size_t)ch * L + pos], aff[C + co]);
+                        t1 = acc[j][4 * q + c] * winv1 + etab[jb * C + co] + x;
+                    }
+                    v[c] = in_seq ? act(t1) : 0.f;                // conv2 zero-pads t1 (and lrelu(0) = 0)
+                }
+                put4(Ts + col * ROWB + (8 * q + 4 * hk) * 2, v);
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2_j ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
+        conv_phase(std::integral_constant<int, 2>{}, p.w2[jb], jb + 1 < p.nk ? p.w1[jb + 1] : p.w2[jb], Ts, wn0 + lr + (p.h2max - h2), W - 1, K, d2);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const unsigned char* trow = Ts + (wn0 + j * 32 + lr + p.h2max) * ROWB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y[4];
+                if constexpr (BF) {
+                    const b4 hi = *reinterpret_cast<const b4*>(trow + (8 * q + 4 * hk) * 2);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[c] = (float)hi[c];
+                } else {
+                    const h4 hi = *reinterpret_cast<const h4*>(trow + (8 * q + 4 * hk) * 2);
+                    const h4 lo = *reinterpret_cast<const h4*>(trow + (8 * q + 4 * hk) * 2 + 64);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[c] = (float)hi[c] + (float)lo[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int co = 8 * q + 4 * hk + c;
+                    const float t1 = y[c] >= 0.f ? y[c] : y[c] / slope;     // undo the leaky_relu applied at staging
+                    const float r = (acc[j][4 * q + c] * winv2 + etab[V2W_SS_MAXB * C + jb * C + co]) + t1;
+                    oacc[j][4 * q + c] = jb == 0 ? r : oacc[j][4 * q + c] + r;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int co = F::row(e, hk);
+        const size_t orow = ((size_t)b * C + co) * L;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = wn0 + j * 32 + lr, pos = n0 + col;
+            if (col >= p.nto || pos >= L) continue;
+            float v = oacc[j][e];
+            if (p.out_div != 0.f) v = v / p.out_div;
+            p.out[orow + pos] = v;
+        }
+    }
+}
+
+template <int NI, int WN>
+int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
+    constexpr int W = 32 * NI * WN;
+    StageSplitArgs p{};
+    p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.out = q->out;
+    p.nk = q->nk; p.B = q->B; p.L = q->L; p.slope = q->slope; p.out_div = q->out_div;
+    for (int j = 0; j < q->nk; ++j) {
+        p.w1[j] = reinterpret_cast<const unsigned char*>(q->wps1[j]); p.sc1[j] = q->sc1[j]; p.bias1[j] = q->bias1[j];
+        p.w2[j] = reinterpret_cast<const unsigned char*>(q->wps2[j]); p.sc2[j] = q->sc2[j]; p.bias2[j] = q->bias2[j];
+        p.K[j] = q->k[j]; p.d1[j] = q->dil1[j]; p.d2[j] = q->dil2[j];
+        const int h1 = q->dil1[j] * (q->k[j] - 1) / 2, h2 = q->dil2[j] * (q->k[j] - 1) / 2;
+        if (h1 > p.h1max) p.h1max = h1;
+        if (h2 > p.h2max) p.h2max = h2;
+    }
+    p.nto = (W - 2 * p.h2max) & ~3;
+    if (p.nto < W / 2) return V2W_E_SHAPE;
+    const int hsum = p.h1max + p.h2max;
+    p.xoff = ((hsum + 3) & ~3) - hsum;
+    p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
+    p.ntl = (q->L + p.nto - 1) / p.nto;
+    p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
+    const size_t lds = (size_t)(p.xrows + W) * V2W_SS_ROWB + (size_t)(2 * V2W_SS_MAXB + 2) * 32 * sizeof(float);
+    if (lds > 160 * 1024) return V2W_E_SHAPE;
+    auto kern = q->bf16 ? stage_split_kernel<NI, WN, true> : stage_split_kernel<NI, WN, false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(q->B * p.ntl), dim3(64 * WN), lds, stream, p);
+    return v2w_launch_status();
+}
+
+}  // namespace
+
+extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream) {
+    if (!a || !a->in || !a->out || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+    if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
+    if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
+    for (int j = 0; j < a->nk; ++j) {
+        if (!a->wps1[j] || !a->wps2[j] || !a->sc1[j] || !a->sc2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;
+        if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
+    }
+    if (a->C != 32) return V2W_E_SHAPE;
+    return launch_stage_split<2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
+}

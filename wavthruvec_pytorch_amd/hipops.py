@@ -101,6 +101,11 @@ def split_halves(k, c_in, c_out):
     return k * c_in * c_out * 2 + 1024
 
 
+def split_packable(c_in, c_out):
+    """True when pack_split / SplitPlan accept the layer shape (the fused C = 32 stage kernel consumes such fragments too)."""
+    return bool(_hip.load().v2w_split_packable(c_in, c_out))
+
+
 def pack_split(wf, out=None, sc=None, bf16=False):
     """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
     scale record (sc[0] = 1/scale is the kernel's `winv`)."""
@@ -342,6 +347,27 @@ def resblock_pair_multi(problems):
     if rc == -2:
         return False
     _hip.check(rc, 'v2w_resblock_pair_fwd')
+    return True
+
+
+def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False):
+    """Split-operand (f16x3 / bf16) form of resblock2_stage for C == 32.  `branches`: list of dicts(wps1, b1, wps2, b2, k, dil1, dil2)
+    with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken."""
+    B, Cc, L = x.shape
+    a = _hip.StageSplitArgs()
+    a.in_ = x.data_ptr()
+    a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
+    for j, q in enumerate(branches):
+        a.wps1[j], a.sc1[j], a.bias1[j] = q['wps1'][0].data_ptr(), q['wps1'][1].data_ptr(), _hip.ptr(q['b1'])
+        a.wps2[j], a.sc2[j], a.bias2[j] = q['wps2'][0].data_ptr(), q['wps2'][1].data_ptr(), _hip.ptr(q['b2'])
+        a.k[j], a.dil1[j], a.dil2[j] = q['k'], q['dil1'], q['dil2']
+    a.out = out.data_ptr()
+    a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
+    a.slope, a.out_div, a.bf16 = slope, out_div, int(bf16)
+    rc = _hip.load().v2w_resblock2_stage_split_fwd(C.byref(a), _stream(x))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_resblock2_stage_split_fwd')
     return True
 
 

@@ -308,9 +308,13 @@ class Generator(nn.Module):
             return cached[1]
         out, batch = {}, []
         for name, m in self._conv_layers():
-            if m.transposed or name == 'conv_post' or m.out_channels < self.split_min_channels:
+            if m.transposed or name == 'conv_post':
                 continue
-            if not hipops.split_supported(m.in_channels, m.out_channels):
+            # wide layers: the per-layer split kernel; the C = 32 ResBlock2 stage: the fused split stage kernel
+            stage32 = (m.in_channels == 32 and m.out_channels == 32 and 32 in self.fuse_stage and name.startswith('resblocks.')
+                       and '.convs.' in name)
+            wide = m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
+            if not (wide or stage32):
                 continue
             v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
             wpsb = self._buf('wps.' + name, (hipops.split_halves(m.kernel_size, m.in_channels, m.out_channels),), dtype=torch.float16, device=device)
@@ -470,7 +474,14 @@ class Generator(nn.Module):
 
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
-                        if C in fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
+                        if C == 32 and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
+                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
+                                             [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                   wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
+                                             bf16=self.precision == 'bf16')
+                        if not ok and C in fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
                             # the whole residual section of the stage in ONE kernel: x read once, t1_j in LDS, sum in registers
                             ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
                                              [dict(wp1=wp[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
