@@ -43,7 +43,7 @@ extern "C" {
                               * same kernel, tiles and buffers as V2W_ALGO_SPLIT with fragments from v2w_pack_bf16 */
 #define V2W_ALGO_SPLIT  3    /* split-f16 MFMA: x = hi + lo halves, x_hi*w_hi + x_hi*w_lo + x_lo*w_hi accumulated in fp32 (~22-bit
                               * products; v_mfma_f32_32x32x16_f16); needs wps / winv from v2w_pack_split; Conv1d with
-                              * C_in % 32 == 0 and C_out % 64 == 0, else V2W_E_SHAPE */
+                              * C_in % 16 == 0, C_out % 64 == 0 and an odd k >= 3, else V2W_E_SHAPE */
 
 int         v2w_abi_version(void);
 const char* v2w_build_arch(void);       /* "gfx950" */

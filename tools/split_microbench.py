@@ -7,7 +7,8 @@ from wavthruvec_pytorch_amd import hipops
 
 dev = torch.device('cuda:0')
 CASES = [(32, 768, 512, 256, 7, 1), (32, 256, 256, 1280, 11, 1), (32, 256, 256, 1280, 3, 3), (32, 128, 128, 5120, 7, 1),
-         (32, 128, 128, 5120, 11, 3), (32, 64, 64, 20480, 7, 1), (32, 64, 64, 20480, 3, 1)]
+         (32, 128, 128, 5120, 11, 3), (32, 64, 64, 20480, 7, 1), (32, 64, 64, 20480, 3, 1),
+         (32, 256, 256, 1024, 11, 1), (16, 256, 256, 1024, 11, 1), (8, 256, 256, 1024, 11, 1)]   # 512 / 256 / 128 workgroups of 128 x 128
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
 for B, ci, co, L, k, d in CASES:

@@ -41,10 +41,13 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4)));   // one 16-byte
 #define V2W_SPLIT_UNIT 2048     // bytes of the A fragments of one (32-row block, chunk, tap): [hi, lo][64 lanes][16 B]
 #define V2W_SPLIT_HMAX 32       // largest halo per side
 #ifndef V2W_SPLIT_NAB
-#define V2W_SPLIT_NAB 3         // weight stages resident in LDS (NAB - 1 in flight)
+#define V2W_SPLIT_NAB 4         // weight stages resident in LDS: one computing, one published for the next stage, two in flight
 #endif
 #ifndef V2W_SPLIT_WPE
 #define V2W_SPLIT_WPE 2         // waves per SIMD the register allocation targets (= workgroups per CU)
+#endif
+#ifndef V2W_SPLIT_C64
+#define V2W_SPLIT_C64 0
 #endif
 #ifndef V2W_SPLIT_FORCE
 #define V2W_SPLIT_FORCE 0       // experiments: 1 = 64 x 128 tiles, 2 = 128 x 128 tiles for every C_out % 128 == 0 layer
@@ -72,7 +75,6 @@ conv_split_kernel(const MultiArgs m) {
     static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
     constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
     constexpr int NSIG = (CK * ((NT + 2 * V2W_SPLIT_HMAX) / 4) + NTHREADS - 1) / NTHREADS;   // async copies per thread of one raw signal chunk
-    constexpr int RAWB = NSIG * NTHREADS * 16;                  // bytes of the raw (fp32) chunk image in LDS
     constexpr int RS = 72;                                      // floats per row of the epilogue transpose tile (32 x 64 per pass; 4*RS % 64 == 32)
     static_assert(NI % 2 == 0, "the epilogue works on pairs of 32-column blocks");
 
@@ -108,8 +110,10 @@ conv_split_kernel(const MultiArgs m) {
     unsigned char* const Xs0 = smem;
     unsigned char* const As0 = smem + 2 * xbytes;
     unsigned char* const Rs = As0 + NAB * ASTAGE;                // raw fp32 image of the next chunk: [16 ch][xcols], filled by LDS-DMA
-    float* const etab = reinterpret_cast<float*>(smem + p.atab_off);   // bias, res_a, res_s, mask_a, mask_s [MT] each
-    float* const atab = etab + 5 * MT;                           // a[Cin], s[Cin] of this batch item
+    float* const atab = reinterpret_cast<float*>(smem + p.atab_off);   // a[Cin], s[Cin] of this batch item
+    // epilogue constants bias, res_a, res_s, mask_a, mask_s [MT] each: filled AFTER the stage loop, behind the transpose tiles, in
+    // LDS the stage buffers no longer need (keeps the 64 x 256 tile at two workgroups per CU)
+    float* const etab = reinterpret_cast<float*>(smem) + 4 * 32 * RS;
 
     acc_t acc[MI][NI];
 #pragma unroll
@@ -158,25 +162,30 @@ conv_split_kernel(const MultiArgs m) {
     // with no compiler-visible VMEM load in the loop, hipcc adds no vmcnt waits of its own - a register prefetch made it wait
     // for the freshly issued weight copies at every commit, ~2900 cycles per chunk).  Float4 #lin of the image [16][xp4]
     // is copied by thread (lin % 256) in instruction lin / 256; global offsets are fixed per thread, only the chunk base moves.
-    int soff[NSIG];
+    // The region holds exactly the image rounded up to 1 KiB (one wave copy); the wave copies of the last instruction that
+    // would run past it are pulled back to end flush with it (they re-copy the same data to the same place).
+    const int rawb = (CK * xp4 * 16 + 1023) & ~1023;
+    int soff[NSIG], rbase[NSIG];
 #pragma unroll
     for (int i = 0; i < NSIG; ++i) {
-        const int lin = i * NTHREADS + tid;
+        int wb = i * (NTHREADS * 16) + wave * 1024;              // LDS byte offset of this wave's 1 KiB in instruction i
+        wb = wb > rawb - 1024 ? rawb - 1024 : wb;
+        rbase[i] = wb;
+        const int lin = (wb >> 4) + lane;
         int row = lin / xp4, c4 = lin - row * xp4;
         if (row > CK - 1) { row = CK - 1; c4 = 0; }              // beyond the image: a harmless duplicate copy
         int pos = pos0 + c4 * 4;
         pos = pos < 0 ? 0 : (pos > L - 4 ? L - 4 : pos);          // out-of-sequence columns are zeroed at commit
         soff[i] = row * L + pos;
     }
-    const unsigned r_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(Rs + wave * 1024));
+    const unsigned r_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Rs);
     auto prefetch = [&](int ci0) __attribute__((always_inline)) {
         const float* src = p.in + (size_t)(b * p.Cin + ci0) * L;
 #pragma unroll
         for (int i = 0; i < NSIG; ++i) {
             unsigned m0_save;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_save) : "s"(r_lds + i * (NTHREADS * 16)), "v"(src + soff[i]) : "memory");
+                         : "=&s"(m0_save) : "s"(r_lds + __builtin_amdgcn_readfirstlane(rbase[i])), "v"(src + soff[i]) : "memory");
         }
     };
     auto act = [&](float v) __attribute__((always_inline)) {     // leaky_relu, then into the f16 range (see the header)
@@ -246,13 +255,6 @@ conv_split_kernel(const MultiArgs m) {
     };
 
     // ---- prologue
-    for (int c = tid; c < MT; c += NTHREADS) {
-        etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
-        etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
-        etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
-        etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
-        etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
-    }
     if (p.in_a) {
         for (int c = tid; c < p.Cin; c += NTHREADS) {
             atab[c] = p.in_a[b * p.Cin + c];
@@ -306,12 +308,29 @@ conv_split_kernel(const MultiArgs m) {
             if constexpr (!BF) bl[j] = *reinterpret_cast<const raw16*>(xr + j * 32 * ROWB + 32);
         }
     };
+    // ---- software pipeline of the stage loop.  A weight stage is PUBLISHED (copy landed + workgroup barrier) two stages
+    // before its use, so the A fragments of stage st+1 are read from LDS while stage st computes, like the B fragments of the
+    // next tap: a stage starts its MFMAs right after the barrier with every operand already in registers.  The A fragments
+    // alternate between two register sets (A0 / A1); K is odd, so a chunk starts and ends on the same set and the next
+    // chunk starts on the other one: the two chunk bodies below keep every register index static.
     int ring = 0;                                                // ring slot of the stage being computed
 #ifdef V2W_EXP_TIMELINE
     const bool dbg_on = blockIdx.x == 300;
 #endif
-    auto stage = [&](const bool SIG, const bool COMMIT, int ch, int t) __attribute__((always_inline)) {
+    auto read_a = [&](raw16 (&h)[MI], raw16 (&l)[BF ? 1 : MI], int slot) __attribute__((always_inline)) {
+        const unsigned char* Ab = As0 + slot * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            h[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT);
+            if constexpr (!BF) l[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT + 1024);
+        }
+    };
+    auto stage = [&](raw16 (&ah)[MI], raw16 (&al)[BF ? 1 : MI], raw16 (&nh)[MI], raw16 (&nl)[BF ? 1 : MI],
+                     const bool SIG, const bool COMMIT, int ch, int t) __attribute__((always_inline)) {
         V2W_TICK(0);
+#ifdef V2W_EXP_TIMELINE
+        if (dbg_on && st < 64 && lane == 0) v2w_dbg[(wave * 64 + st) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
         const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
         const bool more = ch + 1 < nch;
 #ifdef V2W_EXP_NODMA
@@ -329,19 +348,11 @@ conv_split_kernel(const MultiArgs m) {
         __builtin_amdgcn_sched_barrier(0);
         V2W_TICK(1);
 
-        const unsigned char* Ab = As0 + ring * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
-        ring = ring + 1 == NAB ? 0 : ring + 1;
-        raw16 ah[MI], al[BF ? 1 : MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            ah[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT);
-            if constexpr (!BF) al[i] = *reinterpret_cast<const raw16*>(Ab + i * V2W_SPLIT_UNIT + 1024);
-        }
         if (SIG) read_b(Xs, t);                                  // first tap of a chunk: its tile was committed just before the barrier
+        const int nslot = ring + 1 == NAB ? 0 : ring + 1;
+        if (st + 1 < nst) read_a(nh, nl, nslot);                 // next stage's weights: published by the previous barrier
+        ring = nslot;
         __builtin_amdgcn_sched_barrier(0);
-#ifdef V2W_EXP_TIMELINE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         V2W_TICK(2);
         // term order al*bh, ah*bh, ah*bl: bh has its last use after the second group and bl after the third, so the next tap's
         // fragments are read into the SAME registers right there (no copies) and their LDS latency hides under the
@@ -375,32 +386,52 @@ conv_split_kernel(const MultiArgs m) {
 #ifndef V2W_EXP_NOSIG
         if (COMMIT && more) {
             unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
-            if (VEC && K < 3) { V2W_WAIT_VM(0); V2W_BARRIER(); }  // K >= 3: the tap-1 wait already covered the raw chunk; every wave's part is needed
-            if constexpr (VEC) commit((ch + 1) * CK, Xn);
+            if constexpr (VEC) commit((ch + 1) * CK, Xn);        // K >= 3: the tap-1 wait already covered the raw chunk
             else stage_scalar((ch + 1) * CK, Xn);
         }
 #endif
         V2W_TICK(4);
+        // vmcnt retires in order.  The stage two ahead must have landed before this barrier publishes it: it was issued a stage
+        // ago, so only what THIS stage issued may stay outstanding (its copy, and the signal copies of a SIG stage; an older
+        // signal copy has landed by then as well).  Once no copy is issued any more the counts no longer hold: vmcnt(0).
         if (!dma) V2W_WAIT_VM(0);
-        else if (sig) V2W_WAIT_VM((NAB - 2) * ADMA + NSIG);
-        else V2W_WAIT_VM((NAB - 2) * ADMA);
+        else if (sig) V2W_WAIT_VM(ADMA + NSIG);
+        else V2W_WAIT_VM(ADMA);
         V2W_TICK(5);
-        // the barrier publishes the landed weight stage and the committed tile; LDS reads already in flight (next tap's B
-        // fragments) need not drain first, so only the LDS WRITES of the commit are waited for (COMMIT stages)
+        // LDS reads in flight (next operands) need not drain before the barrier; the LDS WRITES of a commit must
         if (COMMIT) V2W_BARRIER(); else asm volatile("s_barrier" ::: "memory");
         V2W_TICK(6);
         ++st;
     };
-    for (int ch = 0; ch < nch; ++ch) {
-        if (K == 1) { stage(true, true, ch, 0); continue; }
-        stage(true, false, ch, 0);
-        for (int t = 1; t < K - 1; ++t) stage(false, false, ch, t);
-        stage(false, true, ch, K - 1);
+    raw16 a0h[MI], a0l[BF ? 1 : MI], a1h[MI], a1l[BF ? 1 : MI];
+    read_a(a0h, a0l, 0);
+    auto chunk = [&](raw16 (&xh)[MI], raw16 (&xl)[BF ? 1 : MI], raw16 (&yh)[MI], raw16 (&yl)[BF ? 1 : MI], int ch) __attribute__((always_inline)) {
+        stage(xh, xl, yh, yl, true, false, ch, 0);
+        int t = 1;
+        for (; t + 1 < K - 1; t += 2) {
+            stage(yh, yl, xh, xl, false, false, ch, t);
+            stage(xh, xl, yh, yl, false, false, ch, t + 1);
+        }
+        stage(yh, yl, xh, xl, false, false, ch, K - 2);
+        stage(xh, xl, yh, yl, false, true, ch, K - 1);
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        chunk(a0h, a0l, a1h, a1l, ch);
+        if (ch + 1 < nch) chunk(a1h, a1l, a0h, a0l, ch + 1);
     }
 
     // ---- epilogue (same contract as the f32 tile kernel): undo the weight scale, mask, + bias [+ residual] [+ addends]
     // [/ out_div].  The accumulators hold 4 consecutive ROWS per lane; each wave transposes 32 x (32*NI) blocks through its
     // own LDS region (all stages are consumed: the tile buffers are free) so that global traffic is float4 along positions.
+    // (the last stage ended with a workgroup barrier: every wave is done with the stage buffers)
+    for (int c = tid; c < MT; c += NTHREADS) {
+        etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
+        etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
+        etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
+        etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
+        etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
+    }
+    __syncthreads();
     float* const T = reinterpret_cast<float*>(smem) + wave * (32 * RS);
     // one pass = 32 rows x 64 positions (two accumulator blocks): bounded registers for any NI.  The passes are spelled out
     // with STATIC accumulator indices below: left as a loop hipcc does not always unroll it, indexes `acc` dynamically and
@@ -494,6 +525,7 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
     for (int i = 0; i < nprob; ++i) {
         TileArgs p = ps[i];
         if (p.Cout % MT != 0 || p.Cin % CK != 0 || !p.wps || !p.winv) return V2W_E_SHAPE;
+        if (p.K < 3 || (p.K & 1) == 0) return V2W_E_SHAPE;            // the stage pipeline alternates register sets over an odd tap count
         p.hla = (p.hl + 3) & ~3;
         if (p.hla > V2W_SPLIT_HMAX || p.hr > V2W_SPLIT_HMAX) return V2W_E_SHAPE;
         p.ntl = (p.L + NT - 1) / NT;
@@ -504,12 +536,12 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         p.vec4 = (p.L % 4 == 0) && p.L >= 4 && al16(p.in) && p.in_stride == 1;
         p.evec = (p.L % 4 == 0) && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
-        constexpr int NSIG = (CK * ((NT + 2 * V2W_SPLIT_HMAX) / 4) + NTHREADS - 1) / NTHREADS;
-        size_t l = (size_t)2 * p.xcols * V2W_SPLIT_ROWB + (size_t)V2W_SPLIT_NAB * (MT / 32) * V2W_SPLIT_UNIT + (size_t)NSIG * NTHREADS * 16;
-        const size_t tl = (size_t)4 * 32 * RS * sizeof(float);       // epilogue transpose tiles overlay the stage buffers
+        const size_t rawb = ((size_t)CK * (p.xcols / 4) * 16 + 1023) & ~(size_t)1023;
+        size_t l = (size_t)2 * p.xcols * V2W_SPLIT_ROWB + (size_t)V2W_SPLIT_NAB * (MT / 32) * V2W_SPLIT_UNIT + rawb;
+        const size_t tl = ((size_t)4 * 32 * RS + 5 * MT) * sizeof(float);   // epilogue: transpose tiles + constants overlay the stage buffers
         if (tl > l) l = tl;
         p.atab_off = (int)l;
-        l += ((size_t)5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        l += (p.in_a ? (size_t)2 * p.Cin : 0) * sizeof(float);
         if (l > lds) lds = l;
         m.p[i] = p;
         m.start[i] = grid;
@@ -757,7 +789,11 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
         if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);       // 128 x 128
         return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                // 64 x 128
     }
+#if V2W_SPLIT_C64 == 1
+    return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                    // 64 x 128
+#else
     return launch_split<2, 2, 1, 4>(ps, n, stream, bf);                                    // 64 x 256
+#endif
 }
 
 // Batched form of (v2w_wn_fold_conv + v2w_pack_split) for n Conv1d layers: descs / starts live in DEVICE memory;
