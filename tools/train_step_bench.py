@@ -18,6 +18,7 @@ def main():
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).train()
+    g.precision = sys.argv[4] if len(sys.argv) > 4 else 'f32'
     opt = torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99))
     inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
     dy = torch.randn(B, 1, T * 320, device=dev)

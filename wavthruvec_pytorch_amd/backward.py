@@ -42,6 +42,18 @@ class GeneratorFunction(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+def _dconv(gen, x, wT, out, *, k, **kw):
+    """Input-gradient convolution with the transposed(-flipped) weights wT [k][C_out][C_in]: the forward conv kernel of the
+    generator's precision mode (exact fp32 MFMA, or the split-f16 / bf16 kernel when the layer shape has one)."""
+    co = wT.shape[2]
+    if gen.precision != 'f32' and (k & 1) and k >= 3 and hipops.split_supported(wT.shape[1], co) and co >= gen.split_min_channels \
+            and kw.get('in_stride', 0) <= 1:
+        bf = gen.precision == 'bf16'
+        return hipops.conv1d(x, None, None, out, k=k, algo=hipops.ALGO_BF16 if bf else hipops.ALGO_SPLIT,
+                             wps=hipops.pack_split(wT, bf16=bf), **kw)
+    return hipops.conv1d(x, wT, None, out, k=k, wp=hipops.pack_mfma(wT), **kw)
+
+
 def _wn_grads(grads, name, m, dwf):
     """dW in the [k][C_in][C_out] layout -> gradients of the layer's weight_v / weight_g (or plain weight)."""
     if m.weight_normed:
@@ -98,17 +110,17 @@ def generator_backward(gen, sv, dy):
                     x_aff = aff if n == 0 else None
                     w2T = hipops.transpose_flip(wf[f'{name}.convs2.{n}'])
                     du = torch.empty_like(dr)
-                    hipops.conv1d(dcur, w2T, None, du, k=k, dil=1, slope=1.0, wp=hipops.pack_mfma(w2T),
+                    _dconv(gen, dcur, w2T, du, k=k, dil=1, slope=1.0,
                                   mask=(u, None), mask_slope=LRELU_SLOPE)
                     _wn_grads(grads, f'{name}.convs2.{n}', c2, hipops.wgrad(u, dcur, k=k, dil=1, slope=LRELU_SLOPE))
                     grads[f'{name}.convs2.{n}.bias'] = hipops.channel_sum(dcur) if n < 2 else db2
                     w1T = hipops.transpose_flip(wf[f'{name}.convs1.{n}'])
                     if n > 0:
                         dprev = torch.empty_like(dr)
-                        hipops.conv1d(du, w1T, None, dprev, k=k, dil=c1.dilation, slope=1.0, res=dcur, wp=hipops.pack_mfma(w1T),
+                        _dconv(gen, du, w1T, dprev, k=k, dil=c1.dilation, slope=1.0, res=dcur,
                                       mask=(xin[n], None), mask_slope=LRELU_SLOPE)
                     else:   # into the stage's dx, summed over the branches
-                        hipops.conv1d(du, w1T, None, dx, k=k, dil=c1.dilation, slope=1.0, res=dcur, wp=hipops.pack_mfma(w1T),
+                        _dconv(gen, du, w1T, dx, k=k, dil=c1.dilation, slope=1.0, res=dcur,
                                       mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
                         dprev = None
                     _wn_grads(grads, f'{name}.convs1.{n}', c1,
@@ -121,13 +133,13 @@ def generator_backward(gen, sv, dy):
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
             w2T = hipops.transpose_flip(wf[name + '.convs.1'])
             dt1 = torch.empty_like(dr)
-            hipops.conv1d(dr, w2T, None, dt1, k=k, dil=c2.dilation, slope=1.0, res=dr, wp=hipops.pack_mfma(w2T),
+            _dconv(gen, dr, w2T, dt1, k=k, dil=c2.dilation, slope=1.0, res=dr,
                           mask=(t1, None), mask_slope=LRELU_SLOPE)
             _wn_grads(grads, name + '.convs.1', c2, hipops.wgrad(t1, dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
             grads[name + '.convs.1.bias'] = db2
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx += dt1 + lrelu'(x) * conv(dt1; W1^T flipped)
             w1T = hipops.transpose_flip(wf[name + '.convs.0'])
-            hipops.conv1d(dt1, w1T, None, dx, k=k, dil=c1.dilation, slope=1.0, res=dt1, wp=hipops.pack_mfma(w1T),
+            _dconv(gen, dt1, w1T, dx, k=k, dil=c1.dilation, slope=1.0, res=dt1,
                           mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
             _wn_grads(grads, name + '.convs.0', c1,
                       hipops.wgrad(xr, dt1, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))

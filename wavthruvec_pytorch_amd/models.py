@@ -168,6 +168,7 @@ class Generator(nn.Module):
                                               # C_out >= split_min_channels run on the f16 matrix pipe with split operands
                                               # (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulate; hipops.ALGO_SPLIT)
         self.split_min_channels = 64
+        self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
@@ -307,6 +308,7 @@ class Generator(nn.Module):
         if cached is not None and cached[0] == gen:
             return cached[1]
         out, batch = {}, []
+        self._split_wide = set()          # layers the per-layer split conv kernel takes (the others feed the fused C = 32 stage)
         for name, m in self._conv_layers():
             if m.transposed or name == 'conv_post':
                 continue
@@ -321,6 +323,8 @@ class Generator(nn.Module):
             scb = self._buf('wsc.' + name, (4,), device=device)
             batch.append((v.contiguous(), g, wpsb, scb))
             out[name] = (wpsb, scb)
+            if wide:
+                self._split_wide.add(name)
         if batch:
             key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in batch) + (self.precision,)
             plan = self._fold_key.get('split_plan')
@@ -378,10 +382,10 @@ class Generator(nn.Module):
 
         with torch.no_grad():
             wf, wp = self._fold_weights(dev, need_wf=save is not None)
-            wps = self._split_weights(dev) if save is None else {}
+            wps = self._split_weights(dev)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
 
             def ck(nm):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
-                if nm in wps:
+                if nm in wps and nm in self._split_wide:
                     return dict(algo=hipops.ALGO_BF16 if self.precision == 'bf16' else hipops.ALGO_SPLIT, wps=wps[nm])
                 return dict(algo=algo, wp=wp[nm])
 
