@@ -136,12 +136,12 @@ int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
  * sc: 4 floats of device memory: [0] = 1/scale (the `winv` of v2w_conv1d_args), [1] = scale, [2] = scratch.
  * Activations are split on the fly by the conv kernel and must satisfy |x| <= 65504 (they are clamped there). */
 int v2w_split_supported(int c_in, int c_out, int u);   /* 1 when V2W_ALGO_SPLIT serves this layer shape */
-int v2w_split_packable(int c_in, int c_out);           /* 1 when v2w_pack_split / _bf16 / _batch accept the shape (C_in % 16, C_out % 32) */
+int v2w_split_packable(int c_in, int c_out);           /* 1 when v2w_pack_split / _bf16 / _batch accept the shape (C_in % 16; C_out % 32, or C_out == 16 zero-padded to 32 rows) */
 int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);
 int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream);   /* same buffers, V2W_ALGO_BF16 */
 /* Batched weight-norm fold + split pack of n Conv1d layers straight from the parameters (weight_v (C_out, C_in, k), weight_g or
  * NULL): three launches for all of them.  descs / starts are DEVICE arrays; starts[0..n] = prefix sums of c_out,
- * starts[n+1..2n+1] = prefix sums of (c_out/32)*(c_in/16); nblk_* = their totals; k_max = largest kernel size. */
+ * starts[n+1..2n+1] = prefix sums of ceil(c_out/32)*(c_in/16); nblk_* = their totals; k_max = largest kernel size. */
 typedef struct {
     const float* v; const float* g;   /* weight_v, weight_g (NULL: plain weight) */
     void* wps; float* sc;             /* outputs: as v2w_pack_split */
@@ -184,8 +184,8 @@ typedef struct {
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
 
-/* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32: wps / sc from v2w_pack_split or
- * v2w_pack_bf16 (or the batch) of the (k, 32, 32) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise. */
+/* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16: wps / sc from v2w_pack_split or
+ * v2w_pack_bf16 (or the batch) of the (k, C, C) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise. */
 typedef struct {
     const float* in; const float* in_a; const float* in_s;
     const void*  wps1[4]; const float* sc1[4]; const float* bias1[4];

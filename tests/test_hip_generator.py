@@ -112,7 +112,7 @@ def test_generator_split_precision_tracks_f32_path(dev):
     with torch.no_grad():
         y32 = g32(*inp)
         ysp = gsp(*inp)
-    assert len(gsp._fold_key['wps'][1]) == 25          # conv_pre + the 18 residual convs of stages 0-2 (C_out >= 64) + the 6 of the fused C = 32 stage
+    assert len(gsp._fold_key['wps'][1]) == 31          # conv_pre + the 18 residual convs of stages 0-2 (C_out >= 64) + 6 + 6 of the fused C = 32 / 16 stages
     d = (y32 - ysp).abs().max().item()
     assert d <= 2e-6, f'split vs f32 path: max|dy| = {d}'
     for k, v in g32.state_dict().items():

@@ -166,12 +166,13 @@ def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+@pytest.mark.parametrize('C', [32, 16])
 @pytest.mark.parametrize('B,L,bf16', [(2, 1000, False), (3, 4099, False), (1, 300, False), (2, 1000, True)])
-def test_resblock2_stage_split_c32(dev, B, L, bf16):
-    """Fused C = 32 ResBlock2 stage on the f16 (split) / bf16 matrix pipe against the fp64 math of models.py:65-70,135-141."""
+def test_resblock2_stage_split(dev, B, L, bf16, C):
+    """Fused C = 32 / 16 ResBlock2 stage on the f16 (split) / bf16 matrix pipe against the fp64 math of models.py:65-70,135-141."""
     from wavthruvec_pytorch_amd import hipops
     r = _rng(15)
-    C, nk = 32, 3
+    nk = 3
     x = r.standard_normal((B, C, L), dtype=np.float32)
     a, s_ = (1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), (0.3 * r.standard_normal((B, C))).astype(np.float32)
     xin = (torch.from_numpy(a)[:, :, None] * torch.from_numpy(x) + torch.from_numpy(s_)[:, :, None]).double()

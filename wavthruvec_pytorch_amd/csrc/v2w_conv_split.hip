@@ -597,7 +597,7 @@ pack_split_kernel(const float* __restrict__ wf, h8* __restrict__ wps, const unsi
     const float scale = split_scale_from_bits(amax_bits[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = 1.f / scale; sc[1] = scale; }
     const int nch = Cin / V2W_SPLIT_CK;
-    const size_t total = (size_t)(Cout / 32) * nch * K * 64;            // lanes; each writes its hi and lo fragment element
+    const size_t total = (size_t)((Cout + 31) / 32) * nch * K * 64;     // lanes; each writes its hi and lo fragment element
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int lane = o & 63;
         size_t rest = o >> 6;
@@ -609,7 +609,7 @@ pack_split_kernel(const float* __restrict__ wf, h8* __restrict__ wps, const unsi
         h8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = wf[((size_t)t * Cin + c0 + j) * Cout + co] * scale;
+            const float v = co < Cout ? wf[((size_t)t * Cin + c0 + j) * Cout + co] * scale : 0.f;   // rows past C_out: MFMA padding
             const _Float16 h = (_Float16)v;
             hi[j] = h;
             lo[j] = (_Float16)(v - (float)h);
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256)
 pack_bf16_kernel(const float* __restrict__ wf, b8* __restrict__ wps, float* __restrict__ sc, int K, int Cin, int Cout) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = 1.f; sc[1] = 1.f; }
     const int nch = Cin / V2W_SPLIT_CK;
-    const size_t total = (size_t)(Cout / 32) * nch * K * 64;
+    const size_t total = (size_t)((Cout + 31) / 32) * nch * K * 64;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int lane = o & 63;
         size_t rest = o >> 6;
@@ -636,7 +636,7 @@ pack_bf16_kernel(const float* __restrict__ wf, b8* __restrict__ wps, float* __re
         const int c0 = ch * V2W_SPLIT_CK + 8 * (lane >> 5);
         b8 hi;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hi[j] = (__bf16)wf[((size_t)t * Cin + c0 + j) * Cout + co];
+        for (int j = 0; j < 8; ++j) hi[j] = (__bf16)(co < Cout ? wf[((size_t)t * Cin + c0 + j) * Cout + co] : 0.f);
         wps[(((size_t)(mb * nch + ch) * K + t) * 2) * 64 + lane] = hi;
     }
 }
@@ -696,7 +696,8 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
     const int rlen = V2W_SPLIT_CK * K, rstride = rlen + 1;
     for (int idx = threadIdx.x; idx < 32 * rlen; idx += 256) {
         const int r = idx / rlen, x = idx - r * rlen;
-        tile[r * rstride + x] = d.v[((size_t)(mb * 32 + r) * d.c_in + ch * V2W_SPLIT_CK) * K + x] * d.rowscale[mb * 32 + r] * scale;
+        const int row = mb * 32 + r;                             // rows past C_out (C_out = 16): MFMA padding
+        tile[r * rstride + x] = row < d.c_out ? d.v[((size_t)row * d.c_in + ch * V2W_SPLIT_CK) * K + x] * d.rowscale[row] * scale : 0.f;
     }
     __syncthreads();
     h8* dst = reinterpret_cast<h8*>(d.wps) + (size_t)(mb * nch + ch) * K * 128;
@@ -725,7 +726,10 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
 
 }  // namespace
 
-extern "C" int v2w_split_packable(int c_in, int c_out) { return (c_in > 0 && c_out > 0 && c_in % V2W_SPLIT_CK == 0 && c_out % 32 == 0) ? 1 : 0; }
+// C_out = 16: the 16 rows are zero-padded to one 32-row block (the fused C = 16 stage kernel)
+extern "C" int v2w_split_packable(int c_in, int c_out) {
+    return (c_in > 0 && c_out > 0 && c_in % V2W_SPLIT_CK == 0 && (c_out % 32 == 0 || c_out == 16)) ? 1 : 0;
+}
 
 extern "C" int v2w_split_supported(int c_in, int c_out, int u) {
     return (u == 1 && c_in % V2W_SPLIT_CK == 0 && c_out % 64 == 0) ? 1 : 0;
@@ -743,7 +747,7 @@ extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int 
     const size_t n = (size_t)k * c_in * c_out;
     int g1 = (int)((n + 255) / 256); if (g1 > 256) g1 = 256;
     hipLaunchKernelGGL(split_absmax_kernel, dim3(g1), dim3(256), 0, st, wf, n, amax);
-    const size_t total = n / 8;                                      // one thread per 8 weights
+    const size_t total = (size_t)k * c_in * ((c_out + 31) / 32 * 32) / 8;   // one thread per 8 (padded) weights
     int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
     hipLaunchKernelGGL(pack_split_kernel, dim3(g2), dim3(256), 0, st, wf, reinterpret_cast<h8*>(wps), amax, sc, k, c_in, c_out);
     return v2w_launch_status();
@@ -752,7 +756,7 @@ extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int 
 extern "C" int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c_in, int c_out, void* stream) {
     if (!wf || !wps || !sc || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
     if (!v2w_split_packable(c_in, c_out)) return V2W_E_SHAPE;
-    const size_t total = (size_t)k * c_in * c_out / 8;
+    const size_t total = (size_t)k * c_in * ((c_out + 31) / 32 * 32) / 8;
     int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), sc, k, c_in, c_out);
     return v2w_launch_status();

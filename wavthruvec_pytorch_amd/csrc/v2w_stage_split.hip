@@ -1,4 +1,4 @@
-// Whole residual section of the C = 32 ResBlock2 stage in ONE kernel on the f16 / bf16 matrix pipe
+// Whole residual section of a narrow ResBlock2 stage (C = 32 or C = 16) in ONE kernel on the f16 / bf16 matrix pipe
 // (models.py:135-141 with ResBlock2.forward, models.py:65-70, inlined):
 //   out = ( sum_j [ t1_j + conv_{k_j,d2_j}(lrelu(t1_j)) + b2_j ] ) / nk ,   t1_j = x + conv_{k_j,d1_j}(lrelu(x)) + b1_j ,  x = a*in + s
 //
@@ -13,8 +13,9 @@
 //   Residuals: conv1 adds x itself, re-read from global memory (L2) in accumulator layout and affine-folded on the fly:
 //          exact.  conv2 adds t1, which exists nowhere in fp32: it is rebuilt from its staged halves,
 //          t1 = unlrelu(hi + lo), accurate to 2^-22 |t1| (the precision of the products themselves).
-//   Weights: the (hi, lo) fragment stream of v2w_pack_split for C_out = 32 (row block 0: [chunk 2][tap K][hi | lo][64 lanes][16 B]),
-//          read straight from L2 into registers with a one-unit ping-pong: no weight barrier at all, two barriers per branch.
+//   Weights: the (hi, lo) fragment stream of v2w_pack_split (row block 0: [chunk C/16][tap K][hi | lo][64 lanes][16 B]; for C = 16
+//          the 16 output rows are zero-padded to the 32 rows of the MFMA: these stages are latency-, not MFMA-bound),
+//          read straight from L2 into registers through a 4-slot ring: no weight barrier at all, two barriers per branch.
 #include "v2w_common.h"
 #include <type_traits>
 
@@ -26,7 +27,6 @@ typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
 
-#define V2W_SS_ROWB 144
 #define V2W_SS_MAXB 4
 
 struct StageSplitArgs {
@@ -42,15 +42,16 @@ struct StageSplitArgs {
     float slope, out_div;
 };
 
-template <int NI, int WN, bool BF>
+template <int NCH, int NI, int WN, bool BF>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 stage_split_kernel(const StageSplitArgs p) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int NTHREADS = 64 * WN;
-    constexpr int C = 32;
+    constexpr int C = 16 * NCH;                     // channels: NCH chunks of one MFMA k-step
+    constexpr int HB = C * 2;                       // bytes of the hi (or lo) half of a row
     constexpr int W = 32 * NI * WN;                 // positions computed per phase
-    constexpr int ROWB = V2W_SS_ROWB;
+    constexpr int ROWB = 2 * HB + 16;               // 144 (C = 32) / 80 (C = 16): conflict-free ds_read_b128 across rows
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x;
@@ -70,7 +71,7 @@ stage_split_kernel(const StageSplitArgs p) {
         v = slope <= 1.f ? fmaxf(v, v * slope) : v2w_lrelu(v, slope);
         return BF ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
     };
-    // 4 consecutive channels of one position -> their (hi, lo) halves at `d` (hi) and `d + 64` (lo)
+    // 4 consecutive channels of one position -> their (hi, lo) halves at `d` (hi) and `d + HB` (lo)
     auto put4 = [&](unsigned char* d, const float (&v)[4]) __attribute__((always_inline)) {
         if constexpr (BF) {
             b4 hi;
@@ -86,7 +87,7 @@ stage_split_kernel(const StageSplitArgs p) {
                 lo[c] = (_Float16)(v[c] - (float)h);
             }
             *reinterpret_cast<h4*>(d) = hi;
-            *reinterpret_cast<h4*>(d + 64) = lo;
+            *reinterpret_cast<h4*>(d + HB) = lo;
         }
     };
 
@@ -103,10 +104,10 @@ stage_split_kernel(const StageSplitArgs p) {
         aff[C + c] = p.in_a ? p.in_s[b * C + c] : 0.f;
     }
     if (p.vec4) {
-        // wave w stages channels 8w .. 8w+7 (two groups of 4), lane l the position groups l, l + 64, ...
+        // wave w stages channels (C/4)w .. (C/4)w + C/4 - 1 (NCH groups of 4), lane l the position groups l, l + 64, ...
         const int xp4 = p.xrows >> 2;
-        for (int g = 0; g < 2; ++g) {
-            const int c0 = (wave * 2 + g) * 4;
+        for (int g = 0; g < NCH; ++g) {
+            const int c0 = (wave * NCH + g) * 4;
             float av[4], sv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -142,7 +143,7 @@ stage_split_kernel(const StageSplitArgs p) {
                     const _Float16 h = (_Float16)v;
                     _Float16* d = reinterpret_cast<_Float16*>(Xs + r * ROWB) + c;
                     d[0] = h;
-                    d[32] = (_Float16)(v - (float)h);
+                    d[C] = (_Float16)(v - (float)h);
                 }
             }
         }
@@ -174,7 +175,7 @@ stage_split_kernel(const StageSplitArgs p) {
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const unsigned char* ap = wq + lane * 16;
         const unsigned char* an = wnext + lane * 16;
-        const int nu = 2 * K;
+        const int nu = NCH * K;
         // signal fragments of unit u+1 are read while the MFMAs of unit u run (bn -> bc hand-over in registers)
         raw16 bh[NI], bl[BF ? 1 : NI];
         auto read_b = [&](int u) __attribute__((always_inline)) {
@@ -184,7 +185,7 @@ stage_split_kernel(const StageSplitArgs p) {
                 // columns past the valid outputs of conv2 would read beyond T: clamped (their results are discarded)
                 const unsigned char* xr = src + min(rowbase + j * 32 + t * dil, maxrow) * ROWB + chk * 32 + hk * 16;
                 bh[j] = *reinterpret_cast<const raw16*>(xr);
-                if constexpr (!BF) bl[j] = *reinterpret_cast<const raw16*>(xr + 64);
+                if constexpr (!BF) bl[j] = *reinterpret_cast<const raw16*>(xr + HB);
             }
         };
         read_b(0);
@@ -206,16 +207,30 @@ stage_split_kernel(const StageSplitArgs p) {
                 for (int j = 0; j < NI; ++j) acc[j] = mma(acc[j], rl[sl], ch_[j]);
             }
         };
-        for (int u0 = 0; u0 < nu; u0 += 4) {                     // nu is even: units come in pairs
+        for (int u0 = 0; u0 < nu; u0 += 4) {
             unit(std::integral_constant<int, 0>{}, u0);
-            unit(std::integral_constant<int, 1>{}, u0 + 1);
-            if (u0 + 2 < nu) {
-                unit(std::integral_constant<int, 2>{}, u0 + 2);
-                unit(std::integral_constant<int, 3>{}, u0 + 3);
-            }
+            if (u0 + 1 < nu) unit(std::integral_constant<int, 1>{}, u0 + 1);
+            if (u0 + 2 < nu) unit(std::integral_constant<int, 2>{}, u0 + 2);
+            if (u0 + 3 < nu) unit(std::integral_constant<int, 3>{}, u0 + 3);
         }
     };
-    // a stream has 2K units and K is odd: 2K = 2 (mod 4), so conv1 of every branch starts at ring slot 0 and conv2 at slot 2
+    // C = 32: a stream has 2K units and K is odd, 2K = 2 (mod 4): conv1 of every branch starts at ring slot 0 and conv2 at
+    // slot 2 (static).  C = 16: K units per stream, the start slot walks: the phase body is selected by a switch.
+    int s0 = 0;
+    auto run_phase = [&](auto conv2_c, const unsigned char* wq, const unsigned char* wnext, const unsigned char* src, int rowbase,
+                         int maxrow, int K, int dil) __attribute__((always_inline)) {
+        if constexpr (NCH == 2) {
+            conv_phase(std::integral_constant<int, decltype(conv2_c)::value ? 2 : 0>{}, wq, wnext, src, rowbase, maxrow, K, dil);
+        } else {
+            switch (s0) {
+                case 0: conv_phase(std::integral_constant<int, 0>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
+                case 1: conv_phase(std::integral_constant<int, 1>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
+                case 2: conv_phase(std::integral_constant<int, 2>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
+                default: conv_phase(std::integral_constant<int, 3>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
+            }
+            s0 = (s0 + K) & 3;
+        }
+    };
     ld(std::integral_constant<int, 0>{}, p.w1[0] + lane * 16);
     ld(std::integral_constant<int, 1>{}, p.w1[0] + lane * 16 + 2048);
     ld(std::integral_constant<int, 2>{}, p.w1[0] + lane * 16 + 4096);
@@ -226,7 +241,7 @@ stage_split_kernel(const StageSplitArgs p) {
         const float winv1 = p.sc1[jb][0], winv2 = p.sc2[jb][0];
 
         // ---- conv1_j -> t1_j on positions [n0 - h2max, n0 - h2max + W): X row of output column c, tap 0 = c + xoff + h1max - h1
-        conv_phase(std::integral_constant<int, 0>{}, p.w1[jb], p.w2[jb], Xs, wn0 + lr + p.xoff + (p.h1max - h1), p.xrows - 1, K, d1);
+        run_phase(std::false_type{}, p.w1[jb], p.w2[jb], Xs, wn0 + lr + p.xoff + (p.h1max - h1), p.xrows - 1, K, d1);
         if (jb > 0) __syncthreads();              // conv2 of the previous branch has finished reading T
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -234,7 +249,7 @@ stage_split_kernel(const StageSplitArgs p) {
             const int pos = n0 - p.h2max + col;
             const bool in_seq = pos >= 0 && pos < L;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2 * NCH; ++q) {                   // accumulator rows 8q + 4hk + c < C (C = 16: the padded rows are skipped)
                 float v[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -253,12 +268,12 @@ stage_split_kernel(const StageSplitArgs p) {
         __syncthreads();
 
         // ---- conv2_j ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        conv_phase(std::integral_constant<int, 2>{}, p.w2[jb], jb + 1 < p.nk ? p.w1[jb + 1] : p.w2[jb], Ts, wn0 + lr + (p.h2max - h2), W - 1, K, d2);
+        run_phase(std::true_type{}, p.w2[jb], jb + 1 < p.nk ? p.w1[jb + 1] : p.w2[jb], Ts, wn0 + lr + (p.h2max - h2), W - 1, K, d2);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const unsigned char* trow = Ts + (wn0 + j * 32 + lr + p.h2max) * ROWB;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2 * NCH; ++q) {
                 float y[4];
                 if constexpr (BF) {
                     const b4 hi = *reinterpret_cast<const b4*>(trow + (8 * q + 4 * hk) * 2);
@@ -266,7 +281,7 @@ stage_split_kernel(const StageSplitArgs p) {
                     for (int c = 0; c < 4; ++c) y[c] = (float)hi[c];
                 } else {
                     const h4 hi = *reinterpret_cast<const h4*>(trow + (8 * q + 4 * hk) * 2);
-                    const h4 lo = *reinterpret_cast<const h4*>(trow + (8 * q + 4 * hk) * 2 + 64);
+                    const h4 lo = *reinterpret_cast<const h4*>(trow + (8 * q + 4 * hk) * 2 + HB);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) y[c] = (float)hi[c] + (float)lo[c];
                 }
@@ -282,7 +297,7 @@ stage_split_kernel(const StageSplitArgs p) {
     }
 
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 8 * NCH; ++e) {                          // rows >= C are MFMA padding
         const int co = F::row(e, hk);
         const size_t orow = ((size_t)b * C + co) * L;
 #pragma unroll
@@ -296,9 +311,9 @@ stage_split_kernel(const StageSplitArgs p) {
     }
 }
 
-template <int NI, int WN>
+template <int NCH, int NI, int WN>
 int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
-    constexpr int W = 32 * NI * WN;
+    constexpr int W = 32 * NI * WN, C = 16 * NCH, ROWB = 4 * C + 16;
     StageSplitArgs p{};
     p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.out = q->out;
     p.nk = q->nk; p.B = q->B; p.L = q->L; p.slope = q->slope; p.out_div = q->out_div;
@@ -317,9 +332,9 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
     p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
     p.ntl = (q->L + p.nto - 1) / p.nto;
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
-    const size_t lds = (size_t)(p.xrows + W) * V2W_SS_ROWB + (size_t)(2 * V2W_SS_MAXB + 2) * 32 * sizeof(float);
+    const size_t lds = (size_t)(p.xrows + W) * ROWB + (size_t)(2 * V2W_SS_MAXB + 2) * C * sizeof(float);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
-    auto kern = q->bf16 ? stage_split_kernel<NI, WN, true> : stage_split_kernel<NI, WN, false>;
+    auto kern = q->bf16 ? stage_split_kernel<NCH, NI, WN, true> : stage_split_kernel<NCH, NI, WN, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -338,6 +353,7 @@ extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void
         if (!a->wps1[j] || !a->wps2[j] || !a->sc1[j] || !a->sc2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
     }
-    if (a->C != 32) return V2W_E_SHAPE;
-    return launch_stage_split<2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
+    if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
+    if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
+    return V2W_E_SHAPE;
 }

@@ -98,7 +98,7 @@ def split_supported(c_in, c_out, u=1):
 def split_halves(k, c_in, c_out):
     """Elements (f16) of the wps buffer of one layer: two halves per weight + one 2 KiB unit of padding (the kernel's
     stage copies always move whole tap pairs)."""
-    return k * c_in * c_out * 2 + 1024
+    return k * c_in * ((c_out + 31) // 32 * 32) * 2 + 1024      # C_out = 16 is zero-padded to one 32-row block
 
 
 def split_packable(c_in, c_out):
@@ -310,7 +310,7 @@ class SplitPlan:
             d.c_in, d.c_out, d.k, d.mode = ci, co, k, int(bf16)
             starts[i], starts[n + 1 + i] = off, blocks
             off += co
-            blocks += (co // 32) * (ci // 16)
+            blocks += ((co + 31) // 32) * (ci // 16)
         starts[n], starts[2 * n + 1] = off, blocks
         self.nblk_rows, self.nblk_pack = off, blocks
         self.k_max = max(v.shape[2] for v, *_ in layers)

@@ -308,13 +308,13 @@ class Generator(nn.Module):
         if cached is not None and cached[0] == gen:
             return cached[1]
         out, batch = {}, []
-        self._split_wide = set()          # layers the per-layer split conv kernel takes (the others feed the fused C = 32 stage)
+        self._split_wide = set()          # layers the per-layer split conv kernel takes (the others feed the fused C = 32 / 16 stages)
         for name, m in self._conv_layers():
             if m.transposed or name == 'conv_post':
                 continue
-            # wide layers: the per-layer split kernel; the C = 32 ResBlock2 stage: the fused split stage kernel
-            stage32 = (m.in_channels == 32 and m.out_channels == 32 and 32 in self.fuse_stage and name.startswith('resblocks.')
-                       and '.convs.' in name)
+            # wide layers: the per-layer split kernel; the C = 32 / 16 ResBlock2 stages: the fused split stage kernel
+            stage32 = (m.in_channels == m.out_channels and m.out_channels in (16, 32) and m.out_channels in self.fuse_stage
+                       and name.startswith('resblocks.') and '.convs.' in name)
             wide = m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
             if not (wide or stage32):
                 continue
@@ -478,7 +478,7 @@ class Generator(nn.Module):
 
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
-                        if C == 32 and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
+                        if C in (16, 32) and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
                             ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
                                              [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                                    wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
