@@ -170,9 +170,9 @@ def main():
             g(x, spk, nz)                   # back on the fp32 fragments for the profiling pass below
         alt = dict(precision='f16x3', value=samples_per_step * args.steps / alt_elapsed, unit='samples/s',
                    ms_per_step=alt_elapsed / args.steps * 1e3, max_abs_diff_vs_f32_path=diff, parity_bar=1e-4,
-                   arithmetic='Conv1d layers with C_out >= 64 and the fused C = 32 residual stage: x = x_hi + x_lo (f16), '
-                              'x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; transposed convs, the '
-                              'C = 16 stage, BatchNorm and conv_post exact fp32')
+                   arithmetic='Conv1d layers with C_out >= 64 and the fused C = 32 / 16 residual stages: x = x_hi + x_lo (f16), '
+                              'x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; transposed convs, '
+                              'BatchNorm and conv_post exact fp32')
 
     # ---- roofline of the dominant kernel: events around every conv launch, on the launching stream, live
     roof = None
@@ -217,8 +217,8 @@ def main():
             if fused:
                 kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                         ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
-                if staged and args.precision != 'f32' and ls[0]['cout'] == 32:
-                    kname = 'stage_split_kernel<2, 4, %s>' % ('true' if args.precision == 'bf16' else 'false')
+                if staged and args.precision != 'f32':
+                    kname = 'stage_split_kernel<%d, 2, 4, %s>' % (ls[0]['cout'] // 16, 'true' if args.precision == 'bf16' else 'false')
             nbytes = sum(l['bytes'] for l in ls)
             if fused:                              # the intermediate is neither written nor re-read
                 nbytes -= sum(2 * B * l['cout'] * l['L'] * 4 for l in ls[::2])
