@@ -185,7 +185,9 @@ typedef struct {
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
 
 /* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16: wps / sc from v2w_pack_split or
- * v2w_pack_bf16 (or the batch) of the (k, C, C) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise. */
+ * v2w_pack_bf16 (or the batch) of the (k, C, C) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise.
+ * The 2*nk fragment streams must lie BACK TO BACK in execution order (wps1[0], wps2[0], wps1[1], ...; (C/16)*k units of 2 KiB each,
+ * pack them into slices of one buffer): the kernel prefetches along one pointer; V2W_E_ARG if they do not. */
 typedef struct {
     const float* in; const float* in_a; const float* in_s;
     const void*  wps1[4]; const float* sc1[4]; const float* bias1[4];

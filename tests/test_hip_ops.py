@@ -177,7 +177,10 @@ def test_resblock2_stage_split(dev, B, L, bf16, C):
     a, s_ = (1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), (0.3 * r.standard_normal((B, C))).astype(np.float32)
     xin = (torch.from_numpy(a)[:, :, None] * torch.from_numpy(x) + torch.from_numpy(s_)[:, :, None]).double()
     branches, want = [], 0
-    for k in (3, 7, 11):
+    ks = (3, 7, 11)
+    arena = torch.zeros((sum(2 * hipops.split_units_halves(k, C, C) for k in ks) + 1024,), device=dev, dtype=torch.float16)
+    off = 0                                                      # the kernel wants the six streams back to back
+    for k in ks:
         ws = [(r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for _ in range(2)]
         bs = [r.standard_normal(C).astype(np.float32) * 0.1 for _ in range(2)]
         q = lambda t: t.bfloat16().double() if bf16 else t.double()      # the configuration's stated operand precision
@@ -185,13 +188,19 @@ def test_resblock2_stage_split(dev, B, L, bf16, C):
         rj = t1 + F.conv1d(q(F.leaky_relu(t1, 0.1)), q(torch.from_numpy(ws[1])), torch.from_numpy(bs[1]).double(), padding=3 * (k - 1) // 2, dilation=3)
         want = want + rj
         wfs = [_t(_relayout(torch.from_numpy(w)).numpy(), dev) for w in ws]
-        branches.append(dict(wps1=hipops.pack_split(wfs[0], bf16=bf16), b1=_t(bs[0], dev), wps2=hipops.pack_split(wfs[1], bf16=bf16),
-                             b2=_t(bs[1], dev), k=k, dil1=1, dil2=3))
+        n = hipops.split_units_halves(k, C, C)
+        packed = [hipops.pack_split(wfs[i], out=arena[off + i * n: off + (i + 1) * n], bf16=bf16) for i in range(2)]
+        off += 2 * n
+        branches.append(dict(wps1=packed[0], b1=_t(bs[0], dev), wps2=packed[1], b2=_t(bs[1], dev), k=k, dil1=1, dil2=3))
     want = want / nk
     out = torch.full((B, C, L), float('nan'), device=dev)
     assert hipops.resblock2_stage_split(_t(x, dev), (_t(a, dev), _t(s_, dev)), branches, out, slope=0.1, out_div=float(nk), bf16=bf16)
     err = (out.cpu().double() - want).abs().max().item()
     assert err <= (2e-2 if bf16 else 2e-5), f'max err {err}'    # bf16: t1 itself is only carried with 8 bits through the LDS tile
+    from wavthruvec_pytorch_amd._hip import HipLibraryError
+    branches[1], branches[2] = branches[2], branches[1]          # streams no longer back to back in execution order
+    with pytest.raises(HipLibraryError):
+        hipops.resblock2_stage_split(_t(x, dev), (_t(a, dev), _t(s_, dev)), branches, out, slope=0.1, out_div=float(nk), bf16=bf16)
 
 
 def test_conv1d_split_multi_and_rejects(dev):

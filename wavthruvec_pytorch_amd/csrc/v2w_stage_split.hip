@@ -34,6 +34,8 @@ struct StageSplitArgs {
     const unsigned char* w1[V2W_SS_MAXB]; const float* sc1[V2W_SS_MAXB]; const float* bias1[V2W_SS_MAXB];
     const unsigned char* w2[V2W_SS_MAXB]; const float* sc2[V2W_SS_MAXB]; const float* bias2[V2W_SS_MAXB];
     int K[V2W_SS_MAXB], d1[V2W_SS_MAXB], d2[V2W_SS_MAXB];
+    const unsigned char* wbase;   // the 2*nk weight streams lie back to back in execution order (w1_0, w2_0, w1_1, ...): unit g at wbase + g*2048
+    int ntot;                     // units of all streams
     float* out;
     int nk, B, L;
     int h1max, h2max;
@@ -166,16 +168,16 @@ stage_split_kernel(const StageSplitArgs p) {
         rh[sl] = *reinterpret_cast<const raw16*>(ptr);
         if constexpr (!BF) rl[sl] = *reinterpret_cast<const raw16*>(ptr + 1024);
     };
-    auto conv_phase = [&](auto s0_c, const unsigned char* wq, const unsigned char* wnext, const unsigned char* src, int rowbase,
-                          int maxrow, int K, int dil) __attribute__((always_inline)) {
+    auto conv_phase = [&](auto s0_c, int ug0, const unsigned char* src, int rowbase, int maxrow, int K, int dil) __attribute__((always_inline)) {
         constexpr int S0 = decltype(s0_c)::value;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        const unsigned char* ap = wq + lane * 16;
-        const unsigned char* an = wnext + lane * 16;
         const int nu = NCH * K;
+        // ring prefetch pointer: the streams are contiguous, so the unit three ahead is simply + 3 units (clamped at the very end)
+        const unsigned char* wp_ = p.wbase + (size_t)(ug0 + 3) * 2048 + lane * 16;
+        const unsigned char* const wend = p.wbase + (size_t)(p.ntot - 1) * 2048 + lane * 16;
         // signal fragments of unit u+1 are read while the MFMAs of unit u run (bn -> bc hand-over in registers)
         raw16 bh[NI], bl[BF ? 1 : NI];
         auto read_b = [&](int u) __attribute__((always_inline)) {
@@ -191,8 +193,8 @@ stage_split_kernel(const StageSplitArgs p) {
         read_b(0);
         auto unit = [&](auto s_c, int u) __attribute__((always_inline)) {
             constexpr int sl = (S0 + decltype(s_c)::value) & 3, slp = (sl + 3) & 3;
-            const int up = u + 3;
-            ld(std::integral_constant<int, slp>{}, up < nu ? ap + (size_t)up * 2048 : an + (size_t)(up - nu) * 2048);
+            ld(std::integral_constant<int, slp>{}, wp_ < wend ? wp_ : wend);
+            wp_ += 2048;
             __builtin_amdgcn_sched_barrier(0);
             raw16 ch_[NI], cl_[BF ? 1 : NI];
 #pragma unroll
@@ -217,23 +219,24 @@ stage_split_kernel(const StageSplitArgs p) {
     // C = 32: a stream has 2K units and K is odd, 2K = 2 (mod 4): conv1 of every branch starts at ring slot 0 and conv2 at
     // slot 2 (static).  C = 16: K units per stream, the start slot walks: the phase body is selected by a switch.
     int s0 = 0;
-    auto run_phase = [&](auto conv2_c, const unsigned char* wq, const unsigned char* wnext, const unsigned char* src, int rowbase,
-                         int maxrow, int K, int dil) __attribute__((always_inline)) {
+    int ug = 0;                                                  // global index of the next phase's first unit
+    auto run_phase = [&](auto conv2_c, const unsigned char* src, int rowbase, int maxrow, int K, int dil) __attribute__((always_inline)) {
         if constexpr (NCH == 2) {
-            conv_phase(std::integral_constant<int, decltype(conv2_c)::value ? 2 : 0>{}, wq, wnext, src, rowbase, maxrow, K, dil);
+            conv_phase(std::integral_constant<int, decltype(conv2_c)::value ? 2 : 0>{}, ug, src, rowbase, maxrow, K, dil);
         } else {
             switch (s0) {
-                case 0: conv_phase(std::integral_constant<int, 0>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
-                case 1: conv_phase(std::integral_constant<int, 1>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
-                case 2: conv_phase(std::integral_constant<int, 2>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
-                default: conv_phase(std::integral_constant<int, 3>{}, wq, wnext, src, rowbase, maxrow, K, dil); break;
+                case 0: conv_phase(std::integral_constant<int, 0>{}, ug, src, rowbase, maxrow, K, dil); break;
+                case 1: conv_phase(std::integral_constant<int, 1>{}, ug, src, rowbase, maxrow, K, dil); break;
+                case 2: conv_phase(std::integral_constant<int, 2>{}, ug, src, rowbase, maxrow, K, dil); break;
+                default: conv_phase(std::integral_constant<int, 3>{}, ug, src, rowbase, maxrow, K, dil); break;
             }
             s0 = (s0 + K) & 3;
         }
+        ug += NCH * K;
     };
-    ld(std::integral_constant<int, 0>{}, p.w1[0] + lane * 16);
-    ld(std::integral_constant<int, 1>{}, p.w1[0] + lane * 16 + 2048);
-    ld(std::integral_constant<int, 2>{}, p.w1[0] + lane * 16 + 4096);
+    ld(std::integral_constant<int, 0>{}, p.wbase + lane * 16);
+    ld(std::integral_constant<int, 1>{}, p.wbase + lane * 16 + 2048);
+    ld(std::integral_constant<int, 2>{}, p.wbase + lane * 16 + 4096);
 
     for (int jb = 0; jb < p.nk; ++jb) {
         const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
@@ -241,7 +244,7 @@ stage_split_kernel(const StageSplitArgs p) {
         const float winv1 = p.sc1[jb][0], winv2 = p.sc2[jb][0];
 
         // ---- conv1_j -> t1_j on positions [n0 - h2max, n0 - h2max + W): X row of output column c, tap 0 = c + xoff + h1max - h1
-        run_phase(std::false_type{}, p.w1[jb], p.w2[jb], Xs, wn0 + lr + p.xoff + (p.h1max - h1), p.xrows - 1, K, d1);
+        run_phase(std::false_type{}, Xs, wn0 + lr + p.xoff + (p.h1max - h1), p.xrows - 1, K, d1);
         if (jb > 0) __syncthreads();              // conv2 of the previous branch has finished reading T
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -268,7 +271,7 @@ stage_split_kernel(const StageSplitArgs p) {
         __syncthreads();
 
         // ---- conv2_j ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        run_phase(std::true_type{}, p.w2[jb], jb + 1 < p.nk ? p.w1[jb + 1] : p.w2[jb], Ts, wn0 + lr + (p.h2max - h2), W - 1, K, d2);
+        run_phase(std::true_type{}, Ts, wn0 + lr + (p.h2max - h2), W - 1, K, d2);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const unsigned char* trow = Ts + (wn0 + j * 32 + lr + p.h2max) * ROWB;
@@ -324,6 +327,16 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
         const int h1 = q->dil1[j] * (q->k[j] - 1) / 2, h2 = q->dil2[j] * (q->k[j] - 1) / 2;
         if (h1 > p.h1max) p.h1max = h1;
         if (h2 > p.h2max) p.h2max = h2;
+    }
+    // the kernel walks ONE weight stream: w1_0, w2_0, w1_1, ... must lie back to back (NCH*k units of 2 KiB each)
+    p.wbase = p.w1[0];
+    const unsigned char* expect = p.wbase;
+    for (int j = 0; j < q->nk; ++j) {
+        if (p.w1[j] != expect) return V2W_E_ARG;
+        expect += (size_t)NCH * q->k[j] * 2048;
+        if (p.w2[j] != expect) return V2W_E_ARG;
+        expect += (size_t)NCH * q->k[j] * 2048;
+        p.ntot += 2 * NCH * q->k[j];
     }
     p.nto = (W - 2 * p.h2max) & ~3;
     if (p.nto < W / 2) return V2W_E_SHAPE;

@@ -106,6 +106,11 @@ def split_packable(c_in, c_out):
     return bool(_hip.load().v2w_split_packable(c_in, c_out))
 
 
+def split_units_halves(k, c_in, c_out):
+    """f16 elements of the fragment units of one layer WITHOUT the trailing padding unit (slices of a shared stage buffer)."""
+    return k * c_in * ((c_out + 31) // 32 * 32) * 2
+
+
 def pack_split(wf, out=None, sc=None, bf16=False):
     """wf [k][C_in][C_out] -> (wps, sc): the (hi, lo) half-precision MFMA fragments of scale*wf for ALGO_SPLIT and the 4-float
     scale record (sc[0] = 1/scale is the kernel's `winv`)."""

@@ -309,6 +309,7 @@ class Generator(nn.Module):
             return cached[1]
         out, batch = {}, []
         self._split_wide = set()          # layers the per-layer split conv kernel takes (the others feed the fused C = 32 / 16 stages)
+        picked = []
         for name, m in self._conv_layers():
             if m.transposed or name == 'conv_post':
                 continue
@@ -316,11 +317,19 @@ class Generator(nn.Module):
             stage32 = (m.in_channels == m.out_channels and m.out_channels in (16, 32) and m.out_channels in self.fuse_stage
                        and name.startswith('resblocks.') and '.convs.' in name)
             wide = m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
-            if not (wide or stage32):
-                continue
+            if wide or stage32:
+                picked.append((name, m, wide))
+        # ONE arena, slices in execution order: the fused stage kernel walks the six streams of a stage as one contiguous
+        # stream; every slice of a wide layer carries the padding unit the conv kernel's stage copies may touch
+        sizes = [hipops.split_halves(m.kernel_size, m.in_channels, m.out_channels) if wide
+                 else hipops.split_units_halves(m.kernel_size, m.in_channels, m.out_channels) for _n, m, wide in picked]
+        arena = self._buf('wps.arena', (sum(sizes) + 1024,), dtype=torch.float16, device=device)
+        scs = self._buf('wsc.arena', (4 * max(1, len(picked)),), device=device)
+        off = 0
+        for i, ((name, m, wide), n) in enumerate(zip(picked, sizes)):
             v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
-            wpsb = self._buf('wps.' + name, (hipops.split_halves(m.kernel_size, m.in_channels, m.out_channels),), dtype=torch.float16, device=device)
-            scb = self._buf('wsc.' + name, (4,), device=device)
+            wpsb, scb = arena[off:off + n], scs[4 * i:4 * i + 4]
+            off += n
             batch.append((v.contiguous(), g, wpsb, scb))
             out[name] = (wpsb, scb)
             if wide:
