@@ -10,9 +10,10 @@
 //   LDS  X [position][32 ch hi | 32 ch lo | pad] (144-B rows: conflict-free ds_read_b128 of 8 channels per lane): the
 //          ACTIVATED operand lrelu(x), exactly 0 outside [0, L); a tap is a row offset.
 //        T  same layout: lrelu(t1_j) on the W positions conv2 needs.
-//   Residuals: conv1 adds x itself, re-read from global memory (L2) in accumulator layout and affine-folded on the fly:
-//          exact.  conv2 adds t1, which exists nowhere in fp32: it is rebuilt from its staged halves,
-//          t1 = unlrelu(hi + lo), accurate to 2^-22 |t1| (the precision of the products themselves).
+//   Residuals: x and t1 exist in LDS only as the halves of their ACTIVATED values; the residual adds rebuild them,
+//          v = unlrelu(hi + lo), accurate to 2^-22 |v| (the precision of the products themselves); in the bf16 form x is
+//          re-read from global memory instead (its tile holds 8 bits), t1 is carried at bf16 precision like every operand.  (Re-reading x from
+//          global memory in the conv1 epilogue is exact but cost ~5000 cycles per branch: 64 latency-exposed loads per thread.)
 //   Weights: the (hi, lo) fragment stream of v2w_pack_split (row block 0: [chunk C/16][tap K][hi | lo][64 lanes][16 B]; for C = 16
 //          the 16 output rows are zero-padded to the 32 rows of the MFMA: these stages are latency-, not MFMA-bound),
 //          read straight from L2 into registers through a 4-slot ring: no weight barrier at all, two barriers per branch.
@@ -44,8 +45,9 @@ struct StageSplitArgs {
     float slope, out_div;
 };
 
+// C = 16: 43 KB of LDS -> three workgroups per CU (register budget 168); C = 32: 79 KB -> two
 template <int NCH, int NI, int WN, bool BF>
-__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 3 : 2, NCH == 1 ? 3 : 2)))
 stage_split_kernel(const StageSplitArgs p) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -116,18 +118,29 @@ stage_split_kernel(const StageSplitArgs p) {
                 av[c] = p.in_a ? p.in_a[b * C + c0 + c] : 1.f;
                 sv[c] = p.in_a ? p.in_s[b * C + c0 + c] : 0.f;
             }
-            for (int pg = lane; pg < xp4; pg += 64) {
+            // every global load of the group is issued before the first conversion: one exposed latency, not one per slice
+            constexpr int NPG = (W + 64 + 4) / 4 / 64 + 1;      // position groups per lane (xrows <= W + 2*32 + 4)
+            f32x4 x4[NPG][4];
+#pragma unroll
+            for (int s = 0; s < NPG; ++s) {
+                const int pg = lane + s * 64;
                 const int pos = pos0 + pg * 4;
-                const bool in_seq = pos >= 0 && pos < L;         // L % 4 == 0, pos % 4 == 0: whole float4 in or out
-                f32x4 x4[4];
+                const bool in_seq = pg < xp4 && pos >= 0 && pos < L;      // L % 4 == 0, pos % 4 == 0: whole float4 in or out
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    x4[c] = in_seq ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(b * C + c0 + c) * L + pos) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x4[s][c] = in_seq ? *reinterpret_cast<const f32x4*>(p.in + (size_t)(b * C + c0 + c) * L + pos) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < NPG; ++s) {
+                const int pg = lane + s * 64;
+                if (pg >= xp4) continue;
+                const int pos = pos0 + pg * 4;
+                const bool in_seq = pos >= 0 && pos < L;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = in_seq ? act(fmaf(av[c], x4[c][e], sv[c])) : 0.f;
+                    for (int c = 0; c < 4; ++c) v[c] = in_seq ? act(fmaf(av[c], x4[s][c][e], sv[c])) : 0.f;
                     put4(Xs + (pg * 4 + e) * ROWB + c0 * 2, v);
                 }
             }
@@ -251,18 +264,29 @@ stage_split_kernel(const StageSplitArgs p) {
             const int col = wn0 + j * 32 + lr;
             const int pos = n0 - p.h2max + col;
             const bool in_seq = pos >= 0 && pos < L;
+            const unsigned char* xrow_ = Xs + (col + p.xoff + p.h1max) * ROWB;     // the x tile row of this output position
 #pragma unroll
             for (int q = 0; q < 2 * NCH; ++q) {                   // accumulator rows 8q + 4hk + c < C (C = 16: the padded rows are skipped)
-                float v[4];
+                float xv[4], v[4];
+                if constexpr (BF) {
+                    // bf16 operands carry 8 bits: the residual path must not go through them.  x is re-read from global memory
+                    // (L2) and affine-folded on the fly; xv holds the ACTIVATED value like the split branch below
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int co = 8 * q + 4 * hk + c;
+                        xv[c] = in_seq ? v2w_lrelu(fmaf(aff[co], p.in[(size_t)(b * C + co) * L + pos], aff[C + co]), slope) : 0.f;
+                    }
+                } else {
+                    const h4 hi = *reinterpret_cast<const h4*>(xrow_ + (8 * q + 4 * hk) * 2);
+                    const h4 lo = *reinterpret_cast<const h4*>(xrow_ + (8 * q + 4 * hk) * 2 + HB);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = (float)hi[c] + (float)lo[c];
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int co = 8 * q + 4 * hk + c;            // accumulator register 4*q + c
-                    float t1 = 0.f;
-                    if (in_seq) {
-                        const int ch = b * C + co;
-                        const float x = fmaf(aff[co], p.in[(size_t)ch * L + pos], aff[C + co]);
-                        t1 = acc[j][4 * q + c] * winv1 + etab[jb * C + co] + x;
-                    }
+                    const float x = xv[c] >= 0.f ? xv[c] : xv[c] / slope;      // undo the leaky_relu applied at staging
+                    const float t1 = acc[j][4 * q + c] * winv1 + etab[jb * C + co] + x;
                     v[c] = in_seq ? act(t1) : 0.f;                // conv2 zero-pads t1 (and lrelu(0) = 0)
                 }
                 put4(Ts + col * ROWB + (8 * q + 4 * hk) * 2, v);
