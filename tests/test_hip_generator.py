@@ -320,6 +320,61 @@ def test_data_parallel_condbn_two_ranks_one_gpu(dev, tmp_path):
                 assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k
 
 
+def _ddp_worker(rank, world, port, B, T, out_dir):
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from wavthruvec_pytorch_amd.distributed import shard_batch
+    dev = torch.device('cuda:0')
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    g = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    ddp = DistributedDataParallel(g)                                   # vec2wav/train.py:92
+    full = synthetic.make_inputs(h, B, T, seed=99)
+    dy = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 1, T * 320)).astype(np.float32))
+    mine = shard_batch(full, rank, world)
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    y = ddp(*to_dev(mine, dev))
+    (y * dy[lo:hi].to(dev)).sum().backward()
+    torch.save({n: p.grad.cpu() for n, p in g.named_parameters()}, os.path.join(out_dir, f'grad{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_ddp_wrapped_generator_two_ranks_one_gpu(dev, tmp_path):
+    """`DistributedDataParallel(generator)` (train.py:92) over the HIP autograd path: two ranks on batch shards with synchronised
+    CondBN statistics (forward AND backward sums) - the averaged gradients x world equal the single-process global-batch gradients."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    B, T, world = 4, 10, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(world, port, B, T, str(tmp_path)), nprocs=world, join=True)
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    full = synthetic.make_inputs(h, B, T, seed=99)
+    dy = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 1, T * 320)).astype(np.float32))
+    g = build_generator(h, sd, dev, training=True)
+    y = g(*to_dev(full, dev))
+    (y * dy.to(dev)).sum().backward()
+    g0 = torch.load(os.path.join(str(tmp_path), 'grad0.pt'))
+    g1 = torch.load(os.path.join(str(tmp_path), 'grad1.pt'))
+    bad = {}
+    for n, p in g.named_parameters():
+        assert torch.equal(g0[n], g1[n]), n                           # DDP left identical (averaged) gradients on both ranks
+        ref = p.grad.cpu()
+        floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6   # analytically zero under train-mode BN
+        err = (g0[n] * world - ref).abs().max().item() / max(ref.abs().max().item(), floor)
+        if err > 4e-3:
+            bad[n] = err
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
 def test_graph_capture_matches_eager(dev):
     """HIP-graph replay of the eval forward (inference sizes are launch-bound) == the eager launches, bit for bit."""
     h = synthetic.make_hparams(num_wv_feat=768)
