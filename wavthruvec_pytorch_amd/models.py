@@ -316,7 +316,8 @@ class Generator(nn.Module):
             # wide layers: the per-layer split kernel; the C = 32 / 16 ResBlock2 stages: the fused split stage kernel
             stage32 = (m.in_channels == m.out_channels and m.out_channels in (16, 32) and m.out_channels in self.fuse_stage
                        and name.startswith('resblocks.') and '.convs.' in name)
-            wide = m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
+            wide = (m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
+                    and m.kernel_size % 2 == 1 and m.kernel_size >= 3)       # the split kernel pipelines over an odd tap count
             if wide or stage32:
                 picked.append((name, m, wide))
         # ONE arena, slices in execution order: the fused stage kernel walks the six streams of a stage as one contiguous
