@@ -91,12 +91,15 @@ def main(argv=None) -> int:
     ap.add_argument('--remove-weight-norm', action='store_true')
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--device', default='cuda:0')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'bf16'],
+                    help="Generator.precision: exact fp32 (default), split-f16 (fp32-level accuracy, faster) or bf16 operands")
     args = ap.parse_args(argv)
     feat = load_latents(args.feat)
     spk = load_speaker_embedding(args.spk_emb)
     resblock = '1' if str(args.resblock) == "'1'" or args.resblock == '1s' else args.resblock
     h = synthetic.make_hparams(num_wv_feat=args.num_wv_feat or feat.shape[1], resblock=resblock)
     g = build_generator(args.checkpoint, h, torch.device(args.device), args.remove_weight_norm)
+    g.precision = args.precision
     y = synthesize(g, feat, spk, seed=args.seed)
     write_wav(args.out, y, args.sampling_rate)
     print(f'{args.out}: {y.shape[-1]} samples ({y.shape[-1] / args.sampling_rate:.2f} s) from {feat.shape[-1]} frames')
