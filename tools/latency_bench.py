@@ -15,6 +15,8 @@ def main():
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).eval()
+    g.precision = os.environ.get('V2W_PRECISION', 'f32')
+    print('precision', g.precision)
     shapes = [(1, 50), (1, 256), (4, 256)]
     if len(sys.argv) > 2:
         shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
