@@ -574,6 +574,10 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
     }
+    // latency-bound sizes (inference at B = 1): fewer than two 64 x 64 tiles per CU -> 64 x 64 tiles: the most workgroups and one
+    // MFMA per k-step and wave, i.e. the shortest serial chain through the K loop (cfg1: 1.54 -> 1.23 ms per forward)
+    if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 64 == 0 && (long)n * a->B * ((a->L + 63) / 64) * (a->C_out / 64) < 512)
+        return launch_tile<32, 1, 1, 1, 2, 2, 32>(ps, n, stream);
     if (cfg.mf == 32 && cfg.ck == 32 && a->C_out % 128 == 0) {
         // 128 x 128 tiles unless that leaves fewer than ~4 tiles per CU: then 128 x 64 halves the tail imbalance
         if (tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32>(ps, n, stream);
