@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 10
+#define V2W_ABI_VERSION 11
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -304,6 +304,15 @@ int v2w_cond_bwd(const float* dgb, const float* z, const float* sn_w, const floa
  * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
 int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
                        int B, int C_in, int L, int k, float slope, void* stream);
+
+/* ---- mel_spectrogram of the generated audio (vec2wav/dataset.py:53-77, train.py:172-174,266-269).
+ * The STFT itself is a Conv1d over the hop-phase de-interleaved signal and runs through v2w_conv1d_fwd (hop input channels,
+ * n_fft/hop taps, pad_left = 0, windowed DFT rows as weights: see wavthruvec_pytorch_amd/mel.py); these are its two ends:
+ *   v2w_mel_phases: y (B, L) -> xp (B, hop, FP), xp[b][p][f] = reflect_pad(y, pad)[f*hop + p] (0 past the padded signal)
+ *   v2w_mel_finish: spec (B, Cs, FP) (rows [0,nb) = Re, [nb,2nb) = Im), basis (n_mels, nb) -> out (B, n_mels, F) =
+ *                   log(clamp(basis @ sqrt(Re^2 + Im^2 + 1e-9), 1e-5))                                    (dataset.py:31-41,72-75) */
+int v2w_mel_phases(const float* y, float* xp, int B, int L, int hop, int pad, int FP, void* stream);
+int v2w_mel_finish(const float* spec, const float* basis, float* out, int B, int Cs, int FP, int F, int nb, int n_mels, void* stream);
 
 #ifdef __cplusplus
 }

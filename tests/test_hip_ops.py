@@ -633,3 +633,18 @@ def test_convt1d_dgrad_matches_autograd(dev, B, cin, cout, L, k, u):
     out = torch.full((B, cin, L), float('nan'), device=dev)
     hipops.convt1d_dgrad(_t(dy.numpy(), dev), wf, out, k=k, u=u, mask=(_t(x.detach().numpy(), dev), None), mask_slope=0.1)
     assert (out.cpu() - x.grad).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize('B,L', [(2, 8192), (3, 81920), (1, 5000)])
+def test_mel_spectrogram_matches_oracle(dev, B, L):
+    """mel_spectrogram (dataset.py:53-77) on the HIP path against the CPU restatement (torch.stft + the restated Slaney filterbank)."""
+    from oracle import mel_oracle as M
+    from wavthruvec_pytorch_amd.mel import mel_spectrogram, mel_filterbank
+    y = torch.from_numpy(np.tanh(_rng(16).standard_normal((B, L))).astype(np.float32) * 0.9)
+    want = M.mel_spectrogram(y, 1024, 80, 16000, 256, 1024, 0, None, dtype=torch.float64)
+    got = mel_spectrogram(y.to(dev), 1024, 80, 16000, 256, 1024, 0, None).cpu()
+    assert got.shape == want.shape == (B, 80, L // 256)
+    assert (got.double() - want).abs().max().item() <= 2e-4        # log of fp32 sums of 513 magnitudes
+    assert np.array_equal(mel_filterbank(16000, 1024, 80, 0, 8000), M.mel_filterbank(16000, 1024, 80, 0, 8000))
+    with pytest.raises(NotImplementedError):
+        mel_spectrogram(y.to(dev), 1024, 80, 16000, 256, 1024, 0, None, center=True)

@@ -88,3 +88,34 @@ def test_fp64_oracle_noise_floor():
     y64, _ = O.generator_forward(sd, h, *inp, training=True, dtype=torch.float64)
     assert (y32.double() - y64).abs().max().item() < 5e-6
     assert np.abs(y64.numpy() - z['y']).max() < 5e-6
+
+
+def test_mel_oracle_stft_half_and_filterbank_properties():
+    """The mel oracle's STFT half is torch.stft as in the reference (dataset.py:69-72); its frame/DFT form (what the HIP path
+    computes: windowed DFT rows applied to hop-strided frames of the reflect-padded signal) must agree with it.  The Slaney
+    filterbank is restated (librosa is absent: unpinned against the reference) - its published invariants are checked."""
+    import numpy as np
+    import torch
+    from oracle import mel_oracle as M
+    y = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (2, 4096)))
+    n_fft, hop = 1024, 256
+    pad = (n_fft - hop) // 2
+    yp = torch.nn.functional.pad(y.unsqueeze(1), (pad, pad), mode='reflect').squeeze(1)
+    ref = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft, dtype=torch.float64), center=False,
+                     onesided=True, return_complex=True)
+    frames = yp.unfold(1, n_fft, hop)                                        # (B, F, n_fft)
+    t = torch.arange(n_fft, dtype=torch.float64)
+    win = 0.5 - 0.5 * torch.cos(2 * np.pi * t / n_fft)
+    ang = 2 * np.pi * torch.outer(torch.arange(n_fft // 2 + 1, dtype=torch.float64), t) / n_fft
+    re = torch.einsum('bft,ct->bcf', frames * win, torch.cos(ang))
+    im = torch.einsum('bft,ct->bcf', frames * win, -torch.sin(ang))
+    assert (re - ref.real).abs().max() < 1e-9 and (im - ref.imag).abs().max() < 1e-9
+    fb = M.mel_filterbank(16000, 1024, 80, 0, 8000)
+    assert fb.shape == (80, 513) and (fb >= 0).all()
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) > 0).all()                                        # centre frequencies increase
+    # Slaney normalisation: every triangle has (nearly) the same area in Hz; below 1 kHz the scale is linear (equal spacing)
+    area = fb.sum(1) * (8000 / 512)
+    assert abs(area[10:].mean() - 1.0) < 0.02 and area[10:].std() < 0.02
+    lin = peaks[: int(np.searchsorted(peaks * (8000 / 512), 1000))]
+    assert np.ptp(np.diff(lin)) <= 1
