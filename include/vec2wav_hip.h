@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 11
+#define V2W_ABI_VERSION 12
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -313,6 +313,14 @@ int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, floa
  *                   log(clamp(basis @ sqrt(Re^2 + Im^2 + 1e-9), 1e-5))                                    (dataset.py:31-41,72-75) */
 int v2w_mel_phases(const float* y, float* xp, int B, int L, int hop, int pad, int FP, void* stream);
 int v2w_mel_finish(const float* spec, const float* basis, float* out, int B, int Cs, int FP, int F, int nb, int n_mels, void* stream);
+/* Their backward (the training loss F.l1_loss(y_mel, mel_spectrogram(y_g_hat)) back-propagates through it, train.py:172-174,204):
+ *   v2w_mel_finish_bwd: gout (B, n_mels, F), the forward's spec, basis and basisT (nb, n_mels) -> dspec (B, Cs, FP); the caller
+ *                       zero-fills dspec (pad rows and frames >= F are not written).  d log(clamp(x, 1e-5)) = 1/x for x >= 1e-5.
+ *   v2w_mel_phases_bwd: dxp (B, hop, FP) -> dy (B, L): every sample sums the padded positions that read it (reflections fold back).
+ * Between them the DFT conv's input gradient is v2w_conv1d_fwd with the tap-flipped transposed weights and pad_left = k - 1. */
+int v2w_mel_finish_bwd(const float* spec, const float* basis, const float* basisT, const float* gout, float* dspec,
+                       int B, int Cs, int FP, int F, int nb, int n_mels, void* stream);
+int v2w_mel_phases_bwd(const float* dxp, float* dy, int B, int L, int hop, int pad, int FP, void* stream);
 
 #ifdef __cplusplus
 }

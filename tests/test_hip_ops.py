@@ -648,3 +648,37 @@ def test_mel_spectrogram_matches_oracle(dev, B, L):
     assert np.array_equal(mel_filterbank(16000, 1024, 80, 0, 8000), M.mel_filterbank(16000, 1024, 80, 0, 8000))
     with pytest.raises(NotImplementedError):
         mel_spectrogram(y.to(dev), 1024, 80, 16000, 256, 1024, 0, None, center=True)
+
+
+@pytest.mark.parametrize('B,L', [(2, 8192), (1, 5000), (2, 20480)])
+def test_mel_spectrogram_backward_matches_oracle_autograd(dev, B, L):
+    """d mel_spectrogram / d y (the training loss back-propagates through it, train.py:172-174,204) against torch autograd through
+    the fp64 CPU restatement: a smooth weighted sum, and the reference's own L1 loss against a target mel."""
+    from oracle import mel_oracle as M
+    from wavthruvec_pytorch_amd.mel import mel_spectrogram
+    r = _rng(23)
+    y0 = torch.from_numpy(np.tanh(r.standard_normal((B, L))).astype(np.float32) * 0.9)
+    tgt = torch.from_numpy(np.tanh(r.standard_normal((B, L))).astype(np.float32) * 0.5)
+    G = torch.from_numpy(r.standard_normal((B, 80, L // 256)).astype(np.float32))
+    args = (1024, 80, 16000, 256, 1024, 0, None)
+    yo = y0.double().requires_grad_(True)
+    mo = M.mel_spectrogram(yo, *args, dtype=torch.float64)
+    (mo * G.double()).sum().backward()
+    yd = y0.to(dev).requires_grad_(True)
+    md = mel_spectrogram(yd, *args)
+    assert md.requires_grad and (md.detach().cpu().double() - mo.detach()).abs().max().item() <= 2e-4
+    (md * G.to(dev)).sum().backward()
+    scale = yo.grad.abs().max().item()
+    assert (yd.grad.cpu().double() - yo.grad).abs().max().item() <= 2e-4 * scale
+    # the reflect padding folds the edge gradients back: the first / last (n_fft - hop)/2 samples carry two contributions
+    assert (yd.grad.cpu().double()[:, :400] - yo.grad[:, :400]).abs().max().item() <= 2e-4 * scale
+    assert (yd.grad.cpu().double()[:, -400:] - yo.grad[:, -400:]).abs().max().item() <= 2e-4 * scale
+    # train.py:204  loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45  (sign() gradients: compared where the residual is not ~0)
+    y_mel = M.mel_spectrogram(tgt, *args)
+    yo.grad = None
+    (torch.nn.functional.l1_loss(y_mel.double(), M.mel_spectrogram(yo, *args, dtype=torch.float64)) * 45).backward()
+    yd.grad = None
+    (torch.nn.functional.l1_loss(y_mel.to(dev), mel_spectrogram(yd, *args)) * 45).backward()
+    assert (yd.grad.cpu().double() - yo.grad).abs().max().item() <= 1e-3 * yo.grad.abs().max().item()
+    # no graph when the input does not ask for one
+    assert not mel_spectrogram(y0.to(dev), *args).requires_grad

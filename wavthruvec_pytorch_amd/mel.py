@@ -2,8 +2,8 @@
 
 Mirror of the reference's `dataset.mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False)`
 (vec2wav/dataset.py:53-77; call sites train.py:172-174, 266-269, 282-284): same name, argument order and result
-`(B, num_mels, frames)` = log(clamp(mel_basis @ |STFT|, 1e-5)).  Forward only (validation / logging; the training loss
-back-propagates through it in the reference - that backward is not built here).
+`(B, num_mels, frames)` = log(clamp(mel_basis @ |STFT|, 1e-5)), differentiable with respect to y (the training loss
+back-propagates through it, train.py:204).
 
 The STFT runs as ONE fused Conv1d on the f32 MFMA tile kernel: the reflect-padded signal is de-interleaved by hop phase
 (`v2w_mel_phases`), the windowed DFT rows are the conv weights (hop input channels x n_fft/hop taps), and `v2w_mel_finish`
@@ -74,14 +74,9 @@ def _constants(n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, d
     return c
 
 
-@torch.no_grad()
-def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
-    """y (B, L) float32 on the GPU -> (B, num_mels, frames) float32."""
-    if center:
-        raise NotImplementedError('mel_spectrogram (HIP): center=False only (the reference never passes True)')
-    if not y.is_cuda:
-        raise RuntimeError('mel_spectrogram runs on the MI355X HIP path only (no CPU fallback)')
-    y = y.detach().contiguous().float()
+def _forward(y, cfg):
+    """-> (out, spec, geometry): the three launches of the forward; `spec` is what the backward needs."""
+    n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax = cfg
     B, L = y.shape
     c = _constants(n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, y.device)
     pad = int((n_fft - hop_size) / 2)
@@ -97,4 +92,56 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
     out = torch.empty((B, num_mels, F), device=y.device)
     _hip.check(lib.v2w_mel_finish(spec.data_ptr(), c['basis'].data_ptr(), out.data_ptr(), B, c['cs'], FP, F, c['nb'], num_mels, st),
                'v2w_mel_finish')
-    return out
+    return out, spec, (B, L, pad, F, FP)
+
+
+def _backward(g, spec, geom, cfg):
+    """d out (B, num_mels, F) -> d y (B, L): finish^T -> the DFT conv's input gradient (the same MFMA conv kernel with the
+    tap-flipped transposed rows, pad_left = k-1) -> phase re-interleave with the reflections folded back."""
+    n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax = cfg
+    B, L, pad, F, FP = geom
+    dev = spec.device
+    c = _constants(n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, dev)
+    if 'wT' not in c:
+        # wT[j'][row c][phase p] = Wd[c][(k-1-j')*hop + p]
+        c['wT'] = c['wf'].flip(0).transpose(1, 2).contiguous()
+        c['wTp'] = hipops.pack_mfma(c['wT'])
+        c['basisT'] = c['basis'].t().contiguous()
+    lib, st = _hip.load(), torch.cuda.current_stream(dev).cuda_stream
+    g = g.contiguous().float()
+    dspec = torch.zeros_like(spec)
+    _hip.check(lib.v2w_mel_finish_bwd(spec.data_ptr(), c['basis'].data_ptr(), c['basisT'].data_ptr(), g.data_ptr(), dspec.data_ptr(),
+                                      B, c['cs'], FP, F, c['nb'], num_mels, st), 'v2w_mel_finish_bwd')
+    dxp = torch.empty((B, hop_size, FP), device=dev)
+    hipops.conv1d(dspec, c['wT'], None, dxp, k=c['k'], dil=1, slope=1.0, pad_left=c['k'] - 1, wp=c['wTp'])
+    dy = torch.empty((B, L), device=dev)
+    _hip.check(lib.v2w_mel_phases_bwd(dxp.data_ptr(), dy.data_ptr(), B, L, hop_size, pad, FP, st), 'v2w_mel_phases_bwd')
+    return dy
+
+
+class _MelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, cfg):
+        out, spec, geom = _forward(y.detach().contiguous().float(), cfg)
+        ctx.save_for_backward(spec)
+        ctx.geom, ctx.cfg = geom, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (spec,) = ctx.saved_tensors
+        return _backward(g, spec, ctx.geom, ctx.cfg), None
+
+
+def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
+    """y (B, L) float32 on the GPU -> (B, num_mels, frames) float32; differentiable with respect to y (the training loss
+    F.l1_loss(y_mel, mel_spectrogram(y_g_hat.squeeze(1), ...)), train.py:172-174,204)."""
+    if center:
+        raise NotImplementedError('mel_spectrogram (HIP): center=False only (the reference never passes True)')
+    if not y.is_cuda:
+        raise RuntimeError('mel_spectrogram runs on the MI355X HIP path only (no CPU fallback)')
+    cfg = (n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax)
+    if torch.is_grad_enabled() and y.requires_grad:
+        return _MelFn.apply(y, cfg)
+    with torch.no_grad():
+        return _forward(y.detach().contiguous().float(), cfg)[0]

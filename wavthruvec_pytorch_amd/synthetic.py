@@ -40,6 +40,8 @@ DEFAULT_HPARAMS = dict(
     upsample_initial_channel=512,
     resblock_kernel_sizes=[3, 7, 11],
     resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    # audio front end read by mel_spectrogram's call sites (hparams.py:50-61)
+    num_mels=80, n_fft=1024, hop_size=256, win_size=1024, sampling_rate=16000, fmin=0, fmax=8000, fmax_for_loss=None,
 )
 
 
