@@ -11,8 +11,13 @@ from wavthruvec_pytorch_amd import synthetic
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def golden_names():
+def all_golden_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+
+
+def golden_names():
+    """Generator cases (the discriminator fixtures are `disc_golden_names`)."""
+    return [n for n in all_golden_names() if not n.startswith('disc_')]
 
 
 def load_golden(name):
@@ -43,3 +48,52 @@ def probe_summary(t: torch.Tensor):
 def tol_for(meta):
     """|dy| tolerance: 1e-4 is the north_star bar; the ill-conditioned synthetic-eval case gets 5e-3."""
     return 5e-3 if meta['mode'] == 'eval' else 1e-4
+
+
+def fmap_probe(t: torch.Tensor):
+    """Reduction applied to every discriminator feature map (B, C, L) or (B, C, H, p) by tools/gen_disc_goldens.py and by the
+    tests on their own outputs: shape, head / tail of 4 channels over the flattened trailing axes, fp64 sum and sum|.|."""
+    t = t.detach().cpu()
+    f = t.reshape(t.shape[0], t.shape[1], -1)
+    C, L = f.shape[1], f.shape[2]
+    ch = sorted(set([0, C // 3, (2 * C) // 3, C - 1]))
+    n = min(32, L)
+    return dict(shape=np.array(t.shape, dtype=np.int64), head=f[:, ch, :n].contiguous().numpy().copy(),
+                tail=f[:, ch, L - n:].contiguous().numpy().copy(),
+                sum=np.float64(f.double().sum().item()), abssum=np.float64(f.double().abs().sum().item()))
+
+
+def disc_golden_names():
+    return [n for n in all_golden_names() if n.startswith('disc_')]
+
+
+def disc_case_setup(meta, device='cpu'):
+    """(state_dict, y, y_hat) of a discriminator golden case, rebuilt from its seeds."""
+    spec = synthetic.mpd_state_dict_spec() if meta['kind'] == 'mpd' else synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=meta['weight_seed'], device=device)
+    y, y_hat = synthetic.make_audio_pair(meta['B'], meta['T'], seed=meta['audio_seed'], device=device)
+    return sd, y, y_hat
+
+
+def check_disc_outputs(z, outs, tol):
+    """Compare (y_d_rs, y_d_gs, fmap_rs, fmap_gs) with a golden: scores in full, fmaps through their probes.  -> worst error."""
+    y_d_rs, y_d_gs, fmap_rs, fmap_gs = outs
+    worst = 0.0
+    for d in range(len(y_d_rs)):
+        for key, t in ((f'r{d}', y_d_rs[d]), (f'g{d}', y_d_gs[d])):
+            want = z[key]
+            assert tuple(t.shape) == want.shape, (key, t.shape, want.shape)
+            worst = max(worst, float(np.abs(t.detach().cpu().numpy() - want).max()))
+        for side, fm in (('r', fmap_rs[d]), ('g', fmap_gs[d])):
+            i = 0
+            while f'fmap_{side}{d}_{i}_sum' in z.files:
+                pr = fmap_probe(fm[i])
+                pre = f'fmap_{side}{d}_{i}_'
+                assert list(pr['shape']) == list(z[pre + 'shape']), (pre, pr['shape'], z[pre + 'shape'])
+                worst = max(worst, float(np.abs(pr['head'] - z[pre + 'head']).max()), float(np.abs(pr['tail'] - z[pre + 'tail']).max()))
+                n = max(1, int(np.prod(pr['shape'])))
+                assert abs(pr['sum'] - float(z[pre + 'sum'])) <= tol * n and abs(pr['abssum'] - float(z[pre + 'abssum'])) <= tol * n, pre
+                i += 1
+            assert i == len(fm), (side, d, i, len(fm))
+    assert worst <= tol, worst
+    return worst

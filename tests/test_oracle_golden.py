@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import vec2wav_oracle as O
+from tests import golden_util
 from tests.golden_util import golden_names, load_golden, case_setup, probe_summary, tol_for
 
 
@@ -119,3 +120,23 @@ def test_mel_oracle_stft_half_and_filterbank_properties():
     assert abs(area[10:].mean() - 1.0) < 0.02 and area[10:].std() < 0.02
     lin = peaks[: int(np.searchsorted(peaks * (8000 / 512), 1000))]
     assert np.ptp(np.diff(lin)) <= 1
+
+
+@pytest.mark.parametrize('name', golden_util.disc_golden_names())
+def test_disc_oracle_matches_reference_goldens(name):
+    """oracle/disc_oracle.py (MPD / MSD restated as functions of a state_dict) against the fixtures captured from the reference
+    modules (tools/gen_disc_goldens.py): every score, every feature map's probes, the spectral-norm buffers after the forward."""
+    from oracle import disc_oracle as D
+    z, meta = golden_util.load_golden(name)
+    sd, y, y_hat = golden_util.disc_case_setup(meta)
+    with torch.no_grad():
+        if meta['kind'] == 'mpd':
+            outs = D.mpd_forward(sd, y, y_hat)
+        else:
+            if meta['mode'] == 'traineval':
+                D.msd_forward(sd, y_hat, y, training=True)
+            outs = D.msd_forward(sd, y, y_hat, training=meta['mode'] == 'train')
+    golden_util.check_disc_outputs(z, outs, 2e-5)
+    for k in z.files:
+        if k.startswith('buf_'):
+            assert np.abs(sd[k[4:]].numpy() - z[k]).max() <= 1e-6, k

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/disc_*.npz by running the REFERENCE MultiPeriodDiscriminator / MultiScaleDiscriminator
+(vec2wav/models.py:158-275), imported in place from /root/reference (build container only; nothing is copied).
+
+Committed per case: the seeds that rebuild weights (`synthetic.make_disc_state_dict`) and audio (`synthetic.make_audio_pair`),
+every score tensor in full, per-fmap probes (head / tail slices of 4 channels + fp64 sum and sum|.|) and, for the MSD, the
+spectral-norm u / v buffers after the forward.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_disc_goldens.py
+"""
+import os
+import sys
+import types
+import warnings
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference/vec2wav')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+warnings.filterwarnings('ignore', category=FutureWarning)
+import hparams as ref_hp  # noqa: E402  (reference)
+import models as ref_models  # noqa: E402  (reference)
+
+from wavthruvec_pytorch_amd import synthetic  # noqa: E402
+from tests.golden_util import fmap_probe  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+CASES = [
+    dict(name='disc_mpd_b2_t8192', kind='mpd', B=2, T=8192, mode='train'),
+    dict(name='disc_mpd_b1_t1000', kind='mpd', B=1, T=1000, mode='train'),
+    dict(name='disc_msd_b2_t8192_train', kind='msd', B=2, T=8192, mode='train'),
+    dict(name='disc_msd_b2_t8192_traineval', kind='msd', B=2, T=8192, mode='traineval'),   # one train forward, then eval
+    dict(name='disc_msd_b1_t1000_train', kind='msd', B=1, T=1000, mode='train'),
+]
+
+
+def run_case(case):
+    torch.manual_seed(0)
+    if case['kind'] == 'mpd':
+        h = types.SimpleNamespace(periods=list(ref_hp.periods))
+        assert h.periods == synthetic.DEFAULT_PERIODS
+        m = ref_models.MultiPeriodDiscriminator(h)
+        spec = synthetic.mpd_state_dict_spec(h.periods)
+    else:
+        m = ref_models.MultiScaleDiscriminator()
+        spec = synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=3)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), 'state_dict key order differs from the spec'
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), (k, ref_sd[k].shape, sd[k].shape)
+    m.load_state_dict(sd)
+    y, y_hat = synthetic.make_audio_pair(case['B'], case['T'], seed=77)
+    with torch.no_grad():
+        m.train()
+        if case['mode'] == 'traineval':    # the stored u / v of a fresh state_dict are random: iterate once, then use them frozen
+            m(y_hat, y)
+            m.eval()
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = m(y, y_hat)
+    out = dict(meta_case=np.array(repr(dict(case, weight_seed=3, audio_seed=77))))
+    for d in range(len(y_d_rs)):
+        out[f'r{d}'] = y_d_rs[d].numpy().copy()
+        out[f'g{d}'] = y_d_gs[d].numpy().copy()
+        for side, fm in (('r', fmap_rs[d]), ('g', fmap_gs[d])):
+            for i, t in enumerate(fm):
+                for k, v in fmap_probe(t).items():
+                    out[f'fmap_{side}{d}_{i}_{k}'] = v
+    if case['kind'] == 'msd':
+        for k, v in m.state_dict().items():
+            if k.endswith('weight_u') or (k.startswith('discriminators.0.') and k.endswith('weight_v')):
+                out['buf_' + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **out)
+    print(case['name'], 'scores', [tuple(t.shape) for t in y_d_rs], 'fmaps', [tuple(t.shape) for t in fmap_rs[0]],
+          'max|fmap|', max(t.abs().max().item() for t in fmap_rs[0]))
+
+
+if __name__ == '__main__':
+    for c in CASES:
+        run_case(c)

@@ -187,3 +187,88 @@ def total_upsample(h) -> int:
     for u in h.upsample_rates:
         r *= int(u)
     return r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MPD / MSD discriminators (models.py:158-275): state_dict surface and deterministic weights
+
+# DiscriminatorP conv stack (models.py:164-170): (C_in, C_out, k, stride, pad) along the folded time axis
+DISC_P_LAYERS = [(1, 32, 5, 3, 2), (32, 128, 5, 3, 2), (128, 512, 5, 3, 2), (512, 1024, 5, 3, 2), (1024, 1024, 5, 1, 2)]
+DISC_P_POST = (1024, 1, 3, 1, 1)
+# DiscriminatorS conv stack (models.py:220-229): (C_in, C_out, k, stride, groups, pad)
+DISC_S_LAYERS = [(1, 128, 15, 1, 1, 7), (128, 128, 41, 2, 4, 20), (128, 256, 41, 2, 16, 20), (256, 512, 41, 4, 16, 20),
+                 (512, 1024, 41, 4, 16, 20), (1024, 1024, 41, 1, 16, 20), (1024, 1024, 5, 1, 1, 2)]
+DISC_S_POST = (1024, 1, 3, 1, 1, 1)
+DEFAULT_PERIODS = [13, 17, 19]     # hparams.py:46
+
+
+def mpd_state_dict_spec(periods=DEFAULT_PERIODS) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Ordered (key, shape, kind) of MultiPeriodDiscriminator.state_dict(): weight-normed Conv2d with (k, 1) kernels."""
+    spec = []
+    for d in range(len(periods)):
+        layers = [(f'discriminators.{d}.convs.{i}', L) for i, L in enumerate(DISC_P_LAYERS)] + \
+                 [(f'discriminators.{d}.conv_post', DISC_P_POST)]
+        for name, (ci, co, k, _s, _p) in layers:
+            spec.append((name + '.bias', (co,), 'conv_bias'))
+            spec.append((name + '.weight_g', (co, 1, 1, 1), 'conv_g'))
+            spec.append((name + '.weight_v', (co, ci, k, 1), 'conv_v'))
+    return spec
+
+
+def msd_state_dict_spec() -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Ordered (key, shape, kind) of MultiScaleDiscriminator.state_dict(): discriminator 0 is spectral-normed
+    (bias, weight_orig, weight_u, weight_v), 1 and 2 weight-normed (models.py:249-253)."""
+    spec = []
+    for d in range(3):
+        layers = [(f'discriminators.{d}.convs.{i}', L) for i, L in enumerate(DISC_S_LAYERS)] + \
+                 [(f'discriminators.{d}.conv_post', DISC_S_POST)]
+        for name, (ci, co, k, _s, g, _p) in layers:
+            spec.append((name + '.bias', (co,), 'conv_bias'))
+            if d == 0:
+                spec.append((name + '.weight_orig', (co, ci // g, k), 'conv_w'))
+                spec.append((name + '.weight_u', (co,), 'sn_u'))
+                spec.append((name + '.weight_v', (ci // g * k,), 'sn_v'))
+            else:
+                spec.append((name + '.weight_g', (co, 1, 1), 'conv_g'))
+                spec.append((name + '.weight_v', (co, ci // g, k), 'conv_v'))
+    return spec
+
+
+def make_disc_state_dict(spec, seed: int = 0, device='cpu'):
+    """Deterministic weights for a discriminator spec: v ~ U(-a, a) with a = sqrt(3 / fan_in) * 1.4 (unit-variance-preserving
+    through leaky_relu(0.1) stacks, so all fmaps stay O(1)), g = |v| * (1 + 0.1 N), small biases, unit u / v."""
+    import torch
+    from collections import OrderedDict
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = OrderedDict()
+    pending_g = None
+    for key, shape, kind in spec:
+        if kind == 'conv_g':
+            pending_g = (key, shape); sd[key] = None
+        elif kind in ('conv_v', 'conv_w'):
+            fan_in = int(np.prod(shape[1:]))
+            a = 1.4 * math.sqrt(3.0 / fan_in)
+            v = rng.uniform(-a, a, size=shape).astype(np.float32)
+            sd[key] = v
+            if kind == 'conv_v':
+                gkey, gshape = pending_g
+                norm = np.sqrt((v.astype(np.float64) ** 2).reshape(shape[0], -1).sum(axis=1)).reshape(gshape)
+                sd[gkey] = (norm * (1.0 + 0.1 * rng.standard_normal(gshape))).astype(np.float32)
+                pending_g = None
+        elif kind == 'conv_bias':
+            sd[key] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        elif kind in ('sn_u', 'sn_v'):
+            x = rng.standard_normal(shape)
+            sd[key] = (x / np.linalg.norm(x)).astype(np.float32)
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)).to(device)) for k, v in sd.items())
+
+
+def make_audio_pair(batch: int, n_samples: int, seed: int = 77, device='cpu'):
+    """(y, y_hat), each (B, 1, n_samples) in (-1, 1): the real / generated waveforms the discriminators compare."""
+    import torch
+    rng = np.random.default_rng(seed)
+    y = np.tanh(rng.standard_normal((batch, 1, n_samples))).astype(np.float32) * 0.9
+    y_hat = np.tanh(y + 0.3 * rng.standard_normal((batch, 1, n_samples))).astype(np.float32)
+    return torch.from_numpy(y).to(device), torch.from_numpy(y_hat).to(device)
