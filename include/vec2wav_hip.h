@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 12
+#define V2W_ABI_VERSION 13
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -124,6 +124,12 @@ typedef struct {
     int32_t pad_left;             /* -1: symmetric padding dil*(k-1)/2.  >= 0: taps sit at offsets -pad_left + t*dil (k may be even) */
     const void*  wps;             /* V2W_ALGO_SPLIT: v2w_pack_split() fragments of this layer; else ignored */
     const float* winv;            /* V2W_ALGO_SPLIT: device pointer to 1/scale of the layer (sc[0] of v2w_pack_split) */
+    int32_t in_ct, out_ct;        /* 0: plain.  > 0: `in` / `out` (and res, add, mask_src) point at the first channel of a C_in / C_out
+                                   * channel slice of tensors with in_ct / out_ct channels per batch item: one group of a grouped
+                                   * Conv1d (models.py:222-227), one launch per group (or 4 per launch through _fwd_multi).
+                                   * Not combined with the per-(b, channel) affines; f32 MFMA and direct kernels only */
+    float   out_slope;            /* 0 or 1: none.  Else leaky_relu(value, out_slope) on what is stored (applied last): the
+                                   * discriminators keep the ACTIVATED feature maps (models.py:184-186, 236-238) */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
@@ -321,6 +327,18 @@ int v2w_mel_finish(const float* spec, const float* basis, float* out, int B, int
 int v2w_mel_finish_bwd(const float* spec, const float* basis, const float* basisT, const float* gout, float* dspec,
                        int B, int Cs, int FP, int F, int nb, int n_mels, void* stream);
 int v2w_mel_phases_bwd(const float* dxp, float* dy, int B, int L, int hop, int pad, int FP, void* stream);
+
+/* ---- MPD / MSD discriminator forwards (models.py:158-275): the memory-bound ends; the convolutions run
+ * through v2w_conv1d_fwd (in_ct / out_ct for groups, out_slope for the activated feature maps, dil = period for the (k, 1) Conv2d).
+ *   v2w_phase_split: x (B, C, L, inner) -> out (B, s*C, ceil(L/s), inner), out[b][((c/Cg)*s + r)*Cg + c%Cg][u][w] = x[b][c][s*u + r][w]
+ *                    (0 past L): a stride-s conv becomes a stride-1 conv over the stacked phases (Cg = channels per group).
+ *   v2w_unfold1:     x (B, T) read as (H, inner) rows, reflect-padded on the right to H*inner (models.py:176-181) ->
+ *                    out (B, rows, U*inner), out[b][j][u*inner + w] = xpad[(s*u + j - pad)*inner + w], U = (H + 2 pad - k)/s + 1,
+ *                    rows >= k (the extra rows are 0): the C_in = 1 layers as 1-tap convs over `rows` channels.
+ *   v2w_avgpool4:    AvgPool1d(4, 2, padding=2) (models.py:255-258): x (B, L) -> out (B, L/2 + 1). */
+int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, void* stream);
+int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, void* stream);
+int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+"""GPU parity of the MPD / MSD discriminator forwards (reference vec2wav/models.py:158-275) through the
+C ABI: against the fixtures captured from the reference modules, and against the CPU oracle at other sizes."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import disc_oracle as D
+from tests import golden_util
+from wavthruvec_pytorch_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4      # the north_star bar on O(1) feature maps
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from wavthruvec_pytorch_amd import _hip
+    _hip.load()
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def build(kind, sd, dev, training=True):
+    from wavthruvec_pytorch_amd.discriminators import MultiPeriodDiscriminator, MultiScaleDiscriminator
+    m = MultiPeriodDiscriminator(SimpleNamespace(periods=synthetic.DEFAULT_PERIODS)) if kind == 'mpd' else MultiScaleDiscriminator()
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    return m.train() if training else m.eval()
+
+
+@pytest.mark.parametrize('name', golden_util.disc_golden_names())
+def test_discriminators_match_reference_goldens(dev, name):
+    z, meta = golden_util.load_golden(name)
+    sd, y, y_hat = golden_util.disc_case_setup(meta)
+    m = build(meta['kind'], sd, dev)
+    with torch.no_grad():
+        if meta['mode'] == 'traineval':
+            m(y_hat.to(dev), y.to(dev))
+            m.eval()
+        outs = m(y.to(dev), y_hat.to(dev))
+    golden_util.check_disc_outputs(z, outs, TOL)
+    for k in z.files:          # spectral-norm buffers after the forward(s): two power iterations per training forward
+        if k.startswith('buf_'):
+            assert np.abs(m.state_dict()[k[4:]].cpu().numpy() - z[k]).max() <= 1e-5, k
+
+
+@pytest.mark.parametrize('kind,B,T', [('mpd', 3, 5120), ('msd', 3, 5120), ('mpd', 1, 247), ('msd', 1, 333), ('mpd', 2, 16000),
+                                      ('msd', 2, 16001)])
+def test_discriminators_match_oracle(dev, kind, B, T):
+    """Every score and EVERY feature-map element against the CPU restatement (ragged lengths: not multiples of the periods,
+    odd lengths through the stride-2/4 layers and the mean pools)."""
+    spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=11)
+    y, y_hat = synthetic.make_audio_pair(B, T, seed=5)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        want = D.mpd_forward(sdo, y, y_hat) if kind == 'mpd' else D.msd_forward(sdo, y, y_hat, training=True)
+        m = build(kind, sd, dev)
+        got = m(y.to(dev), y_hat.to(dev))
+    for a, b in zip(want[0] + want[1], got[0] + got[1]):
+        assert a.shape == b.shape and (a - b.cpu()).abs().max().item() <= TOL
+    for fw, fg in zip(want[2] + want[3], got[2] + got[3]):
+        assert len(fw) == len(fg)
+        for a, b in zip(fw, fg):
+            assert a.shape == b.shape, (a.shape, b.shape)
+            assert (a - b.cpu()).abs().max().item() <= TOL
+
+
+def test_discriminator_losses_and_guards(dev):
+    """The loss helpers of models.py:278-310 on the HIP outputs equal the oracle's; autograd use raises (backward not built)."""
+    from wavthruvec_pytorch_amd.discriminators import feature_loss, discriminator_loss, generator_loss
+    sd = synthetic.make_disc_state_dict(synthetic.mpd_state_dict_spec(), seed=2)
+    y, y_hat = synthetic.make_audio_pair(2, 4000, seed=9)
+    with torch.no_grad():
+        want = D.mpd_forward(sd, y, y_hat)
+        m = build('mpd', sd, dev)
+        got = m(y.to(dev), y_hat.to(dev))
+        assert abs(feature_loss(got[2], got[3]).item() - feature_loss(want[2], want[3]).item()) <= 1e-4
+        assert abs(discriminator_loss(got[0], got[1])[0].item() - discriminator_loss(want[0], want[1])[0].item()) <= 1e-4
+        assert abs(generator_loss(got[1])[0].item() - generator_loss(want[1])[0].item()) <= 1e-4
+    with pytest.raises(NotImplementedError):
+        m(y.to(dev), y_hat.to(dev))

@@ -122,3 +122,26 @@ def test_synthesize_wire_formats(tmp_path):
     with pytest.raises(ValueError):
         np.save(os.path.join(str(tmp_path), 'bad.npy'), np.zeros((2, 3, 4), np.float32))
         S.load_latents(os.path.join(str(tmp_path), 'bad.npy'))
+
+
+def test_discriminator_state_dict_surface():
+    """MultiPeriodDiscriminator(hp) / MultiScaleDiscriminator() hold the reference's keys and shapes (models.py:158-258; the spec
+    itself is asserted against the reference modules by tools/gen_disc_goldens.py), and refuse to run off the GPU."""
+    import pytest
+    import torch
+    from types import SimpleNamespace
+    from wavthruvec_pytorch_amd import synthetic
+    from wavthruvec_pytorch_amd.discriminators import MultiPeriodDiscriminator, MultiScaleDiscriminator
+    mpd = MultiPeriodDiscriminator(SimpleNamespace(periods=[13, 17, 19]))
+    msd = MultiScaleDiscriminator()
+    for m, spec in ((mpd, synthetic.mpd_state_dict_spec()), (msd, synthetic.msd_state_dict_spec())):
+        sd = m.state_dict()
+        assert list(sd.keys()) == [k for k, _, _ in spec]
+        for k, shape, _ in spec:
+            assert tuple(sd[k].shape) == shape, k
+        m.load_state_dict(synthetic.make_disc_state_dict(spec, seed=1))
+    y = torch.zeros(1, 1, 1000)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        mpd(y, y)
+    with pytest.raises(NotImplementedError):       # autograd through the discriminators is not built
+        msd(y, y)

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -28,7 +28,7 @@ class Conv1dArgs(C.Structure):
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
                 ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
                 ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32),
-                ('wps', _fp), ('winv', _fp)]
+                ('wps', _fp), ('winv', _fp), ('in_ct', C.c_int32), ('out_ct', C.c_int32), ('out_slope', C.c_float)]
 
 
 class ConvT1dArgs(C.Structure):
@@ -100,6 +100,9 @@ SIGNATURES = {
     'v2w_mel_phases': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_mel_finish': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_mel_finish_bwd': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_phase_split': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_unfold1': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_avgpool4': (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     'v2w_mel_phases_bwd': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_packable': (C.c_int, [C.c_int, C.c_int]),
     'v2w_resblock2_stage_split_fwd': (C.c_int, [C.POINTER(StageSplitArgs), _fp]),

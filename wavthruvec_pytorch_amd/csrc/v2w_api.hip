@@ -24,6 +24,12 @@ static int check_conv1d(const v2w_conv1d_args* a) {
     if (a->add0 && a->accumulate) return V2W_E_ARG;               // either the running sum in `out` or explicit addends
     if ((a->mask_a == nullptr) != (a->mask_s == nullptr)) return V2W_E_ARG;
     if (a->mask_a && !a->mask_src) return V2W_E_ARG;
+    if (a->in_ct < 0 || a->out_ct < 0 || (a->in_ct > 0 && a->in_ct < a->C_in) || (a->out_ct > 0 && a->out_ct < a->C_out)) return V2W_E_ARG;
+    if (((a->in_ct > 0 && a->in_ct != a->C_in) && a->in_a) || ((a->out_ct > 0 && a->out_ct != a->C_out) && (a->res_a || a->mask_a)))
+        return V2W_E_ARG;                                          // the affine tables are indexed by the slice's own channel count
+    if (a->out_slope < 0.f) return V2W_E_ARG;
+    const bool ext = (a->in_ct > 0 && a->in_ct != a->C_in) || (a->out_ct > 0 && a->out_ct != a->C_out) || (a->out_slope != 0.f && a->out_slope != 1.f);
+    if (ext && (a->algo == V2W_ALGO_SPLIT || a->algo == V2W_ALGO_BF16)) return V2W_E_SHAPE;
     return 0;
 }
 

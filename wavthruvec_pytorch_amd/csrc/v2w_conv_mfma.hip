@@ -104,7 +104,7 @@ conv_tile_kernel(const MultiArgs m) {
         in_seq = in_img && pos >= 0 && pos < L;
     };
     auto prefetch = [&](int ci0) {
-        const float* src = p.in + (size_t)(b * p.Cin + ci0) * L + pos0;
+        const float* src = p.in + (size_t)(b * p.CinT + ci0) * L + pos0;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             int row, col; bool in_img, in_seq;
@@ -131,7 +131,7 @@ conv_tile_kernel(const MultiArgs m) {
     };
     auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment / input stride: dword loads straight into LDS
         for (int c = wave; c < CK; c += WM * WN) {
-            const int ch = b * p.Cin + ci0 + c;
+            const int ch = b * p.CinT + ci0 + c;
             const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
             const float av = p.in_a ? p.in_a[ch] : 1.f;
             const float sv = p.in_s ? p.in_s[ch] : 0.f;
@@ -257,7 +257,7 @@ conv_tile_kernel(const MultiArgs m) {
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
                     const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
-                    const size_t orow = ((size_t)b * p.Cout + co) * Lout;
+                    const size_t orow = ((size_t)b * p.CoutT + co) * Lout;
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int q = n0 + wn0 + j * MF + lr;
@@ -271,7 +271,7 @@ conv_tile_kernel(const MultiArgs m) {
                 for (int ee = 0; ee < EG; ++ee) {
                     const int e = e0 + ee;
                     const int col = wm0 + i * MF + F::row(e, hk);
-                    const size_t orow = ((size_t)b * p.Cout + m0 + col) * Lout;
+                    const size_t orow = ((size_t)b * p.CoutT + m0 + col) * Lout;
                     const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
@@ -285,6 +285,8 @@ conv_tile_kernel(const MultiArgs m) {
                         if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
                         else if (p.accumulate || p.add0) v += ov[ee][j];
                         if (p.out_div != 0.f) v = v / p.out_div;
+                        if constexpr (MASK)   // (shares the instantiation so the forward kernels keep their register budget)
+                            if (p.out_slope != 1.f) v = v > 0.f ? v : v * p.out_slope;
                         p.out[orow + q] = v;
                     }
                 }
@@ -294,7 +296,7 @@ conv_tile_kernel(const MultiArgs m) {
             for (int e = 0; e < F::NREG; ++e) {
                 const int co = m0 + wm0 + i * MF + F::row(e, hk);
                 const float bias = etab[co - m0];
-                const size_t orow = ((size_t)b * p.Cout + co) * Lout;
+                const size_t orow = ((size_t)b * p.CoutT + co) * Lout;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int q = n0 + wn0 + j * MF + lr;
@@ -400,7 +402,7 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     m.start[nprob] = grid;
     for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     bool mask = false;
-    for (int i = 0; i < nprob; ++i) mask = mask || m.p[i].mask_src != nullptr;
+    for (int i = 0; i < nprob; ++i) mask = mask || m.p[i].mask_src != nullptr || m.p[i].out_slope != 1.f;
     auto kern = mask ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
@@ -567,6 +569,8 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.add0 = q->add0; p.add1 = q->add1;
         p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
+        p.CinT = q->in_ct > 0 ? q->in_ct : q->C_in; p.CoutT = q->out_ct > 0 ? q->out_ct : q->C_out;
+        p.out_slope = q->out_slope > 0.f ? q->out_slope : 1.f;
         p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
         if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
         p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
@@ -598,6 +602,7 @@ int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out
     p.cfg_out = cfg_out;
     p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = 1;
+    p.CinT = p.Cin; p.CoutT = p.Cout; p.out_slope = 1.f;
     p.pad = (a->k - a->u) / 2;
     p.slope = a->slope; p.accumulate = 0; p.out_div = 0.f;
     // halo over all phases: offsets c_r - m, m in [0, nt_r)

@@ -12,9 +12,10 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
     if (l >= a.L) return;
     const int pad = a.pad_left >= 0 ? a.pad_left : a.dil * (a.k - 1) / 2;
     const int istr = a.in_stride > 0 ? a.in_stride : 1;
+    const int cit = a.in_ct > 0 ? a.in_ct : a.C_in, cot = a.out_ct > 0 ? a.out_ct : a.C_out;
     float acc = 0.f;
     for (int ci = 0; ci < a.C_in; ++ci) {
-        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L * istr + a.in_phase;
+        const float* src = a.in + ((size_t)b * cit + ci) * a.L * istr + a.in_phase;
         const float av = a.in_a ? a.in_a[b * a.C_in + ci] : 1.f;
         const float sv = a.in_s ? a.in_s[b * a.C_in + ci] : 0.f;
         for (int t = 0; t < a.k; ++t) {
@@ -24,7 +25,7 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
             acc = fmaf(a.wf[((size_t)t * a.C_in + ci) * a.C_out + co], x, acc);
         }
     }
-    const size_t o = ((size_t)b * a.C_out + co) * a.L + l;
+    const size_t o = ((size_t)b * cot + co) * a.L + l;
     float v = acc;
     if (a.mask_src) {
         const float ma = a.mask_a ? a.mask_a[b * a.C_out + co] : 1.f, ms = a.mask_a ? a.mask_s[b * a.C_out + co] : 0.f;
@@ -40,6 +41,7 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
     else if (a.add0) v += a.add0[o];
     else if (a.accumulate) v += a.out[o];
     if (a.out_div != 0.f) v = v / a.out_div;
+    if (a.out_slope != 0.f && a.out_slope != 1.f) v = v > 0.f ? v : v * a.out_slope;
     a.out[o] = v;
 }
 

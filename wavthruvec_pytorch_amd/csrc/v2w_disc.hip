@@ -1,0 +1,101 @@
+// Memory-bound ends of the MPD / MSD discriminator forwards (reference vec2wav/models.py:158-275).
+// The convolutions themselves run on the f32 MFMA tile kernel (v2w_conv1d_fwd) as stride-1 problems:
+//   * a stride-s Conv1d (k taps, padding P) over x equals a stride-1 conv over the s phase-de-interleaved copies of x stacked as
+//     channels:  j - P = s*q + r  ->  out[t] = sum_{q,r,c} w[c][s*q + r + P] * x_r[c][t + q],  x_r[c][u] = x[c][s*u + r];
+//   * DiscriminatorP's (k, 1) Conv2d over the (B, C, H, p) view is that same conv along H for p independent columns: on the
+//     flattened (H*p) axis it is a Conv1d with dilation p (zero padding in H and in H*p coincide since every shift is a
+//     multiple of p), so feature maps stay in the reference's (B, C, H, p) layout with no transposes;
+//   * the first layers (C_in = 1) are unfolded into k (padded to 16) shifted rows and run as 1-tap MFMA convs.
+#include "v2w_common.h"
+
+namespace {
+
+// x (B, C, L, inner) -> out (B, s*C, U, inner), U = ceil(L / s):
+//   out[b][((c / Cg)*s + r)*Cg + c % Cg][u][w] = x[b][c][s*u + r][w]  (0 past L); Cg = channels per conv group (C when ungrouped)
+__global__ void __launch_bounds__(256)
+phase_split_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int Cg, int L, int inner, int s, int U) {
+    const int b = blockIdx.y;
+    const size_t row = (size_t)U * inner;
+    const size_t total = (size_t)s * C * row;
+    const float* xb = x + (size_t)b * C * L * inner;
+    float* ob = out + (size_t)b * total;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int cs = (int)(idx / row);
+        const int rem = (int)(idx - (size_t)cs * row);
+        const int u = rem / inner, w = rem - u * inner;
+        const int g = cs / (s * Cg), rr = cs - g * s * Cg;
+        const int r = rr / Cg, c = g * Cg + (rr - r * Cg);
+        const int l = s * u + r;
+        ob[idx] = l < L ? xb[((size_t)c * L + l) * inner + w] : 0.f;
+    }
+}
+
+// x (B, T) single-channel audio, read as (H, inner) rows with a reflect pad on the right up to H*inner samples
+// (models.py:176-181) -> out (B, rows, U*inner): out[b][j][u*inner + w] = xpad[(s*u + j - pad)*inner + w] for j < k and
+// 0 <= s*u + j - pad < H, else 0.  Turns the C_in = 1 first layers into rows-channel 1-tap convs.
+__global__ void __launch_bounds__(256)
+unfold1_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int H, int inner, int s, int k, int pad, int rows, int U) {
+    const int b = blockIdx.y;
+    const size_t row = (size_t)U * inner;
+    const size_t total = (size_t)rows * row;
+    const float* xb = x + (size_t)b * T;
+    float* ob = out + (size_t)b * total;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx / row);
+        const int rem = (int)(idx - (size_t)j * row);
+        const int u = rem / inner, w = rem - u * inner;
+        const int h = s * u + j - pad;
+        float v = 0.f;
+        if (j < k && h >= 0 && h < H) {
+            const int i = h * inner + w;
+            v = xb[i < T ? i : 2 * (T - 1) - i];
+        }
+        ob[idx] = v;
+    }
+}
+
+// AvgPool1d(4, 2, padding=2) (models.py:255-258; zero padding counted): out[t] = (x[2t-2] + x[2t-1] + x[2t] + x[2t+1]) / 4
+__global__ void __launch_bounds__(256)
+avgpool4_kernel(const float* __restrict__ x, float* __restrict__ out, int L, int Lo) {
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * L;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Lo; t += gridDim.x * 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 2 * t + j - 2;
+            if (i >= 0 && i < L) acc += xb[i];
+        }
+        out[(size_t)b * Lo + t] = acc * 0.25f;
+    }
+}
+
+}  // namespace
+
+extern "C" int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || Cg <= 0 || C % Cg || L <= 0 || inner <= 0 || s <= 0) return V2W_E_ARG;
+    const int U = (L + s - 1) / s;
+    const size_t total = (size_t)s * C * U * inner;
+    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, void* stream) {
+    if (!x || !out || B <= 0 || T <= 1 || H <= 0 || inner <= 0 || s <= 0 || k <= 0 || pad < 0 || rows < k) return V2W_E_ARG;
+    if ((long long)H * inner < T || (long long)H * inner - T >= T) return V2W_E_ARG;     // reflect pad shorter than the signal
+    if (H + 2 * pad < k) return V2W_E_SHAPE;
+    const int U = (H + 2 * pad - k) / s + 1;
+    const size_t total = (size_t)rows * U * inner;
+    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(unfold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, T, H, inner, s, k, pad, rows, U);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream) {
+    if (!x || !out || B <= 0 || L <= 0) return V2W_E_ARG;
+    const int Lo = L / 2 + 1;
+    int gx = (Lo + 255) / 256; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(avgpool4_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, L, Lo);
+    return v2w_launch_status();
+}

@@ -17,6 +17,8 @@ struct TileArgs {
     float* out;
     float* stats_part;   // convT only, optional: [ntiles][Cout][2] per-tile (sum, sumsq) of the output for BatchNorm
     int B, Cin, Cout, L, K, dil;
+    int CinT, CoutT;   // channel counts of the tensors `in` / `out` (res, add, mask) live in: > Cin / Cout for one group of a grouped conv
+    float out_slope;   // MASK instantiations only: leaky_relu on the stored value (1 = none)
     int pad;      // convT only: (K-U)/2
     int hl, hr;   // halo (input positions) left / right of the tile
     int hla;      // hl rounded up to a multiple of 4: LDS column 0 <-> position n0 - hla (16-B aligned rows)

@@ -1,0 +1,297 @@
+"""MPD / MSD discriminator FORWARDS on the MI355X.
+
+Mirror of /root/reference/vec2wav/models.py:158-275 - `DiscriminatorP`, `MultiPeriodDiscriminator(hp)`, `DiscriminatorS`,
+`MultiScaleDiscriminator()`, the same `forward(y, y_hat) -> (y_d_rs, y_d_gs, fmap_rs, fmap_gs)`, identical `state_dict` keys and
+shapes (weight_norm: bias / weight_g / weight_v with Conv2d (k, 1) shapes for the period discriminators; legacy spectral_norm on
+the first scale discriminator: bias / weight_orig / weight_u / weight_v) - so `do_%08d` checkpoints load.
+
+Forward only: the backward (both training steps of train.py:188-215 differentiate through them) is not built; calling with
+autograd enabled on anything that requires grad raises.  No PyTorch/CPU fallback: the convolutions run on the f32 MFMA tile
+kernel through the C ABI as stride-1 problems (csrc/v2w_disc.hip explains the mapping):
+  stride-s layers  -> `v2w_phase_split` + a conv over the s stacked phases (ceil(k/s)-ish taps),
+  (k, 1) Conv2d    -> Conv1d with dilation = period on the flattened (H * period) axis, feature maps kept as (B, C, H, period),
+  grouped Conv1d   -> one problem per group on channel slices (`in_ct` / `out_ct`), four groups per launch,
+  C_in = 1 layers  -> `v2w_unfold1` (k shifted rows, padded to 16) + a 1-tap conv,
+  leaky_relu       -> the conv epilogue (`out_slope`): feature maps are stored activated, as the reference returns them.
+Weight preparation (weight-norm fold on the HIP kernel; spectral-norm power iteration, tap re-indexing for the stride / group
+forms with torch index ops on the weight tensors) is cached per parameter version.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _hip, hipops
+from .synthetic import DISC_P_LAYERS, DISC_P_POST, DISC_S_LAYERS, DISC_S_POST
+
+LRELU_SLOPE = 0.1   # models.py:9
+_UNFOLD_ROWS = 16   # C_in = 1 layers: the k shifted copies padded to the MFMA kernel's smallest channel block
+
+
+class _DiscConv(nn.Module):
+    """Parameter holder of one (weight- or spectral-)normed conv of a discriminator; `wshape` is the reference's weight shape
+    (C_out, C_in / groups, k) or (C_out, C_in, k, 1)."""
+
+    def __init__(self, c_in, c_out, k, stride, groups, padding, spectral, conv2d):
+        super().__init__()
+        self.c_in, self.c_out, self.k, self.stride, self.groups, self.padding = c_in, c_out, k, stride, groups, padding
+        self.spectral = spectral
+        wshape = (c_out, c_in // groups, k, 1) if conv2d else (c_out, c_in // groups, k)
+        fan_in = c_in // groups * k
+        bound = 1.0 / math.sqrt(fan_in)
+        w = torch.empty(wshape).uniform_(-bound, bound)
+        self.bias = nn.Parameter(torch.empty(c_out).uniform_(-bound, bound))
+        if spectral:
+            self.weight_orig = nn.Parameter(w)
+            self.register_buffer('weight_u', F.normalize(torch.randn(c_out), dim=0, eps=1e-12))
+            self.register_buffer('weight_v', F.normalize(torch.randn(fan_in), dim=0, eps=1e-12))
+        else:
+            self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(c_out, *([1] * (len(wshape) - 1))).clone())
+            self.weight_v = nn.Parameter(w)
+        self._cache = None
+
+    def extra_repr(self):
+        return f'{self.c_in}, {self.c_out}, k={self.k}, stride={self.stride}, groups={self.groups}, ' \
+               f'{"spectral_norm" if self.spectral else "weight_norm"}'
+
+    # -- weights in kernel form --------------------------------------------------------------------------------------
+    def _folded(self):
+        """-> wf [k][C_in / groups][C_out], normalisation applied (one power iteration first for spectral_norm in training)."""
+        co, cig, k = self.c_out, self.c_in // self.groups, self.k
+        if not self.spectral:
+            return hipops.fold_conv_weight(self.weight_v.detach().reshape(co, cig, k), self.weight_g.detach().reshape(co, 1, 1))
+        w = self.weight_orig.detach()
+        wm = w.reshape(co, -1)
+        if self.training:      # legacy torch.nn.utils.spectral_norm: v <- norm(W^T u), u <- norm(W v), in place, per forward
+            self.weight_v.copy_(F.normalize(torch.mv(wm.t(), self.weight_u), dim=0, eps=1e-12))
+            self.weight_u.copy_(F.normalize(torch.mv(wm, self.weight_v), dim=0, eps=1e-12))
+        sigma = torch.dot(self.weight_u, torch.mv(wm, self.weight_v))
+        return hipops.fold_conv_weight((w / sigma).reshape(co, cig, k), None)
+
+    def kernel_weights(self):
+        """Per-group stride-1 weights: dict(wf=[G] of [k'][s * C_in/G][C_out/G], wp=[G] packed or None, kp, pad_left_taps).
+        With j - P = s*q + r:  wf'[q + Q][r * cig + c][o] = wf[s*q + r + P][c][o]  (0 where the tap does not exist)."""
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._cache is not None and self._cache[0] == key and not (self.spectral and self.training):
+            return self._cache[1]
+        wf = self._folded()                                  # [k][cig][co]
+        k, s, P, G = self.k, self.stride, self.padding, self.groups
+        cig, cog = self.c_in // G, self.c_out // G
+        dev = wf.device
+        if self.c_in == 1:                                   # unfolded: rows = taps
+            w2 = torch.zeros((1, _UNFOLD_ROWS, self.c_out), device=dev)
+            w2[0, :k] = wf[:, 0, :]
+            groups, kp, Q = [w2], 1, 0
+        else:
+            Q = -(-P // s)
+            kp = Q + (k - 1 - P) // s + 1
+            q = torch.arange(kp, device=dev).view(kp, 1) - Q
+            r = torch.arange(s, device=dev).view(1, s)
+            j = s * q + r + P
+            j = torch.where((j >= 0) & (j < k), j, torch.full_like(j, k))
+            wpad = torch.cat([wf, torch.zeros((1, cig, self.c_out), device=dev)], 0)
+            w5 = wpad[j.reshape(-1)].reshape(kp, s * cig, G, cog)          # rows (r, c), columns (g, o)
+            groups = [w5[:, :, g, :].contiguous() for g in range(G)]
+        packable = groups[0].shape[1] % 16 == 0 and (groups[0].shape[2] % 32 == 0 or groups[0].shape[2] == 16)
+        rec = dict(wf=groups, wp=[hipops.pack_mfma(w) for w in groups] if packable else [None] * len(groups), kp=kp, Q=Q)
+        self._cache = (key, rec)
+        return rec
+
+
+def _check_no_grad(mod, *xs):
+    if torch.is_grad_enabled() and (any(x.requires_grad for x in xs) or any(p.requires_grad for p in mod.parameters())):
+        raise NotImplementedError('the discriminator backward is not built on the HIP path: call the forward under torch.no_grad()')
+    for x in xs:
+        if not x.is_cuda:
+            raise RuntimeError('the discriminators run on the MI355X HIP path only (no CPU fallback)')
+
+
+def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
+    """x (B, C_in, L_in * inner) activated feature map -> (B, C_out, U * inner), U = L_out of the strided conv."""
+    B = x.shape[0]
+    s, G = layer.stride, layer.groups
+    rec = layer.kernel_weights()
+    lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
+    if s > 1:
+        U = -(-L_in // s)
+        xs = torch.empty((B, s * layer.c_in, U * inner), device=x.device)
+        _hip.check(lib.v2w_phase_split(x.data_ptr(), xs.data_ptr(), B, layer.c_in, layer.c_in // G, L_in, inner, s, st), 'v2w_phase_split')
+    else:
+        U, xs = L_in, x
+    out = torch.empty((B, layer.c_out, U * inner), device=x.device)
+    cig, cog = s * layer.c_in // G, layer.c_out // G
+    kw = dict(k=rec['kp'], dil=inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
+    if G == 1:
+        hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
+    else:
+        bias = layer.bias.detach()
+        probs = [(xs, rec['wf'][g], bias[g * cog:(g + 1) * cog], out, dict(kw, wp=rec['wp'][g], group=(g, cig, cog))) for g in range(G)]
+        for i in range(0, G, 4):
+            hipops.conv1d_multi(probs[i:i + 4])
+    return out, U
+
+
+def _first_layer(layer: _DiscConv, x, T, H, inner):
+    """C_in = 1: x (B, 1, T) -> activated (B, C_out, U * inner) through the unfolded 1-tap form."""
+    B = x.shape[0]
+    lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
+    U = (H + 2 * layer.padding - layer.k) // layer.stride + 1
+    if U < 1:
+        raise RuntimeError('discriminator input is shorter than the first kernel')
+    xu = torch.empty((B, _UNFOLD_ROWS, U * inner), device=x.device)
+    _hip.check(lib.v2w_unfold1(x.data_ptr(), xu.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding, _UNFOLD_ROWS, st),
+               'v2w_unfold1')
+    rec = layer.kernel_weights()
+    out = torch.empty((B, layer.c_out, U * inner), device=x.device)
+    hipops.conv1d(xu, rec['wf'][0], layer.bias.detach(), out, k=1, dil=1, slope=1.0, wp=rec['wp'][0], out_slope=LRELU_SLOPE)
+    return out, U
+
+
+class DiscriminatorP(nn.Module):
+    """models.py:158-193."""
+
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        if kernel_size != 5 or stride != 3:
+            raise NotImplementedError('DiscriminatorP (HIP): the reference configuration kernel_size=5, stride=3')
+        self.period = period
+        self.convs = nn.ModuleList([_DiscConv(ci, co, k, s, 1, p, use_spectral_norm, True) for ci, co, k, s, p in DISC_P_LAYERS])
+        ci, co, k, s, p = DISC_P_POST
+        self.conv_post = _DiscConv(ci, co, k, s, 1, p, use_spectral_norm, True)
+
+    def forward(self, x):
+        _check_no_grad(self, x)
+        with torch.no_grad():
+            x = x.detach().contiguous().float()
+            b, c, t = x.shape
+            p = self.period
+            H = -(-t // p)                                   # reflect pad to a multiple of the period happens inside unfold1
+            if H * p - t >= t:
+                raise RuntimeError('reflect padding needs an input longer than the pad')
+            fmap = []
+            f, Hc = _first_layer(self.convs[0], x, t, H, p)
+            fmap.append(f.view(b, -1, Hc, p))
+            for layer in list(self.convs)[1:]:
+                f, Hc = _conv_layer(layer, f, Hc, p, LRELU_SLOPE)
+                fmap.append(f.view(b, -1, Hc, p))
+            f, Hc = _conv_layer(self.conv_post, f, Hc, p, 0.0)
+            fmap.append(f.view(b, 1, Hc, p))
+            return torch.flatten(fmap[-1], 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    """models.py:196-216."""
+
+    def __init__(self, hp):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorP(prd) for prd in hp.periods])
+
+    def forward(self, y, y_hat):
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            y_d_r, fmap_r = d(y)
+            y_d_g, fmap_g = d(y_hat)
+            y_d_rs.append(y_d_r); fmap_rs.append(fmap_r)
+            y_d_gs.append(y_d_g); fmap_gs.append(fmap_g)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class DiscriminatorS(nn.Module):
+    """models.py:219-243."""
+
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        self.convs = nn.ModuleList([_DiscConv(ci, co, k, s, g, p, use_spectral_norm, False) for ci, co, k, s, g, p in DISC_S_LAYERS])
+        ci, co, k, s, g, p = DISC_S_POST
+        self.conv_post = _DiscConv(ci, co, k, s, g, p, use_spectral_norm, False)
+
+    def forward(self, x):
+        _check_no_grad(self, x)
+        with torch.no_grad():
+            x = x.detach().contiguous().float()
+            b, c, t = x.shape
+            fmap = []
+            f, L = _first_layer(self.convs[0], x, t, t, 1)
+            fmap.append(f)
+            for layer in list(self.convs)[1:]:
+                f, L = _conv_layer(layer, f, L, 1, LRELU_SLOPE)
+                fmap.append(f)
+            f, L = _conv_layer(self.conv_post, f, L, 1, 0.0)
+            fmap.append(f)
+            return torch.flatten(f, 1, -1), fmap
+
+
+def avg_pool(x):
+    """AvgPool1d(4, 2, padding=2) of models.py:255-258 on (B, 1, L)."""
+    if not x.is_cuda:
+        raise RuntimeError('the discriminators run on the MI355X HIP path only (no CPU fallback)')
+    x = x.detach().contiguous().float()
+    B, C, L = x.shape
+    out = torch.empty((B, C, L // 2 + 1), device=x.device)
+    _hip.check(_hip.load().v2w_avgpool4(x.data_ptr(), out.data_ptr(), B * C, L, torch.cuda.current_stream(x.device).cuda_stream),
+               'v2w_avgpool4')
+    return out
+
+
+class _MeanPool(nn.Module):
+    def forward(self, x):
+        return avg_pool(x)
+
+
+class MultiScaleDiscriminator(nn.Module):
+    """models.py:246-275."""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorS(use_spectral_norm=True), DiscriminatorS(), DiscriminatorS()])
+        self.meanpools = nn.ModuleList([_MeanPool(), _MeanPool()])
+
+    def forward(self, y, y_hat):
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for i, d in enumerate(self.discriminators):
+            if i != 0:
+                y = self.meanpools[i - 1](y)
+                y_hat = self.meanpools[i - 1](y_hat)
+            y_d_r, fmap_r = d(y)
+            y_d_g, fmap_g = d(y_hat)
+            y_d_rs.append(y_d_r); fmap_rs.append(fmap_r)
+            y_d_gs.append(y_d_g); fmap_gs.append(fmap_g)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+def feature_loss(fmap_r, fmap_g):
+    """models.py:278-284."""
+    loss = 0
+    for dr, dg in zip(fmap_r, fmap_g):
+        for rl, gl in zip(dr, dg):
+            loss += torch.mean(torch.abs(rl - gl))
+    return loss * 2
+
+
+def discriminator_loss(disc_real_outputs, disc_generated_outputs):
+    """models.py:287-299."""
+    loss = 0
+    r_losses, g_losses = [], []
+    for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
+        r_loss = torch.mean((1 - dr) ** 2)
+        g_loss = torch.mean(dg ** 2)
+        loss += (r_loss + g_loss)
+        r_losses.append(r_loss.item())
+        g_losses.append(g_loss.item())
+    return loss, r_losses, g_losses
+
+
+def generator_loss(disc_outputs):
+    """models.py:302-310."""
+    loss = 0
+    gen_losses = []
+    for dg in disc_outputs:
+        l = torch.mean((1 - dg) ** 2)
+        gen_losses.append(l)
+        loss += l
+    return loss, gen_losses

@@ -126,11 +126,19 @@ def pack_split(wf, out=None, sc=None, bf16=False):
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
                  accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None):
+                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None):
     B, ci, Lx = x.shape
     L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
+    co = out.shape[1]
+    a.out_slope = out_slope
+    xoff = ooff = 0
+    if group is not None:             # (g, C_in per group, C_out per group): this call computes ONE group of a grouped conv
+        g, cig, cog = group
+        a.in_ct, a.out_ct = ci, co
+        xoff, ooff = g * cig * Lx * 4, g * cog * out.shape[2] * 4
+        ci, co = cig, cog
     a.in_stride, a.in_phase, a.pad_left = in_stride, in_phase, pad_left
-    a.in_ = x.data_ptr()
+    a.in_ = x.data_ptr() + xoff
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
     a.wf = _hip.ptr(wf); a.wp = _hip.ptr(wp); a.bias = _hip.ptr(bias)
     if wps is not None:           # (fragments, scale record) of pack_split
@@ -144,8 +152,8 @@ def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, re
         a.mask_src = mask[0].data_ptr()
         a.mask_a, a.mask_s = (mask[1][0].data_ptr(), mask[1][1].data_ptr()) if mask[1] is not None else (None, None)
     a.mask_slope = mask_slope
-    a.out = out.data_ptr()
-    a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, out.shape[1], L, k, dil
+    a.out = out.data_ptr() + ooff
+    a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, ci, co, L, k, dil
     a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
 
 
