@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 13
+#define V2W_ABI_VERSION 14
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -336,8 +336,13 @@ int v2w_mel_phases_bwd(const float* dxp, float* dy, int B, int L, int hop, int p
  *                    out (B, rows, U*inner), out[b][j][u*inner + w] = xpad[(s*u + j - pad)*inner + w], U = (H + 2 pad - k)/s + 1,
  *                    rows >= k (the extra rows are 0): the C_in = 1 layers as 1-tap convs over `rows` channels.
  *   v2w_avgpool4:    AvgPool1d(4, 2, padding=2) (models.py:255-258): x (B, L) -> out (B, L/2 + 1). */
-int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, void* stream);
-int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, void* stream);
+int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch, void* stream);
+int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, int opitch, void* stream);
+/* Row pitches (floats between consecutive channel rows; 0 = dense): the f32 MFMA kernel's float4 staging needs rows that are
+ * multiples of 4 floats, so the discriminators keep (B, C, pitch) buffers with pitch = roundup4(length), run the convs at
+ * L = pitch and return the feature maps as [:, :, :length] views.  The tail positions come out of a conv as ordinary
+ * positions; v2w_zero_tail restores the zero padding before a stride-1 conv reads that buffer directly. */
+int v2w_zero_tail(float* x, long long rows, int pitch, int valid, void* stream);
 int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
 
 #ifdef __cplusplus

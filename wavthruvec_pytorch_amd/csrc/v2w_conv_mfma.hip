@@ -360,10 +360,11 @@ conv_tile_kernel(const MultiArgs m) {
     }
 }
 
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK>
+// HMAX: largest halo (each side) the staging slots cover: 32 for the generator (k = 11, dilation 5 -> 25); the 48 variants serve
+// DiscriminatorP's dilation = period convs (k = 5, period 19 -> 38) at one more prefetch slot per thread.
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int HMAX = 32>
 int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * WM * WN;
-    constexpr int HMAX = 32;                                       // largest halo (each side) the staging slots cover
     constexpr int NPF = (CK * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
     constexpr int KSTEP = MF == 32 ? 2 : 4;
     constexpr int RING = (U == 1 && CK / (4 * KSTEP) == 4) ? 4 : 2;
@@ -577,6 +578,13 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
+    }
+    int halo = 0;
+    for (int i = 0; i < n; ++i) { const int h = ((ps[i].hl + 3) & ~3) > ps[i].hr ? ((ps[i].hl + 3) & ~3) : ps[i].hr; if (h > halo) halo = h; }
+    if (halo > 32) {            // wide-halo variants (see launch_tile): dense layers of the period discriminators
+        if (halo > 48 || cfg.mf != 32 || cfg.ck != 32 || a->C_out % 64 != 0) return V2W_E_SHAPE;
+        if (a->C_out % 128 == 0 && tiles128 >= 4 * 256) return launch_tile<32, 1, 2, 2, 2, 2, 32, 48>(ps, n, stream);
+        return launch_tile<32, 1, 1, 2, 2, 2, 32, 48>(ps, n, stream);
     }
     // latency-bound sizes (inference at B = 1): fewer than two 64 x 64 tiles per CU -> 64 x 64 tiles: the most workgroups and one
     // MFMA per k-step and wave, i.e. the shortest serial chain through the K loop (cfg1: 1.54 -> 1.23 ms per forward)

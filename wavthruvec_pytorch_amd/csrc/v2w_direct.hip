@@ -45,6 +45,35 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
     a.out[o] = v;
 }
 
+// C_out = 1 (the discriminators' conv_post, models.py:171,230): a reduction over C_in * k, HBM-bound on reading the input once.
+// One block = 64 output positions of one batch item; the 4 waves split the input channels and meet in LDS.
+__global__ void __launch_bounds__(256)
+conv1d_cout1_kernel(const v2w_conv1d_args a) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int pad = a.pad_left >= 0 ? a.pad_left : a.dil * (a.k - 1) / 2;
+    const int cit = a.in_ct > 0 ? a.in_ct : a.C_in;
+    float acc = 0.f;
+    if (l < a.L) {
+        for (int ci = wv; ci < a.C_in; ci += 4) {
+            const float* src = a.in + ((size_t)b * cit + ci) * a.L;
+            for (int t = 0; t < a.k; ++t) {
+                const int li = l + t * a.dil - pad;
+                if (li < 0 || li >= a.L) continue;
+                acc = fmaf(a.wf[(size_t)t * a.C_in + ci], v2w_lrelu(src[li], a.slope), acc);
+            }
+        }
+    }
+    red[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && l < a.L) {
+        float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]) + (a.bias ? a.bias[0] : 0.f);
+        if (a.out_slope != 0.f && a.out_slope != 1.f) v = v > 0.f ? v : v * a.out_slope;
+        a.out[((size_t)b * (a.out_ct > 0 ? a.out_ct : 1)) * a.L + l] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 convt1d_direct_kernel(const v2w_convt1d_args a) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;   // output position
@@ -147,6 +176,11 @@ conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict
 }  // namespace
 
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
+    const int istr = a->in_stride > 0 ? a->in_stride : 1;
+    if (a->C_out == 1 && istr == 1 && !a->in_a && !a->res && !a->add0 && !a->mask_src && !a->accumulate && a->out_div == 0.f) {
+        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((a->L + 63) / 64, a->B), dim3(256), 0, stream, *a);
+        return v2w_launch_status();
+    }
     dim3 grid((a->L + 255) / 256, a->C_out, a->B);
     hipLaunchKernelGGL(conv1d_direct_kernel, grid, dim3(256), 0, stream, *a);
     return v2w_launch_status();

@@ -12,21 +12,23 @@ namespace {
 
 // x (B, C, L, inner) -> out (B, s*C, U, inner), U = ceil(L / s):
 //   out[b][((c / Cg)*s + r)*Cg + c % Cg][u][w] = x[b][c][s*u + r][w]  (0 past L); Cg = channels per conv group (C when ungrouped)
+// Rows of x / out are ipitch / opitch floats apart (>= L*inner / U*inner; the out tail is zero-filled): the conv kernel's float4
+// staging wants rows that are multiples of 4 floats, whatever the period.
 __global__ void __launch_bounds__(256)
-phase_split_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int Cg, int L, int inner, int s, int U) {
+phase_split_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int Cg, int L, int inner, int s, int U,
+                   int ipitch, int opitch) {
     const int b = blockIdx.y;
-    const size_t row = (size_t)U * inner;
-    const size_t total = (size_t)s * C * row;
-    const float* xb = x + (size_t)b * C * L * inner;
+    const size_t total = (size_t)s * C * opitch;
+    const float* xb = x + (size_t)b * C * ipitch;
     float* ob = out + (size_t)b * total;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int cs = (int)(idx / row);
-        const int rem = (int)(idx - (size_t)cs * row);
+        const int cs = (int)(idx / opitch);
+        const int rem = (int)(idx - (size_t)cs * opitch);
         const int u = rem / inner, w = rem - u * inner;
         const int g = cs / (s * Cg), rr = cs - g * s * Cg;
         const int r = rr / Cg, c = g * Cg + (rr - r * Cg);
         const int l = s * u + r;
-        ob[idx] = l < L ? xb[((size_t)c * L + l) * inner + w] : 0.f;
+        ob[idx] = (u < U && l < L) ? xb[(size_t)c * ipitch + (size_t)l * inner + w] : 0.f;
     }
 }
 
@@ -34,9 +36,10 @@ phase_split_kernel(const float* __restrict__ x, float* __restrict__ out, int C, 
 // (models.py:176-181) -> out (B, rows, U*inner): out[b][j][u*inner + w] = xpad[(s*u + j - pad)*inner + w] for j < k and
 // 0 <= s*u + j - pad < H, else 0.  Turns the C_in = 1 first layers into rows-channel 1-tap convs.
 __global__ void __launch_bounds__(256)
-unfold1_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int H, int inner, int s, int k, int pad, int rows, int U) {
+unfold1_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int H, int inner, int s, int k, int pad, int rows, int U,
+               int opitch) {
     const int b = blockIdx.y;
-    const size_t row = (size_t)U * inner;
+    const size_t row = (size_t)opitch;
     const size_t total = (size_t)rows * row;
     const float* xb = x + (size_t)b * T;
     float* ob = out + (size_t)b * total;
@@ -46,7 +49,7 @@ unfold1_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int 
         const int u = rem / inner, w = rem - u * inner;
         const int h = s * u + j - pad;
         float v = 0.f;
-        if (j < k && h >= 0 && h < H) {
+        if (j < k && u < U && h >= 0 && h < H) {
             const int i = h * inner + w;
             v = xb[i < T ? i : 2 * (T - 1) - i];
         }
@@ -72,23 +75,48 @@ avgpool4_kernel(const float* __restrict__ x, float* __restrict__ out, int L, int
 
 }  // namespace
 
-extern "C" int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, void* stream) {
+extern "C" int v2w_phase_split(const float* x, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch,
+                               void* stream) {
     if (!x || !out || B <= 0 || C <= 0 || Cg <= 0 || C % Cg || L <= 0 || inner <= 0 || s <= 0) return V2W_E_ARG;
     const int U = (L + s - 1) / s;
-    const size_t total = (size_t)s * C * U * inner;
+    if (ipitch <= 0) ipitch = L * inner;
+    if (opitch <= 0) opitch = U * inner;
+    if (ipitch < L * inner || opitch < U * inner) return V2W_E_ARG;
+    const size_t total = (size_t)s * C * opitch;
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U);
+    hipLaunchKernelGGL(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U, ipitch, opitch);
     return v2w_launch_status();
 }
 
-extern "C" int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, void* stream) {
+// x: `rows` rows of `pitch` floats: zero [valid, pitch) of every row (the conv kernel computed them as ordinary positions;
+// a stride-1 consumer must see the reference's zero padding there).
+__global__ void __launch_bounds__(256)
+zero_tail_kernel(float* __restrict__ x, long rows, int pitch, int valid) {
+    const int n = pitch - valid;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < rows * n; idx += (long)gridDim.x * 256)
+        x[(idx / n) * pitch + valid + idx % n] = 0.f;
+}
+
+extern "C" int v2w_zero_tail(float* x, long long rows, int pitch, int valid, void* stream) {
+    if (!x || rows <= 0 || pitch <= 0 || valid < 0 || valid > pitch) return V2W_E_ARG;
+    if (valid == pitch) return 0;
+    const long total = rows * (pitch - valid);
+    int gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, (long)rows, pitch, valid);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int s, int k, int pad, int rows, int opitch,
+                           void* stream) {
     if (!x || !out || B <= 0 || T <= 1 || H <= 0 || inner <= 0 || s <= 0 || k <= 0 || pad < 0 || rows < k) return V2W_E_ARG;
     if ((long long)H * inner < T || (long long)H * inner - T >= T) return V2W_E_ARG;     // reflect pad shorter than the signal
     if (H + 2 * pad < k) return V2W_E_SHAPE;
     const int U = (H + 2 * pad - k) / s + 1;
-    const size_t total = (size_t)rows * U * inner;
+    if (opitch <= 0) opitch = U * inner;
+    if (opitch < U * inner) return V2W_E_ARG;
+    const size_t total = (size_t)rows * opitch;
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(unfold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, T, H, inner, s, k, pad, rows, U);
+    hipLaunchKernelGGL(unfold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, T, H, inner, s, k, pad, rows, U, opitch);
     return v2w_launch_status();
 }
 

@@ -12,7 +12,9 @@ kernel through the C ABI as stride-1 problems (csrc/v2w_disc.hip explains the ma
   (k, 1) Conv2d    -> Conv1d with dilation = period on the flattened (H * period) axis, feature maps kept as (B, C, H, period),
   grouped Conv1d   -> one problem per group on channel slices (`in_ct` / `out_ct`), four groups per launch,
   C_in = 1 layers  -> `v2w_unfold1` (k shifted rows, padded to 16) + a 1-tap conv,
-  leaky_relu       -> the conv epilogue (`out_slope`): feature maps are stored activated, as the reference returns them.
+  leaky_relu       -> the conv epilogue (`out_slope`): feature maps are stored activated, as the reference returns them,
+  row pitch        -> feature maps live in (B, C, roundup4(length)) buffers (the kernel's float4 staging) and are returned as
+                      `[:, :, :length]` views: same shapes and values as the reference, strided when length % 4 != 0.
 Weight preparation (weight-norm fold on the HIP kernel; spectral-norm power iteration, tap re-indexing for the stride / group
 forms with torch index ops on the weight tensors) is cached per parameter version.
 """
@@ -111,19 +113,31 @@ def _check_no_grad(mod, *xs):
             raise RuntimeError('the discriminators run on the MI355X HIP path only (no CPU fallback)')
 
 
+def _pitch(n):
+    """Row pitch of a feature-map buffer: the MFMA kernel's float4 staging wants rows that are multiples of 4 floats."""
+    return (n + 3) // 4 * 4
+
+
 def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
-    """x (B, C_in, L_in * inner) activated feature map -> (B, C_out, U * inner), U = L_out of the strided conv."""
+    """x (B, C_in, pitch(L_in * inner)) activated feature-map buffer (valid part [:L_in * inner]) ->
+    (out buffer (B, C_out, pitch(U * inner)), U), U = L_out of the strided conv.  The convs run at L = pitch: the tail columns
+    are ordinary positions to the kernel, hold zeros on the input side (phase_split / unfold fill them; `v2w_zero_tail` before a
+    stride-1 layer reads a conv output directly) and are never part of the returned views."""
     B = x.shape[0]
     s, G = layer.stride, layer.groups
     rec = layer.kernel_weights()
     lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
+    pin = x.shape[2]
     if s > 1:
         U = -(-L_in // s)
-        xs = torch.empty((B, s * layer.c_in, U * inner), device=x.device)
-        _hip.check(lib.v2w_phase_split(x.data_ptr(), xs.data_ptr(), B, layer.c_in, layer.c_in // G, L_in, inner, s, st), 'v2w_phase_split')
+        P = _pitch(U * inner)
+        xs = torch.empty((B, s * layer.c_in, P), device=x.device)
+        _hip.check(lib.v2w_phase_split(x.data_ptr(), xs.data_ptr(), B, layer.c_in, layer.c_in // G, L_in, inner, s, pin, P, st),
+                   'v2w_phase_split')
     else:
-        U, xs = L_in, x
-    out = torch.empty((B, layer.c_out, U * inner), device=x.device)
+        U, xs, P = L_in, x, pin
+        _hip.check(lib.v2w_zero_tail(x.data_ptr(), B * layer.c_in, pin, L_in * inner, st), 'v2w_zero_tail')
+    out = torch.empty((B, layer.c_out, P), device=x.device)
     cig, cog = s * layer.c_in // G, layer.c_out // G
     kw = dict(k=rec['kp'], dil=inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
     if G == 1:
@@ -137,17 +151,18 @@ def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
 
 
 def _first_layer(layer: _DiscConv, x, T, H, inner):
-    """C_in = 1: x (B, 1, T) -> activated (B, C_out, U * inner) through the unfolded 1-tap form."""
+    """C_in = 1: x (B, 1, T) -> activated buffer (B, C_out, pitch(U * inner)) through the unfolded 1-tap form."""
     B = x.shape[0]
     lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
     U = (H + 2 * layer.padding - layer.k) // layer.stride + 1
     if U < 1:
         raise RuntimeError('discriminator input is shorter than the first kernel')
-    xu = torch.empty((B, _UNFOLD_ROWS, U * inner), device=x.device)
-    _hip.check(lib.v2w_unfold1(x.data_ptr(), xu.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding, _UNFOLD_ROWS, st),
+    P = _pitch(U * inner)
+    xu = torch.empty((B, _UNFOLD_ROWS, P), device=x.device)
+    _hip.check(lib.v2w_unfold1(x.data_ptr(), xu.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding, _UNFOLD_ROWS, P, st),
                'v2w_unfold1')
     rec = layer.kernel_weights()
-    out = torch.empty((B, layer.c_out, U * inner), device=x.device)
+    out = torch.empty((B, layer.c_out, P), device=x.device)
     hipops.conv1d(xu, rec['wf'][0], layer.bias.detach(), out, k=1, dil=1, slope=1.0, wp=rec['wp'][0], out_slope=LRELU_SLOPE)
     return out, U
 
@@ -175,12 +190,12 @@ class DiscriminatorP(nn.Module):
                 raise RuntimeError('reflect padding needs an input longer than the pad')
             fmap = []
             f, Hc = _first_layer(self.convs[0], x, t, H, p)
-            fmap.append(f.view(b, -1, Hc, p))
+            fmap.append(f[:, :, :Hc * p].view(b, -1, Hc, p))      # (views of pitched buffers: strided when Hc * p % 4 != 0)
             for layer in list(self.convs)[1:]:
                 f, Hc = _conv_layer(layer, f, Hc, p, LRELU_SLOPE)
-                fmap.append(f.view(b, -1, Hc, p))
+                fmap.append(f[:, :, :Hc * p].view(b, -1, Hc, p))
             f, Hc = _conv_layer(self.conv_post, f, Hc, p, 0.0)
-            fmap.append(f.view(b, 1, Hc, p))
+            fmap.append(f[:, :, :Hc * p].view(b, 1, Hc, p))
             return torch.flatten(fmap[-1], 1, -1), fmap
 
 
@@ -217,13 +232,13 @@ class DiscriminatorS(nn.Module):
             b, c, t = x.shape
             fmap = []
             f, L = _first_layer(self.convs[0], x, t, t, 1)
-            fmap.append(f)
+            fmap.append(f[:, :, :L])
             for layer in list(self.convs)[1:]:
                 f, L = _conv_layer(layer, f, L, 1, LRELU_SLOPE)
-                fmap.append(f)
+                fmap.append(f[:, :, :L])
             f, L = _conv_layer(self.conv_post, f, L, 1, 0.0)
-            fmap.append(f)
-            return torch.flatten(f, 1, -1), fmap
+            fmap.append(f[:, :, :L])
+            return torch.flatten(fmap[-1], 1, -1), fmap
 
 
 def avg_pool(x):
