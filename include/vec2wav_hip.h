@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 14
+#define V2W_ABI_VERSION 15
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -343,6 +343,9 @@ int v2w_unfold1(const float* x, float* out, int B, int T, int H, int inner, int 
  * L = pitch and return the feature maps as [:, :, :length] views.  The tail positions come out of a conv as ordinary
  * positions; v2w_zero_tail restores the zero padding before a stride-1 conv reads that buffer directly. */
 int v2w_zero_tail(float* x, long long rows, int pitch, int valid, void* stream);
+/* x (B, C, L, inner) -> out (B, k*C, U, inner), out[b][j*C + c][u][w] = x[b][c][s*u + j - pad][w] (0 outside), U = (L + 2 pad - k)/s + 1:
+ * a short strided conv (DiscriminatorP: k = 5, stride 3) as one 1-tap conv over k*C channels with the reference's exact MAC count. */
+int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, int inner, int s, int k, int pad, int ipitch, int opitch, void* stream);
 int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
 
 #ifdef __cplusplus

@@ -82,3 +82,18 @@ def test_discriminator_losses_and_guards(dev):
         assert abs(generator_loss(got[1])[0].item() - generator_loss(want[1])[0].item()) <= 1e-4
     with pytest.raises(NotImplementedError):
         m(y.to(dev), y_hat.to(dev))
+
+
+def test_mpd_unfolded_tap_form(dev, monkeypatch):
+    """V2W_DISC_UNFOLD=1: the k = 5 / stride 3 layers as 1-tap convs over k*C unfolded channels (v2w_unfold_taps) - same results."""
+    monkeypatch.setenv('V2W_DISC_UNFOLD', '1')
+    sd = synthetic.make_disc_state_dict(synthetic.mpd_state_dict_spec(), seed=4)
+    y, y_hat = synthetic.make_audio_pair(2, 6000, seed=8)
+    with torch.no_grad():
+        want = D.mpd_forward(sd, y, y_hat)
+        m = build('mpd', sd, dev)
+        assert m.discriminators[0].convs[1].unfolded and not m.discriminators[0].convs[4].unfolded
+        got = m(y.to(dev), y_hat.to(dev))
+    for fw, fg in zip(want[2] + want[3], got[2] + got[3]):
+        for a, b in zip(fw, fg):
+            assert a.shape == b.shape and (a - b.cpu()).abs().max().item() <= TOL

@@ -46,29 +46,37 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
 }
 
 // C_out = 1 (the discriminators' conv_post, models.py:171,230): a reduction over C_in * k, HBM-bound on reading the input once.
-// One block = 64 output positions of one batch item; the 4 waves split the input channels and meet in LDS.
+// One block = 32 output positions of one batch item; 8 channel groups of 32 lanes split the input channels (4 independent
+// accumulation chains each) and meet in LDS.
 __global__ void __launch_bounds__(256)
 conv1d_cout1_kernel(const v2w_conv1d_args a) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int l = blockIdx.x * 64 + lane, b = blockIdx.y;
+    __shared__ float red[8][32];
+    const int lane = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int l = blockIdx.x * 32 + lane, b = blockIdx.y;
     const int pad = a.pad_left >= 0 ? a.pad_left : a.dil * (a.k - 1) / 2;
     const int cit = a.in_ct > 0 ? a.in_ct : a.C_in;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (l < a.L) {
-        for (int ci = wv; ci < a.C_in; ci += 4) {
-            const float* src = a.in + ((size_t)b * cit + ci) * a.L;
-            for (int t = 0; t < a.k; ++t) {
-                const int li = l + t * a.dil - pad;
-                if (li < 0 || li >= a.L) continue;
-                acc = fmaf(a.wf[(size_t)t * a.C_in + ci], v2w_lrelu(src[li], a.slope), acc);
+        for (int t = 0; t < a.k; ++t) {
+            const int li = l + t * a.dil - pad;
+            if (li < 0 || li >= a.L) continue;
+            const float* src = a.in + (size_t)b * cit * a.L + li;
+            const float* w = a.wf + (size_t)t * a.C_in;
+            int ci = cg;
+            for (; ci + 24 < a.C_in; ci += 32) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] = fmaf(w[ci + 8 * u], v2w_lrelu(src[(size_t)(ci + 8 * u) * a.L], a.slope), acc[u]);
             }
+            for (; ci < a.C_in; ci += 8) acc[0] = fmaf(w[ci], v2w_lrelu(src[(size_t)ci * a.L], a.slope), acc[0]);
         }
     }
-    red[wv][lane] = acc;
+    red[cg][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
-    if (wv == 0 && l < a.L) {
-        float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]) + (a.bias ? a.bias[0] : 0.f);
+    if (cg == 0 && l < a.L) {
+        float v = a.bias ? a.bias[0] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += red[g][lane];
         if (a.out_slope != 0.f && a.out_slope != 1.f) v = v > 0.f ? v : v * a.out_slope;
         a.out[((size_t)b * (a.out_ct > 0 ? a.out_ct : 1)) * a.L + l] = v;
     }
@@ -178,7 +186,7 @@ conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
     const int istr = a->in_stride > 0 ? a->in_stride : 1;
     if (a->C_out == 1 && istr == 1 && !a->in_a && !a->res && !a->add0 && !a->mask_src && !a->accumulate && a->out_div == 0.f) {
-        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((a->L + 63) / 64, a->B), dim3(256), 0, stream, *a);
+        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((a->L + 31) / 32, a->B), dim3(256), 0, stream, *a);
         return v2w_launch_status();
     }
     dim3 grid((a->L + 255) / 256, a->C_out, a->B);

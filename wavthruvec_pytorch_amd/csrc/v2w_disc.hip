@@ -57,6 +57,26 @@ unfold1_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int 
     }
 }
 
+// x (B, C, L, inner) -> out (B, k*C, U, inner), U = (L + 2 pad - k)/s + 1: out[b][j*C + c][u][w] = x[b][c][s*u + j - pad][w] (0 outside
+// [0, L)): a short strided conv (DiscriminatorP's k = 5, stride 3) as ONE 1-tap conv over k*C channels: exactly the reference's
+// k*C*C_out MACs per output (the phase-stacked form pads 5 taps to 6 slots) and no halo.
+__global__ void __launch_bounds__(256)
+unfold_taps_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int L, int inner, int s, int k, int pad, int U,
+                   int ipitch, int opitch) {
+    const int b = blockIdx.y;
+    const size_t total = (size_t)k * C * opitch;
+    const float* xb = x + (size_t)b * C * ipitch;
+    float* ob = out + (size_t)b * total;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int jc = (int)(idx / opitch);
+        const int rem = (int)(idx - (size_t)jc * opitch);
+        const int u = rem / inner, w = rem - u * inner;
+        const int j = jc / C, c = jc - j * C;
+        const int l = s * u + j - pad;
+        ob[idx] = (u < U && l >= 0 && l < L) ? xb[(size_t)c * ipitch + (size_t)l * inner + w] : 0.f;
+    }
+}
+
 // AvgPool1d(4, 2, padding=2) (models.py:255-258; zero padding counted): out[t] = (x[2t-2] + x[2t-1] + x[2t] + x[2t+1]) / 4
 __global__ void __launch_bounds__(256)
 avgpool4_kernel(const float* __restrict__ x, float* __restrict__ out, int L, int Lo) {
@@ -125,5 +145,20 @@ extern "C" int v2w_avgpool4(const float* x, float* out, int B, int L, void* stre
     const int Lo = L / 2 + 1;
     int gx = (Lo + 255) / 256; if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(avgpool4_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, L, Lo);
+    return v2w_launch_status();
+}
+
+
+extern "C" int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, int inner, int s, int k, int pad, int ipitch, int opitch,
+                               void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || L <= 0 || inner <= 0 || s <= 0 || k <= 0 || pad < 0) return V2W_E_ARG;
+    if (L + 2 * pad < k) return V2W_E_SHAPE;
+    const int U = (L + 2 * pad - k) / s + 1;
+    if (ipitch <= 0) ipitch = L * inner;
+    if (opitch <= 0) opitch = U * inner;
+    if (ipitch < L * inner || opitch < U * inner) return V2W_E_ARG;
+    const size_t total = (size_t)k * C * opitch;
+    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(unfold_taps_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, L, inner, s, k, pad, U, ipitch, opitch);
     return v2w_launch_status();
 }
