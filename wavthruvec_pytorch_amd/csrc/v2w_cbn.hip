@@ -105,23 +105,27 @@ cond_linear_kernel(const v2w_cond_args a) {
     }
 }
 
-// ---- per-channel partial sums; grid (V2W_BN_SPLITS, C); each block covers a slice of L for every batch item
+// ---- per-channel partial sums; grid (V2W_BN_SPLITS, C); each block covers a slice of L for every batch item: its four waves
+// take batch items round-robin (a slice may be as short as 64 positions), 64 lanes along the slice
 __global__ void __launch_bounds__(256)
 bn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, int B, int C, int L, int slice) {
     __shared__ double red[16];
     const int sp = blockIdx.x, c = blockIdx.y;
     const int lo = sp * slice, hi = min(L, lo + slice);
-    float s1 = 0.f, s2 = 0.f;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double d1 = 0.0, d2 = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = wv; b < B; b += 4) {
         const float* row = x + ((size_t)b * C + c) * L;
-        for (int l = lo + threadIdx.x; l < hi; l += 256) {
-            const float v = row[l];
-            s1 += v;
-            s2 = fmaf(v, v, s2);
+        float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
+        int l = lo + lane;
+        for (; l + 64 < hi; l += 128) {            // two independent chains per lane
+            const float v = row[l], w = row[l + 64];
+            s1 += v; s2 = fmaf(v, v, s2);
+            u1 += w; u2 = fmaf(w, w, u2);
         }
-        // spill the fp32 running sums into fp64 once per batch item: bounds the fp32 chain length to slice/256
-        d1 += (double)s1; d2 += (double)s2; s1 = 0.f; s2 = 0.f;
+        if (l < hi) { const float v = row[l]; s1 += v; s2 = fmaf(v, v, s2); }
+        // spill the fp32 running sums into fp64 once per batch item: bounds the fp32 chain length to slice/128
+        d1 += (double)s1 + (double)u1; d2 += (double)s2 + (double)u2;
     }
     const double t1 = v2w_block_sum(d1, red);
     const double t2 = v2w_block_sum(d2, red);
