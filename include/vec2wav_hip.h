@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 15
+#define V2W_ABI_VERSION 16
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -347,6 +347,26 @@ int v2w_zero_tail(float* x, long long rows, int pitch, int valid, void* stream);
  * a short strided conv (DiscriminatorP: k = 5, stride 3) as one 1-tap conv over k*C channels with the reference's exact MAC count. */
 int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, int inner, int s, int k, int pad, int ipitch, int opitch, void* stream);
 int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
+
+/* ---- discriminator backward (train.py:188-215 differentiates through MPD / MSD in both optimisation steps).  Input gradients of
+ * the convs run through v2w_conv1d_fwd with v2w_wf_transpose_flip weights; weight gradients through v2w_wgrad_slice:
+ *   v2w_wgrad_slice: v2w_wgrad for a Conv1d whose taps sit at offsets (t - tap0)*dil (tap0 = -1: symmetric) on channel slices:
+ *                    x / dy point at the first channel of a c_in / c_out slice of tensors with x_ct / dy_ct channels per batch
+ *                    item (0: dense).  slab_ws as for v2w_wgrad.
+ *   v2w_disc_dz:     dz = (g + d) * lrelu'(f) over `rows` rows of `pitch` floats ([valid, pitch) = 0): f the ACTIVATED feature map,
+ *                    g the gradient that arrived on the returned map (dense rows x valid, or NULL), d the next conv's input
+ *                    gradient (pitched, or NULL); slope = 1: no activation (conv_post).
+ *   v2w_phase_merge: inverse of v2w_phase_split (gradient of the stacked phases back to (B, C, L, inner)).
+ *   v2w_fold1:       backward of v2w_unfold1: dxu (B, rows, ipitch) -> dx (B, T), the reflected tail folded back.
+ *   v2w_avgpool4_bwd: backward of v2w_avgpool4: dout (B, L/2 + 1) -> dx (B, L).
+ *   v2w_cout1_wgrad: weight gradient of a C_out = 1 conv: dwf [k][C] = sum_{b,l} x[b][c][l + (t - tap0)*dil] * dz[b][l]. */
+int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
+                    int k, int dil, int tap0, int x_ct, int dy_ct, void* stream);
+int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope, void* stream);
+int v2w_phase_merge(const float* dxs, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch, void* stream);
+int v2w_fold1(const float* dxu, float* dx, int B, int T, int H, int inner, int s, int k, int pad, int rows, int ipitch, void* stream);
+int v2w_avgpool4_bwd(const float* dout, float* dx, int B, int L, void* stream);
+int v2w_cout1_wgrad(const float* x, const float* dz, float* dwf, int B, int C, int L, int k, int dil, int tap0, void* stream);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,38 @@ def fmap_probe(t: torch.Tensor):
 
 
 def disc_golden_names():
-    return [n for n in all_golden_names() if n.startswith('disc_')]
+    return [n for n in all_golden_names() if n.startswith('disc_') and not n.endswith('_grad')]
+
+
+def disc_grad_golden_names():
+    return [n for n in all_golden_names() if n.startswith('disc_') and n.endswith('_grad')]
+
+
+def check_disc_grads(z, named_grads, grad_y_hat, rtol=2e-3, head=True):
+    """Parameter gradients (through their probes: fp64 sum, sum|.|, first 16 entries) and dL/dy_hat in full against a gradient
+    fixture.  Bar: rtol of the largest entry / of sum|.| of that gradient.  -> worst relative error."""
+    worst = 0.0
+    want = z['grad_y_hat']
+    err = float(np.abs(grad_y_hat.detach().cpu().numpy() - want).max()) / float(np.abs(want).max())
+    assert err <= rtol, ('grad_y_hat', err)
+    worst = max(worst, err)
+    seen = 0
+    for k, g in named_grads:
+        assert g is not None, k
+        g = g.detach().cpu().reshape(-1)
+        gabs = float(z['gabs_' + k])
+        n = g.numel()
+        scale = max(gabs / n, 1e-12)                 # mean |entry|
+        e1 = abs(g.double().sum().item() - float(z['gsum_' + k])) / max(gabs, 1e-12)
+        e2 = abs(g.double().abs().sum().item() - gabs) / max(gabs, 1e-12)
+        e3 = float(np.abs(g[:16].numpy() - z['ghead_' + k]).max()) / max(float(np.abs(z['ghead_' + k]).max()), scale)
+        # single entries: weight_v gradients are differences of nearly equal terms, and a sign() / leaky_relu' flip at a
+        # borderline element moves one entry by more than rounding: 5x the bar of the sums
+        assert max(e1, e2) <= rtol and (not head or e3 <= 5 * rtol), (k, e1, e2, e3)
+        worst = max(worst, e1, e2, e3)
+        seen += 1
+    assert seen == sum(1 for f in z.files if f.startswith('gsum_')), 'parameter list differs from the fixture'
+    return worst
 
 
 def disc_case_setup(meta, device='cpu'):

@@ -143,5 +143,5 @@ def test_discriminator_state_dict_surface():
     y = torch.zeros(1, 1, 1000)
     with torch.no_grad(), pytest.raises(RuntimeError):
         mpd(y, y)
-    with pytest.raises(NotImplementedError):       # autograd through the discriminators is not built
+    with pytest.raises(RuntimeError):              # under autograd too: CPU tensors are refused, nothing falls back to torch
         msd(y, y)

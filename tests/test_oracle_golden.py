@@ -140,3 +140,18 @@ def test_disc_oracle_matches_reference_goldens(name):
     for k in z.files:
         if k.startswith('buf_'):
             assert np.abs(sd[k[4:]].numpy() - z[k]).max() <= 1e-6, k
+
+
+@pytest.mark.parametrize('name', golden_util.disc_grad_golden_names())
+def test_disc_oracle_autograd_matches_reference_gradients(name):
+    """torch autograd through oracle/disc_oracle.py against the gradients captured from the reference modules' own backward
+    (feature + generator + discriminator losses; parameters incl. the spectral-normed weight_orig, and dL/dy_hat)."""
+    from oracle import disc_oracle as D
+    z, meta = golden_util.load_golden(name)
+    sd, y, y_hat = golden_util.disc_case_setup(meta)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith('weight_u') or (k.endswith('weight_v') and k.replace('weight_v', 'weight_orig') in sd))}
+    sdo = dict(sd); sdo.update(leaves)
+    y_hat = y_hat.clone().requires_grad_(True)
+    outs = D.mpd_forward(sdo, y, y_hat) if meta['kind'] == 'mpd' else D.msd_forward(sdo, y, y_hat, training=True)
+    D.mixed_loss(outs).backward()
+    golden_util.check_disc_grads(z, [(k, v.grad) for k, v in leaves.items()], y_hat.grad, rtol=1e-3)   # sign() of the L1 feature loss: a few entries flip

@@ -37,6 +37,9 @@ CASES = [
     dict(name='disc_msd_b2_t8192_train', kind='msd', B=2, T=8192, mode='train'),
     dict(name='disc_msd_b2_t8192_traineval', kind='msd', B=2, T=8192, mode='traineval'),   # one train forward, then eval
     dict(name='disc_msd_b1_t1000_train', kind='msd', B=1, T=1000, mode='train'),
+    # backward: d(feature + generator + discriminator losses) / d(parameters, y_hat) through the reference modules
+    dict(name='disc_mpd_b2_t4100_grad', kind='mpd', B=2, T=4100, mode='grad'),
+    dict(name='disc_msd_b2_t4100_grad', kind='msd', B=2, T=4100, mode='grad'),
 ]
 
 
@@ -57,6 +60,25 @@ def run_case(case):
         assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), (k, ref_sd[k].shape, sd[k].shape)
     m.load_state_dict(sd)
     y, y_hat = synthetic.make_audio_pair(case['B'], case['T'], seed=77)
+    if case['mode'] == 'grad':
+        from oracle.disc_oracle import mixed_loss
+        m.train()
+        y_hat.requires_grad_(True)
+        outs = m(y, y_hat)
+        mixed_loss(outs).backward()
+        out = dict(meta_case=np.array(repr(dict(case, weight_seed=3, audio_seed=77))))
+        out['grad_y_hat'] = y_hat.grad.numpy().copy()
+        for k, p in m.named_parameters():      # (spectral norm: parameters are bias and weight_orig)
+            g = p.grad.detach().reshape(-1)
+            out['gsum_' + k] = np.float64(g.double().sum().item())
+            out['gabs_' + k] = np.float64(g.double().abs().sum().item())
+            out['ghead_' + k] = g[:16].numpy().copy()
+        for d in range(len(outs[0])):
+            out[f'r{d}'] = outs[0][d].detach().numpy().copy()
+            out[f'g{d}'] = outs[1][d].detach().numpy().copy()
+        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **out)
+        print(case['name'], 'max|dL/dy_hat|', y_hat.grad.abs().max().item())
+        return
     with torch.no_grad():
         m.train()
         if case['mode'] == 'traineval':    # the stored u / v of a fresh state_dict are random: iterate once, then use them frozen

@@ -162,3 +162,159 @@ extern "C" int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, 
     hipLaunchKernelGGL(unfold_taps_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, L, inner, s, k, pad, U, ipitch, opitch);
     return v2w_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the discriminators (both training steps of train.py:188-215 differentiate through them).  The convolutions' input
+// gradients run on the forward conv kernel (transposed, tap-flipped weights), the weight gradients on v2w_wgrad_slice; below are
+// the memory-bound pieces between them.
+namespace {
+
+// dz = (g + d) * lrelu'(f): g = gradient that arrived on the returned feature map (dense (rows, valid) or NULL), d = input
+// gradient of the next conv (pitched, or NULL), f = the ACTIVATED map (sign(f) = sign of the pre-activation since slope > 0).
+// slope == 1: no activation (conv_post).  The pitch tail is written as 0: those columns are ordinary positions to the kernels.
+__global__ void __launch_bounds__(256)
+disc_dz_kernel(const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ d, float* __restrict__ dz,
+               long rows, int pitch, int valid, float slope) {
+    const long total = rows * pitch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / pitch;
+        const int t = (int)(idx - row * pitch);
+        float v = 0.f;
+        if (t < valid) {
+            v = (g ? g[row * valid + t] : 0.f) + (d ? d[idx] : 0.f);
+            if (slope != 1.f && !(f[idx] > 0.f)) v *= slope;
+        }
+        dz[idx] = v;
+    }
+}
+
+// inverse of phase_split_kernel: out[b][c][l][w] = dxs[b][((c/Cg)*s + r)*Cg + c%Cg][u][w], l = s*u + r < L
+__global__ void __launch_bounds__(256)
+phase_merge_kernel(const float* __restrict__ dxs, float* __restrict__ out, int C, int Cg, int L, int inner, int s, int ipitch, int opitch) {
+    const int b = blockIdx.y;
+    const size_t row = (size_t)L * inner;
+    const size_t total = (size_t)C * row;
+    const float* xb = dxs + (size_t)b * s * C * ipitch;
+    float* ob = out + (size_t)b * C * opitch;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx / row);
+        const int rem = (int)(idx - (size_t)c * row);
+        const int l = rem / inner, w = rem - l * inner;
+        const int u = l / s, r = l - u * s;
+        const int cs = ((c / Cg) * s + r) * Cg + c % Cg;
+        ob[(size_t)c * opitch + rem] = xb[(size_t)cs * ipitch + (size_t)u * inner + w];
+    }
+}
+
+// backward of unfold1_kernel: dx[b][i] = sum of dxu over every (row j, column) that read sample i, reflected tail included
+__global__ void __launch_bounds__(256)
+fold1_kernel(const float* __restrict__ dxu, float* __restrict__ dx, int T, int H, int inner, int s, int k, int pad, int rows, int U, int ipitch) {
+    const int b = blockIdx.y;
+    const float* xb = dxu + (size_t)b * rows * ipitch;
+    auto at = [&](int pos) {            // gradient that reached padded position pos = h*inner + w
+        const int h = pos / inner, w = pos - h * inner;
+        float v = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int n = h + pad - j;
+            if (n < 0 || n % s) continue;
+            const int u = n / s;
+            if (u < U) v += xb[(size_t)j * ipitch + (size_t)u * inner + w];
+        }
+        return v;
+    };
+    const int Tp = H * inner;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < T; i += gridDim.x * 256) {
+        float v = at(i);
+        const int m = 2 * (T - 1) - i;       // the right reflect pad reads sample i at position m
+        if (m >= T && m < Tp) v += at(m);
+        dx[(size_t)b * T + i] = v;
+    }
+}
+
+// backward of avgpool4_kernel: dx[i] = 0.25 * sum of dout[t] over 2t + j - 2 = i, j < 4
+__global__ void __launch_bounds__(256)
+avgpool4_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int L, int Lo) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = i + 2 - j;
+            if (n >= 0 && (n & 1) == 0 && (n >> 1) < Lo) acc += dout[(size_t)b * Lo + (n >> 1)];
+        }
+        dx[(size_t)b * L + i] = acc * 0.25f;
+    }
+}
+
+// weight gradient of a C_out = 1 conv (conv_post): dwf[t][ci] = sum_{b,l} x[b][ci][l + (t - tap0)*dil] * dz[b][l]; one block per ci
+__global__ void __launch_bounds__(256)
+cout1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dwf, int B, int C, int L, int k, int dil, int tap0) {
+    __shared__ double red[16];
+    const int ci = blockIdx.x;
+    for (int t = 0; t < k; ++t) {
+        const int off = (t - tap0) * dil;
+        double acc = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const float* xr = x + ((size_t)b * C + ci) * L;
+            const float* dr = dz + (size_t)b * L;
+            float a = 0.f;
+            for (int l = threadIdx.x; l < L; l += 256) {
+                const int li = l + off;
+                if (li >= 0 && li < L) a = fmaf(xr[li], dr[l], a);
+            }
+            acc += (double)a;
+        }
+        const double tot = v2w_block_sum(acc, red);
+        if (threadIdx.x == 0) dwf[(size_t)t * C + ci] = (float)tot;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope,
+                           void* stream) {
+    if (!f || !dz || rows <= 0 || pitch <= 0 || valid < 0 || valid > pitch || slope <= 0.f) return V2W_E_ARG;
+    const long total = rows * pitch;
+    int gx = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(disc_dz_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, f, g, d, dz, (long)rows, pitch, valid, slope);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_phase_merge(const float* dxs, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch,
+                               void* stream) {
+    if (!dxs || !out || B <= 0 || C <= 0 || Cg <= 0 || C % Cg || L <= 0 || inner <= 0 || s <= 0) return V2W_E_ARG;
+    const int U = (L + s - 1) / s;
+    if (ipitch <= 0) ipitch = U * inner;
+    if (opitch <= 0) opitch = L * inner;
+    if (ipitch < U * inner || opitch < L * inner) return V2W_E_ARG;
+    const size_t total = (size_t)C * L * inner;
+    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(phase_merge_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxs, out, C, Cg, L, inner, s, ipitch, opitch);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_fold1(const float* dxu, float* dx, int B, int T, int H, int inner, int s, int k, int pad, int rows, int ipitch,
+                         void* stream) {
+    if (!dxu || !dx || B <= 0 || T <= 1 || H <= 0 || inner <= 0 || s <= 0 || k <= 0 || pad < 0 || rows < k) return V2W_E_ARG;
+    if ((long long)H * inner < T || (long long)H * inner - T >= T || H + 2 * pad < k) return V2W_E_ARG;
+    const int U = (H + 2 * pad - k) / s + 1;
+    if (ipitch <= 0) ipitch = U * inner;
+    if (ipitch < U * inner) return V2W_E_ARG;
+    int gx = (T + 255) / 256; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(fold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxu, dx, T, H, inner, s, k, pad, rows, U, ipitch);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_avgpool4_bwd(const float* dout, float* dx, int B, int L, void* stream) {
+    if (!dout || !dx || B <= 0 || L <= 0) return V2W_E_ARG;
+    int gx = (L + 255) / 256; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(avgpool4_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dout, dx, L, L / 2 + 1);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_cout1_wgrad(const float* x, const float* dz, float* dwf, int B, int C, int L, int k, int dil, int tap0, void* stream) {
+    if (!x || !dz || !dwf || B <= 0 || C <= 0 || L <= 0 || k <= 0 || dil <= 0 || tap0 < 0 || tap0 >= k) return V2W_E_ARG;
+    hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dz, dwf, B, C, L, k, dil, tap0);
+    return v2w_launch_status();
+}

@@ -22,6 +22,7 @@ struct WgradArgs {
     const float* dy;                                       // (B, Cout, Ldy), Ldy = u * Lq
     float* slab;                                           // [S*WP][K][Cin][Cout]
     int B, Cin, Cout, Lq, K;
+    int CinT, CoutT;          // channels per batch item of the tensors x / dy live in (> Cin / Cout: one group of a grouped conv)
     int u, r;                 // dy position = u*q + r
     int ntap;                 // taps of this launch
     int tap[V2W_WG_TG];       // real tap index (slab row)
@@ -79,7 +80,7 @@ wgrad_kernel(const WgradArgs p) {
                 const int row = idx >> 5, col = (idx & 31) * 4;           // PT / 4 == 32 float4 per row
                 const int q = q0 + col;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q < Lq) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.Cout + co0 + row) * Ldy + q);
+                if (q < Lq) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + co0 + row) * Ldy + q);
                 float* d = DYs + row * p.ptw + col;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
@@ -88,7 +89,7 @@ wgrad_kernel(const WgradArgs p) {
             for (int idx = tid; idx < CI_T * xc4; idx += 256) {
                 const int row = idx / xc4, col = (idx - row * xc4) * 4;
                 const int q = qa + col;
-                const int ch = b * p.Cin + ci0 + row;
+                const int ch = b * p.CinT + ci0 + row;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q >= 0 && q < Lq) {
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.x + (size_t)ch * Lq + q);
@@ -103,12 +104,12 @@ wgrad_kernel(const WgradArgs p) {
             for (int idx = tid; idx < CO_T * PT; idx += 256) {
                 const int row = idx / PT, col = idx - row * PT;
                 const int q = q0 + col;
-                DYs[row * p.ptw + col] = q < Lq ? p.dy[((size_t)b * p.Cout + co0 + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
+                DYs[row * p.ptw + col] = q < Lq ? p.dy[((size_t)b * p.CoutT + co0 + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
             }
             for (int idx = tid; idx < CI_T * xcols; idx += 256) {
                 const int row = idx / xcols, col = idx - row * xcols;
                 const int q = q0 - p.hla + col;
-                const int ch = b * p.Cin + ci0 + row;
+                const int ch = b * p.CinT + ci0 + row;
                 float v = 0.f;
                 if (q >= 0 && q < Lq) {
                     const float av = p.x_a ? p.x_a[ch] : 1.f, sv = p.x_a ? p.x_s[ch] : 0.f;
@@ -202,10 +203,10 @@ wgrad_pipe_kernel(const WgradArgs p) {
             const int idx = tid + i * 256;
             const int row = idx / DYC4, pos = q0 * U + (idx - row * DYC4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < CO_T && pos < Ldy) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.Cout + co0 + row) * Ldy + pos);
+            if (row < CO_T && pos < Ldy) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + co0 + row) * Ldy + pos);
             dyv[i] = v;
         }
-        const int ch = b * p.Cin + ci0 + xrow;
+        const int ch = b * p.CinT + ci0 + xrow;
         const float* xsrc = p.x + (size_t)ch * Lq + (q0 - p.hla);
         if (p.x_a) { xa = p.x_a[ch]; xs = p.x_s[ch]; }
 #pragma unroll
@@ -369,8 +370,25 @@ extern "C" int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq) {
 }
 
 // dwf [k][C_in][C_out] = weight gradient; u = 1 / pad ignored for Conv1d (dil used), stride u and pad = (k-u)/2 for ConvTranspose1d.
+static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
+                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, void* stream);
+
 extern "C" int v2w_wgrad(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
                          int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, void* stream) {
+    return wgrad_impl(x, x_a, x_s, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, u, slope, -1, 0, 0, stream);
+}
+
+// Conv1d weight gradient with the taps at offsets (t - tap0) * dil (tap0 = -1: symmetric (k-1)/2) on channel slices: x / dy point at
+// the first channel of a c_in / c_out slice of tensors with x_ct / dy_ct channels per batch item (0: dense) - one group of a
+// grouped conv, or the asymmetric tap sets of the discriminators' phase-stacked strided convs.
+extern "C" int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
+                               int k, int dil, int tap0, int x_ct, int dy_ct, void* stream) {
+    if (tap0 < -1 || tap0 >= k || x_ct < 0 || dy_ct < 0 || (x_ct > 0 && x_ct < c_in) || (dy_ct > 0 && dy_ct < c_out)) return V2W_E_ARG;
+    return wgrad_impl(x, nullptr, nullptr, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, 1, 1.f, tap0, x_ct, dy_ct, stream);
+}
+
+static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
+                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, void* stream) {
     if (!x || !dy || !dwf || !slab_ws || B <= 0 || c_in <= 0 || c_out <= 0 || Lq <= 0 || k <= 0 || dil <= 0 || u <= 0) return V2W_E_ARG;
     if ((x_a == nullptr) != (x_s == nullptr)) return V2W_E_ARG;
     const int nslab = v2w_wgrad_slabs(B, c_in, c_out, Lq);
@@ -379,6 +397,7 @@ extern "C" int v2w_wgrad(const float* x, const float* x_a, const float* x_s, con
     WgradArgs p{};
     p.x = x; p.x_a = x_a; p.x_s = x_s; p.dy = dy; p.slab = slab_ws;
     p.B = B; p.Cin = c_in; p.Cout = c_out; p.Lq = Lq; p.K = k; p.u = u; p.slope = slope;
+    p.CinT = x_ct > 0 ? x_ct : c_in; p.CoutT = dy_ct > 0 ? dy_ct : c_out;
     p.wco = (c_out % (2 * mf) == 0) ? 2 : 1;
     p.wci = (c_in % (2 * mf) == 0 && p.wco * 2 <= 4) ? 2 : 1;
     p.wp = 4 / (p.wco * p.wci);
@@ -413,7 +432,7 @@ extern "C" int v2w_wgrad(const float* x, const float* x_a, const float* x_s, con
     int taps[64], offs[64], phs[64], n = 0;
     for (int t = 0; t < k && n < 64; ++t, ++n) {
         taps[n] = t;
-        if (u == 1) { phs[n] = 0; offs[n] = (t - (k - 1) / 2) * dil; }
+        if (u == 1) { phs[n] = 0; offs[n] = (t - (tap0 >= 0 ? tap0 : (k - 1) / 2)) * dil; }
         else {
             const int r = ((t - pad) % u + u) % u;
             const int t0 = (r + pad) % u, c = (r + pad) / u, m = (t - t0) / u;

@@ -1,13 +1,14 @@
-"""MPD / MSD discriminator FORWARDS on the MI355X.
+"""MPD / MSD discriminators on the MI355X, forward and backward.
 
 Mirror of /root/reference/vec2wav/models.py:158-275 - `DiscriminatorP`, `MultiPeriodDiscriminator(hp)`, `DiscriminatorS`,
 `MultiScaleDiscriminator()`, the same `forward(y, y_hat) -> (y_d_rs, y_d_gs, fmap_rs, fmap_gs)`, identical `state_dict` keys and
 shapes (weight_norm: bias / weight_g / weight_v with Conv2d (k, 1) shapes for the period discriminators; legacy spectral_norm on
 the first scale discriminator: bias / weight_orig / weight_u / weight_v) - so `do_%08d` checkpoints load.
 
-Forward only: the backward (both training steps of train.py:188-215 differentiate through them) is not built; calling with
-autograd enabled on anything that requires grad raises.  No PyTorch/CPU fallback: the convolutions run on the f32 MFMA tile
-kernel through the C ABI as stride-1 problems (csrc/v2w_disc.hip explains the mapping):
+Differentiable: each discriminator call is one `autograd.Function` (`_DiscFn`) whose backward runs on the same C ABI (input
+gradients on the forward conv kernel with transposed tap-flipped weights, weight gradients on `v2w_wgrad_slice`, weight-norm
+backward on `v2w_wn_bwd`), so both optimisation steps of train.py:188-215 work.  No PyTorch/CPU fallback: the convolutions run on
+the f32 MFMA tile kernel through the C ABI as stride-1 problems (csrc/v2w_disc.hip explains the mapping):
   stride-s layers  -> `v2w_phase_split` + a conv over the s stacked phases (ceil(k/s)-ish taps),
   (k, 1) Conv2d    -> Conv1d with dilation = period on the flattened (H * period) axis, feature maps kept as (B, C, H, period),
   grouped Conv1d   -> one problem per group on channel slices (`in_ct` / `out_ct`), four groups per launch,
@@ -56,6 +57,8 @@ class _DiscConv(nn.Module):
             self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(c_out, *([1] * (len(wshape) - 1))).clone())
             self.weight_v = nn.Parameter(w)
         self._cache = None
+        self._last_sn = None
+        self._jmap = None
         # optional form of the short strided ungrouped convs (DiscriminatorP k = 5, stride 3): taps unfolded into channels of a
         # 1-tap conv (exact MAC count, no halo).  Measured equal to the phase-stacked default (40.6 vs 40.4 ms per MPD forward):
         # one tap per staged chunk makes the kernel staging-bound, which cancels the 6/5 tap-slot saving.
@@ -77,6 +80,7 @@ class _DiscConv(nn.Module):
             self.weight_v.copy_(F.normalize(torch.mv(wm.t(), self.weight_u), dim=0, eps=1e-12))
             self.weight_u.copy_(F.normalize(torch.mv(wm, self.weight_v), dim=0, eps=1e-12))
         sigma = torch.dot(self.weight_u, torch.mv(wm, self.weight_v))
+        self._last_sn = (sigma, self.weight_u.clone(), self.weight_v.clone())
         return hipops.fold_conv_weight((w / sigma).reshape(co, cig, k), None)
 
     def kernel_weights(self):
@@ -105,16 +109,41 @@ class _DiscConv(nn.Module):
             j = torch.where((j >= 0) & (j < k), j, torch.full_like(j, k))
             wpad = torch.cat([wf, torch.zeros((1, cig, self.c_out), device=dev)], 0)
             w5 = wpad[j.reshape(-1)].reshape(kp, s * cig, G, cog)          # rows (r, c), columns (g, o)
+            self._jmap = j.reshape(-1)
             groups = [w5[:, :, g, :].contiguous() for g in range(G)]
         packable = groups[0].shape[1] % 16 == 0 and (groups[0].shape[2] % 32 == 0 or groups[0].shape[2] == 16)
         rec = dict(wf=groups, wp=[hipops.pack_mfma(w) for w in groups] if packable else [None] * len(groups), kp=kp, Q=Q)
         self._cache = (key, rec)
         return rec
 
+    def param_grads(self, db, dws, sn):
+        """Gradients of this layer's parameters (parameters() order) from the bias gradient and the per-group weight gradients
+        of the stacked stride-1 form, dws[g] [k'][s * C_in/G][C_out/G] (the inverse of `kernel_weights`' re-indexing)."""
+        k, s, G = self.k, self.stride, self.groups
+        co, cig = self.c_out, self.c_in // G
+        dev = db.device
+        if self.c_in == 1:
+            dwf = dws[0][0, :k, :].reshape(k, 1, co)
+        elif self.unfolded:
+            dwf = dws[0].reshape(k, cig, co)
+        else:
+            kp = dws[0].shape[0]
+            d5 = torch.stack(dws, 2).reshape(kp * s, cig, co)            # rows (q, r), then c; columns (g, o)
+            dwf = torch.zeros((k + 1, cig, co), device=dev).index_add_(0, self._jmap, d5)[:k]
+        dwf = dwf.contiguous()
+        if not self.spectral:
+            v, g = self.weight_v.detach(), self.weight_g.detach()
+            dv, dg = hipops.wn_backward(dwf, v.reshape(co, cig, k), g.reshape(co, 1, 1), False)
+            return [db, dg.reshape(g.shape), dv.reshape(v.shape)]
+        # W = weight_orig / sigma, sigma = u^T W v with u, v constants (the power iteration runs under no_grad)
+        sigma, u, vv = sn
+        w = self.weight_orig.detach()
+        dW = dwf.permute(2, 1, 0).reshape(w.shape)
+        dot = (dW * w).sum() / (sigma * sigma)
+        return [db, dW / sigma - dot * torch.outer(u, vv).reshape(w.shape)]
 
-def _check_no_grad(mod, *xs):
-    if torch.is_grad_enabled() and (any(x.requires_grad for x in xs) or any(p.requires_grad for p in mod.parameters())):
-        raise NotImplementedError('the discriminator backward is not built on the HIP path: call the forward under torch.no_grad()')
+
+def _check_cuda(*xs):
     for x in xs:
         if not x.is_cuda:
             raise RuntimeError('the discriminators run on the MI355X HIP path only (no CPU fallback)')
@@ -125,16 +154,16 @@ def _pitch(n):
     return (n + 3) // 4 * 4
 
 
-def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
-    """x (B, C_in, pitch(L_in * inner)) activated feature-map buffer (valid part [:L_in * inner]) ->
-    (out buffer (B, C_out, pitch(U * inner)), U), U = L_out of the strided conv.  The convs run at L = pitch: the tail columns
-    are ordinary positions to the kernel, hold zeros on the input side (phase_split / unfold fill them; `v2w_zero_tail` before a
-    stride-1 layer reads a conv output directly) and are never part of the returned views."""
-    B = x.shape[0]
+def _stream(x):
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def _stacked_input(layer: _DiscConv, x, L_in, inner):
+    """The stride-1 form's input of a layer: x (B, C_in, pitch) activated feature-map buffer (valid [:L_in * inner]) ->
+    (xs (B, C_in', P), U): phases stacked (stride > 1), taps unfolded (optional) or x itself with its tail zeroed (stride 1)."""
+    B, pin = x.shape[0], x.shape[2]
     s, G = layer.stride, layer.groups
-    rec = layer.kernel_weights()
-    lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
-    pin = x.shape[2]
+    lib, st = _hip.load(), _stream(x)
     if s > 1 and layer.unfolded:
         U = (L_in + 2 * layer.padding - layer.k) // s + 1
         P = _pitch(U * inner)
@@ -148,10 +177,20 @@ def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
         _hip.check(lib.v2w_phase_split(x.data_ptr(), xs.data_ptr(), B, layer.c_in, layer.c_in // G, L_in, inner, s, pin, P, st),
                    'v2w_phase_split')
     else:
-        U, xs, P = L_in, x, pin
+        U, xs = L_in, x
         _hip.check(lib.v2w_zero_tail(x.data_ptr(), B * layer.c_in, pin, L_in * inner, st), 'v2w_zero_tail')
-    out = torch.empty((B, layer.c_out, P), device=x.device)
-    cig, cog = s * layer.c_in // G, layer.c_out // G
+    return xs, U
+
+
+def _conv_layer(layer: _DiscConv, rec, x, L_in, inner, out_slope):
+    """x (B, C_in, pitch(L_in * inner)) -> (out buffer (B, C_out, pitch(U * inner)), U), U = L_out of the strided conv.  The convs
+    run at L = pitch: the tail columns are ordinary positions to the kernel, hold zeros on the input side (phase_split / unfold
+    fill them; `v2w_zero_tail` before a stride-1 layer reads a conv output directly) and are never part of the returned views."""
+    B = x.shape[0]
+    G = layer.groups
+    xs, U = _stacked_input(layer, x, L_in, inner)
+    out = torch.empty((B, layer.c_out, xs.shape[2]), device=x.device)
+    cig, cog = xs.shape[1] // G, layer.c_out // G
     kw = dict(k=rec['kp'], dil=1 if rec['kp'] == 1 else inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
     if G == 1:
         hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
@@ -163,24 +202,159 @@ def _conv_layer(layer: _DiscConv, x, L_in, inner, out_slope):
     return out, U
 
 
-def _first_layer(layer: _DiscConv, x, T, H, inner):
-    """C_in = 1: x (B, 1, T) -> activated buffer (B, C_out, pitch(U * inner)) through the unfolded 1-tap form."""
+def _unfold_first(layer: _DiscConv, x, T, H, inner):
     B = x.shape[0]
-    lib, st = _hip.load(), torch.cuda.current_stream(x.device).cuda_stream
     U = (H + 2 * layer.padding - layer.k) // layer.stride + 1
     if U < 1:
         raise RuntimeError('discriminator input is shorter than the first kernel')
     P = _pitch(U * inner)
     xu = torch.empty((B, _UNFOLD_ROWS, P), device=x.device)
-    _hip.check(lib.v2w_unfold1(x.data_ptr(), xu.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding, _UNFOLD_ROWS, P, st),
-               'v2w_unfold1')
-    rec = layer.kernel_weights()
-    out = torch.empty((B, layer.c_out, P), device=x.device)
+    _hip.check(_hip.load().v2w_unfold1(x.data_ptr(), xu.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding, _UNFOLD_ROWS,
+                                       P, _stream(x)), 'v2w_unfold1')
+    return xu, U
+
+
+def _first_layer(layer: _DiscConv, rec, x, T, H, inner):
+    """C_in = 1: x (B, 1, T) -> activated buffer (B, C_out, pitch(U * inner)) through the unfolded 1-tap form."""
+    xu, U = _unfold_first(layer, x, T, H, inner)
+    out = torch.empty((x.shape[0], layer.c_out, xu.shape[2]), device=x.device)
     hipops.conv1d(xu, rec['wf'][0], layer.bias.detach(), out, k=1, dil=1, slope=1.0, wp=rec['wp'][0], out_slope=LRELU_SLOPE)
     return out, U
 
 
-class DiscriminatorP(nn.Module):
+class _DiscBase(nn.Module):
+    """Shared driver of DiscriminatorP / DiscriminatorS: `inner` columns per row (the period, or 1)."""
+
+    def _layers(self):
+        return list(self.convs) + [self.conv_post]
+
+    def _geometry(self, t):
+        raise NotImplementedError
+
+    def _run(self, x):
+        """x (B, 1, T) -> state for the views / the backward: per layer (buffer (B, C, pitch), rows U) + the weights used."""
+        b, c, t = x.shape
+        inner, H = self._geometry(t)
+        layers = self._layers()
+        recs = [l.kernel_weights() for l in layers]             # (spectral norm: the power iteration of this call happens here)
+        sn = [l._last_sn for l in layers]
+        bufs = []
+        f, U = _first_layer(layers[0], recs[0], x, t, H, inner)
+        bufs.append((f, U))
+        for i in range(1, len(layers)):
+            f, U = _conv_layer(layers[i], recs[i], f, U, inner, LRELU_SLOPE if i + 1 < len(layers) else 0.0)
+            bufs.append((f, U))
+        return dict(bufs=bufs, recs=recs, sn=sn, inner=inner, H=H, T=t)
+
+    def _views(self, st, b):
+        inner = st['inner']
+        if inner == 1:
+            return [f[:, :, :U] for f, U in st['bufs']]
+        return [f[:, :, :U * inner].view(b, f.shape[1], U, inner) for f, U in st['bufs']]      # strided when U * inner % 4 != 0
+
+    def forward(self, x):
+        _check_cuda(x)
+        params = [p for l in self._layers() for p in l.parameters()]
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            fmap = list(_DiscFn.apply(self, x, *params))
+        else:
+            with torch.no_grad():
+                x = x.detach().contiguous().float()
+                fmap = self._views(self._run(x), x.shape[0])
+        return torch.flatten(fmap[-1], 1, -1), fmap
+
+
+class _DiscFn(torch.autograd.Function):
+    """One discriminator call under autograd: forward = `_DiscBase._run`, backward below (the D step and the G step of
+    train.py:188-215 both differentiate through it).  Inputs: x and every parameter in `_layers()` order."""
+
+    @staticmethod
+    def forward(ctx, disc, x, *params):
+        xd = x.detach().contiguous().float()
+        st = disc._run(xd)
+        ctx.disc, ctx.st, ctx.x = disc, st, xd
+        ctx.need_dx = x.requires_grad
+        return tuple(disc._views(st, xd.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        disc, st, x = ctx.disc, ctx.st, ctx.x
+        lib, stream = _hip.load(), _stream(x)
+        layers = disc._layers()
+        inner, H, T = st['inner'], st['H'], st['T']
+        B, dev = x.shape[0], x.device
+        n = len(layers)
+        grads = [None] * n           # per layer: tuple of parameter gradients in parameters() order
+        dnext, dx = None, None       # gradient wrt the activated map of layer l arriving from layer l + 1 (pitched)
+        for l in reversed(range(n)):
+            layer, rec = layers[l], st['recs'][l]
+            f, U = st['bufs'][l]
+            P, valid, C = f.shape[2], st['bufs'][l][1] * inner, layer.c_out
+            g = gouts[l]
+            if g is None and dnext is None:
+                continue                                     # nothing flows through this layer (nor, so far, below it)
+            if g is not None:
+                g = g.contiguous().float()
+            dz = torch.empty((B, C, P), device=dev)
+            _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), B * C, P, valid,
+                                       LRELU_SLOPE if l + 1 < n else 1.0, stream), 'v2w_disc_dz')
+            db = hipops.channel_sum(dz)
+            # the layer's stride-1 input, rebuilt from the saved map below it (not kept: a memory-bound pass)
+            if l == 0:
+                xs, _ = _unfold_first(layer, x, T, H, inner)
+            else:
+                xs, _ = _stacked_input(layer, st['bufs'][l - 1][0], st['bufs'][l - 1][1], inner)
+            G = layer.groups
+            cigp, cog = xs.shape[1] // G, C // G
+            kp, Q = rec['kp'], rec['Q']
+            dil = 1 if kp == 1 else inner
+            # ---- weight gradient in the stacked form, then back to the reference's (C_out, C_in / groups, k)
+            if C == 1:
+                dwp = torch.empty((kp, xs.shape[1], 1), device=dev)
+                _hip.check(lib.v2w_cout1_wgrad(xs.data_ptr(), dz.data_ptr(), dwp.data_ptr(), B, xs.shape[1], P, kp, dil, Q, stream),
+                           'v2w_cout1_wgrad')
+                dws = [dwp]
+            else:
+                ns = lib.v2w_wgrad_slabs(B, cigp, cog, P)
+                if ns == 0:
+                    raise _hip.HipLibraryError(f'v2w_wgrad_slice: no configuration for C_in={cigp}, C_out={cog}')
+                slab = torch.empty((ns * kp * cigp * cog,), device=dev)
+                dws = []
+                for gi in range(G):
+                    dw = torch.empty((kp, cigp, cog), device=dev)
+                    _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4, dw.data_ptr(),
+                                                   slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C, stream), 'v2w_wgrad_slice')
+                    dws.append(dw)
+            grads[l] = layer.param_grads(db, dws, st['sn'][l])
+            # ---- input gradient: the forward conv kernel with the transposed, tap-flipped weights
+            if l > 0 or ctx.need_dx:
+                dxs = torch.empty((B, xs.shape[1], P), device=dev)
+                for gi in range(G):
+                    wT = hipops.transpose_flip(rec['wf'][gi])                  # [kp][cog][cigp]
+                    packable = cog % 16 == 0 and (cigp % 32 == 0 or cigp == 16)
+                    hipops.conv1d(dz, wT, None, dxs, k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil,
+                                  wp=hipops.pack_mfma(wT) if packable else None, group=(gi, cog, cigp) if G > 1 else None)
+                if l == 0:
+                    dx = torch.empty((B, 1, T), device=dev)
+                    _hip.check(lib.v2w_fold1(dxs.data_ptr(), dx.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding,
+                                             _UNFOLD_ROWS, P, stream), 'v2w_fold1')
+                elif layer.stride > 1 and not layer.unfolded:
+                    fp, Lp = st['bufs'][l - 1]
+                    dnext = torch.empty_like(fp)
+                    _hip.check(lib.v2w_phase_merge(dxs.data_ptr(), dnext.data_ptr(), B, layer.c_in, layer.c_in // G, Lp, inner,
+                                                   layer.stride, P, fp.shape[2], stream), 'v2w_phase_merge')
+                elif layer.stride > 1:
+                    raise NotImplementedError('backward of the unfolded-tap form (V2W_DISC_UNFOLD=1) is not built')
+                else:
+                    dnext = dxs
+        flat = []
+        for l in range(n):
+            npar = len(list(layers[l].parameters()))
+            flat.extend(grads[l] if grads[l] is not None else [None] * npar)
+        return (None, dx if ctx.need_dx else None, *flat)
+
+
+class DiscriminatorP(_DiscBase):
     """models.py:158-193."""
 
     def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
@@ -192,24 +366,12 @@ class DiscriminatorP(nn.Module):
         ci, co, k, s, p = DISC_P_POST
         self.conv_post = _DiscConv(ci, co, k, s, 1, p, use_spectral_norm, True)
 
-    def forward(self, x):
-        _check_no_grad(self, x)
-        with torch.no_grad():
-            x = x.detach().contiguous().float()
-            b, c, t = x.shape
-            p = self.period
-            H = -(-t // p)                                   # reflect pad to a multiple of the period happens inside unfold1
-            if H * p - t >= t:
-                raise RuntimeError('reflect padding needs an input longer than the pad')
-            fmap = []
-            f, Hc = _first_layer(self.convs[0], x, t, H, p)
-            fmap.append(f[:, :, :Hc * p].view(b, -1, Hc, p))      # (views of pitched buffers: strided when Hc * p % 4 != 0)
-            for layer in list(self.convs)[1:]:
-                f, Hc = _conv_layer(layer, f, Hc, p, LRELU_SLOPE)
-                fmap.append(f[:, :, :Hc * p].view(b, -1, Hc, p))
-            f, Hc = _conv_layer(self.conv_post, f, Hc, p, 0.0)
-            fmap.append(f[:, :, :Hc * p].view(b, 1, Hc, p))
-            return torch.flatten(fmap[-1], 1, -1), fmap
+    def _geometry(self, t):
+        p = self.period
+        H = -(-t // p)                   # the reflect pad to a multiple of the period (models.py:176-181) happens inside unfold1
+        if H * p - t >= t:
+            raise RuntimeError('reflect padding needs an input longer than the pad')
+        return p, H
 
 
 class MultiPeriodDiscriminator(nn.Module):
@@ -229,7 +391,7 @@ class MultiPeriodDiscriminator(nn.Module):
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
 
-class DiscriminatorS(nn.Module):
+class DiscriminatorS(_DiscBase):
     """models.py:219-243."""
 
     def __init__(self, use_spectral_norm=False):
@@ -238,32 +400,39 @@ class DiscriminatorS(nn.Module):
         ci, co, k, s, g, p = DISC_S_POST
         self.conv_post = _DiscConv(ci, co, k, s, g, p, use_spectral_norm, False)
 
-    def forward(self, x):
-        _check_no_grad(self, x)
-        with torch.no_grad():
-            x = x.detach().contiguous().float()
-            b, c, t = x.shape
-            fmap = []
-            f, L = _first_layer(self.convs[0], x, t, t, 1)
-            fmap.append(f[:, :, :L])
-            for layer in list(self.convs)[1:]:
-                f, L = _conv_layer(layer, f, L, 1, LRELU_SLOPE)
-                fmap.append(f[:, :, :L])
-            f, L = _conv_layer(self.conv_post, f, L, 1, 0.0)
-            fmap.append(f[:, :, :L])
-            return torch.flatten(fmap[-1], 1, -1), fmap
+    def _geometry(self, t):
+        return 1, t
+
+
+def _avg_pool_fwd(x):
+    B, C, L = x.shape
+    out = torch.empty((B, C, L // 2 + 1), device=x.device)
+    _hip.check(_hip.load().v2w_avgpool4(x.data_ptr(), out.data_ptr(), B * C, L, _stream(x)), 'v2w_avgpool4')
+    return out
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return _avg_pool_fwd(x.detach().contiguous().float())
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, L = ctx.shape
+        g = g.contiguous().float()
+        dx = torch.empty((B, C, L), device=g.device)
+        _hip.check(_hip.load().v2w_avgpool4_bwd(g.data_ptr(), dx.data_ptr(), B * C, L, _stream(g)), 'v2w_avgpool4_bwd')
+        return dx
 
 
 def avg_pool(x):
-    """AvgPool1d(4, 2, padding=2) of models.py:255-258 on (B, 1, L)."""
-    if not x.is_cuda:
-        raise RuntimeError('the discriminators run on the MI355X HIP path only (no CPU fallback)')
-    x = x.detach().contiguous().float()
-    B, C, L = x.shape
-    out = torch.empty((B, C, L // 2 + 1), device=x.device)
-    _hip.check(_hip.load().v2w_avgpool4(x.data_ptr(), out.data_ptr(), B * C, L, torch.cuda.current_stream(x.device).cuda_stream),
-               'v2w_avgpool4')
-    return out
+    """AvgPool1d(4, 2, padding=2) of models.py:255-258 on (B, 1, L); differentiable."""
+    _check_cuda(x)
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _AvgPoolFn.apply(x)
+    with torch.no_grad():
+        return _avg_pool_fwd(x.detach().contiguous().float())
 
 
 class _MeanPool(nn.Module):
