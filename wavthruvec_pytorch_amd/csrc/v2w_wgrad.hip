@@ -298,6 +298,8 @@ static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t s
 template <int MF, int WCO, int WCI>
 static bool launch_pipe_nt(const WgradArgs& p, int tiles, size_t lds, hipStream_t st) {
     switch (p.ntap) {
+        case 1: return launch_pipe<MF, WCO, WCI, 1, 1>(p, tiles, lds, st);     // 1, 2: the discriminators' unfolded / phase-stacked layers
+        case 2: return launch_pipe<MF, WCO, WCI, 2, 1>(p, tiles, lds, st);
         case 3: return launch_pipe<MF, WCO, WCI, 3, 1>(p, tiles, lds, st);
         case 4: return launch_pipe<MF, WCO, WCI, 4, 1>(p, tiles, lds, st);
         case 5: return launch_pipe<MF, WCO, WCI, 5, 1>(p, tiles, lds, st);
@@ -353,20 +355,35 @@ wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dwf, siz
 
 }  // namespace
 
-// Number of partial slabs ([k][C_in][C_out] floats each) v2w_wgrad needs for this problem; 0 = shape not supported.
-extern "C" int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq) {
+// Wave arrangement of a workgroup's 4 waves over (C_out, C_in, positions) and the number of partial slabs.  Conv1d (u = 1):
+// 2 x 2 x 1 when both channel counts allow two MFMA row blocks, else 1 x 1 x 4 - the shapes the pipelined kernel is instantiated
+// for (a mixed 2 x 1 would take the scalar kernel).  Transposed convs keep the arrangement their instantiations were tuned with.
+static int v2w_wgrad_plan(int B, int c_in, int c_out, int Lq, int u, int* mf_o, int* wco_o, int* wci_o) {
     const int mf = (c_out % 32 == 0 && c_in % 32 == 0) ? 32 : ((c_out % 16 == 0 && c_in % 16 == 0) ? 16 : 0);
     if (!mf) return 0;
     int wco = 1, wci = 1;
-    if (c_out % (2 * mf) == 0) wco = 2;
-    if (c_in % (2 * mf) == 0 && wco * 2 <= 4) wci = 2;
+    if (u == 1) {
+        if (c_out % (2 * mf) == 0 && c_in % (2 * mf) == 0) wco = wci = 2;
+    } else {
+        if (c_out % (2 * mf) == 0) wco = 2;
+        if (c_in % (2 * mf) == 0 && wco * 2 <= 4) wci = 2;
+    }
     const int wp = 4 / (wco * wci);
     const int tiles = (c_out / (wco * mf)) * (c_in / (wci * mf));
     const int items = B * ((Lq + 127) / 128);
     int S = (2 * 256 + tiles - 1) / tiles;       // ~2 workgroups per CU in flight
     if (S > items) S = items;
     if (S < 1) S = 1;
+    if (mf_o) { *mf_o = mf; *wco_o = wco; *wci_o = wci; }
     return S * wp;
+}
+
+// Number of partial slabs ([k][C_in][C_out] floats each) v2w_wgrad / v2w_wgrad_slice need for this problem (an upper bound over the
+// conv and transposed-conv arrangements); 0 = shape not supported.
+extern "C" int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq) {
+    const int a = v2w_wgrad_plan(B, c_in, c_out, Lq, 1, nullptr, nullptr, nullptr);
+    const int b = v2w_wgrad_plan(B, c_in, c_out, Lq, 2, nullptr, nullptr, nullptr);
+    return a > b ? a : b;
 }
 
 // dwf [k][C_in][C_out] = weight gradient; u = 1 / pad ignored for Conv1d (dil used), stride u and pad = (k-u)/2 for ConvTranspose1d.
@@ -391,15 +408,14 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
                       int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, void* stream) {
     if (!x || !dy || !dwf || !slab_ws || B <= 0 || c_in <= 0 || c_out <= 0 || Lq <= 0 || k <= 0 || dil <= 0 || u <= 0) return V2W_E_ARG;
     if ((x_a == nullptr) != (x_s == nullptr)) return V2W_E_ARG;
-    const int nslab = v2w_wgrad_slabs(B, c_in, c_out, Lq);
+    int mf = 0, wco = 1, wci = 1;
+    const int nslab = v2w_wgrad_plan(B, c_in, c_out, Lq, u, &mf, &wco, &wci);
     if (!nslab) return V2W_E_SHAPE;
-    const int mf = (c_out % 32 == 0 && c_in % 32 == 0) ? 32 : 16;
     WgradArgs p{};
     p.x = x; p.x_a = x_a; p.x_s = x_s; p.dy = dy; p.slab = slab_ws;
     p.B = B; p.Cin = c_in; p.Cout = c_out; p.Lq = Lq; p.K = k; p.u = u; p.slope = slope;
     p.CinT = x_ct > 0 ? x_ct : c_in; p.CoutT = dy_ct > 0 ? dy_ct : c_out;
-    p.wco = (c_out % (2 * mf) == 0) ? 2 : 1;
-    p.wci = (c_in % (2 * mf) == 0 && p.wco * 2 <= 4) ? 2 : 1;
+    p.wco = wco; p.wci = wci;
     p.wp = 4 / (p.wco * p.wci);
     p.S = nslab / p.wp;
     const int tiles = (c_out / (p.wco * mf)) * (c_in / (p.wci * mf));
