@@ -15,6 +15,7 @@
 namespace {
 
 #define V2W_WG_TG 7   // taps accumulated per launch (TG * 16 accumulator registers)
+#define V2W_WG_XC4_WIDE 56
 #define V2W_WG_XC4 40 // float4 columns of the widest signal tile the pipelined kernel stages (128 + 2*16 positions)
 
 struct WgradArgs {
@@ -156,7 +157,8 @@ static constexpr int v2w_wg_xc4(int u) { return u == 1 ? V2W_WG_XC4 : (v2w_wg_pt
 // compile-time wave arrangement, tap count and stride; float4 global loads for item i+1 are issued BEFORE the MFMA loop of
 // item i and parked in registers (the HBM/L2 latency hides under ~NT*PTQ/KSTEP MFMAs per wave); LDS is written with the
 // activation applied.  For U > 1 the dy tile holds all U phases (contiguous, coalesced) and every tap reads its own phase.
-template <int MF, int WCO, int WCI, int NT, int U>
+// WIDE: the signal tile may span V2W_WG_XC4_WIDE float4 columns (DiscriminatorP's dilation = period conv: 5 taps at +-2*19).
+template <int MF, int WCO, int WCI, int NT, int U, bool WIDE = false>
 __global__ void __launch_bounds__(256, (NT > 6 && Frag<MF>::NREG * WCO * WCI == 64) ? 1 : 2)
 wgrad_pipe_kernel(const WgradArgs p) {
     typedef Frag<MF> F;
@@ -165,7 +167,7 @@ wgrad_pipe_kernel(const WgradArgs p) {
     constexpr int CO_T = WCO * MF, CI_T = WCI * MF, SUB = PTQ / WP;
     constexpr int DYC4 = PTQ * U / 4;                               // float4 columns of the dy tile
     constexpr int NDY = (CO_T * DYC4 + 255) / 256;                  // float4 dy loads per thread and item
-    constexpr int NXM = (CI_T * v2w_wg_xc4(U) + 255) / 256;         // upper bound of float4 signal loads per thread (= ceil(XC4 / TPR))
+    constexpr int NXM = (CI_T * (WIDE ? V2W_WG_XC4_WIDE : v2w_wg_xc4(U)) + 255) / 256;         // upper bound of float4 signal loads per thread (= ceil(XC4 / TPR))
     static_assert(SUB % KSTEP == 0 && (PTQ * U) % 4 == 0, "tile shape");
     extern __shared__ float smem[];
     float* const DYs = smem;
@@ -285,10 +287,10 @@ wgrad_pipe_kernel(const WgradArgs p) {
         }
 }
 
-template <int MF, int WCO, int WCI, int NT, int U>
+template <int MF, int WCO, int WCI, int NT, int U, bool WIDE = false>
 static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t st) {
     if (!tiles) return true;                                       // dry run: "is this shape instantiated?"
-    auto kern = wgrad_pipe_kernel<MF, WCO, WCI, NT, U>;
+    auto kern = wgrad_pipe_kernel<MF, WCO, WCI, NT, U, WIDE>;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(tiles, p.S), dim3(256), lds, st, p);
@@ -312,8 +314,10 @@ static bool launch_pipe_nt(const WgradArgs& p, int tiles, size_t lds, hipStream_
 // true = launched on the pipelined kernel (the instantiated shapes are the generator's own layers; anything else takes
 // the generic kernel above)
 static bool try_pipe(const WgradArgs& p, int mf, int tiles, size_t lds, hipStream_t st) {
-    if (!p.vec4 || p.xc4 > v2w_wg_xc4(p.u)) return false;
     const int cfg = mf * 100 + p.wco * 10 + p.wci;
+    if (p.vec4 && p.u == 1 && cfg == 3222 && p.ntap == 5 && p.xc4 > V2W_WG_XC4 && p.xc4 <= V2W_WG_XC4_WIDE)
+        return launch_pipe<32, 2, 2, 5, 1, true>(p, tiles, lds, st);
+    if (!p.vec4 || p.xc4 > v2w_wg_xc4(p.u)) return false;
     if (p.u == 1) {
         if (cfg == 3222) return launch_pipe_nt<32, 2, 2>(p, tiles, lds, st);
         if (cfg == 3211) return launch_pipe_nt<32, 1, 1>(p, tiles, lds, st);
