@@ -74,7 +74,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     stock = len(sys.argv) > 4 and sys.argv[4] == 'stock'
     dev = torch.device('cuda:0')
-    torch.backends.cudnn.benchmark = True           # train.py:24
+    torch.backends.cudnn.benchmark = os.environ.get("V2W_CUDNN_BENCHMARK", "1") == "1"          # train.py:24 sets True
     h = synthetic.make_hparams(num_wv_feat=768)
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
