@@ -188,6 +188,33 @@ disc_dz_kernel(const float* __restrict__ f, const float* __restrict__ g, const f
     }
 }
 
+// disc_dz_kernel with the phase merge folded in: d is the input gradient of a strided layer in its phase-stacked form
+// dxs (B, s*C, dpitch); dz[b][c][l*inner + w] = (g + dxs[b][((c/Cg)*s + l%s)*Cg + c%Cg][(l/s)*inner + w]) * lrelu'(f)
+__global__ void __launch_bounds__(256)
+disc_dz_merge_kernel(const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ dxs, float* __restrict__ dz,
+                     int C, int Cg, int L, int inner, int s, int dpitch, int pitch, float slope) {
+    const int b = blockIdx.y;
+    const int valid = L * inner;
+    const size_t total = (size_t)C * pitch;
+    const float* fb = f + (size_t)b * total;
+    const float* gb = g ? g + (size_t)b * C * valid : nullptr;
+    const float* db = dxs + (size_t)b * s * C * dpitch;
+    float* ob = dz + (size_t)b * total;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx / pitch);
+        const int t = (int)(idx - (size_t)c * pitch);
+        float v = 0.f;
+        if (t < valid) {
+            const int l = t / inner, w = t - l * inner;
+            const int u = l / s, r = l - u * s;
+            const int cs = ((c / Cg) * s + r) * Cg + c % Cg;
+            v = db[(size_t)cs * dpitch + (size_t)u * inner + w] + (gb ? gb[(size_t)c * valid + t] : 0.f);
+            if (slope != 1.f && !(fb[idx] > 0.f)) v *= slope;
+        }
+        ob[idx] = v;
+    }
+}
+
 // inverse of phase_split_kernel: out[b][c][l][w] = dxs[b][((c/Cg)*s + r)*Cg + c%Cg][u][w], l = s*u + r < L
 __global__ void __launch_bounds__(256)
 phase_merge_kernel(const float* __restrict__ dxs, float* __restrict__ out, int C, int Cg, int L, int inner, int s, int ipitch, int opitch) {
@@ -316,5 +343,19 @@ extern "C" int v2w_avgpool4_bwd(const float* dout, float* dx, int B, int L, void
 extern "C" int v2w_cout1_wgrad(const float* x, const float* dz, float* dwf, int B, int C, int L, int k, int dil, int tap0, void* stream) {
     if (!x || !dz || !dwf || B <= 0 || C <= 0 || L <= 0 || k <= 0 || dil <= 0 || tap0 < 0 || tap0 >= k) return V2W_E_ARG;
     hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dz, dwf, B, C, L, k, dil, tap0);
+    return v2w_launch_status();
+}
+
+
+// v2w_disc_dz with d given in the phase-stacked form of the strided layer above (v2w_phase_merge folded in): f, dz (B, C, pitch),
+// g dense (B, C, L*inner) or NULL, dxs (B, s*C, dpitch).
+extern "C" int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, int B, int C, int Cg, int L, int inner,
+                                 int s, int dpitch, int pitch, float slope, void* stream) {
+    if (!f || !dxs || !dz || B <= 0 || C <= 0 || Cg <= 0 || C % Cg || L <= 0 || inner <= 0 || s <= 0 || slope <= 0.f) return V2W_E_ARG;
+    const int U = (L + s - 1) / s;
+    if (pitch < L * inner || dpitch < U * inner) return V2W_E_ARG;
+    const size_t total = (size_t)C * pitch;
+    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(disc_dz_merge_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, f, g, dxs, dz, C, Cg, L, inner, s, dpitch, pitch, slope);
     return v2w_launch_status();
 }

@@ -182,13 +182,15 @@ def _stacked_input(layer: _DiscConv, x, L_in, inner):
     return xs, U
 
 
-def _conv_layer(layer: _DiscConv, rec, x, L_in, inner, out_slope):
+def _conv_layer(layer: _DiscConv, rec, x, L_in, inner, out_slope, keep=None):
     """x (B, C_in, pitch(L_in * inner)) -> (out buffer (B, C_out, pitch(U * inner)), U), U = L_out of the strided conv.  The convs
     run at L = pitch: the tail columns are ordinary positions to the kernel, hold zeros on the input side (phase_split / unfold
     fill them; `v2w_zero_tail` before a stride-1 layer reads a conv output directly) and are never part of the returned views."""
     B = x.shape[0]
     G = layer.groups
     xs, U = _stacked_input(layer, x, L_in, inner)
+    if keep is not None:
+        keep.append(xs)
     out = torch.empty((B, layer.c_out, xs.shape[2]), device=x.device)
     cig, cog = xs.shape[1] // G, layer.c_out // G
     kw = dict(k=rec['kp'], dil=1 if rec['kp'] == 1 else inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
@@ -231,7 +233,7 @@ class _DiscBase(nn.Module):
     def _geometry(self, t):
         raise NotImplementedError
 
-    def _run(self, x):
+    def _run(self, x, keep=False):
         """x (B, 1, T) -> state for the views / the backward: per layer (buffer (B, C, pitch), rows U) + the weights used."""
         b, c, t = x.shape
         inner, H = self._geometry(t)
@@ -239,12 +241,13 @@ class _DiscBase(nn.Module):
         recs = [l.kernel_weights() for l in layers]             # (spectral norm: the power iteration of this call happens here)
         sn = [l._last_sn for l in layers]
         bufs = []
+        xss = [None] if keep else None                           # stacked inputs kept for the weight gradients (288 GB of HBM)
         f, U = _first_layer(layers[0], recs[0], x, t, H, inner)
         bufs.append((f, U))
         for i in range(1, len(layers)):
-            f, U = _conv_layer(layers[i], recs[i], f, U, inner, LRELU_SLOPE if i + 1 < len(layers) else 0.0)
+            f, U = _conv_layer(layers[i], recs[i], f, U, inner, LRELU_SLOPE if i + 1 < len(layers) else 0.0, xss)
             bufs.append((f, U))
-        return dict(bufs=bufs, recs=recs, sn=sn, inner=inner, H=H, T=t)
+        return dict(bufs=bufs, recs=recs, sn=sn, inner=inner, H=H, T=t, xss=xss)
 
     def _views(self, st, b):
         inner = st['inner']
@@ -271,7 +274,7 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, x, *params):
         xd = x.detach().contiguous().float()
-        st = disc._run(xd)
+        st = disc._run(xd, keep=True)
         ctx.disc, ctx.st, ctx.x = disc, st, xd
         ctx.need_dx = x.requires_grad
         return tuple(disc._views(st, xd.shape[0]))
@@ -285,25 +288,30 @@ class _DiscFn(torch.autograd.Function):
         B, dev = x.shape[0], x.device
         n = len(layers)
         grads = [None] * n           # per layer: tuple of parameter gradients in parameters() order
-        dnext, dx = None, None       # gradient wrt the activated map of layer l arriving from layer l + 1 (pitched)
+        dnext, dx = None, None       # gradient wrt the activated map of layer l arriving from layer l + 1: a pitched buffer, or
+        merge = None                 # the phase-stacked input gradient of a strided layer + its geometry (merged inside disc_dz)
         for l in reversed(range(n)):
             layer, rec = layers[l], st['recs'][l]
             f, U = st['bufs'][l]
             P, valid, C = f.shape[2], st['bufs'][l][1] * inner, layer.c_out
             g = gouts[l]
-            if g is None and dnext is None:
+            if g is None and dnext is None and merge is None:
                 continue                                     # nothing flows through this layer (nor, so far, below it)
             if g is not None:
                 g = g.contiguous().float()
             dz = torch.empty((B, C, P), device=dev)
-            _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), B * C, P, valid,
-                                       LRELU_SLOPE if l + 1 < n else 1.0, stream), 'v2w_disc_dz')
-            db = hipops.channel_sum(dz)
-            # the layer's stride-1 input, rebuilt from the saved map below it (not kept: a memory-bound pass)
-            if l == 0:
-                xs, _ = _unfold_first(layer, x, T, H, inner)
+            slope = LRELU_SLOPE if l + 1 < n else 1.0
+            if merge is not None:
+                dxs_up, cg_up, s_up = merge
+                _hip.check(lib.v2w_disc_dz_merge(f.data_ptr(), _hip.ptr(g), dxs_up.data_ptr(), dz.data_ptr(), B, C, cg_up, U, inner, s_up,
+                                                 dxs_up.shape[2], P, slope, stream), 'v2w_disc_dz_merge')
             else:
-                xs, _ = _stacked_input(layer, st['bufs'][l - 1][0], st['bufs'][l - 1][1], inner)
+                _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), B * C, P, valid, slope, stream),
+                           'v2w_disc_dz')
+            dnext, merge = None, None
+            db = hipops.channel_sum(dz)
+            # the layer's stride-1 input: kept by the forward (the 16-row unfold of the first layer is rebuilt)
+            xs = _unfold_first(layer, x, T, H, inner)[0] if l == 0 else st['xss'][l]
             G = layer.groups
             cigp, cog = xs.shape[1] // G, C // G
             kp, Q = rec['kp'], rec['Q']
@@ -329,20 +337,20 @@ class _DiscFn(torch.autograd.Function):
             # ---- input gradient: the forward conv kernel with the transposed, tap-flipped weights
             if l > 0 or ctx.need_dx:
                 dxs = torch.empty((B, xs.shape[1], P), device=dev)
-                for gi in range(G):
-                    wT = hipops.transpose_flip(rec['wf'][gi])                  # [kp][cog][cigp]
+                if 'wT' not in rec:                                            # shared by the y / y_hat calls of one step
                     packable = cog % 16 == 0 and (cigp % 32 == 0 or cigp == 16)
-                    hipops.conv1d(dz, wT, None, dxs, k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil,
-                                  wp=hipops.pack_mfma(wT) if packable else None, group=(gi, cog, cigp) if G > 1 else None)
+                    rec['wT'] = [hipops.transpose_flip(w) for w in rec['wf']]    # [kp][cog][cigp]
+                    rec['wTp'] = [hipops.pack_mfma(w) if packable else None for w in rec['wT']]
+                probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
+                                                             group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
+                for i in range(0, G, 4):
+                    hipops.conv1d_multi(probs[i:i + 4])
                 if l == 0:
                     dx = torch.empty((B, 1, T), device=dev)
                     _hip.check(lib.v2w_fold1(dxs.data_ptr(), dx.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding,
                                              _UNFOLD_ROWS, P, stream), 'v2w_fold1')
                 elif layer.stride > 1 and not layer.unfolded:
-                    fp, Lp = st['bufs'][l - 1]
-                    dnext = torch.empty_like(fp)
-                    _hip.check(lib.v2w_phase_merge(dxs.data_ptr(), dnext.data_ptr(), B, layer.c_in, layer.c_in // G, Lp, inner,
-                                                   layer.stride, P, fp.shape[2], stream), 'v2w_phase_merge')
+                    merge = (dxs, layer.c_in // G, layer.stride)           # un-stacked by the next iteration's disc_dz
                 elif layer.stride > 1:
                     raise NotImplementedError('backward of the unfolded-tap form (V2W_DISC_UNFOLD=1) is not built')
                 else:
