@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 17
+#define V2W_ABI_VERSION 19
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -73,6 +73,8 @@ int v2w_wf_gather_transpose(const float* wf, float* out, int k, int c_in, int c_
  * tile configuration (C_in % 16 != 0, C_out neither 16 nor a multiple of 32, unsupported stride): such layers run on
  * the direct kernel with wp = NULL. */
 int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream);
+/* n matrices back to back -> n packed streams back to back in one launch (the groups of a grouped conv) */
+int v2w_pack_mfma_batch(const float* wf, float* wp, int k, int c_in, int c_out, int u, int n, void* stream);
 
 /* Batched form of fold + pack for every MFMA layer of a generator: two launches instead of three per layer.
  *   v2w_fold_plan       (host only) fills mf/ck of each descriptor and starts[2*(n+1)] (block prefix sums of the scale
@@ -362,6 +364,10 @@ int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
  *   v2w_cout1_wgrad: weight gradient of a C_out = 1 conv: dwf [k][C] = sum_{b,l} x[b][c][l + (t - tap0)*dil] * dz[b][l]. */
 int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                     int k, int dil, int tap0, int x_ct, int dy_ct, void* stream);
+/* every group of a grouped Conv1d in one launch per tap group (grid.z = group): x (B, G*c_in, Lq), dy (B, G*c_out, Lq),
+ * dwf [G][k][c_in][c_out]; slab_ws: G * v2w_wgrad_slabs(B, c_in, c_out, Lq) * k*c_in*c_out floats */
+int v2w_wgrad_groups(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
+                     int k, int dil, int tap0, int ngroups, void* stream);
 int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope, void* stream);
 /* v2w_disc_dz with d in the phase-stacked form dxs (B, s*C, dpitch) of the strided layer above (v2w_phase_merge folded in) */
 int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, int B, int C, int Cg, int L, int inner, int s,

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 17
+ABI_VERSION = 19
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -95,6 +95,7 @@ SIGNATURES = {
     'v2w_wf_transpose_flip': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wf_gather_transpose': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_mfma_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_mel_phases': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     'v2w_unfold1': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_unfold_taps': (C.c_int, [_fp, _fp] + [C.c_int] * 9 + [_fp]),
     'v2w_wgrad_slice': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp]),
+    'v2w_wgrad_groups': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp]),
     'v2w_disc_dz': (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_float, _fp]),
     'v2w_disc_dz_merge': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [C.c_float, _fp]),
     'v2w_phase_merge': (C.c_int, [_fp, _fp] + [C.c_int] * 8 + [_fp]),

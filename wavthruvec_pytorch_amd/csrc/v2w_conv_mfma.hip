@@ -427,10 +427,11 @@ int launch_convt_u(TileArgs p, hipStream_t stream) {
 // where ts runs over the taps in the order the tile kernel consumes them: 0..K-1 for a conv, phase by phase
 // (r = 0..U-1: t = (r+pad)%U, +U, ...) for a transposed conv.
 __global__ void __launch_bounds__(256)
-pack_mfma_kernel(const float* __restrict__ wf, float* __restrict__ wp, int K, int Cin, int Cout, int MF, int CK, int U) {
+pack_mfma_kernel(const float* wf, float* wp, int K, int Cin, int Cout, int MF, int CK, int U) {
     const int KSTEP = MF == 32 ? 2 : 4, CKG = 4 * KSTEP, GPC = CK / CKG, nch = Cin / CK;
     const int pad = (K - U) / 2;
     const size_t total = (size_t)K * Cin * Cout;
+    wf += (size_t)blockIdx.y * total; wp += (size_t)blockIdx.y * total;       // grid.y = matrix of a batch (v2w_pack_mfma_batch)
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int j = o & 3;
         const int lane = (o >> 2) & 63;
@@ -548,6 +549,18 @@ extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
+    return v2w_launch_status();
+}
+
+// n matrices [k][c_in][c_out] back to back -> n packed streams back to back, one launch (the groups of a grouped conv)
+extern "C" int v2w_pack_mfma_batch(const float* wf, float* wp, int k, int c_in, int c_out, int u, int n, void* stream) {
+    if (n <= 0 || n > 65535) return V2W_E_ARG;
+    if (!wf || !wp || k <= 0 || c_in <= 0 || c_out <= 0 || u <= 0) return V2W_E_ARG;
+    const LayerCfg cfg = v2w_layer_cfg(c_in, c_out, u);
+    if (!cfg.mf) return V2W_E_SHAPE;
+    const size_t total = (size_t)k * c_in * c_out;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid, n), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
     return v2w_launch_status();
 }
 

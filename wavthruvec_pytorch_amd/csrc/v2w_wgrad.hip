@@ -24,6 +24,8 @@ struct WgradArgs {
     float* slab;                                           // [S*WP][K][Cin][Cout]
     int B, Cin, Cout, Lq, K;
     int CinT, CoutT;          // channels per batch item of the tensors x / dy live in (> Cin / Cout: one group of a grouped conv)
+    int ngroups;              // grid.z: group g reads channels [g*Cin, ..) of x, [g*Cout, ..) of dy and owns slab region g
+    int nslab;                // slabs per group
     int u, r;                 // dy position = u*q + r
     int ntap;                 // taps of this launch
     int tap[V2W_WG_TG];       // real tap index (slab row)
@@ -53,6 +55,7 @@ wgrad_kernel(const WgradArgs p) {
     const int cot = p.Cout / CO_T;
     const int co0 = (blockIdx.x % cot) * CO_T, ci0 = (blockIdx.x / cot) * CI_T;
     const int s = blockIdx.y;
+    const int cob = blockIdx.z * p.Cout + co0, cib = blockIdx.z * p.Cin + ci0;     // channel bases inside the x / dy tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & (MF - 1), hk = lane / MF;
@@ -81,7 +84,7 @@ wgrad_kernel(const WgradArgs p) {
                 const int row = idx >> 5, col = (idx & 31) * 4;           // PT / 4 == 32 float4 per row
                 const int q = q0 + col;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q < Lq) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + co0 + row) * Ldy + q);
+                if (q < Lq) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + cob + row) * Ldy + q);
                 float* d = DYs + row * p.ptw + col;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
@@ -90,7 +93,7 @@ wgrad_kernel(const WgradArgs p) {
             for (int idx = tid; idx < CI_T * xc4; idx += 256) {
                 const int row = idx / xc4, col = (idx - row * xc4) * 4;
                 const int q = qa + col;
-                const int ch = b * p.CinT + ci0 + row;
+                const int ch = b * p.CinT + cib + row;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (q >= 0 && q < Lq) {
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.x + (size_t)ch * Lq + q);
@@ -105,12 +108,12 @@ wgrad_kernel(const WgradArgs p) {
             for (int idx = tid; idx < CO_T * PT; idx += 256) {
                 const int row = idx / PT, col = idx - row * PT;
                 const int q = q0 + col;
-                DYs[row * p.ptw + col] = q < Lq ? p.dy[((size_t)b * p.CoutT + co0 + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
+                DYs[row * p.ptw + col] = q < Lq ? p.dy[((size_t)b * p.CoutT + cob + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
             }
             for (int idx = tid; idx < CI_T * xcols; idx += 256) {
                 const int row = idx / xcols, col = idx - row * xcols;
                 const int q = q0 - p.hla + col;
-                const int ch = b * p.CinT + ci0 + row;
+                const int ch = b * p.CinT + cib + row;
                 float v = 0.f;
                 if (q >= 0 && q < Lq) {
                     const float av = p.x_a ? p.x_a[ch] : 1.f, sv = p.x_a ? p.x_s[ch] : 0.f;
@@ -133,7 +136,7 @@ wgrad_kernel(const WgradArgs p) {
 
     // ---- partial block of this split -> its slab: rows = ci (accumulator rows), lanes = co (contiguous)
     const int slab_id = s * p.wp + w_p;
-    float* dst = p.slab + (size_t)slab_id * p.K * p.Cin * p.Cout;
+    float* dst = p.slab + ((size_t)blockIdx.z * p.nslab + slab_id) * p.K * p.Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < V2W_WG_TG; ++t) {
         if (t >= p.ntap) continue;
@@ -176,6 +179,7 @@ wgrad_pipe_kernel(const WgradArgs p) {
     const int cot = p.Cout / CO_T;
     const int co0 = (blockIdx.x % cot) * CO_T, ci0 = (blockIdx.x / cot) * CI_T;
     const int s = blockIdx.y;
+    const int cob = blockIdx.z * p.Cout + co0, cib = blockIdx.z * p.Cin + ci0;     // channel bases inside the x / dy tensors
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & (MF - 1), hk = lane / MF;
@@ -205,10 +209,10 @@ wgrad_pipe_kernel(const WgradArgs p) {
             const int idx = tid + i * 256;
             const int row = idx / DYC4, pos = q0 * U + (idx - row * DYC4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < CO_T && pos < Ldy) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + co0 + row) * Ldy + pos);
+            if (row < CO_T && pos < Ldy) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + cob + row) * Ldy + pos);
             dyv[i] = v;
         }
-        const int ch = b * p.CinT + ci0 + xrow;
+        const int ch = b * p.CinT + cib + xrow;
         const float* xsrc = p.x + (size_t)ch * Lq + (q0 - p.hla);
         if (p.x_a) { xa = p.x_a[ch]; xs = p.x_s[ch]; }
 #pragma unroll
@@ -276,7 +280,7 @@ wgrad_pipe_kernel(const WgradArgs p) {
     }
 
     const int slab_id = s * WP + w_p;
-    float* dst = p.slab + (size_t)slab_id * p.K * p.Cin * p.Cout;
+    float* dst = p.slab + ((size_t)blockIdx.z * p.nslab + slab_id) * p.K * p.Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -293,7 +297,7 @@ static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t s
     auto kern = wgrad_pipe_kernel<MF, WCO, WCI, NT, U, WIDE>;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(tiles, p.S), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
     return true;
 }
 
@@ -335,10 +339,11 @@ static bool try_pipe(const WgradArgs& p, int mf, int tiles, size_t lds, hipStrea
 // dwf[i] = sum_s slab[s][i]: a block covers 256 consecutive outputs (one float4 per lane) x 4 slab lanes (one per wave);
 // every wave sums each 4th slab with 4 loads in flight, the four partial sums are combined in fixed order (deterministic).
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dwf, size_t n, int nslab) {
+wgrad_reduce_kernel(const float* slab, float* dwf, size_t n, int nslab) {
     __shared__ f32x4 part[4][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t i = ((size_t)blockIdx.x * 64 + o) * 4;             // n % 4 == 0: weights are k * C_in * C_out, C % 16 == 0
+    slab += (size_t)blockIdx.y * nslab * n; dwf += (size_t)blockIdx.y * n;   // grid.y = group
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
         int s = g;
@@ -392,11 +397,11 @@ extern "C" int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq) {
 
 // dwf [k][C_in][C_out] = weight gradient; u = 1 / pad ignored for Conv1d (dil used), stride u and pad = (k-u)/2 for ConvTranspose1d.
 static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
-                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, void* stream);
+                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, int ngroups, void* stream);
 
 extern "C" int v2w_wgrad(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
                          int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, void* stream) {
-    return wgrad_impl(x, x_a, x_s, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, u, slope, -1, 0, 0, stream);
+    return wgrad_impl(x, x_a, x_s, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, u, slope, -1, 0, 0, 1, stream);
 }
 
 // Conv1d weight gradient with the taps at offsets (t - tap0) * dil (tap0 = -1: symmetric (k-1)/2) on channel slices: x / dy point at
@@ -405,11 +410,19 @@ extern "C" int v2w_wgrad(const float* x, const float* x_a, const float* x_s, con
 extern "C" int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                                int k, int dil, int tap0, int x_ct, int dy_ct, void* stream) {
     if (tap0 < -1 || tap0 >= k || x_ct < 0 || dy_ct < 0 || (x_ct > 0 && x_ct < c_in) || (dy_ct > 0 && dy_ct < c_out)) return V2W_E_ARG;
-    return wgrad_impl(x, nullptr, nullptr, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, 1, 1.f, tap0, x_ct, dy_ct, stream);
+    return wgrad_impl(x, nullptr, nullptr, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, 1, 1.f, tap0, x_ct, dy_ct, 1, stream);
+}
+
+// All `ngroups` groups of a grouped Conv1d in ONE launch per tap group (grid.z = group): x (B, ngroups*c_in, Lq), dy (B, ngroups*c_out, Lq),
+// dwf [ngroups][k][c_in][c_out]; slab_ws: ngroups * v2w_wgrad_slabs(...) * k*c_in*c_out floats.
+extern "C" int v2w_wgrad_groups(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
+                                int k, int dil, int tap0, int ngroups, void* stream) {
+    if (tap0 < -1 || tap0 >= k || ngroups < 1 || ngroups > 65535) return V2W_E_ARG;
+    return wgrad_impl(x, nullptr, nullptr, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, 1, 1.f, tap0, ngroups * c_in, ngroups * c_out, ngroups, stream);
 }
 
 static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
-                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, void* stream) {
+                      int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, int tap0, int x_ct, int dy_ct, int ngroups, void* stream) {
     if (!x || !dy || !dwf || !slab_ws || B <= 0 || c_in <= 0 || c_out <= 0 || Lq <= 0 || k <= 0 || dil <= 0 || u <= 0) return V2W_E_ARG;
     if ((x_a == nullptr) != (x_s == nullptr)) return V2W_E_ARG;
     int mf = 0, wco = 1, wci = 1;
@@ -419,9 +432,11 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
     p.x = x; p.x_a = x_a; p.x_s = x_s; p.dy = dy; p.slab = slab_ws;
     p.B = B; p.Cin = c_in; p.Cout = c_out; p.Lq = Lq; p.K = k; p.u = u; p.slope = slope;
     p.CinT = x_ct > 0 ? x_ct : c_in; p.CoutT = dy_ct > 0 ? dy_ct : c_out;
+    p.ngroups = ngroups;
     p.wco = wco; p.wci = wci;
     p.wp = 4 / (p.wco * p.wci);
     p.S = nslab / p.wp;
+    p.nslab = nslab;
     const int tiles = (c_out / (p.wco * mf)) * (c_in / (p.wci * mf));
     const int pad = u > 1 ? (k - u) / 2 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -495,15 +510,15 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
                 if (lds > 160 * 1024) return V2W_E_SHAPE;
                 if (mf == 32) {
                     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, p.S), dim3(256), lds, st, p);
+                    hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 } else {
                     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, p.S), dim3(256), lds, st, p);
+                    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 }
             }
         }
     }
     const size_t nw = (size_t)k * c_in * c_out;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
     return v2w_launch_status();
 }

@@ -33,6 +33,7 @@ from . import _hip, hipops
 from .synthetic import DISC_P_LAYERS, DISC_P_POST, DISC_S_LAYERS, DISC_S_POST
 
 LRELU_SLOPE = 0.1   # models.py:9
+_WGRAD_GROUPED = os.environ.get('V2W_DISC_WGRAD_GROUPS', '1') == '1'   # all groups of a layer in one wgrad launch (grid.z)
 _UNFOLD_ROWS = 16   # C_in = 1 layers: the k shifted copies padded to the MFMA kernel's smallest channel block
 
 
@@ -110,9 +111,12 @@ class _DiscConv(nn.Module):
             wpad = torch.cat([wf, torch.zeros((1, cig, self.c_out), device=dev)], 0)
             w5 = wpad[j.reshape(-1)].reshape(kp, s * cig, G, cog)          # rows (r, c), columns (g, o)
             self._jmap = j.reshape(-1)
-            groups = [w5[:, :, g, :].contiguous() for g in range(G)]
-        packable = groups[0].shape[1] % 16 == 0 and (groups[0].shape[2] % 32 == 0 or groups[0].shape[2] == 16)
-        rec = dict(wf=groups, wp=[hipops.pack_mfma(w) for w in groups] if packable else [None] * len(groups), kp=kp, Q=Q)
+            groups = w5.permute(2, 0, 1, 3).contiguous()                   # [G][kp][s * cig][cog]
+        if not torch.is_tensor(groups):
+            groups = torch.stack(groups, 0)
+        packable = groups.shape[2] % 16 == 0 and (groups.shape[3] % 32 == 0 or groups.shape[3] == 16)
+        rec = dict(w4=groups, wf=list(groups.unbind(0)), kp=kp, Q=Q,
+                   wp=list(hipops.pack_mfma_batch(groups).unbind(0)) if packable else [None] * groups.shape[0])
         self._cache = (key, rec)
         return rec
 
@@ -326,21 +330,27 @@ class _DiscFn(torch.autograd.Function):
                 ns = lib.v2w_wgrad_slabs(B, cigp, cog, P)
                 if ns == 0:
                     raise _hip.HipLibraryError(f'v2w_wgrad_slice: no configuration for C_in={cigp}, C_out={cog}')
-                slab = torch.empty((ns * kp * cigp * cog,), device=dev)
-                dws = []
-                for gi in range(G):
-                    dw = torch.empty((kp, cigp, cog), device=dev)
-                    _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4, dw.data_ptr(),
-                                                   slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C, stream), 'v2w_wgrad_slice')
-                    dws.append(dw)
+                dwg = torch.empty((G, kp, cigp, cog), device=dev)
+                if _WGRAD_GROUPED:
+                    slab = torch.empty((G * ns * kp * cigp * cog,), device=dev)
+                    _hip.check(lib.v2w_wgrad_groups(xs.data_ptr(), dz.data_ptr(), dwg.data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil,
+                                                    Q, G, stream), 'v2w_wgrad_groups')
+                else:
+                    slab = torch.empty((ns * kp * cigp * cog,), device=dev)
+                    for gi in range(G):
+                        _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4,
+                                                       dwg[gi].data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C,
+                                                       stream), 'v2w_wgrad_slice')
+                dws = list(dwg.unbind(0))
             grads[l] = layer.param_grads(db, dws, st['sn'][l])
             # ---- input gradient: the forward conv kernel with the transposed, tap-flipped weights
             if l > 0 or ctx.need_dx:
                 dxs = torch.empty((B, xs.shape[1], P), device=dev)
                 if 'wT' not in rec:                                            # shared by the y / y_hat calls of one step
                     packable = cog % 16 == 0 and (cigp % 32 == 0 or cigp == 16)
-                    rec['wT'] = [hipops.transpose_flip(w) for w in rec['wf']]    # [kp][cog][cigp]
-                    rec['wTp'] = [hipops.pack_mfma(w) if packable else None for w in rec['wT']]
+                    wT4 = rec['w4'].flip(1).transpose(2, 3).contiguous()        # [G][kp][cog][cigp], taps reversed
+                    rec['wT'] = list(wT4.unbind(0))
+                    rec['wTp'] = list(hipops.pack_mfma_batch(wT4).unbind(0)) if packable else [None] * G
                 probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
                                                              group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
                 for i in range(0, G, 4):

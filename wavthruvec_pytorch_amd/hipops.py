@@ -90,6 +90,15 @@ def pack_mfma(wf, out=None, u=1):
     return out
 
 
+def pack_mfma_batch(w4):
+    """w4 [n][k][C_in][C_out] contiguous -> the n packed MFMA streams [n][k*C_in*C_out] in one launch."""
+    _chk(w4, 'w4')
+    n, k, ci, co = w4.shape
+    out = torch.empty((n, k * ci * co), device=w4.device, dtype=torch.float32)
+    _hip.check(_hip.load().v2w_pack_mfma_batch(w4.data_ptr(), out.data_ptr(), k, ci, co, 1, n, _stream(w4)), 'v2w_pack_mfma_batch')
+    return out
+
+
 def split_supported(c_in, c_out, u=1):
     """True when the split-f16 kernel (ALGO_SPLIT) serves this layer shape."""
     return bool(_hip.load().v2w_split_supported(c_in, c_out, u))
