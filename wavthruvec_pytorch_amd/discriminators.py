@@ -60,6 +60,7 @@ class _DiscConv(nn.Module):
         self._cache = None
         self._last_sn = None
         self._jmap = None
+        self._wpad = None
         # optional form of the short strided ungrouped convs (DiscriminatorP k = 5, stride 3): taps unfolded into channels of a
         # 1-tap conv (exact MAC count, no halo).  Measured equal to the phase-stacked default (40.6 vs 40.4 ms per MPD forward):
         # one tap per staged chunk makes the kernel staging-bound, which cancels the 6/5 tap-slot saving.
@@ -70,11 +71,11 @@ class _DiscConv(nn.Module):
                f'{"spectral_norm" if self.spectral else "weight_norm"}'
 
     # -- weights in kernel form --------------------------------------------------------------------------------------
-    def _folded(self):
+    def _folded(self, out=None):
         """-> wf [k][C_in / groups][C_out], normalisation applied (one power iteration first for spectral_norm in training)."""
         co, cig, k = self.c_out, self.c_in // self.groups, self.k
         if not self.spectral:
-            return hipops.fold_conv_weight(self.weight_v.detach().reshape(co, cig, k), self.weight_g.detach().reshape(co, 1, 1))
+            return hipops.fold_conv_weight(self.weight_v.detach().reshape(co, cig, k), self.weight_g.detach().reshape(co, 1, 1), out=out)
         w = self.weight_orig.detach()
         wm = w.reshape(co, -1)
         if self.training:      # legacy torch.nn.utils.spectral_norm: v <- norm(W^T u), u <- norm(W v), in place, per forward
@@ -82,7 +83,7 @@ class _DiscConv(nn.Module):
             self.weight_u.copy_(F.normalize(torch.mv(wm, self.weight_v), dim=0, eps=1e-12))
         sigma = torch.dot(self.weight_u, torch.mv(wm, self.weight_v))
         self._last_sn = (sigma, self.weight_u.clone(), self.weight_v.clone())
-        return hipops.fold_conv_weight((w / sigma).reshape(co, cig, k), None)
+        return hipops.fold_conv_weight((w / sigma).reshape(co, cig, k), None, out=out)
 
     def kernel_weights(self):
         """Per-group stride-1 weights: dict(wf=[G] of [k'][s * C_in/G][C_out/G], wp=[G] packed or None, kp, pad_left_taps).
@@ -91,10 +92,20 @@ class _DiscConv(nn.Module):
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._cache is not None and self._cache[0] == key and not (self.spectral and self.training):
             return self._cache[1]
-        wf = self._folded()                                  # [k][cig][co]
         k, s, P, G = self.k, self.stride, self.padding, self.groups
         cig, cog = self.c_in // G, self.c_out // G
-        dev = wf.device
+        stacked = not self.unfolded and self.c_in > 1
+        dev = self.bias.device
+        if stacked and (self._wpad is None or self._wpad.device != dev):
+            # constants of the re-indexing, built once: the tap map j[q][r] (k = "no such tap" -> the zero row of wpad)
+            self._Q = -(-P // s)
+            self._kp = self._Q + (k - 1 - P) // s + 1
+            q = torch.arange(self._kp, device=dev).view(self._kp, 1) - self._Q
+            r = torch.arange(s, device=dev).view(1, s)
+            j = s * q + r + P
+            self._jmap = torch.where((j >= 0) & (j < k), j, torch.full_like(j, k)).reshape(-1)
+            self._wpad = torch.zeros((k + 1, cig, self.c_out), device=dev)
+        wf = self._folded(self._wpad[:k] if stacked else None)            # [k][cig][co]
         if self.unfolded:                                    # rows (j, c): the taps become channels of a 1-tap conv
             groups, kp, Q = [wf.reshape(1, k * cig, self.c_out)], 1, 0
         elif self.c_in == 1:                                 # unfolded: rows = taps
@@ -102,15 +113,8 @@ class _DiscConv(nn.Module):
             w2[0, :k] = wf[:, 0, :]
             groups, kp, Q = [w2], 1, 0
         else:
-            Q = -(-P // s)
-            kp = Q + (k - 1 - P) // s + 1
-            q = torch.arange(kp, device=dev).view(kp, 1) - Q
-            r = torch.arange(s, device=dev).view(1, s)
-            j = s * q + r + P
-            j = torch.where((j >= 0) & (j < k), j, torch.full_like(j, k))
-            wpad = torch.cat([wf, torch.zeros((1, cig, self.c_out), device=dev)], 0)
-            w5 = wpad[j.reshape(-1)].reshape(kp, s * cig, G, cog)          # rows (r, c), columns (g, o)
-            self._jmap = j.reshape(-1)
+            kp, Q, wpad = self._kp, self._Q, self._wpad
+            w5 = wpad[self._jmap].reshape(kp, s * cig, G, cog)             # rows (r, c), columns (g, o)
             groups = w5.permute(2, 0, 1, 3).contiguous()                   # [G][kp][s * cig][cog]
         if not torch.is_tensor(groups):
             groups = torch.stack(groups, 0)
