@@ -154,3 +154,36 @@ def test_mpd_unfolded_tap_form(dev, monkeypatch):
     for fw, fg in zip(want[2] + want[3], got[2] + got[3]):
         for a, b in zip(fw, fg):
             assert a.shape == b.shape and (a - b.cpu()).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize('kind', ['mpd', 'msd'])
+def test_discriminator_weights_follow_the_optimizer(dev, kind):
+    """The folded / packed kernel weights are cached per parameter version: after `optimizer.step()` (train.py:199) the next forward
+    must run on the updated parameters - it equals, bit for bit, a fresh module loaded from the stepped state_dict, differs from the
+    forward before the step, and a second backward accumulates into .grad like torch's."""
+    spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=13)
+    y, y_hat = synthetic.make_audio_pair(2, 2500, seed=3)
+    y, y_hat = y.to(dev), y_hat.to(dev)
+    m = build(kind, sd, dev)
+    opt = torch.optim.AdamW(m.parameters(), 1e-2, betas=(0.8, 0.99))
+    out1 = m(y, y_hat)
+    D.smooth_loss(out1).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    opt.step()
+    stepped = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out2 = m(y, y_hat)
+    m2 = build(kind, stepped, dev)
+    with torch.no_grad():
+        out3 = m2(y, y_hat)
+    for a, b, c in zip(out1[1], out2[1], out3[1]):
+        assert torch.equal(b, c)
+        assert (a.detach() - b).abs().max().item() > 1e-4          # the step moved the scores
+    for fa, fb in zip(out2[3], out3[3]):
+        for a, b in zip(fa, fb):
+            assert torch.equal(a, b)
+    # gradients accumulate over backward calls (no zero_grad in between)
+    D.smooth_loss(m(y, y_hat)).backward()
+    moved = sum(int(not torch.equal(p.grad, g1[k])) for k, p in m.named_parameters())
+    assert moved == len(g1)
