@@ -462,3 +462,35 @@ def test_generator_backward_matches_oracle_autograd(dev, training, B, T, resbloc
     with torch.no_grad():
         y2 = g2(*to_dev(inp, dev))
     assert (y2 - y.detach()).abs().max().item() <= (1e-6 if precision == 'f32' else 5e-6)
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_generator_weights_follow_the_optimizer(dev, precision):
+    """The folded / packed weights are cached per parameter version: after `optim_g.step()` (train.py:215) the next forward - train
+    mode and the eval-mode cache alike - runs on the updated parameters: equal to a fresh module loaded from the stepped
+    state_dict and different from the forward before the step."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = to_dev(synthetic.make_inputs(h, 2, 9, seed=31), dev)
+    g = build_generator(h, sd, dev, training=True)
+    g.precision = precision
+    opt = torch.optim.AdamW(g.parameters(), 1e-2, betas=(0.8, 0.99))
+    y1 = g(*inp)
+    y1.square().mean().backward()
+    opt.step()
+    g.eval()
+    with torch.no_grad():
+        e1 = g(*inp)                  # eval forward: fills the eval-mode fold cache
+    g.train()
+    g(*inp).square().mean().backward()
+    opt.step()                        # parameters move again: the eval cache is stale now
+    stepped = {k: v.clone() for k, v in g.state_dict().items()}
+    g.eval()
+    with torch.no_grad():
+        e2 = g(*inp)
+    g2 = build_generator(h, stepped, dev, training=False)
+    g2.precision = precision
+    with torch.no_grad():
+        e3 = g2(*inp)
+    assert torch.equal(e2, e3)
+    assert (e2 - e1).abs().max().item() > 1e-4 and (y1.detach() - e1).abs().max().item() > 1e-4
