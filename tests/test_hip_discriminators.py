@@ -187,3 +187,22 @@ def test_discriminator_weights_follow_the_optimizer(dev, kind):
     D.smooth_loss(m(y, y_hat)).backward()
     moved = sum(int(not torch.equal(p.grad, g1[k])) for k, p in m.named_parameters())
     assert moved == len(g1)
+
+
+@pytest.mark.parametrize('kind', ['mpd', 'msd'])
+def test_frozen_discriminators_give_the_same_input_gradient(dev, kind):
+    """`with frozen(mpd, msd):` around the generator step's discriminator forwards: dL/dy_hat is bit-identical, no parameter
+    gradient is produced (train.py discards them with the next optim_d.zero_grad()), requires_grad is restored on exit."""
+    from wavthruvec_pytorch_amd.discriminators import frozen
+    spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=17)
+    y, y_hat = synthetic.make_audio_pair(2, 2100, seed=12)
+    m, outs, gy = _hip_grads(kind, sd, y, y_hat, dev, loss=D.smooth_loss)
+    m2 = build(kind, sd, dev)
+    yh = y_hat.to(dev).requires_grad_(True)
+    with frozen(m2):
+        assert not any(p.requires_grad for p in m2.parameters())
+        outs2 = m2(y.to(dev), yh)
+    D.smooth_loss(outs2).backward()
+    assert all(p.requires_grad for p in m2.parameters()) and all(p.grad is None for p in m2.parameters())
+    assert torch.equal(yh.grad, gy)

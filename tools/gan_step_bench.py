@@ -2,7 +2,9 @@
 """One full vec2wav GAN training iteration as vec2wav/train.py:160-215 runs it - generator forward, mel of the generated audio,
 discriminator step (MPD + MSD on y and y_g_hat.detach(), backward, AdamW), generator step (MPD + MSD again, feature / LSGAN /
 L1-mel losses, backward through the discriminators, the mel and the generator, AdamW) - entirely on the HIP path.
-argv: B T steps [stock]   ('stock': the discriminators as stock torch.nn conv stacks (MIOpen + torch autograd) for comparison)"""
+argv: B T steps [stock] [frozen]   ('stock': the discriminators as stock torch.nn conv stacks (MIOpen + torch autograd) for comparison;
+'frozen': `with discriminators.frozen(mpd, msd)` around the G step's discriminator forwards - same trajectory, no wasted D gradients)"""
+import contextlib
 import os
 import sys
 import time
@@ -73,6 +75,7 @@ def main():
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     stock = len(sys.argv) > 4 and sys.argv[4] == 'stock'
+    freeze = 'frozen' in sys.argv[4:]      # discriminator parameters do not require grad during the G step (their grads are discarded anyway)
     dev = torch.device('cuda:0')
     torch.backends.cudnn.benchmark = os.environ.get("V2W_CUDNN_BENCHMARK", "1") == "1"          # train.py:24 sets True
     h = synthetic.make_hparams(num_wv_feat=768)
@@ -101,8 +104,8 @@ def main():
         times[name] = times.get(name, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
-    for it in range(steps + 1):
-        if it == 1:
+    for it in range(steps + 2):          # two untimed iterations: the caching allocator reaches its working set (tens of GB)
+        if it == 2:
             times.clear()
             torch.cuda.synchronize(); t_all = time.perf_counter()
         t0 = time.perf_counter()
@@ -120,8 +123,9 @@ def main():
         t0 = tick('D step: backward + AdamW', t0)
         optim_g.zero_grad()
         loss_mel = F.l1_loss(y_mel, y_g_hat_mel) * 45
-        y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = mpd(y, y_g_hat)
-        y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
+        with (HD.frozen(mpd, msd) if freeze else contextlib.nullcontext()):
+            y_df_hat_r, y_df_hat_g, fmap_f_r, fmap_f_g = mpd(y, y_g_hat)
+            y_ds_hat_r, y_ds_hat_g, fmap_s_r, fmap_s_g = msd(y, y_g_hat)
         loss_gen_all = HD.generator_loss(y_ds_hat_g)[0] + HD.generator_loss(y_df_hat_g)[0] + HD.feature_loss(fmap_s_r, fmap_s_g) \
             + HD.feature_loss(fmap_f_r, fmap_f_g) + loss_mel
         t0 = tick('G step: discriminator forwards + losses', t0)
@@ -130,7 +134,7 @@ def main():
         t0 = tick('G step: backward (D, mel, G) + AdamW', t0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t_all) / steps
-    print(f'{"stock torch discriminators" if stock else "HIP discriminators"}  B={B} T={T}: {dt * 1e3:.1f} ms per GAN iteration '
+    print(f'{"stock torch discriminators" if stock else "HIP discriminators"}{" (frozen in the G step)" if freeze else ""}  B={B} T={T}: {dt * 1e3:.1f} ms per GAN iteration '
           f'({B * T * 320 / dt / 1e6:.2f} M samples/s trained), loss_gen {loss_gen_all.item():.4f}')
     for k, v in times.items():
         print(f'    {k:45s} {v / steps * 1e3:8.1f} ms')

@@ -285,6 +285,7 @@ class _DiscFn(torch.autograd.Function):
         st = disc._run(xd, keep=True)
         ctx.disc, ctx.st, ctx.x = disc, st, xd
         ctx.need_dx = x.requires_grad
+        ctx.need_dw = any(p.requires_grad for p in params)
         return tuple(disc._views(st, xd.shape[0]))
 
     @staticmethod
@@ -317,7 +318,7 @@ class _DiscFn(torch.autograd.Function):
                 _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), B * C, P, valid, slope, stream),
                            'v2w_disc_dz')
             dnext, merge = None, None
-            db = hipops.channel_sum(dz)
+            db = hipops.channel_sum(dz) if ctx.need_dw else None
             # the layer's stride-1 input: kept by the forward (the 16-row unfold of the first layer is rebuilt)
             xs = _unfold_first(layer, x, T, H, inner)[0] if l == 0 else st['xss'][l]
             G = layer.groups
@@ -325,28 +326,29 @@ class _DiscFn(torch.autograd.Function):
             kp, Q = rec['kp'], rec['Q']
             dil = 1 if kp == 1 else inner
             # ---- weight gradient in the stacked form, then back to the reference's (C_out, C_in / groups, k)
-            if C == 1:
-                dwp = torch.empty((kp, xs.shape[1], 1), device=dev)
-                _hip.check(lib.v2w_cout1_wgrad(xs.data_ptr(), dz.data_ptr(), dwp.data_ptr(), B, xs.shape[1], P, kp, dil, Q, stream),
-                           'v2w_cout1_wgrad')
-                dws = [dwp]
-            else:
-                ns = lib.v2w_wgrad_slabs(B, cigp, cog, P)
-                if ns == 0:
-                    raise _hip.HipLibraryError(f'v2w_wgrad_slice: no configuration for C_in={cigp}, C_out={cog}')
-                dwg = torch.empty((G, kp, cigp, cog), device=dev)
-                if _WGRAD_GROUPED:
-                    slab = torch.empty((G * ns * kp * cigp * cog,), device=dev)
-                    _hip.check(lib.v2w_wgrad_groups(xs.data_ptr(), dz.data_ptr(), dwg.data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil,
-                                                    Q, G, stream), 'v2w_wgrad_groups')
+            if ctx.need_dw:                   # (frozen discriminators - `frozen()` around the G step - skip all of this)
+                if C == 1:
+                    dwp = torch.empty((kp, xs.shape[1], 1), device=dev)
+                    _hip.check(lib.v2w_cout1_wgrad(xs.data_ptr(), dz.data_ptr(), dwp.data_ptr(), B, xs.shape[1], P, kp, dil, Q, stream),
+                               'v2w_cout1_wgrad')
+                    dws = [dwp]
                 else:
-                    slab = torch.empty((ns * kp * cigp * cog,), device=dev)
-                    for gi in range(G):
-                        _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4,
-                                                       dwg[gi].data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C,
-                                                       stream), 'v2w_wgrad_slice')
-                dws = list(dwg.unbind(0))
-            grads[l] = layer.param_grads(db, dws, st['sn'][l])
+                    ns = lib.v2w_wgrad_slabs(B, cigp, cog, P)
+                    if ns == 0:
+                        raise _hip.HipLibraryError(f'v2w_wgrad_slice: no configuration for C_in={cigp}, C_out={cog}')
+                    dwg = torch.empty((G, kp, cigp, cog), device=dev)
+                    if _WGRAD_GROUPED:
+                        slab = torch.empty((G * ns * kp * cigp * cog,), device=dev)
+                        _hip.check(lib.v2w_wgrad_groups(xs.data_ptr(), dz.data_ptr(), dwg.data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil,
+                                                        Q, G, stream), 'v2w_wgrad_groups')
+                    else:
+                        slab = torch.empty((ns * kp * cigp * cog,), device=dev)
+                        for gi in range(G):
+                            _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4,
+                                                           dwg[gi].data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C,
+                                                           stream), 'v2w_wgrad_slice')
+                    dws = list(dwg.unbind(0))
+                grads[l] = layer.param_grads(db, dws, st['sn'][l])
             # ---- input gradient: the forward conv kernel with the transposed, tap-flipped weights
             if l > 0 or ctx.need_dx:
                 dxs = torch.empty((B, xs.shape[1], P), device=dev)
@@ -481,6 +483,28 @@ class MultiScaleDiscriminator(nn.Module):
             y_d_rs.append(y_d_r); fmap_rs.append(fmap_r)
             y_d_gs.append(y_d_g); fmap_gs.append(fmap_g)
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class frozen:
+    """Context manager: the parameters of the given discriminators do not require grad inside.  train.py's generator step
+    (train.py:201-215) back-propagates through MPD / MSD only to reach `y_g_hat`; the discriminator parameter gradients it also
+    produces are discarded by the next `optim_d.zero_grad()`.  Wrapping that step's discriminator forwards in
+    `with frozen(mpd, msd):` gives the same training trajectory while the real-audio branch needs no backward at all and the
+    generated branch only its input gradients."""
+
+    def __init__(self, *modules):
+        self.params = [p for m in modules for p in m.parameters()]
+
+    def __enter__(self):
+        self.state = [p.requires_grad for p in self.params]
+        for p in self.params:
+            p.requires_grad_(False)
+        return self
+
+    def __exit__(self, *exc):
+        for p, r in zip(self.params, self.state):
+            p.requires_grad_(r)
+        return False
 
 
 def feature_loss(fmap_r, fmap_g):
