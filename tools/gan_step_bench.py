@@ -138,6 +138,7 @@ def main():
           f'({B * T * 320 / dt / 1e6:.2f} M samples/s trained), loss_gen {loss_gen_all.item():.4f}')
     for k, v in times.items():
         print(f'    {k:45s} {v / steps * 1e3:8.1f} ms')
+    print(f'    peak device memory (torch allocator)          {torch.cuda.max_memory_allocated() / 2 ** 30:8.1f} GiB')
 
 
 if __name__ == '__main__':
