@@ -206,3 +206,51 @@ def test_frozen_discriminators_give_the_same_input_gradient(dev, kind):
     D.smooth_loss(outs2).backward()
     assert all(p.requires_grad for p in m2.parameters()) and all(p.grad is None for p in m2.parameters())
     assert torch.equal(yh.grad, gy)
+
+
+def _disc_ddp_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    res = {}
+    for kind in ('mpd', 'msd'):
+        spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
+        sd = synthetic.make_disc_state_dict(spec, seed=5)
+        y, y_hat = synthetic.make_audio_pair(4, 1800, seed=40)
+        lo, hi = rank * 2, rank * 2 + 2                                  # this rank's batch shard
+        ys, yhs = y[lo:hi].to(dev), y_hat[lo:hi].to(dev)
+        local = build(kind, sd, dev)
+        D.smooth_loss(local(ys, yhs)).backward()
+        ddp = DistributedDataParallel(build(kind, sd, dev))              # vec2wav/train.py:93-94
+        D.smooth_loss(ddp(ys, yhs)).backward()
+        res[kind] = ({k: p.grad.cpu() for k, p in local.named_parameters()},
+                     {k: p.grad.cpu() for k, p in ddp.module.named_parameters()})
+    torch.save(res, os.path.join(out_dir, f'disc_grad{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_ddp_wrapped_discriminators_two_ranks_one_gpu(dev, tmp_path):
+    """`DistributedDataParallel(mpd)` / `(msd)` (train.py:93-94) over the HIP autograd Functions: after backward both ranks hold the
+    same gradients and they are the average of the two ranks' own (un-wrapped) shard gradients.  (The discriminators have no
+    cross-sample statistics, so the path needs no collective of its own: the gradient all-reduce is DDP's.)"""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_disc_ddp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), 'disc_grad0.pt'))
+    r1 = torch.load(os.path.join(str(tmp_path), 'disc_grad1.pt'))
+    for kind in ('mpd', 'msd'):
+        (l0, d0), (l1, d1) = r0[kind], r1[kind]
+        for k in d0:
+            assert torch.equal(d0[k], d1[k]), (kind, k)
+            want = (l0[k] + l1[k]) / 2
+            assert (d0[k] - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1e-6), (kind, k)
