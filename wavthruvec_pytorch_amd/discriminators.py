@@ -398,21 +398,21 @@ class DiscriminatorP(_DiscBase):
         return p, H
 
 
+def _pairwise(discs, inputs):
+    """Run every discriminator on its (y, y_hat) pair -> (scores_real, scores_generated, fmaps_real, fmaps_generated)."""
+    outs = [(d(y), d(y_hat)) for d, (y, y_hat) in zip(discs, inputs)]
+    return ([r[0] for r, _ in outs], [g[0] for _, g in outs], [r[1] for r, _ in outs], [g[1] for _, g in outs])
+
+
 class MultiPeriodDiscriminator(nn.Module):
-    """models.py:196-216."""
+    """models.py:196-216: one DiscriminatorP per period of `hp.periods`, each applied to y then y_hat."""
 
     def __init__(self, hp):
         super().__init__()
         self.discriminators = nn.ModuleList([DiscriminatorP(prd) for prd in hp.periods])
 
     def forward(self, y, y_hat):
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d in self.discriminators:
-            y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
-            y_d_rs.append(y_d_r); fmap_rs.append(fmap_r)
-            y_d_gs.append(y_d_g); fmap_gs.append(fmap_g)
-        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+        return _pairwise(self.discriminators, [(y, y_hat)] * len(self.discriminators))
 
 
 class DiscriminatorS(_DiscBase):
@@ -465,7 +465,7 @@ class _MeanPool(nn.Module):
 
 
 class MultiScaleDiscriminator(nn.Module):
-    """models.py:246-275."""
+    """models.py:246-275: a spectral-normed and two weight-normed DiscriminatorS on the 1x, 1/2x, 1/4x mean-pooled audio."""
 
     def __init__(self):
         super().__init__()
@@ -473,16 +473,10 @@ class MultiScaleDiscriminator(nn.Module):
         self.meanpools = nn.ModuleList([_MeanPool(), _MeanPool()])
 
     def forward(self, y, y_hat):
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for i, d in enumerate(self.discriminators):
-            if i != 0:
-                y = self.meanpools[i - 1](y)
-                y_hat = self.meanpools[i - 1](y_hat)
-            y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
-            y_d_rs.append(y_d_r); fmap_rs.append(fmap_r)
-            y_d_gs.append(y_d_g); fmap_gs.append(fmap_g)
-        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+        pyramid = [(y, y_hat)]
+        for pool in self.meanpools:
+            pyramid.append((pool(pyramid[-1][0]), pool(pyramid[-1][1])))
+        return _pairwise(self.discriminators, pyramid)
 
 
 class frozen:
@@ -508,33 +502,21 @@ class frozen:
 
 
 def feature_loss(fmap_r, fmap_g):
-    """models.py:278-284."""
-    loss = 0
-    for dr, dg in zip(fmap_r, fmap_g):
-        for rl, gl in zip(dr, dg):
-            loss += torch.mean(torch.abs(rl - gl))
-    return loss * 2
+    """2 x the sum over every feature map of mean |real - generated| (models.py:278-284)."""
+    terms = [torch.mean(torch.abs(real - fake)) for maps_r, maps_g in zip(fmap_r, fmap_g) for real, fake in zip(maps_r, maps_g)]
+    return 2 * sum(terms)
 
 
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
-    """models.py:287-299."""
-    loss = 0
-    r_losses, g_losses = [], []
-    for dr, dg in zip(disc_real_outputs, disc_generated_outputs):
-        r_loss = torch.mean((1 - dr) ** 2)
-        g_loss = torch.mean(dg ** 2)
-        loss += (r_loss + g_loss)
-        r_losses.append(r_loss.item())
-        g_losses.append(g_loss.item())
-    return loss, r_losses, g_losses
+    """LSGAN discriminator loss: sum over discriminators of mean (1 - D(y))^2 + mean D(y_hat)^2; also the per-discriminator
+    values as Python floats (models.py:287-299)."""
+    real_terms = [torch.mean((1 - score) ** 2) for score in disc_real_outputs]
+    fake_terms = [torch.mean(score ** 2) for score in disc_generated_outputs]
+    total = sum(r + f for r, f in zip(real_terms, fake_terms))
+    return total, [t.item() for t in real_terms], [t.item() for t in fake_terms]
 
 
 def generator_loss(disc_outputs):
-    """models.py:302-310."""
-    loss = 0
-    gen_losses = []
-    for dg in disc_outputs:
-        l = torch.mean((1 - dg) ** 2)
-        gen_losses.append(l)
-        loss += l
-    return loss, gen_losses
+    """LSGAN generator loss: sum over discriminators of mean (1 - D(y_hat))^2, and the terms (models.py:302-310)."""
+    terms = [torch.mean((1 - score) ** 2) for score in disc_outputs]
+    return sum(terms), terms
