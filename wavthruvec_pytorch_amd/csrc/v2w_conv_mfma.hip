@@ -26,9 +26,10 @@
 
 namespace {
 
-// MASK: the backward-only epilogue (leaky_relu-derivative mask) is compiled in.  It costs 8 VGPRs (one occupancy step on
-// the 128 x 128 tile), so forward launches use the MASK = false instantiation.
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, bool MASK>
+// EPI: which optional epilogue is compiled in.  0 = none (the generator's forward kernels).  1 = the backward-only leaky_relu-
+// derivative mask (+ out_slope): it costs 8 VGPRs (one occupancy step on the 128 x 128 tile, 5-12 % of a layer's time), so it is
+// its own instantiation.  2 = out_slope only (the discriminators' activated feature maps): no extra registers.
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_tile_kernel(const MultiArgs m) {
     typedef Frag<MF> F;
@@ -253,6 +254,7 @@ conv_tile_kernel(const MultiArgs m) {
             constexpr int EG = (MI == 1 && F::NREG >= 8) ? 8 : 4;
 #pragma unroll
             for (int e0 = 0; e0 < F::NREG; e0 += EG) {
+                constexpr bool MASK = EPI == 1;
                 float rv[EG][NI], ov[EG][NI], o2[EG][NI], mv[MASK ? EG : 1][MASK ? NI : 1];
 #pragma unroll
                 for (int ee = 0; ee < EG; ++ee) {
@@ -285,7 +287,7 @@ conv_tile_kernel(const MultiArgs m) {
                         if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
                         else if (p.accumulate || p.add0) v += ov[ee][j];
                         if (p.out_div != 0.f) v = v / p.out_div;
-                        if constexpr (MASK)   // (shares the instantiation so the forward kernels keep their register budget)
+                        if constexpr (EPI != 0)   // (not in the EPI = 0 instantiations: the forward kernels keep their exact code)
                             if (p.out_slope != 1.f) v = v > 0.f ? v : v * p.out_slope;
                         p.out[orow + q] = v;
                     }
@@ -402,9 +404,13 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     for (int i = nprob; i <= V2W_MAX_MULTI; ++i) m.start[i] = i == nprob ? grid : 0x7fffffff;
     m.start[nprob] = grid;
     for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
-    bool mask = false;
-    for (int i = 0; i < nprob; ++i) mask = mask || m.p[i].mask_src != nullptr || m.p[i].out_slope != 1.f;
-    auto kern = mask ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, false>;
+    int epi = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if (m.p[i].mask_src != nullptr) epi = 1;
+        else if (m.p[i].out_slope != 1.f && epi == 0) epi = 2;
+    }
+    auto kern = epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1>
+              : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0>);
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -265,7 +265,7 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
         rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
     if rc != 0:
         return None
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', false>'   # forward instantiation (MASK = false)
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0>'   # forward instantiation (EPI = 0: no optional epilogue)
 
 
 def convt_stats_tiles(B, c_in, c_out, L, k, u):
