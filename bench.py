@@ -28,6 +28,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA = f32 vect
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def baseline_metric() -> str:
+    """The metric string of BASELINE.json (the file travels with the repo); the built-in name if it is missing."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'BASELINE.json')) as f:
+            return json.load(f)['metric']
+    except Exception:
+        return 'audio samples/sec (16 kHz) Vec2Wav generator forward'
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually run on: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -273,7 +282,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            'metric': 'audio samples/sec (16 kHz) Vec2Wav generator forward',
+            'metric': baseline_metric(),
             'value': samples_per_step * args.steps / elapsed,
             'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
