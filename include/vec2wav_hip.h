@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 19
+#define V2W_ABI_VERSION 20
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -365,7 +365,9 @@ int v2w_avgpool4(const float* x, float* out, int B, int L, void* stream);
 int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                     int k, int dil, int tap0, int x_ct, int dy_ct, void* stream);
 /* every group of a grouped Conv1d in one launch per tap group (grid.z = group): x (B, G*c_in, Lq), dy (B, G*c_out, Lq),
- * dwf [G][k][c_in][c_out]; slab_ws: G * v2w_wgrad_slabs(B, c_in, c_out, Lq) * k*c_in*c_out floats */
+ * dwf [G][k][c_in][c_out]; slab_ws: G * v2w_wgrad_group_slabs(B, c_in, c_out, Lq, G) * k*c_in*c_out floats (the position splits
+ * that fill the GPU are shared out over the G groups of the launch) */
+int v2w_wgrad_group_slabs(int B, int c_in, int c_out, int Lq, int ngroups);
 int v2w_wgrad_groups(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                      int k, int dil, int tap0, int ngroups, void* stream);
 int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope, void* stream);

@@ -367,7 +367,7 @@ wgrad_reduce_kernel(const float* slab, float* dwf, size_t n, int nslab) {
 // Wave arrangement of a workgroup's 4 waves over (C_out, C_in, positions) and the number of partial slabs.  Conv1d (u = 1):
 // 2 x 2 x 1 when both channel counts allow two MFMA row blocks, else 1 x 1 x 4 - the shapes the pipelined kernel is instantiated
 // for (a mixed 2 x 1 would take the scalar kernel).  Transposed convs keep the arrangement their instantiations were tuned with.
-static int v2w_wgrad_plan(int B, int c_in, int c_out, int Lq, int u, int* mf_o, int* wco_o, int* wci_o) {
+static int v2w_wgrad_plan(int B, int c_in, int c_out, int Lq, int u, int* mf_o, int* wco_o, int* wci_o, int ngroups = 1) {
     const int mf = (c_out % 32 == 0 && c_in % 32 == 0) ? 32 : ((c_out % 16 == 0 && c_in % 16 == 0) ? 16 : 0);
     if (!mf) return 0;
     int wco = 1, wci = 1;
@@ -380,7 +380,7 @@ static int v2w_wgrad_plan(int B, int c_in, int c_out, int Lq, int u, int* mf_o, 
     const int wp = 4 / (wco * wci);
     const int tiles = (c_out / (wco * mf)) * (c_in / (wci * mf));
     const int items = B * ((Lq + 127) / 128);
-    int S = (2 * 256 + tiles - 1) / tiles;       // ~2 workgroups per CU in flight
+    int S = (2 * 256 + tiles * ngroups - 1) / (tiles * ngroups);       // ~2 workgroups per CU in flight (all groups of one launch together)
     if (S > items) S = items;
     if (S < 1) S = 1;
     if (mf_o) { *mf_o = mf; *wco_o = wco; *wci_o = wci; }
@@ -413,8 +413,14 @@ extern "C" int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, floa
     return wgrad_impl(x, nullptr, nullptr, dy, dwf, slab_ws, B, c_in, c_out, Lq, k, dil, 1, 1.f, tap0, x_ct, dy_ct, 1, stream);
 }
 
+// Slabs PER GROUP of v2w_wgrad_groups (the position splits are shared out over the groups of the launch); 0 = unsupported shape.
+extern "C" int v2w_wgrad_group_slabs(int B, int c_in, int c_out, int Lq, int ngroups) {
+    if (ngroups < 1) return 0;
+    return v2w_wgrad_plan(B, c_in, c_out, Lq, 1, nullptr, nullptr, nullptr, ngroups);
+}
+
 // All `ngroups` groups of a grouped Conv1d in ONE launch per tap group (grid.z = group): x (B, ngroups*c_in, Lq), dy (B, ngroups*c_out, Lq),
-// dwf [ngroups][k][c_in][c_out]; slab_ws: ngroups * v2w_wgrad_slabs(...) * k*c_in*c_out floats.
+// dwf [ngroups][k][c_in][c_out]; slab_ws: ngroups * v2w_wgrad_group_slabs(...) * k*c_in*c_out floats.
 extern "C" int v2w_wgrad_groups(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                                 int k, int dil, int tap0, int ngroups, void* stream) {
     if (tap0 < -1 || tap0 >= k || ngroups < 1 || ngroups > 65535) return V2W_E_ARG;
@@ -426,7 +432,7 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
     if (!x || !dy || !dwf || !slab_ws || B <= 0 || c_in <= 0 || c_out <= 0 || Lq <= 0 || k <= 0 || dil <= 0 || u <= 0) return V2W_E_ARG;
     if ((x_a == nullptr) != (x_s == nullptr)) return V2W_E_ARG;
     int mf = 0, wco = 1, wci = 1;
-    const int nslab = v2w_wgrad_plan(B, c_in, c_out, Lq, u, &mf, &wco, &wci);
+    const int nslab = v2w_wgrad_plan(B, c_in, c_out, Lq, u, &mf, &wco, &wci, ngroups);
     if (!nslab) return V2W_E_SHAPE;
     WgradArgs p{};
     p.x = x; p.x_a = x_a; p.x_s = x_s; p.dy = dy; p.slab = slab_ws;

@@ -338,7 +338,7 @@ class _DiscFn(torch.autograd.Function):
                         raise _hip.HipLibraryError(f'v2w_wgrad_slice: no configuration for C_in={cigp}, C_out={cog}')
                     dwg = torch.empty((G, kp, cigp, cog), device=dev)
                     if _WGRAD_GROUPED:
-                        slab = torch.empty((G * ns * kp * cigp * cog,), device=dev)
+                        slab = torch.empty((G * lib.v2w_wgrad_group_slabs(B, cigp, cog, P, G) * kp * cigp * cog,), device=dev)
                         _hip.check(lib.v2w_wgrad_groups(xs.data_ptr(), dz.data_ptr(), dwg.data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil,
                                                         Q, G, stream), 'v2w_wgrad_groups')
                     else:
