@@ -682,3 +682,180 @@ def test_mel_spectrogram_backward_matches_oracle_autograd(dev, B, L):
     assert (yd.grad.cpu().double() - yo.grad).abs().max().item() <= 1e-3 * yo.grad.abs().max().item()
     # no graph when the input does not ask for one
     assert not mel_spectrogram(y0.to(dev), *args).requires_grad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# entry points of the discriminator path (include/vec2wav_hip.h: v2w_phase_split ... v2w_wgrad_groups), one by one
+def _lib_stream(dev):
+    from wavthruvec_pytorch_amd import _hip
+    return _hip, _hip.load(), torch.cuda.current_stream(dev).cuda_stream
+
+
+@pytest.mark.parametrize('B,C,Cg,L,inner,s', [(2, 8, 8, 37, 1, 2), (2, 12, 4, 50, 1, 4), (1, 6, 6, 20, 13, 3), (3, 4, 2, 7, 5, 3)])
+def test_phase_split_and_merge(dev, B, C, Cg, L, inner, s):
+    """v2w_phase_split against its definition (pitched rows, zero tails), v2w_phase_merge as its exact inverse on the valid part."""
+    _hip, lib, st = _lib_stream(dev)
+    r = _rng(3)
+    U = -(-L // s)
+    ip, op = (L * inner + 3) // 4 * 4, (U * inner + 3) // 4 * 4
+    x = torch.zeros(B, C, ip)
+    x[:, :, :L * inner] = torch.from_numpy(r.standard_normal((B, C, L * inner)).astype(np.float32))
+    xd = x.to(dev)
+    out = torch.full((B, s * C, op), float('nan'), device=dev)
+    _hip.check(lib.v2w_phase_split(xd.data_ptr(), out.data_ptr(), B, C, Cg, L, inner, s, ip, op, st), 'v2w_phase_split')
+    x4 = x[:, :, :L * inner].view(B, C, L, inner)
+    want = torch.zeros(B, s * C, op)
+    for c in range(C):
+        for rr in range(s):
+            rows = x4[:, c, rr::s, :]                                  # (B, n_u, inner)
+            cs = ((c // Cg) * s + rr) * Cg + c % Cg
+            want[:, cs, :rows.shape[1] * inner] = rows.reshape(B, -1)
+    assert torch.equal(out.cpu(), want)
+    back = torch.full((B, C, ip), float('nan'), device=dev)
+    _hip.check(lib.v2w_phase_merge(out.data_ptr(), back.data_ptr(), B, C, Cg, L, inner, s, op, ip, st), 'v2w_phase_merge')
+    assert torch.equal(back.cpu()[:, :, :L * inner], x[:, :, :L * inner])
+
+
+@pytest.mark.parametrize('B,T,inner,s,k,pad', [(2, 1000, 13, 3, 5, 2), (1, 250, 19, 3, 5, 2), (3, 333, 1, 1, 15, 7)])
+def test_unfold1_and_its_adjoint(dev, B, T, inner, s, k, pad):
+    """v2w_unfold1 (right reflect pad to a multiple of `inner`, k shifted rows) against torch, v2w_fold1 as its adjoint:
+    <unfold1(x), y> == <x, fold1(y)>."""
+    _hip, lib, st = _lib_stream(dev)
+    r = _rng(4)
+    H = -(-T // inner)
+    U = (H + 2 * pad - k) // s + 1
+    P = (U * inner + 3) // 4 * 4
+    x = torch.from_numpy(r.standard_normal((B, T)).astype(np.float32))
+    out = torch.full((B, 16, P), float('nan'), device=dev)
+    xd = x.to(dev)                        # (device copies are held in variables: a temporary would be freed before the launch)
+    _hip.check(lib.v2w_unfold1(xd.data_ptr(), out.data_ptr(), B, T, H, inner, s, k, pad, 16, P, st), 'v2w_unfold1')
+    xp = F.pad(x.unsqueeze(1), (0, H * inner - T), 'reflect').squeeze(1) if H * inner > T else x
+    x2 = F.pad(xp.view(B, H, inner), (0, 0, pad, pad))                # zero rows above / below
+    want = torch.zeros(B, 16, P)
+    for j in range(k):
+        rows = x2[:, j:j + s * (U - 1) + 1:s, :]                       # (B, U, inner)
+        want[:, j, :U * inner] = rows.reshape(B, -1)
+    assert torch.equal(out.cpu(), want)
+    y = torch.zeros(B, 16, P)
+    y[:, :k, :U * inner] = torch.from_numpy(r.standard_normal((B, k, U * inner)).astype(np.float32))
+    dx = torch.full((B, T), float('nan'), device=dev)
+    yd = y.to(dev)
+    _hip.check(lib.v2w_fold1(yd.data_ptr(), dx.data_ptr(), B, T, H, inner, s, k, pad, 16, P, st), 'v2w_fold1')
+    lhs = (want.double() * y.double()).sum().item()
+    rhs = (x.double() * dx.cpu().double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize('B,L', [(2, 100), (3, 101), (1, 7)])
+def test_avgpool4_and_backward(dev, B, L):
+    _hip, lib, st = _lib_stream(dev)
+    x = torch.from_numpy(_rng(5).standard_normal((B, 1, L)).astype(np.float32)).requires_grad_(True)
+    want = F.avg_pool1d(x, 4, 2, padding=2)
+    g = torch.from_numpy(_rng(6).standard_normal(tuple(want.shape)).astype(np.float32))
+    want.backward(g)
+    out = torch.empty((B, L // 2 + 1), device=dev)
+    xd, gd = x.detach().to(dev), g.to(dev)
+    _hip.check(lib.v2w_avgpool4(xd.data_ptr(), out.data_ptr(), B, L, st), 'v2w_avgpool4')
+    assert out.shape[1] == want.shape[2] and (out.cpu() - want.detach().squeeze(1)).abs().max().item() <= 1e-6
+    dx = torch.empty((B, L), device=dev)
+    _hip.check(lib.v2w_avgpool4_bwd(gd.data_ptr(), dx.data_ptr(), B, L, st), 'v2w_avgpool4_bwd')
+    assert (dx.cpu() - x.grad.squeeze(1)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('G,cig,cog,k,L', [(4, 32, 32, 5, 200), (16, 16, 16, 3, 96), (2, 64, 64, 7, 130), (16, 64, 64, 41, 64)])
+def test_grouped_conv_slices_out_slope_and_wgrad_groups(dev, G, cig, cog, k, L):
+    """One group per problem through in_ct / out_ct (four per launch), leaky_relu on the stored value (out_slope), the input
+    gradient with the transposed tap-flipped weights and v2w_wgrad_groups - against torch's grouped Conv1d and its autograd."""
+    from wavthruvec_pytorch_amd import hipops
+    _hip, lib, st = _lib_stream(dev)
+    r = _rng(7)
+    B = 2
+    x = torch.from_numpy(r.standard_normal((B, G * cig, L)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((r.standard_normal((G * cog, cig, k)) / np.sqrt(cig * k)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(r.standard_normal(G * cog).astype(np.float32))
+    z = F.conv1d(x, w, b, padding=(k - 1) // 2, groups=G)
+    want = F.leaky_relu(z, 0.1)
+    gz = torch.from_numpy(r.standard_normal(tuple(z.shape)).astype(np.float32))
+    z.backward(gz)
+    w4 = w.detach().view(G, cog, cig, k).permute(0, 3, 2, 1).contiguous().to(dev)          # [G][k][cig][cog]
+    wp = hipops.pack_mfma_batch(w4)
+    xd, bd = x.detach().to(dev), b.to(dev)
+    out = torch.full((B, G * cog, L), float('nan'), device=dev)
+    probs = [(xd, w4[g], bd[g * cog:(g + 1) * cog], out, dict(k=k, dil=1, slope=1.0, out_slope=0.1, wp=wp[g], group=(g, cig, cog)))
+             for g in range(G)]
+    for i in range(0, G, 4):
+        hipops.conv1d_multi(probs[i:i + 4])
+    assert (out.cpu() - want.detach()).abs().max().item() <= 3e-5
+    # input gradient
+    gzd = gz.to(dev)
+    wT4 = w4.flip(1).transpose(2, 3).contiguous()
+    wTp = hipops.pack_mfma_batch(wT4)
+    dx = torch.full((B, G * cig, L), float('nan'), device=dev)
+    for g in range(G):
+        hipops.conv1d(gzd, wT4[g], None, dx, k=k, dil=1, slope=1.0, wp=wTp[g], group=(g, cog, cig))
+    assert (dx.cpu() - x.grad).abs().max().item() <= 3e-5 * max(1.0, x.grad.abs().max().item())
+    # weight gradient, all groups in one launch
+    ns = lib.v2w_wgrad_group_slabs(B, cig, cog, L, G)
+    assert 0 < ns <= lib.v2w_wgrad_slabs(B, cig, cog, L)
+    slab = torch.empty((G * ns * k * cig * cog,), device=dev)
+    dw = torch.full((G, k, cig, cog), float('nan'), device=dev)
+    _hip.check(lib.v2w_wgrad_groups(xd.data_ptr(), gzd.data_ptr(), dw.data_ptr(), slab.data_ptr(), B, cig, cog, L, k, 1, -1, G, st),
+               'v2w_wgrad_groups')
+    ref = w.grad.view(G, cog, cig, k).permute(0, 3, 2, 1)
+    assert (dw.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('B,C,L,k,dil,tap0', [(2, 64, 100, 3, 1, 1), (3, 128, 57, 3, 13, 1), (1, 32, 40, 2, 5, 1)])
+def test_cout1_conv_and_wgrad(dev, B, C, L, k, dil, tap0):
+    """The C_out = 1 reduction kernel behind v2w_conv1d_fwd (conv_post of the discriminators) and v2w_cout1_wgrad."""
+    from wavthruvec_pytorch_amd import hipops
+    _hip, lib, st = _lib_stream(dev)
+    r = _rng(8)
+    x = torch.from_numpy(r.standard_normal((B, C, L)).astype(np.float32))
+    w = torch.from_numpy((r.standard_normal((1, C, k)) / np.sqrt(C * k)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(r.standard_normal(1).astype(np.float32))
+    xp = F.pad(x, (tap0 * dil, dil * (k - 1) - tap0 * dil))
+    want = F.conv1d(xp, w, b, dilation=dil)
+    g = torch.from_numpy(r.standard_normal(tuple(want.shape)).astype(np.float32))
+    want.backward(g)
+    wf = w.detach().permute(2, 1, 0).contiguous().to(dev)
+    out = torch.full((B, 1, L), float('nan'), device=dev)
+    xd, bd, gd = x.to(dev), b.to(dev), g.to(dev)
+    hipops.conv1d(xd, wf, bd, out, k=k, dil=dil, slope=1.0, pad_left=tap0 * dil)
+    assert (out.cpu() - want.detach()).abs().max().item() <= 2e-5
+    dwf = torch.full((k, C, 1), float('nan'), device=dev)
+    _hip.check(lib.v2w_cout1_wgrad(xd.data_ptr(), gd.data_ptr(), dwf.data_ptr(), B, C, L, k, dil, tap0, st),
+               'v2w_cout1_wgrad')
+    assert (dwf.cpu() - w.grad.permute(2, 1, 0)).abs().max().item() <= 1e-4 * max(1.0, w.grad.abs().max().item())
+
+
+def test_disc_dz_and_merge_and_zero_tail(dev):
+    """v2w_disc_dz / v2w_disc_dz_merge (gradient sum x leaky_relu' of the ACTIVATED map, zero pitch tail) and v2w_zero_tail."""
+    _hip, lib, st = _lib_stream(dev)
+    r = _rng(9)
+    B, C, L, inner, s, Cg = 2, 6, 10, 3, 2, 3
+    valid, P = L * inner, (L * inner + 3) // 4 * 4
+    f = torch.from_numpy(r.standard_normal((B, C, P)).astype(np.float32))
+    g = torch.from_numpy(r.standard_normal((B, C, valid)).astype(np.float32))
+    d = torch.from_numpy(r.standard_normal((B, C, P)).astype(np.float32))
+    mask = torch.where(f[:, :, :valid] > 0, torch.tensor(1.0), torch.tensor(0.1))
+    dz = torch.full((B, C, P), float('nan'), device=dev)
+    fd, gd, dd = f.to(dev), g.to(dev), d.to(dev)
+    _hip.check(lib.v2w_disc_dz(fd.data_ptr(), gd.data_ptr(), dd.data_ptr(), dz.data_ptr(), B * C, P, valid, 0.1, st),
+               'v2w_disc_dz')
+    assert torch.equal(dz.cpu()[:, :, valid:], torch.zeros(B, C, P - valid))
+    assert (dz.cpu()[:, :, :valid] - (g + d[:, :, :valid]) * mask).abs().max().item() <= 1e-6
+    # merge form: d given as the phase-stacked gradient of a stride-s layer
+    U = -(-L // s)
+    dp = (U * inner + 3) // 4 * 4
+    dxs = torch.from_numpy(r.standard_normal((B, s * C, dp)).astype(np.float32)).to(dev)
+    merged = torch.full((B, C, P), float('nan'), device=dev)
+    _hip.check(lib.v2w_phase_merge(dxs.data_ptr(), merged.data_ptr(), B, C, Cg, L, inner, s, dp, P, st), 'v2w_phase_merge')
+    dz2 = torch.full((B, C, P), float('nan'), device=dev)
+    _hip.check(lib.v2w_disc_dz_merge(fd.data_ptr(), gd.data_ptr(), dxs.data_ptr(), dz2.data_ptr(), B, C, Cg, L, inner, s, dp, P,
+                                     0.1, st), 'v2w_disc_dz_merge')
+    want = (g + merged.cpu()[:, :, :valid]) * mask
+    assert (dz2.cpu()[:, :, :valid] - want).abs().max().item() <= 1e-6 and torch.equal(dz2.cpu()[:, :, valid:], torch.zeros(B, C, P - valid))
+    t = torch.ones((B * C, P), device=dev)
+    _hip.check(lib.v2w_zero_tail(t.data_ptr(), B * C, P, valid, st), 'v2w_zero_tail')
+    assert torch.equal(t.cpu()[:, :valid], torch.ones(B * C, valid)) and torch.equal(t.cpu()[:, valid:], torch.zeros(B * C, P - valid))
