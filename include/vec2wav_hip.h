@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 20
+#define V2W_ABI_VERSION 21
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -370,10 +370,14 @@ int v2w_wgrad_slice(const float* x, const float* dy, float* dwf, float* slab_ws,
 int v2w_wgrad_group_slabs(int B, int c_in, int c_out, int Lq, int ngroups);
 int v2w_wgrad_groups(const float* x, const float* dy, float* dwf, float* slab_ws, int B, int c_in, int c_out, int Lq,
                      int k, int dil, int tap0, int ngroups, void* stream);
-int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope, void* stream);
+/* rowsum (optional, one float per row): the sum of each dz row, produced by the same pass; v2w_rowsum_reduce adds them over the
+ * batch items (fp64, fixed order) into the bias gradient db (C). */
+int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, float* rowsum, long long rows, int pitch, int valid, float slope,
+                void* stream);
+int v2w_rowsum_reduce(const float* rowsum, float* db, int B, int C, void* stream);
 /* v2w_disc_dz with d in the phase-stacked form dxs (B, s*C, dpitch) of the strided layer above (v2w_phase_merge folded in) */
-int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, int B, int C, int Cg, int L, int inner, int s,
-                      int dpitch, int pitch, float slope, void* stream);
+int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, float* rowsum, int B, int C, int Cg, int L, int inner,
+                      int s, int dpitch, int pitch, float slope, void* stream);
 int v2w_phase_merge(const float* dxs, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch, void* stream);
 int v2w_fold1(const float* dxu, float* dx, int B, int T, int H, int inner, int s, int k, int pad, int rows, int ipitch, void* stream);
 int v2w_avgpool4_bwd(const float* dout, float* dx, int B, int L, void* stream);

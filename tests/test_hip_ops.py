@@ -841,8 +841,12 @@ def test_disc_dz_and_merge_and_zero_tail(dev):
     mask = torch.where(f[:, :, :valid] > 0, torch.tensor(1.0), torch.tensor(0.1))
     dz = torch.full((B, C, P), float('nan'), device=dev)
     fd, gd, dd = f.to(dev), g.to(dev), d.to(dev)
-    _hip.check(lib.v2w_disc_dz(fd.data_ptr(), gd.data_ptr(), dd.data_ptr(), dz.data_ptr(), B * C, P, valid, 0.1, st),
+    rs = torch.full((B * C,), float('nan'), device=dev)
+    _hip.check(lib.v2w_disc_dz(fd.data_ptr(), gd.data_ptr(), dd.data_ptr(), dz.data_ptr(), rs.data_ptr(), B * C, P, valid, 0.1, st),
                'v2w_disc_dz')
+    db = torch.full((C,), float('nan'), device=dev)
+    _hip.check(lib.v2w_rowsum_reduce(rs.data_ptr(), db.data_ptr(), B, C, st), 'v2w_rowsum_reduce')
+    assert (db.cpu() - ((g + d[:, :, :valid]) * mask).sum(dim=(0, 2))).abs().max().item() <= 1e-5
     assert torch.equal(dz.cpu()[:, :, valid:], torch.zeros(B, C, P - valid))
     assert (dz.cpu()[:, :, :valid] - (g + d[:, :, :valid]) * mask).abs().max().item() <= 1e-6
     # merge form: d given as the phase-stacked gradient of a stride-s layer
@@ -852,7 +856,7 @@ def test_disc_dz_and_merge_and_zero_tail(dev):
     merged = torch.full((B, C, P), float('nan'), device=dev)
     _hip.check(lib.v2w_phase_merge(dxs.data_ptr(), merged.data_ptr(), B, C, Cg, L, inner, s, dp, P, st), 'v2w_phase_merge')
     dz2 = torch.full((B, C, P), float('nan'), device=dev)
-    _hip.check(lib.v2w_disc_dz_merge(fd.data_ptr(), gd.data_ptr(), dxs.data_ptr(), dz2.data_ptr(), B, C, Cg, L, inner, s, dp, P,
+    _hip.check(lib.v2w_disc_dz_merge(fd.data_ptr(), gd.data_ptr(), dxs.data_ptr(), dz2.data_ptr(), None, B, C, Cg, L, inner, s, dp, P,
                                      0.1, st), 'v2w_disc_dz_merge')
     want = (g + merged.cpu()[:, :, :valid]) * mask
     assert (dz2.cpu()[:, :, :valid] - want).abs().max().item() <= 1e-6 and torch.equal(dz2.cpu()[:, :, valid:], torch.zeros(B, C, P - valid))

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -107,8 +107,9 @@ SIGNATURES = {
     'v2w_wgrad_slice': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp]),
     'v2w_wgrad_group_slabs': (C.c_int, [C.c_int] * 5),
     'v2w_wgrad_groups': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp]),
-    'v2w_disc_dz': (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_float, _fp]),
-    'v2w_disc_dz_merge': (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [C.c_float, _fp]),
+    'v2w_disc_dz': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_float, _fp]),
+    'v2w_rowsum_reduce': (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    'v2w_disc_dz_merge': (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 8 + [C.c_float, _fp]),
     'v2w_phase_merge': (C.c_int, [_fp, _fp] + [C.c_int] * 8 + [_fp]),
     'v2w_fold1': (C.c_int, [_fp, _fp] + [C.c_int] * 9 + [_fp]),
     'v2w_avgpool4_bwd': (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),

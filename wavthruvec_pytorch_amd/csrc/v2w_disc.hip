@@ -170,49 +170,64 @@ extern "C" int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, 
 namespace {
 
 // dz = (g + d) * lrelu'(f): g = gradient that arrived on the returned feature map (dense (rows, valid) or NULL), d = input
-// gradient of the next conv (pitched, or NULL), f = the ACTIVATED map (sign(f) = sign of the pre-activation since slope > 0).
-// slope == 1: no activation (conv_post).  The pitch tail is written as 0: those columns are ordinary positions to the kernels.
+// gradient of the next conv, f = the ACTIVATED map (sign(f) = sign of the pre-activation since slope > 0).  slope == 1: no
+// activation (conv_post).  The pitch tail is written as 0: those columns are ordinary positions to the kernels.
+// d comes either pitched like f (MERGE = false) or in the phase-stacked form dxs (B, s*C, dpitch) of the strided layer above
+// (MERGE = true, v2w_phase_merge folded in): d[b][c][l*inner + w] = dxs[b][((c/Cg)*s + l%s)*Cg + c%Cg][(l/s)*inner + w].
+// Row-structured: a block owns one (b, c) row (four rows, one wave each, when rows are short), so the per-row sum of dz - the bias
+// gradient's partial - falls out of the same pass (rowsum, optional; summed over b in fixed order by rowsum_reduce_kernel).
+template <bool MERGE>
 __global__ void __launch_bounds__(256)
-disc_dz_kernel(const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ d, float* __restrict__ dz,
-               long rows, int pitch, int valid, float slope) {
-    const long total = rows * pitch;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long row = idx / pitch;
-        const int t = (int)(idx - row * pitch);
-        float v = 0.f;
-        if (t < valid) {
-            v = (g ? g[row * valid + t] : 0.f) + (d ? d[idx] : 0.f);
-            if (slope != 1.f && !(f[idx] > 0.f)) v *= slope;
+disc_dz_rows_kernel(const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ d, float* __restrict__ dz,
+                    float* __restrict__ rowsum, long rows, int C, int Cg, int inner, int s, int dpitch, int pitch, int valid,
+                    float slope, int rpb) {
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = rpb == 1 ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
+    const int t0 = rpb == 1 ? threadIdx.x : lane, tstep = rpb == 1 ? 256 : 64;
+    float acc = 0.f;
+    if (row < rows) {
+        const long b = row / C;
+        const int c = (int)(row - b * C);
+        const float* fr = f + row * pitch;
+        const float* gr = g ? g + row * valid : nullptr;
+        float* zr = dz + row * pitch;
+        const float* dr = d ? (MERGE ? d + (size_t)b * s * C * dpitch : d + row * pitch) : nullptr;
+        const int csb = MERGE ? (c / Cg) * s * Cg + c % Cg : 0;
+        for (int t = t0; t < pitch; t += tstep) {
+            float v = 0.f;
+            if (t < valid) {
+                if (MERGE) {
+                    const int l = t / inner, w = t - l * inner;
+                    const int u = l / s, r = l - u * s;
+                    v = dr[(size_t)(csb + r * Cg) * dpitch + (size_t)u * inner + w];
+                } else if (dr) {
+                    v = dr[t];
+                }
+                if (gr) v += gr[t];
+                if (slope != 1.f && !(fr[t] > 0.f)) v *= slope;
+            }
+            zr[t] = v;
+            acc += v;
         }
-        dz[idx] = v;
+    }
+    if (!rowsum) return;                                  // (uniform over the block)
+    if (rpb == 1) {
+        const float tot = v2w_block_sum(acc, red);
+        if (threadIdx.x == 0) rowsum[row] = tot;
+    } else {
+        const float tot = v2w_wave_sum(acc);
+        if (lane == 0 && row < rows) rowsum[row] = tot;
     }
 }
 
-// disc_dz_kernel with the phase merge folded in: d is the input gradient of a strided layer in its phase-stacked form
-// dxs (B, s*C, dpitch); dz[b][c][l*inner + w] = (g + dxs[b][((c/Cg)*s + l%s)*Cg + c%Cg][(l/s)*inner + w]) * lrelu'(f)
-__global__ void __launch_bounds__(256)
-disc_dz_merge_kernel(const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ dxs, float* __restrict__ dz,
-                     int C, int Cg, int L, int inner, int s, int dpitch, int pitch, float slope) {
-    const int b = blockIdx.y;
-    const int valid = L * inner;
-    const size_t total = (size_t)C * pitch;
-    const float* fb = f + (size_t)b * total;
-    const float* gb = g ? g + (size_t)b * C * valid : nullptr;
-    const float* db = dxs + (size_t)b * s * C * dpitch;
-    float* ob = dz + (size_t)b * total;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx / pitch);
-        const int t = (int)(idx - (size_t)c * pitch);
-        float v = 0.f;
-        if (t < valid) {
-            const int l = t / inner, w = t - l * inner;
-            const int u = l / s, r = l - u * s;
-            const int cs = ((c / Cg) * s + r) * Cg + c % Cg;
-            v = db[(size_t)cs * dpitch + (size_t)u * inner + w] + (gb ? gb[(size_t)c * valid + t] : 0.f);
-            if (slope != 1.f && !(fb[idx] > 0.f)) v *= slope;
-        }
-        ob[idx] = v;
-    }
+// db[c] = sum_b rowsum[b][c], fp64 accumulation in fixed order
+__global__ void rowsum_reduce_kernel(const float* __restrict__ rowsum, float* __restrict__ db, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int b = 0; b < B; ++b) a += (double)rowsum[(size_t)b * C + c];
+    db[c] = (float)a;
 }
 
 // inverse of phase_split_kernel: out[b][c][l][w] = dxs[b][((c/Cg)*s + r)*Cg + c%Cg][u][w], l = s*u + r < L
@@ -299,13 +314,25 @@ cout1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, fl
 
 }  // namespace
 
-extern "C" int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, long long rows, int pitch, int valid, float slope,
-                           void* stream) {
-    if (!f || !dz || rows <= 0 || pitch <= 0 || valid < 0 || valid > pitch || slope <= 0.f) return V2W_E_ARG;
-    const long total = rows * pitch;
-    int gx = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(disc_dz_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, f, g, d, dz, (long)rows, pitch, valid, slope);
+static int disc_dz_launch(bool merge, const float* f, const float* g, const float* d, float* dz, float* rowsum, long rows, int C, int Cg,
+                          int inner, int s, int dpitch, int pitch, int valid, float slope, hipStream_t st) {
+    const int rpb = pitch > 256 ? 1 : 4;
+    const long blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 0x7fffffffL) return V2W_E_SHAPE;
+    if (merge)
+        hipLaunchKernelGGL(disc_dz_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
+                           dpitch, pitch, valid, slope, rpb);
+    else
+        hipLaunchKernelGGL(disc_dz_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
+                           dpitch, pitch, valid, slope, rpb);
     return v2w_launch_status();
+}
+
+// rowsum (optional, rows floats): the sum of every dz row - the bias gradient is v2w_rowsum_reduce over the batch items.
+extern "C" int v2w_disc_dz(const float* f, const float* g, const float* d, float* dz, float* rowsum, long long rows, int pitch, int valid,
+                           float slope, void* stream) {
+    if (!f || !dz || rows <= 0 || pitch <= 0 || valid < 0 || valid > pitch || slope <= 0.f) return V2W_E_ARG;
+    return disc_dz_launch(false, f, g, d, dz, rowsum, (long)rows, 1, 1, 1, 1, 0, pitch, valid, slope, (hipStream_t)stream);
 }
 
 extern "C" int v2w_phase_merge(const float* dxs, float* out, int B, int C, int Cg, int L, int inner, int s, int ipitch, int opitch,
@@ -349,13 +376,17 @@ extern "C" int v2w_cout1_wgrad(const float* x, const float* dz, float* dwf, int 
 
 // v2w_disc_dz with d given in the phase-stacked form of the strided layer above (v2w_phase_merge folded in): f, dz (B, C, pitch),
 // g dense (B, C, L*inner) or NULL, dxs (B, s*C, dpitch).
-extern "C" int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, int B, int C, int Cg, int L, int inner,
-                                 int s, int dpitch, int pitch, float slope, void* stream) {
+extern "C" int v2w_disc_dz_merge(const float* f, const float* g, const float* dxs, float* dz, float* rowsum, int B, int C, int Cg, int L,
+                                 int inner, int s, int dpitch, int pitch, float slope, void* stream) {
     if (!f || !dxs || !dz || B <= 0 || C <= 0 || Cg <= 0 || C % Cg || L <= 0 || inner <= 0 || s <= 0 || slope <= 0.f) return V2W_E_ARG;
     const int U = (L + s - 1) / s;
     if (pitch < L * inner || dpitch < U * inner) return V2W_E_ARG;
-    const size_t total = (size_t)C * pitch;
-    int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(disc_dz_merge_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, f, g, dxs, dz, C, Cg, L, inner, s, dpitch, pitch, slope);
+    return disc_dz_launch(true, f, g, dxs, dz, rowsum, (long)B * C, C, Cg, inner, s, dpitch, pitch, L * inner, slope, (hipStream_t)stream);
+}
+
+// db[c] = sum over the B batch items of rowsum[b][c] (fp64, fixed order): the bias gradient from v2w_disc_dz's row sums
+extern "C" int v2w_rowsum_reduce(const float* rowsum, float* db, int B, int C, void* stream) {
+    if (!rowsum || !db || B <= 0 || C <= 0) return V2W_E_ARG;
+    hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, rowsum, db, B, C);
     return v2w_launch_status();
 }

@@ -310,15 +310,19 @@ class _DiscFn(torch.autograd.Function):
                 g = g.contiguous().float()
             dz = torch.empty((B, C, P), device=dev)
             slope = LRELU_SLOPE if l + 1 < n else 1.0
+            rowsum = torch.empty((B * C,), device=dev) if ctx.need_dw else None     # bias gradient partials from the same pass
             if merge is not None:
                 dxs_up, cg_up, s_up = merge
-                _hip.check(lib.v2w_disc_dz_merge(f.data_ptr(), _hip.ptr(g), dxs_up.data_ptr(), dz.data_ptr(), B, C, cg_up, U, inner, s_up,
-                                                 dxs_up.shape[2], P, slope, stream), 'v2w_disc_dz_merge')
+                _hip.check(lib.v2w_disc_dz_merge(f.data_ptr(), _hip.ptr(g), dxs_up.data_ptr(), dz.data_ptr(), _hip.ptr(rowsum), B, C, cg_up, U,
+                                                 inner, s_up, dxs_up.shape[2], P, slope, stream), 'v2w_disc_dz_merge')
             else:
-                _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), B * C, P, valid, slope, stream),
-                           'v2w_disc_dz')
+                _hip.check(lib.v2w_disc_dz(f.data_ptr(), _hip.ptr(g), _hip.ptr(dnext), dz.data_ptr(), _hip.ptr(rowsum), B * C, P, valid, slope,
+                                           stream), 'v2w_disc_dz')
             dnext, merge = None, None
-            db = hipops.channel_sum(dz) if ctx.need_dw else None
+            db = None
+            if ctx.need_dw:
+                db = torch.empty((C,), device=dev)
+                _hip.check(lib.v2w_rowsum_reduce(rowsum.data_ptr(), db.data_ptr(), B, C, stream), 'v2w_rowsum_reduce')
             # the layer's stride-1 input: kept by the forward (the 16-row unfold of the first layer is rebuilt)
             xs = _unfold_first(layer, x, T, H, inner)[0] if l == 0 else st['xss'][l]
             G = layer.groups
