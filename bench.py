@@ -9,12 +9,16 @@ A "step" = one `Generator.forward` (train-mode CondBN: batch statistics, spectra
 weight-norm fold all inside the timed region) over one synthetic batch resident in HBM.
 Workload = BASELINE.json configs[1]: B=32 per GPU, T=256 frames, 768-d latents, x320, fp32, ResBlock2 (default hparams).
 N>1: one process per GPU, weak scaling (B=32 per rank), CondBN statistics all-reduced over RCCL each stage.
-Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment) starts the N ranks itself through
+torch.distributed.run - before anything touches a GPU - and exits non-zero when fewer than N devices are visible:
+it never reports a smaller run than the one asked for.  Rank 0 prints ONE JSON line.
 """
 import argparse
-from statistics import mean
+from statistics import mean, median
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,37 +54,71 @@ def usable_cpus() -> int:
     return n
 
 
-def cpu_baseline(h):
-    """The oracle (CPU restatement of the reference forward) timed on this box's host cores: a reported baseline.
+def _timed_oracle(O, sd, h, inp, training, threads, reps):
+    import torch
+    torch.set_num_threads(threads)
+    O.generator_forward(sd, h, *inp, training=training)          # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.generator_forward(sd, h, *inp, training=training)
+        ts.append(time.perf_counter() - t0)
+    return median(ts)
 
-    Bounded sample: B=4 x T=256 (1/8 of the cfg2 batch, same per-sample work), a short sweep over thread counts
-    (more threads than the problem can feed are slower), best median reported with the thread count used."""
+
+def cpu_baseline(h):
+    """The oracle (CPU restatement of the reference forward, oracle/vec2wav_oracle.py) timed on this box's host cores: a reported
+    baseline, never the target.  Bounded to ~30 s:
+      * cfg1 (BASELINE configs[0]: B=1, T=50, the reference's own CPU-runnable case): 1 thread and all usable cores, train and eval
+        mode, median of 3 after a warm-up (SURVEY 8(d) / BASELINE.md 4);
+      * the cfg2 sample B=4 x T=256 (1/8 of the cfg2 batch, same per-sample work) in train mode: short sweep over thread counts,
+        best median -> `value` / `cores` (more threads than the problem can feed are slower)."""
     from oracle import vec2wav_oracle as O
     from wavthruvec_pytorch_amd import synthetic
     sd = synthetic.make_state_dict(h, seed=0)
+    ncpu = usable_cpus()
+    up = synthetic.total_upsample(h)
+    t_end = time.time() + 40.0
+    cfg1 = {}
+    inp1 = synthetic.make_inputs(h, 1, 50, seed=1234)
+    for mode, training in (('train', True), ('eval', False)):
+        for th in sorted({1, ncpu}):
+            if time.time() > t_end:
+                break
+            cfg1[f'{mode}_threads{th}'] = 50 * up / _timed_oracle(O, sd, h, inp1, training, th, 3)
     B, T = 4, 256
     inp = synthetic.make_inputs(h, B, T, seed=1234)
-    ncpu = usable_cpus()
     cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
     best = None
-    t_budget = time.time() + 30.0
     for th in cands:
-        torch.set_num_threads(th)
-        O.generator_forward(sd, h, *inp, training=True)   # warm-up
-        times = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            O.generator_forward(sd, h, *inp, training=True)
-            times.append(time.perf_counter() - t0)
-        med = sorted(times)[1]
+        med = _timed_oracle(O, sd, h, inp, True, th, 3)
         if best is None or med < best[0]:
             best = (med, th)
-        if time.time() > t_budget:
+        if time.time() > t_end:
             break
     med, th = best
-    return dict(value=B * T * synthetic.total_upsample(h) / med, unit='samples/s', cores=th, kind='port',
+    return dict(value=B * T * up / med, unit='samples/s', cores=th, kind='port',
                 sample=f'oracle (torch CPU fp32 restatement of the reference forward), train mode, B={B} T={T} 768-d, '
-                       f'median of 3 at {th} threads (best of thread counts {cands}; {ncpu} usable CPUs)')
+                       f'median of 3 at {th} threads (best of thread counts {cands}; {ncpu} usable CPUs)',
+                cfg1_B1_T50_samples_per_s=cfg1)
+
+
+def self_launch(args) -> int:
+    """`--gpus N` (N > 1) without a launcher: start N ranks with torch.distributed.run as a CHILD process and pass its exit
+    code on.  Nothing here initialises the GPU (torch.cuda.device_count() does not), so no initialised process forks or execs."""
+    import torch
+    have = torch.cuda.device_count()
+    pinned = os.environ.get('V2W_BENCH_DEVICE') is not None      # test hook: every rank on one device
+    if have < (1 if pinned else args.gpus):
+        print(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible', file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -97,13 +135,19 @@ def main():
                     help="precision mode of the TIMED steps (default: exact fp32; the others are for profiling that mode)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the run asked for is not the run that was launched')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the Vec2Wav HIP path has no CPU fallback)')
+    if os.environ.get('V2W_BENCH_DEVICE') is None and torch.cuda.device_count() < world:
+        raise SystemExit(f'--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible')
     # test hooks for a 1-GPU box: V2W_BENCH_DEVICE pins every rank to one device, V2W_BENCH_BACKEND=gloo replaces RCCL
     dev_index = int(os.environ.get('V2W_BENCH_DEVICE', local_rank))
     backend = os.environ.get('V2W_BENCH_BACKEND', 'nccl')
@@ -137,17 +181,23 @@ def main():
             else:
                 dist.barrier()
 
+    # the timed region: EXACTLY `steps` forwards between barrier + synchronize pairs (wall clock -> `value`); HIP events on the
+    # launching stream bracket every step as well (event-timed median, reported beside the wall-clock mean)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     with torch.no_grad():
         for _ in range(args.warmup):
             g(x, spk, nz)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        evs[0].record()
+        for i in range(args.steps):
             g(x, spk, nz)
+            evs[i + 1].record()
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     def max_over_ranks(v):
         if world > 1:
             t = torch.tensor([v], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
@@ -156,6 +206,8 @@ def main():
         return v
 
     elapsed = max_over_ranks(elapsed)
+    event_median_ms = max_over_ranks(median(step_ms)) if step_ms else None
+    rccl_ranks = dist.get_world_size() if (world > 1 and backend == 'nccl') else (1 if world == 1 else None)
 
     # ---- the same step with Generator.precision = 'f16x3' (wide Conv1d layers on the f16 matrix pipe with split operands,
     # fp32 accumulation; same parity bar).  Reported BESIDE the exact-fp32 `value`, never instead of it.
@@ -285,7 +337,8 @@ def main():
             'metric': baseline_metric(),
             'value': samples_per_step * args.steps / elapsed,
             'unit': 'samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'ms_per_step_event_median': event_median_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'f16x3': 'f32 as f16 hi+lo (3 MFMA per product), f32 accumulate',
                       'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',

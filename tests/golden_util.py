@@ -17,7 +17,7 @@ def all_golden_names():
 
 def golden_names():
     """Generator cases (the discriminator fixtures are `disc_golden_names`)."""
-    return [n for n in all_golden_names() if not n.startswith('disc_')]
+    return [n for n in all_golden_names() if not n.startswith(('disc_', 'mel_'))]
 
 
 def load_golden(name):

@@ -145,3 +145,23 @@ def test_discriminator_state_dict_surface():
         mpd(y, y)
     with pytest.raises(RuntimeError):              # under autograd too: CPU tensors are refused, nothing falls back to torch
         msd(y, y)
+
+
+def test_bench_refuses_a_run_smaller_than_the_one_asked_for():
+    """bench.py --gpus N without a launcher either starts N ranks or fails: with no GPU visible it must exit non-zero BEFORE
+    touching a device and print no JSON line (it used to print n_gpus 1 for a --gpus 8 request)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    env['CUDA_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert 'only 0 GPU' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    # a launcher that provides a different world size than --gpus is an error too
+    env2 = dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, env=env2,
+                        timeout=300)
+    assert r2.returncode != 0 and 'WORLD_SIZE=2' in r2.stderr

@@ -1,4 +1,6 @@
 """Pin the oracle (oracle/vec2wav_oracle.py) against every fixture captured from the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,34 @@ def test_disc_oracle_autograd_matches_reference_gradients(name):
     outs = D.mpd_forward(sdo, y, y_hat) if meta['kind'] == 'mpd' else D.msd_forward(sdo, y, y_hat, training=True)
     D.mixed_loss(outs).backward()
     golden_util.check_disc_grads(z, [(k, v.grad) for k, v in leaves.items()], y_hat.grad, rtol=1e-3)   # sign() of the L1 feature loss: a few entries flip
+
+
+def test_mel_filterbank_pinned_to_independent_implementation_and_librosa_docs(golden_dir):
+    """`librosa.filters.mel` (dataset.py:9,64) is restated twice here - oracle/mel_oracle.py (checker) and
+    wavthruvec_pytorch_amd/mel.py (product) - because librosa is not installed.  Both are held to tests/golden/mel_filterbank.npz
+    (tools/gen_mel_goldens.py): the matrices of an independent third-party implementation (transformers.audio_utils.mel_filter_bank,
+    Slaney scale + Slaney norm) for the reference's configuration and for librosa's documentation example, and the numeric rows
+    printed in librosa's documentation.  A wrong Slaney constant (200/3 Hz per mel, 1 kHz knee, log(6.4)/27 step, 2/bandwidth norm)
+    fails here."""
+    import numpy as np
+    from oracle import mel_oracle as M
+    from wavthruvec_pytorch_amd import mel as P
+    z = np.load(os.path.join(golden_dir, 'mel_filterbank.npz'))
+    names = [k[len('basis.'):] for k in z.files if k.startswith('basis.')]
+    assert 'ref_16k_1024_80_0_8000' in names and len(names) >= 2
+    for n in names:
+        sr, n_fft, n_mels, fmin, fmax = z['cfg.' + n]
+        want = z['basis.' + n]
+        for impl in (M.mel_filterbank, P.mel_filterbank):
+            got = impl(int(sr), int(n_fft), int(n_mels), float(fmin), float(fmax))
+            assert got.shape == want.shape and got.dtype == np.float32
+            assert np.abs(got - want).max() <= 1e-8, (n, impl.__module__)          # entries are <= 0.04: ~1 ulp of float32
+    for mod in (M, P):
+        for hz, mel in z['doc.hz_to_mel']:
+            assert abs(float(mod._hz_to_mel(hz)) - mel) < 5e-3
+        for mel, hz in z['doc.mel_to_hz']:
+            assert abs(float(mod._mel_to_hz(mel)) - hz) < 5e-4
+        f40 = mod._mel_to_hz(np.linspace(mod._hz_to_mel(0.0), mod._hz_to_mel(11025.0), 40))
+        assert np.abs(f40 - z['doc.mel_frequencies_40']).max() < 5e-4              # printed to 3 decimals
+        row0 = mod.mel_filterbank(22050, 2048, 128)[0, :2]
+        assert np.abs(np.round(row0, 3) - z['doc.filters_mel_22050_2048_row0']).max() < 1e-9

@@ -198,6 +198,26 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def on_tensor_device(fn):
+    """Decorator: run `fn` with the device of its first GPU tensor argument made current.
+
+    The C ABI launches on the stream it is handed and never calls hipSetDevice, so kernel lookup, hipFuncSetAttribute and the
+    workspace allocations of the wrappers all resolve against the CURRENT device.  The reference drives `cuda:{rank}` without
+    torch.cuda.set_device (train.py:63-94), i.e. the current device stays 0 on every rank: every public entry point of the
+    package is therefore wrapped so that streams, buffers and launches agree on the tensors' device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        import torch
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapper
+
+
 def current_stream_handle(device) -> int:
     import torch
     return torch.cuda.current_stream(device).cuda_stream

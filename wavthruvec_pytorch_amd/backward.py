@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import torch
 
-from . import hipops
+from . import _hip, hipops
 
 LRELU_SLOPE = 0.1
 
@@ -35,6 +35,7 @@ class GeneratorFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_hip.on_tensor_device
     def backward(ctx, dy):
         grads = generator_backward(ctx.gen, ctx.saved, dy.contiguous().float())
         ctx.saved = None

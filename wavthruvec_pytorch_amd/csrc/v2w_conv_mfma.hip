@@ -22,6 +22,7 @@
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
+#include <type_traits>
 #include "v2w_tile.h"
 
 namespace {
@@ -153,25 +154,47 @@ conv_tile_kernel(const MultiArgs m) {
     for (int i = 0; i < MI; ++i)
         ap[i] = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)((m0 + wm0) / MF + i) * nfrag) * 64 + lane;
     int fidx = 0;                           // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
+    f32x4 ar[RING][MI];                     // weight ring: RING - 1 fragments in flight (every index below is a compile-time constant)
     auto load_next = [&](f32x4 (&a)[MI]) {
         const int f = fidx < nfrag ? fidx : nfrag - 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = ap[i][(size_t)f * 64];
         ++fidx;
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch HERE: hipcc otherwise sinks it to just before its use
     };
-    // the 4 k-steps of one fragment: B operands are columns of the LDS tile, A operands the 4 floats of the fragment
-    auto mma4 = [&](acc_t (&c)[MI][NI], const f32x4 (&a)[MI], const float* xrow) {
+
+    // ---- B operands (signal): software-pipelined LDS reads.  One tap of one chunk = QT k-steps; k-step q reads row
+    // hk + q*KSTEP of the chunk at the tap's column, so the whole tap is a uniformly strided walk.  The read of k-step q + LOOK
+    // is issued before the MFMAs of k-step q (hipcc alone emits read -> s_waitcnt lgkmcnt(0) -> MFMA with the LDS latency exposed
+    // at every k-step): slot s of `bq` holds k-step q with q % NB == s.  At the end of a tap the reads run on into the next tap
+    // (`xn`; the last tap of a chunk re-reads its own first rows, never used), and each chunk is primed after its barrier.
+    constexpr int QT = 4 * GPC;
+    constexpr int LOOK = (MI * NI >= 4) ? 1 : 3;
+    constexpr int NB = LOOK + 1;
+    static_assert(QT % NB == 0 && LOOK < QT, "operand slots must line up at every tap start");
+    float bq[NB][NI];
+    // RB: ring slot of this tap's first fragment (always 0 unless GPC < RING)
+    auto tap = [&](auto rb_c, acc_t (&c)[MI][NI], const float* xt, const float* xn) {
+        constexpr int RB = decltype(rb_c)::value;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float bb[NI];
+        for (int q = 0; q < QT; ++q) {
+            if ((q & 3) == 0) load_next(ar[(RB + (q >> 2) + RING - 1) % RING]);
+            const int qa = q + LOOK;
+            const float* src = qa < QT ? xt + qa * KSTEP * xw : xn + (qa - QT) * KSTEP * xw;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bb[j] = xrow[kk * KSTEP * xw + j * MF];
+            for (int j = 0; j < NI; ++j) bq[qa % NB][j] = src[j * MF];
+            __builtin_amdgcn_sched_barrier(0);      // reads and weight prefetch stay AHEAD of this k-step's MFMAs
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) c[i][j] = F::mfma(a[i][kk], bb[j], c[i][j]);
+                for (int j = 0; j < NI; ++j)
+                    c[i][j] = F::mfma(ar[(RB + (q >> 2)) % RING][i][q & 3], bq[q % NB][j], c[i][j]);
         }
+    };
+    auto prime = [&](const float* xt) {
+#pragma unroll
+        for (int q = 0; q < LOOK; ++q)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bq[q][j] = xt[q * KSTEP * xw + j * MF];
     };
 
     // ---- prologue: epilogue constants, affine table, chunk 0, first fragments
@@ -191,12 +214,14 @@ conv_tile_kernel(const MultiArgs m) {
     }
     if (p.vec4) { prefetch(0); commit(0, smem); }
     else stage_scalar(0, smem);
-    f32x4 a0[MI], a1[MI], a2[RING == 4 ? MI : 1], a3[RING == 4 ? MI : 1];
-    load_next(a0);
-    if constexpr (RING == 4) { load_next(a1); load_next(a2); }
+#pragma unroll
+    for (int g = 0; g + 1 < RING; ++g) load_next(ar[g]);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
     const int colbase = wn0 + lr + p.hla + hk * xw;   // this lane's LDS column (+ its k row); tap offset added per tap
+    typedef std::integral_constant<int, 0> RB0;
+    typedef std::integral_constant<int, 1> RB1;
     for (int ch = 0; ch < nch; ++ch) {
         const float* Xs = smem + (ch & 1) * (CK * xw);
         float* Xn = smem + ((ch + 1) & 1) * (CK * xw);
@@ -204,35 +229,36 @@ conv_tile_kernel(const MultiArgs m) {
         if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
         __builtin_amdgcn_sched_barrier(0);
 
-        if constexpr (RING == 4) {
-            // one ring revolution per tap: fragment gg of the tap sits in ring slot gg; three fragments stay in flight, so a
-            // wait on the weight stream (vmcnt retires in order) tolerates ~3 steps of latency of the signal prefetch above
-            for (int t = 0; t < K; ++t) {
-                const float* xt = Xs + colbase - p.hl + t * p.dil;
-                load_next(a3); mma4(acc[0], a0, xt);
-                load_next(a0); mma4(acc[0], a1, xt + CKG * xw);
-                load_next(a1); mma4(acc[0], a2, xt + 2 * CKG * xw);
-                load_next(a2); mma4(acc[0], a3, xt + 3 * CKG * xw);
-            }
-        } else {
+        // per phase r (one phase for a conv): taps at columns d0 + m*dstr, m < nt
+        auto phase = [&](int r, int& d0, int& dstr, int& nt) {
+            if (U == 1) { d0 = -p.hl; dstr = p.dil; nt = K; }
+            else { const int rp = r + p.pad, t0 = rp % U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
+        };
+        {
+            int d0, dstr, nt;
+            phase(0, d0, dstr, nt);
+            prime(Xs + colbase + d0);
+        }
 #pragma unroll
-            for (int r = 0; r < U; ++r) {
-                int d0, dstr, nt;
-                if (U == 1) { d0 = -p.hl; dstr = p.dil; nt = K; }
-                else { const int rp = r + p.pad, t0 = rp % U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
-                const int nit = nt * GPC;       // flattened (tap m, fragment gg) loop, two-deep ping-pong
-                int m = 0, gg = 0;
-                auto step = [&](const f32x4 (&use)[MI], f32x4 (&ld)[MI]) {
-                    load_next(ld);
-                    mma4(acc[r], use, Xs + colbase + d0 + m * dstr + gg * CKG * xw);
-                    if (++gg == GPC) { gg = 0; ++m; }
-                };
-                int it = 0;
-                for (; it + 1 < nit; it += 2) { step(a0, a1); step(a1, a0); }
-                if (it < nit) {                 // odd count: the in-flight fragment sits in a1; hand it over
-                    step(a0, a1);
+        for (int r = 0; r < U; ++r) {
+            int d0, dstr, nt;
+            phase(r, d0, dstr, nt);
+            const float* xt = Xs + colbase + d0;
+            const float* xlast = xt;                  // where the reads run on after this phase's last tap
+            if (r + 1 < U) { int d1, s1, n1; phase(r + 1, d1, s1, n1); xlast = Xs + colbase + d1; }
+            if constexpr (GPC >= RING) {
+                for (int m = 0; m < nt; ++m, xt += dstr)
+                    tap(RB0{}, acc[r], xt, m + 1 < nt ? xt + dstr : xlast);
+            } else {                                  // GPC == 1, RING == 2: the ring alternates per tap -> taps in pairs
+                int m = 0;
+                for (; m + 1 < nt; m += 2, xt += 2 * dstr) {
+                    tap(RB0{}, acc[r], xt, xt + dstr);
+                    tap(RB1{}, acc[r], xt + dstr, m + 2 < nt ? xt + 2 * dstr : xlast);
+                }
+                if (m < nt) {                         // odd count: the in-flight fragment sits in slot 1; hand it over
+                    tap(RB0{}, acc[r], xt, xlast);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) a0[i] = a1[i];
+                    for (int i = 0; i < MI; ++i) ar[0][i] = ar[1][i];
                 }
             }
         }

@@ -42,6 +42,146 @@ struct PairMulti {
     int start[V2W_PAIR_MULTI + 1];
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage x = a*in + s (the folded CondBN affine; exactly 0 outside [0, L)) of one (batch item, window) into Xs[C][xw].
+// float4 form: every thread issues ALL its global loads (NPF slots) back to back and only then converts and writes LDS - a plain
+// `for (idx = tid; ...; idx += NTHREADS)` loop compiles to load -> wait -> write per trip, i.e. C*xcols/4/NTHREADS serialised HBM
+// round trips per tile (9 at C = 32) during which the workgroup issues no MFMA.
+template <int C, int NTHREADS>
+struct XStage {
+    static constexpr int HMAX = 32;                                   // largest conv1 halo the slots cover
+    static constexpr int W = 256;
+    static constexpr int NPF = (C * ((W + 2 * HMAX + 8) / 4) + NTHREADS - 1) / NTHREADS;
+    static_assert(NPF * NTHREADS < 8192, "slot index range of the magic division");
+    static bool fits(int xcols) { return C * (xcols >> 2) <= NPF * NTHREADS; }
+
+    static __device__ __forceinline__ void vec4(const float* __restrict__ in, const float* __restrict__ in_a, const float* __restrict__ in_s,
+                                                float* Xs, int b, int L, int pos0, int xcols, int xw, int tid) {
+        const int xw4 = xcols >> 2;
+        const unsigned magic = (unsigned)(((1ull << 32) + xw4 - 1) / xw4);
+        f32x4 g[NPF];
+        float av[NPF], sv[NPF];
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            const int row = (int)__umulhi((unsigned)idx, magic);
+            const int pos = pos0 + (idx - row * xw4) * 4;
+            g[s] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s] = 1.f; sv[s] = 0.f;
+            if (idx < C * xw4 && pos >= 0 && pos < L) {       // L % 4 == 0, pos % 4 == 0: whole float4 inside
+                const int ch = b * C + row;
+                g[s] = *reinterpret_cast<const f32x4*>(in + (size_t)ch * L + pos);
+                if (in_a) { av[s] = in_a[ch]; sv[s] = in_s[ch]; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            if (idx >= C * xw4) continue;
+            const int row = (int)__umulhi((unsigned)idx, magic);
+            const int col = (idx - row * xw4) * 4;
+            const int pos = pos0 + col;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pos >= 0 && pos < L) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(av[s], g[s][e], sv[s]);
+            }
+            *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
+        }
+    }
+    // any L / alignment: dword loads, one channel row per wave at a time
+    static __device__ __forceinline__ void scalar(const float* __restrict__ in, const float* __restrict__ in_a, const float* __restrict__ in_s,
+                                                  float* Xs, int b, int L, int pos0, int xcols, int xw, int wave, int lane) {
+        for (int c = wave; c < C; c += NTHREADS / 64) {
+            const int ch = b * C + c;
+            const float av = in_a ? in_a[ch] : 1.f, sv = in_a ? in_s[ch] : 0.f;
+            for (int j = lane; j < xcols; j += 64) {
+                const int pos = pos0 + j;
+                Xs[c * xw + j] = (pos >= 0 && pos < L) ? fmaf(av, in[(size_t)ch * L + pos], sv) : 0.f;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// One conv phase of the fused kernels: acc[j] += sum over taps t < K and channels c of W[t][c][.] * lrelu(src[c][col + t*dil]).
+// All C channels are one packed chunk, so a tap is QT = 4*GPC k-steps and k-step q reads row hk + q*KSTEP of `src` at the tap's
+// column: a uniformly strided walk.  Both operand streams are software-pipelined by hand (hipcc alone emits
+// ds_read -> s_waitcnt lgkmcnt(0) -> MFMA with the LDS latency exposed at every k-step):
+//   B (signal, LDS): the read of k-step q + LOOK is issued before the MFMAs of k-step q; slot q % NB of `bq` holds k-step q; the
+//                    leaky_relu is applied in registers when a slot is consumed, so the tile also serves as the residual.
+//   A (weights, L2): RING-deep register ring, RING - 1 fragments (1 KiB each) in flight; the stream runs on into the next
+//                    conv's fragments (`ap_next`) so a phase change does not drain it.
+template <int MF, int NI, int RING, int LOOK>
+struct FusedConv {
+    typedef Frag<MF> F;
+    typedef typename F::acc_t acc_t;
+    static constexpr int KSTEP = F::KSTEP, CKG = 4 * KSTEP, GPC = MF / CKG, QT = 4 * GPC, NB = LOOK + 1;
+    static_assert(QT % NB == 0 && LOOK < QT, "operand slots must line up at every tap start");
+    static_assert(GPC % RING == 0 || (GPC == 1 && RING == 2), "ring slot of a tap's first fragment must be static");
+
+    f32x4 ar[RING];
+    float bq[NB][NI];
+    int rb;            // GPC == 1 only: ring slot of the next tap's fragment (alternates per tap)
+
+    // fragment g of the running conv (g >= nfrag: the following conv's stream)
+    static __device__ __forceinline__ f32x4 frag(const f32x4* ap, const f32x4* ap_next, int nfrag, int g) {
+        return g < nfrag ? ap[(size_t)g * 64] : ap_next[(size_t)(g - nfrag) * 64];
+    }
+    // before the first phase: the first RING - 1 fragments of the first conv
+    __device__ __forceinline__ void start(const f32x4* ap) {
+#pragma unroll
+        for (int g = 0; g + 1 < RING; ++g) ar[g] = ap[(size_t)g * 64];
+        rb = 0;
+    }
+    __device__ __forceinline__ void prime(const float* xt, int sw) {
+#pragma unroll
+        for (int q = 0; q < LOOK; ++q)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bq[q][j] = xt[q * KSTEP * sw + j * MF];
+    }
+    template <int RB>
+    __device__ __forceinline__ void tap(acc_t (&acc)[NI], const f32x4* ap, const f32x4* ap_next, int nfrag, int g0,
+                                        const float* xt, const float* xn, int sw, float slope) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if ((q & 3) == 0) ar[(RB + (q >> 2) + RING - 1) % RING] = frag(ap, ap_next, nfrag, g0 + (q >> 2) + RING - 1);
+            const int qa = q + LOOK;
+            const float* src = qa < QT ? xt + qa * KSTEP * sw : xn + (qa - QT) * KSTEP * sw;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bq[qa % NB][j] = src[j * MF];
+            __builtin_amdgcn_sched_barrier(0);      // reads and weight prefetch stay AHEAD of this k-step's MFMAs
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[j] = F::mfma(ar[(RB + (q >> 2)) % RING][q & 3], v2w_lrelu(bq[q % NB][j], slope), acc[j]);
+        }
+    }
+    // the whole phase; x0 = src + hk*sw + (this lane's column of tap 0).  Zeroes acc first.
+    __device__ __forceinline__ void run(acc_t (&acc)[NI], const f32x4* ap, const f32x4* ap_next, int K, const float* x0, int sw,
+                                        int dil, float slope) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < F::NREG; ++e) acc[j][e] = 0.f;
+        const int nfrag = K * GPC;
+        prime(x0, sw);
+        const float* xt = x0;
+        if constexpr (GPC % RING == 0) {
+            for (int t = 0; t < K; ++t, xt += dil)
+                tap<0>(acc, ap, ap_next, nfrag, t * GPC, xt, t + 1 < K ? xt + dil : xt, sw, slope);
+        } else {                                    // GPC == 1, RING == 2: slot parity carried across taps and phases
+            int t = 0;
+            if (rb) { tap<1>(acc, ap, ap_next, nfrag, 0, xt, K > 1 ? xt + dil : xt, sw, slope); ++t; xt += dil; }
+            for (; t + 1 < K; t += 2, xt += 2 * dil) {
+                tap<0>(acc, ap, ap_next, nfrag, t, xt, xt + dil, sw, slope);
+                tap<1>(acc, ap, ap_next, nfrag, t + 1, xt + dil, t + 2 < K ? xt + 2 * dil : xt, sw, slope);
+            }
+            rb = 0;
+            if (t < K) { tap<0>(acc, ap, ap_next, nfrag, t, xt, xt, sw, slope); rb = 1; }
+        }
+    }
+};
+
 template <int MF, int NI, int WN>
 __global__ void __launch_bounds__(64 * WN)
 resblock_pair_kernel(const PairMulti m) {
@@ -76,74 +216,21 @@ resblock_pair_kernel(const PairMulti m) {
     // ---- stage x = a*in + s (0 outside the sequence); X column 0 <-> position pos0 (a multiple of 4)
     const int pos0 = n0 - p.h2 - p.h1 - p.xoff;
     if (tid < C) { etab[tid] = p.bias1 ? p.bias1[tid] : 0.f; etab[C + tid] = p.bias2 ? p.bias2[tid] : 0.f; }
-    if (p.vec4) {
-        const int xw4 = p.xcols >> 2;
-        const unsigned magic = (unsigned)(((1ull << 32) + xw4 - 1) / xw4);
-        for (int idx = tid; idx < C * xw4; idx += NTHREADS) {
-            const int row = (int)__umulhi((unsigned)idx, magic);
-            const int col = (idx - row * xw4) * 4;
-            const int pos = pos0 + col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pos >= 0 && pos < L) {       // L % 4 == 0, pos % 4 == 0: whole float4 inside
-                const int ch = b * C + row;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
-                const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_a ? p.in_s[ch] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(av, g[e], sv);
-            }
-            *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
-        }
-    } else {
-        for (int c = wave; c < C; c += WN) {
-            const int ch = b * C + c;
-            const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_a ? p.in_s[ch] : 0.f;
-            for (int j = lane; j < p.xcols; j += 64) {
-                const int pos = pos0 + j;
-                Xs[c * xw + j] = (pos >= 0 && pos < L) ? fmaf(av, p.in[(size_t)ch * L + pos], sv) : 0.f;
-            }
-        }
-    }
+    if (p.vec4) XStage<C, NTHREADS>::vec4(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, tid);
+    else XStage<C, NTHREADS>::scalar(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, wave, lane);
 
     // ---- weight streams: K*GPC fragments of 1 KiB each per conv, consumed in order
     const int nfrag = K * GPC;
     const f32x4* ap1 = reinterpret_cast<const f32x4*>(p.wp1) + lane;
     const f32x4* ap2 = reinterpret_cast<const f32x4*>(p.wp2) + lane;
-    f32x4 a0, a1;
-    a0 = ap1[0];
+    typedef FusedConv<MF, NI, MF == 32 ? 4 : 2, 3> FC;
+    FC fc;
+    fc.start(ap1);
     __syncthreads();
 
     acc_t acc[NI];
-    // one conv phase: acc[j] = sum over taps / channels of A * lrelu(src[..][col + t*dil])
-    auto conv_phase = [&](const f32x4* ap, const f32x4* ap_next, const float* src, int sw, int colbase, int dil) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < F::NREG; ++e) acc[j][e] = 0.f;
-        int f = 0;
-        auto step = [&](const f32x4& use, f32x4& ld) {
-            // next fragment of this conv, or the first one of the following conv (clamped re-read at the very end)
-            const int fn = f + 1;
-            ld = fn < nfrag ? ap[(size_t)fn * 64] : ap_next[0];
-            __builtin_amdgcn_sched_barrier(0);
-            const int t = f / GPC, gg = f - t * GPC;
-            const float* xrow = src + (gg * CKG + hk) * sw + colbase + t * dil;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float bb[NI];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bb[j] = v2w_lrelu(xrow[kk * KSTEP * sw + j * MF], slope);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[j] = F::mfma(use[kk], bb[j], acc[j]);
-            }
-            ++f;
-        };
-        int it = 0;
-        for (; it + 1 < nfrag; it += 2) { step(a0, a1); step(a1, a0); }
-        if (it < nfrag) { step(a0, a1); a0 = a1; }
-    };
-
     // ---- conv1 -> t1 on positions [n0 - h2, n0 - h2 + W); X column of (position, tap 0) = col + xoff
-    conv_phase(ap1, ap2, Xs, xw, wn0 + lr + p.xoff, p.d1);
+    fc.run(acc, ap1, ap2, K, Xs + hk * xw + wn0 + lr + p.xoff, xw, p.d1, slope);
 #pragma unroll
     for (int e = 0; e < F::NREG; ++e) {
         const int co = F::row(e, hk);
@@ -167,7 +254,7 @@ resblock_pair_kernel(const PairMulti m) {
     __syncthreads();
 
     // ---- conv2 on the first NTO columns' worth of outputs (all W computed, the rest masked); T1 column of tap 0 = col
-    conv_phase(ap2, ap2 + (size_t)(nfrag - 1) * 64, Ts, tw, wn0 + lr, p.d2);
+    fc.run(acc, ap2, ap2, K, Ts + hk * tw + wn0 + lr, tw, p.d2, slope);   // (runs on into a harmless re-read of its own head)
 #pragma unroll
     for (int e = 0; e < F::NREG; ++e) {
         const int co = F::row(e, hk);
@@ -220,6 +307,7 @@ int launch_pair(const v2w_pair_args* a, int n, hipStream_t stream) {
         p.ntl = (q.L + p.nto - 1) / p.nto;
         p.ntiles = q.B * p.ntl;
         p.vec4 = (q.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q.in) & 15) == 0);
+        if (!XStage<MF, 64 * WN>::fits(p.xcols)) return V2W_E_SHAPE;
         p.res_mode = q.res_mode; p.slope = q.slope; p.out_div = q.out_div;
         p.toff = q.res_mode == 0 ? 0 : MF * xw;
         p.eoff = q.res_mode == 0 ? MF * (xw > tw ? xw : tw) : MF * (xw + tw);
@@ -292,76 +380,24 @@ resblock2_stage_kernel(const StageArgs p) {
         etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
         etab[V2W_STAGE_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
     }
-    if (p.vec4) {
-        const int xw4 = p.xcols >> 2;
-        const unsigned magic = (unsigned)(((1ull << 32) + xw4 - 1) / xw4);
-        for (int idx = tid; idx < C * xw4; idx += NTHREADS) {
-            const int row = (int)__umulhi((unsigned)idx, magic);
-            const int col = (idx - row * xw4) * 4;
-            const int pos = pos0 + col;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pos >= 0 && pos < L) {
-                const int ch = b * C + row;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
-                const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_a ? p.in_s[ch] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(av, g[e], sv);
-            }
-            *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
-        }
-    } else {
-        for (int c = wave; c < C; c += WN) {
-            const int ch = b * C + c;
-            const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_a ? p.in_s[ch] : 0.f;
-            for (int j = lane; j < p.xcols; j += 64) {
-                const int pos = pos0 + j;
-                Xs[c * xw + j] = (pos >= 0 && pos < L) ? fmaf(av, p.in[(size_t)ch * L + pos], sv) : 0.f;
-            }
-        }
-    }
+    if (p.vec4) XStage<C, NTHREADS>::vec4(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, tid);
+    else XStage<C, NTHREADS>::scalar(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, wave, lane);
 
-    f32x4 a0, a1;
-    a0 = (reinterpret_cast<const f32x4*>(p.wp1[0]) + lane)[0];
+    typedef FusedConv<MF, NI, MF == 32 ? 4 : 2, 3> FC;
+    FC fc;
+    fc.start(reinterpret_cast<const f32x4*>(p.wp1[0]) + lane);
     __syncthreads();
 
     acc_t acc[NI], oacc[NI];
-    auto conv_phase = [&](const f32x4* ap, const f32x4* ap_next, int nfrag, const float* src, int sw, int colbase, int dil) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < F::NREG; ++e) acc[j][e] = 0.f;
-        int f = 0;
-        auto step = [&](const f32x4& use, f32x4& ld) {
-            const int fn = f + 1;
-            ld = fn < nfrag ? ap[(size_t)fn * 64] : ap_next[0];
-            __builtin_amdgcn_sched_barrier(0);
-            const int t = f / GPC, gg = f - t * GPC;
-            const float* xrow = src + (gg * CKG + hk) * sw + colbase + t * dil;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float bb[NI];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bb[j] = v2w_lrelu(xrow[kk * KSTEP * sw + j * MF], slope);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[j] = F::mfma(use[kk], bb[j], acc[j]);
-            }
-            ++f;
-        };
-        int it = 0;
-        for (; it + 1 < nfrag; it += 2) { step(a0, a1); step(a1, a0); }
-        if (it < nfrag) { step(a0, a1); a0 = a1; }
-    };
-
     for (int jb = 0; jb < p.nk; ++jb) {
         const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
-        const int nfrag = K * GPC;
         const f32x4* ap1 = reinterpret_cast<const f32x4*>(p.wp1[jb]) + lane;
         const f32x4* ap2 = reinterpret_cast<const f32x4*>(p.wp2[jb]) + lane;
-        const f32x4* ap_after = jb + 1 < p.nk ? reinterpret_cast<const f32x4*>(p.wp1[jb + 1]) + lane : ap2 + (size_t)(nfrag - 1) * 64;
+        const f32x4* ap_after = jb + 1 < p.nk ? reinterpret_cast<const f32x4*>(p.wp1[jb + 1]) + lane : ap2;   // last: a harmless re-read
 
         // ---- conv1_j -> t1_j on positions [n0 - h2max, n0 - h2max + W)
-        conv_phase(ap1, ap2, nfrag, Xs, xw, wn0 + lr + p.xoff + (p.h1max - h1), d1);
+        fc.run(acc, ap1, ap2, K, Xs + hk * xw + wn0 + lr + p.xoff + (p.h1max - h1), xw, d1, slope);
 #pragma unroll
         for (int e = 0; e < F::NREG; ++e) {
             const int co = F::row(e, hk);
@@ -384,7 +420,7 @@ resblock2_stage_kernel(const StageArgs p) {
         __syncthreads();
 
         // ---- conv2_j ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        conv_phase(ap2, ap_after, nfrag, Ts, tw, wn0 + lr + (p.h2max - h2), d2);
+        fc.run(acc, ap2, ap_after, K, Ts + hk * tw + wn0 + lr + (p.h2max - h2), tw, d2, slope);
 #pragma unroll
         for (int e = 0; e < F::NREG; ++e) {
             const int co = F::row(e, hk);
@@ -435,6 +471,7 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     p.xw = xw; p.tw = tw;
     p.ntl = (q->L + p.nto - 1) / p.nto;
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
+    if (!XStage<MF, 64 * WN>::fits(p.xcols)) return V2W_E_SHAPE;
     const size_t lds = ((size_t)MF * (xw + tw) + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     auto kern = resblock2_stage_kernel<MF, NI, WN>;

@@ -263,6 +263,7 @@ class _DiscBase(nn.Module):
             return [f[:, :, :U] for f, U in st['bufs']]
         return [f[:, :, :U * inner].view(b, f.shape[1], U, inner) for f, U in st['bufs']]      # strided when U * inner % 4 != 0
 
+    @_hip.on_tensor_device
     def forward(self, x):
         _check_cuda(x)
         params = [p for l in self._layers() for p in l.parameters()]
@@ -289,6 +290,7 @@ class _DiscFn(torch.autograd.Function):
         return tuple(disc._views(st, xd.shape[0]))
 
     @staticmethod
+    @_hip.on_tensor_device
     def backward(ctx, *gouts):
         disc, st, x = ctx.disc, ctx.st, ctx.x
         lib, stream = _hip.load(), _stream(x)
@@ -446,6 +448,7 @@ class _AvgPoolFn(torch.autograd.Function):
         return _avg_pool_fwd(x.detach().contiguous().float())
 
     @staticmethod
+    @_hip.on_tensor_device
     def backward(ctx, g):
         B, C, L = ctx.shape
         g = g.contiguous().float()
@@ -454,6 +457,7 @@ class _AvgPoolFn(torch.autograd.Function):
         return dx
 
 
+@_hip.on_tensor_device
 def avg_pool(x):
     """AvgPool1d(4, 2, padding=2) of models.py:255-258 on (B, 1, L); differentiable."""
     _check_cuda(x)

@@ -128,11 +128,13 @@ class _MelFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_hip.on_tensor_device
     def backward(ctx, g):
         (spec,) = ctx.saved_tensors
         return _backward(g, spec, ctx.geom, ctx.cfg), None
 
 
+@_hip.on_tensor_device
 def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     """y (B, L) float32 on the GPU -> (B, num_mels, frames) float32; differentiable with respect to y (the training loss
     F.l1_loss(y_mel, mel_spectrogram(y_g_hat.squeeze(1), ...)), train.py:172-174,204)."""

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import hipops
+from . import _hip, hipops
 from .modules import ConditionalBatchNorm1d
 from .utils import get_padding, init_weights  # noqa: F401  (re-exported like the reference's models.py)
 
@@ -347,6 +347,7 @@ class Generator(nn.Module):
         return out
 
     # -------------------------------------------------------------------------------------------
+    @_hip.on_tensor_device
     def forward(self, x, spk_emb=None, noise=None):
         """x (B, num_wv_feat, T) channels-first, spk_emb (B, spk_dim), noise (B, noise_dim) -> (B, 1, T*prod(rates))."""
         if spk_emb is None or noise is None:

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import hipops
+from . import _hip, hipops
 
 
 class _BatchNormState(nn.Module):
@@ -57,6 +57,7 @@ class ConditionalBatchNorm1d(nn.Module):
         self.batch_nrom = _BatchNormState(num_features)           # sic: the reference's attribute name
         self.layer = _SpectralNormLinearState(z_channels, num_features * 2)
 
+    @_hip.on_tensor_device
     def forward(self, inputs, noise):
         """outputs = gamma(noise) * BN(inputs) + beta(noise); materialises the result (standalone use).
 
