@@ -65,3 +65,33 @@ template <> struct Frag<16> {
     __device__ static __forceinline__ int row(int reg, int hk) { return hk * 4 + reg; }
 };
 
+
+// ---- in-kernel timeline, DIAGNOSTIC builds only (-DV2W_TIMELINE, built and read by tools/stage_timeline.py / tools/tile_timeline.py):
+// lane 0 of every wave stores s_memtime stamps into a side buffer that no kernel reads.  In the product build V2W_STAMP compiles to
+// nothing and the setters do not exist.  Each instrumented source file owns its buffer pointer (no relocatable device code needed)
+// and exports its setter with V2W_TL_SETTER(name).
+#ifdef V2W_TIMELINE
+#define V2W_TL_SLOTS 32
+static __device__ unsigned long long* v2w_tl_buf;      // [blocks][4 waves][V2W_TL_SLOTS]
+static __device__ int v2w_tl_blocks;
+#define V2W_TL_SETTER(name)                                                                          \
+    extern "C" int name(void* buf, int nblocks) {                                                    \
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(v2w_tl_buf), &buf, sizeof(buf));                  \
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(v2w_tl_blocks), &nblocks, sizeof(nblocks)); \
+        return (int)e;                                                                               \
+    }
+__device__ __forceinline__ void v2w_tl_stamp(int k) {
+    if ((threadIdx.x & 63) == 0 && (int)blockIdx.x < v2w_tl_blocks && (threadIdx.x >> 6) < 4 && k < V2W_TL_SLOTS - 3) {
+        unsigned long long* dst = v2w_tl_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * V2W_TL_SLOTS;
+        dst[k] = __builtin_amdgcn_s_memtime();
+        if (k == 0) {
+            dst[V2W_TL_SLOTS - 1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+            dst[V2W_TL_SLOTS - 2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+            dst[V2W_TL_SLOTS - 3] = __builtin_amdgcn_s_memrealtime();                 // 100 MHz: comparable across CUs
+        }
+    }
+}
+#define V2W_STAMP(k) v2w_tl_stamp(k)
+#else
+#define V2W_STAMP(k) ((void)0)
+#endif

@@ -9,15 +9,20 @@
 //                  (models.py:128-129).
 //
 // GEMM view per workgroup: M = MT output channels, N = NT input-rate positions, K = C_in x taps.
+// What shapes the loop (tools/stage_timeline.py, MI355X): the f32 MFMA shares the SIMD's vector ALU, so every vector instruction
+// issued between two MFMAs costs matrix time (a v_add + ds_read2_b32 pair per k-step: ~10 cycles per 64-cycle MFMA pair).  The
+// main loop therefore contains MFMAs, one ds_read_b128 per four k-steps and column block, one global_load_dwordx4 per four
+// k-steps and row block - and no address arithmetic.
 // A (weights)  : never staged.  v2w_pack_mfma() stores them in MFMA A-fragment order, so one fully coalesced
-//                global_load_dwordx4 per lane (1 KiB per wave) feeds four consecutive MFMA k-steps; the panel is
-//                L2-resident (<= 2.9 MB per layer) and the next fragment is fetched while the current one computes.
-// B (signal)   : LDS tile Xs[c][NT + halo], double buffered over C_in chunks.  Lanes read consecutive positions
-//                (conflict-free ds_read_b32); every tap is a column offset into the SAME tile, so each input element
-//                is fetched from HBM once per M-tile and the activation / CondBN affine is applied once, at staging
-//                time.  The next chunk travels global -> registers while the current one computes (one barrier per
-//                chunk).  vmcnt retires in order, so the weight stream keeps a 4-deep register ring (three fragments in
-//                flight): a wait on it then tolerates ~3 MFMA steps of latency of the signal prefetch issued before it.
+//                global_load_dwordx4 per lane (1 KiB per wave; scalar base + lane offset) feeds four consecutive MFMA k-steps;
+//                the panel is L2-resident (<= 2.9 MB per layer); RING - 1 fragments stay in flight (vmcnt retires in order, so the
+//                ring has to ride out the signal prefetch issued in front of it).
+// B (signal)   : LDS tile Xs[NT + halo positions][CK + pad], double buffered over C_in chunks.  POSITION-major, and the channels of
+//                a row are permuted (slot()) so that the four k-steps of one packed weight fragment are 16 contiguous bytes: a
+//                lane reads its operand for four MFMA k-steps with ONE ds_read_b128 at an immediate offset; row strides of 36 /
+//                20 / 24 floats keep those reads bank-conflict free.  Every tap is a row offset into the SAME tile, so each input
+//                element is fetched from HBM once per M-tile and the activation / CondBN affine is applied once, at staging time.
+//                The next chunk travels global -> registers during the MFMA phase (one barrier per chunk).
 // MFMA         : v_mfma_f32_32x32x2_f32 (C_out >= 32) or v_mfma_f32_16x16x4_f32 (C_out == 16): exact fp32
 //                (bit-identical to an fmaf chain), 64 FLOP/clk/SIMD.
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
@@ -25,13 +30,35 @@
 #include <type_traits>
 #include "v2w_tile.h"
 
+#ifdef V2W_TIMELINE   // diagnostic build only (see v2w_common.h)
+V2W_TL_SETTER(v2w_timeline_set_tile)
+#endif
+
 namespace {
+
+// Geometry of the LDS signal tile: [positions][RS floats], the CK channels of a row permuted so that the four k-steps a lane feeds
+// to one packed weight fragment (v2w_pack_mfma pairs k-step kk, lane half hk with channel 8g + 2kk + hk for the 32x32x2 MFMA and
+// 4kk + hk for 16x16x4) are 16 contiguous bytes.  RS is the smallest 16-byte-aligned stride that keeps the wave's ds_read_b128
+// (lane -> row, lane half -> slot quad) bank-conflict free.  Staging writes slot-adjacent channel PAIRS (c0, c0 + PAIR_DC).
+template <int MF, int CK> struct TileGeom {
+    static constexpr int RS = CK == 32 ? 36 : (MF == 32 ? 20 : 24);
+    static constexpr int PAIR_DC = MF == 32 ? 2 : 4;
+    __host__ __device__ static constexpr int slot(int c) {
+        return MF == 32 ? ((c & ~7) + 4 * (c & 1) + ((c & 7) >> 1)) : (4 * (c & 3) + (c >> 2));
+    }
+    // first channel of the pair that occupies slots 2P, 2P + 1
+    __host__ __device__ static constexpr int pair_c0(int P) {
+        return MF == 32 ? (8 * (P >> 2) + 4 * (P & 1) + ((P >> 1) & 1)) : (8 * (P & 1) + (P >> 1));
+    }
+};
 
 // EPI: which optional epilogue is compiled in.  0 = none (the generator's forward kernels).  1 = the backward-only leaky_relu-
 // derivative mask (+ out_slope): it costs 8 VGPRs (one occupancy step on the 128 x 128 tile, 5-12 % of a layer's time), so it is
 // its own instantiation.  2 = out_slope only (the discriminators' activated feature maps): no extra registers.
+// (second launch bound = waves per SIMD the register allocation must leave room for: the 128 x 128 conv tile runs three
+// workgroups per CU - its LDS footprint allows exactly that - and would otherwise drift to 2 through the epilogue's temporaries)
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN)
+__global__ void __launch_bounds__(64 * WM * WN, (U == 1 && MI * NI >= 4) ? 3 : 1)
 conv_tile_kernel(const MultiArgs m) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
@@ -40,11 +67,12 @@ conv_tile_kernel(const MultiArgs m) {
     constexpr int NT = MF * NI * WN;
     constexpr int KSTEP = F::KSTEP;
     constexpr int CKG = 4 * KSTEP;          // channels covered by one packed A fragment (4 k-steps)
-    constexpr int GPC = CK / CKG;           // A fragments per chunk and tap
+    constexpr int GPC = CK / CKG;           // A fragments (units) per chunk and tap
+    constexpr int RS = TileGeom<MF, CK>::RS;   // floats per position row of the LDS tile
     static_assert(CK % CKG == 0, "chunk must hold whole A fragments");
-    static_assert(RING == 2 || (RING == 4 && U == 1 && GPC == 4), "the 4-deep ring walks exactly one tap per revolution");
+    static_assert(RING == 2 || (RING == 4 && GPC == 4), "the 4-deep ring walks exactly one tap per revolution");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [CK][xw] signal tiles, then a[Cin], s[Cin]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [xrows][RS] signal tiles, then the tables
 
     // ---- which tile: ids that differ by a multiple of 8 tend to share an XCD (and its L2), so the M-tiles that
     // re-read the same input tile are placed 8 apart (speed only, never correctness).
@@ -69,14 +97,15 @@ conv_tile_kernel(const MultiArgs m) {
     const int hk = lane / MF;             // k index inside the MFMA k-step
     const int wm0 = (wave / WN) * (MF * MI);
     const int wn0 = (wave % WN) * (MF * NI);
-    const int xw = p.xw;
     const int L = p.L, K = p.K;
     const float slope = p.slope;
     const int nch = p.Cin / CK;
-    const int pos0 = n0 - p.hla;           // position of LDS column 0
+    const int pos0 = n0 - p.hla;           // position of LDS row 0
+    const int bufsz = p.xrows * RS;        // floats per signal buffer
     float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias, res_a, res_s, mask_a, mask_s [MT] each
     float* const atab = etab + 5 * MT;        // folded CondBN affine of this batch item: a[Cin] then s[Cin]
 
+    V2W_STAMP(0);
     acc_t acc[U][MI][NI];
 #pragma unroll
     for (int r = 0; r < U; ++r)
@@ -87,21 +116,29 @@ conv_tile_kernel(const MultiArgs m) {
 #pragma unroll
                 for (int e = 0; e < F::NREG; ++e) acc[r][i][j][e] = 0.f;
 
-    // ---- signal staging, all waves cooperate: slot s of this thread = float4 #(tid + s*NTHREADS) of the [CK][xw4] chunk
-    // image.  prefetch() only issues the global loads; commit() applies affine + leaky_relu and writes LDS a chunk later.
-    const int xw4 = p.xcols >> 2;
-    const unsigned magic = (unsigned)(((1ull << 32) + xw4 - 1) / xw4);   // idx / xw4 == umulhi(idx, magic) for idx < 8192
-    f32x4 pf[NPF];
+    // ---- signal staging, all waves cooperate.  An item = one slot-adjacent channel pair x 4 positions: two float4 loads, four
+    // 8-byte LDS stores.  Each 16-lane quarter of a wave takes 8 consecutive position quads of 2 pairs: on the global side that is two
+    // full 128-byte lines per row pair (the same line count as a row-contiguous 256 bytes); on the LDS side the stores are 4-way bank
+    // conflicted (rows 4 apart are 16 banks apart at every 16-byte aligned stride) - 48 wave-stores per chunk, noise against its MFMAs.
+    // prefetch() only issues the global loads; commit() applies affine + leaky_relu and writes LDS a chunk later.
+    const int nq = p.xrows >> 2;             // position quads per row of items
+    const int nq8 = (nq + 7) >> 3;           // ... in groups of 8
+    const unsigned magic = (unsigned)(((1ull << 32) + nq8 - 1) / nq8);   // g / nq8 == umulhi(g, magic) for g < 8192
+    f32x4 pf[NPF][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // slot -> (row, col) is recomputed where needed (a multiply-high and a few adds) instead of living in registers
-    auto slot = [&](int s, int& row, int& col, bool& in_img, bool& in_seq) {
+    // item -> (channel c0 of the pair, first row) is recomputed where needed instead of living in registers
+    auto item = [&](int s, int& c0, int& row, bool& in_img, bool& in_seq) {
         int t = tid;
-        asm volatile("" : "+v"(t));     // opaque: keeps hipcc from hoisting 3 registers per slot out of the chunk loop
+        asm volatile("" : "+v"(t));     // opaque: keeps hipcc from hoisting registers per slot out of the chunk loop
         const int idx = t + s * NTHREADS;
-        row = (int)__umulhi((unsigned)idx, magic);
-        col = (idx - row * xw4) * 4;
-        const int pos = pos0 + col;
-        in_img = idx < CK * xw4;
+        const int g = idx >> 4;                                   // group of 16 items: 8 quads x 2 pairs
+        const int pg = (int)__umulhi((unsigned)g, magic);         // pair-of-pairs index
+        const int quad = (g - pg * nq8) * 8 + (idx & 7);
+        const int P = 2 * pg + ((idx >> 3) & 1);
+        row = quad * 4;
+        in_img = quad < nq && P < CK / 2;
+        c0 = TileGeom<MF, CK>::pair_c0(in_img ? P : 0);
+        const int pos = pos0 + row;
         // L % 4 == 0 and pos % 4 == 0: a float4 is entirely inside [0, L) or entirely padding
         in_seq = in_img && pos >= 0 && pos < L;
     };
@@ -109,26 +146,33 @@ conv_tile_kernel(const MultiArgs m) {
         const float* src = p.in + (size_t)(b * p.CinT + ci0) * L + pos0;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
-            int row, col; bool in_img, in_seq;
-            slot(s, row, col, in_img, in_seq);
-            pf[s] = zero4;
-            if (in_seq) pf[s] = *reinterpret_cast<const f32x4*>(src + (size_t)row * L + col);
+            int c0, row; bool in_img, in_seq;
+            item(s, c0, row, in_img, in_seq);
+            pf[s][0] = zero4; pf[s][1] = zero4;
+            if (in_seq) {
+                pf[s][0] = *reinterpret_cast<const f32x4*>(src + (size_t)c0 * L + row);
+                pf[s][1] = *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + TileGeom<MF, CK>::PAIR_DC) * L + row);
+            }
         }
     };
     auto commit = [&](int ci0, float* Xs) {
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
-            int row, col; bool in_img, in_seq;
-            slot(s, row, col, in_img, in_seq);
+            int c0, row; bool in_img, in_seq;
+            item(s, c0, row, in_img, in_seq);
             if (!in_img) continue;
-            f32x4 v = zero4;             // padding stays exactly 0 (it pads the ACTIVATED signal)
-            if (in_seq) {
-                const float av = p.in_a ? atab[ci0 + row] : 1.f;
-                const float sv = p.in_a ? atab[p.Cin + ci0 + row] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v2w_lrelu(fmaf(av, pf[s][e], sv), slope);
+            float a0 = 1.f, s0 = 0.f, a1 = 1.f, s1 = 0.f;
+            if (p.in_a) {
+                a0 = atab[ci0 + c0]; s0 = atab[p.Cin + ci0 + c0];
+                a1 = atab[ci0 + c0 + TileGeom<MF, CK>::PAIR_DC]; s1 = atab[p.Cin + ci0 + c0 + TileGeom<MF, CK>::PAIR_DC];
             }
-            *reinterpret_cast<f32x4*>(Xs + row * xw + col) = v;
+            float* dst = Xs + row * RS + TileGeom<MF, CK>::slot(c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 v = {0.f, 0.f};        // padding stays exactly 0 (it pads the ACTIVATED signal)
+                if (in_seq) { v[0] = v2w_lrelu(fmaf(a0, pf[s][0][e], s0), slope); v[1] = v2w_lrelu(fmaf(a1, pf[s][1][e], s1), slope); }
+                *reinterpret_cast<f32x2*>(dst + e * RS) = v;
+            }
         }
     };
     auto stage_scalar = [&](int ci0, float* Xs) {   // any L / alignment / input stride: dword loads straight into LDS
@@ -137,64 +181,74 @@ conv_tile_kernel(const MultiArgs m) {
             const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
             const float av = p.in_a ? p.in_a[ch] : 1.f;
             const float sv = p.in_s ? p.in_s[ch] : 0.f;
-            for (int j = lane; j < p.xcols; j += 64) {
+            float* dst = Xs + TileGeom<MF, CK>::slot(c);
+            for (int j = lane; j < p.xrows; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
                 if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[(size_t)l * p.in_stride], sv), slope);
-                Xs[c * xw + j] = v;
+                dst[j * RS] = v;
             }
         }
     };
 
     // ---- packed weights (v2w_pack_mfma): per 32-/16-row block mb the fragments lie in exactly the order this loop
-    // consumes them - [chunk][phase-ordered tap][fragment] - 1 KiB (64 lanes x float4) each, so "next" is always +1 KiB
+    // consumes them - [chunk][phase-ordered tap][fragment] - 1 KiB (64 lanes x float4) each, so "next" is always +1 KiB.
+    // The per-row-block base is wave-uniform (scalar registers); the lane only adds its 16-byte offset.
     const int nfrag = nch * K * GPC;        // fragments per row block
     const f32x4* ap[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
-        ap[i] = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)((m0 + wm0) / MF + i) * nfrag) * 64 + lane;
+        ap[i] = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)((m0 + wm0) / MF + i) * nfrag) * 64;
     int fidx = 0;                           // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
     f32x4 ar[RING][MI];                     // weight ring: RING - 1 fragments in flight (every index below is a compile-time constant)
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto load_next = [&](f32x4 (&a)[MI]) {
         const int f = fidx < nfrag ? fidx : nfrag - 1;
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));     // opaque: otherwise hipcc folds base + lane into a loop-invariant VECTOR address and adds the
+                                          // fragment offset with 64-bit vector adds; this way it is global_load_dwordx4 v, v_off, s[base]
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = ap[i][(size_t)f * 64];
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ap[i] + (size_t)f * 64) + l16);
         ++fidx;
     };
 
-    // ---- B operands (signal): software-pipelined LDS reads.  One tap of one chunk = QT k-steps; k-step q reads row
-    // hk + q*KSTEP of the chunk at the tap's column, so the whole tap is a uniformly strided walk.  The read of k-step q + LOOK
-    // is issued before the MFMAs of k-step q (hipcc alone emits read -> s_waitcnt lgkmcnt(0) -> MFMA with the LDS latency exposed
-    // at every k-step): slot s of `bq` holds k-step q with q % NB == s.  At the end of a tap the reads run on into the next tap
-    // (`xn`; the last tap of a chunk re-reads its own first rows, never used), and each chunk is primed after its barrier.
-    constexpr int QT = 4 * GPC;
-    constexpr int LOOK = (MI * NI >= 4) ? 1 : 3;
-    constexpr int NB = LOOK + 1;
-    static_assert(QT % NB == 0 && LOOK < QT, "operand slots must line up at every tap start");
-    float bq[NB][NI];
-    // RB: ring slot of this tap's first fragment (always 0 unless GPC < RING)
+    // ---- B operands: one float4 (four k-steps) per column block and unit.  With few MFMAs per unit (MI*NI < 4) the next unit's
+    // float4s are requested into a second register set at the start of the running unit; otherwise each column block's register is
+    // refilled right after its last use in the running unit (MI*(NI-1) MFMAs before it is needed again).
+    constexpr bool DB = MI * NI < 4;
+    f32x4 bb[DB ? 2 : 1][NI];
+    // RB: ring / operand-set slot of this tap's first unit (always 0 unless GPC == 1)
     auto tap = [&](auto rb_c, acc_t (&c)[MI][NI], const float* xt, const float* xn) {
         constexpr int RB = decltype(rb_c)::value;
 #pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            if ((q & 3) == 0) load_next(ar[(RB + (q >> 2) + RING - 1) % RING]);
-            const int qa = q + LOOK;
-            const float* src = qa < QT ? xt + qa * KSTEP * xw : xn + (qa - QT) * KSTEP * xw;
+        for (int gg = 0; gg < GPC; ++gg) {
+            load_next(ar[(RB + gg + RING - 1) % RING]);
+            const float* src = gg + 1 < GPC ? xt + CKG * (gg + 1) : xn;      // next unit: same rows, next 8 / 16 slots - or the next tap
+            const int cur = DB ? (RB + gg) & 1 : 0;      // compile-time after unrolling
+            if constexpr (DB) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bq[qa % NB][j] = src[j * MF];
-            __builtin_amdgcn_sched_barrier(0);      // reads and weight prefetch stay AHEAD of this k-step's MFMAs
+                for (int j = 0; j < NI; ++j) bb[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(src + j * MF * RS);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // operand requests stay AHEAD of this unit's MFMAs
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    c[i][j] = F::mfma(ar[(RB + (q >> 2)) % RING][i][q & 3], bq[q % NB][j], c[i][j]);
+                for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) c[i][j] = F::mfma(ar[(RB + gg) % RING][i][kk], bb[cur][j][kk], c[i][j]);
+                    if constexpr (!DB) {
+                        if (kk == 3) bb[0][j] = *reinterpret_cast<const f32x4*>(src + j * MF * RS);
+                    }
+                }
+                if constexpr (!DB) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
-    auto prime = [&](const float* xt) {
+    auto prime = [&](auto rb_c, const float* xt) {
+        constexpr int RB = decltype(rb_c)::value;
 #pragma unroll
-        for (int q = 0; q < LOOK; ++q)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bq[q][j] = xt[q * KSTEP * xw + j * MF];
+        for (int j = 0; j < NI; ++j) bb[DB ? (RB & 1) : 0][j] = *reinterpret_cast<const f32x4*>(xt + j * MF * RS);
     };
 
     // ---- prologue: epilogue constants, affine table, chunk 0, first fragments
@@ -218,18 +272,20 @@ conv_tile_kernel(const MultiArgs m) {
     for (int g = 0; g + 1 < RING; ++g) load_next(ar[g]);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    V2W_STAMP(1);
 
-    const int colbase = wn0 + lr + p.hla + hk * xw;   // this lane's LDS column (+ its k row); tap offset added per tap
+    const int lbase = (wn0 + lr + p.hla) * RS + 4 * hk;   // this lane's float4 in LDS row (position n0 + its column), unit 0
     typedef std::integral_constant<int, 0> RB0;
     typedef std::integral_constant<int, 1> RB1;
     for (int ch = 0; ch < nch; ++ch) {
-        const float* Xs = smem + (ch & 1) * (CK * xw);
-        float* Xn = smem + ((ch + 1) & 1) * (CK * xw);
+        const float* Xs = smem + (ch & 1) * bufsz;
+        float* Xn = smem + ((ch + 1) & 1) * bufsz;
         const bool more = ch + 1 < nch;
         if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
         __builtin_amdgcn_sched_barrier(0);
+        if (ch < 6) V2W_STAMP(2 + 4 * ch);
 
-        // per phase r (one phase for a conv): taps at columns d0 + m*dstr, m < nt
+        // per phase r (one phase for a conv): taps at rows d0 + m*dstr, m < nt
         auto phase = [&](int r, int& d0, int& dstr, int& nt) {
             if (U == 1) { d0 = -p.hl; dstr = p.dil; nt = K; }
             else { const int rp = r + p.pad, t0 = rp % U; d0 = rp / U; dstr = -1; nt = (K - t0 + U - 1) / U; }
@@ -237,89 +293,181 @@ conv_tile_kernel(const MultiArgs m) {
         {
             int d0, dstr, nt;
             phase(0, d0, dstr, nt);
-            prime(Xs + colbase + d0);
+            prime(RB0{}, Xs + lbase + d0 * RS);
         }
 #pragma unroll
         for (int r = 0; r < U; ++r) {
             int d0, dstr, nt;
             phase(r, d0, dstr, nt);
-            const float* xt = Xs + colbase + d0;
-            const float* xlast = xt;                  // where the reads run on after this phase's last tap
-            if (r + 1 < U) { int d1, s1, n1; phase(r + 1, d1, s1, n1); xlast = Xs + colbase + d1; }
-            if constexpr (GPC >= RING) {
-                for (int m = 0; m < nt; ++m, xt += dstr)
-                    tap(RB0{}, acc[r], xt, m + 1 < nt ? xt + dstr : xlast);
-            } else {                                  // GPC == 1, RING == 2: the ring alternates per tap -> taps in pairs
-                int m = 0;
-                for (; m + 1 < nt; m += 2, xt += 2 * dstr) {
-                    tap(RB0{}, acc[r], xt, xt + dstr);
-                    tap(RB1{}, acc[r], xt + dstr, m + 2 < nt ? xt + 2 * dstr : xlast);
+            const int step = dstr * RS;
+            const float* xt = Xs + lbase + d0 * RS;
+            const float* xlast = xt;                  // where the reads run on after this phase's last tap (last phase: never used)
+            if (r + 1 < U) { int d1, s1, n1; phase(r + 1, d1, s1, n1); xlast = Xs + lbase + d1 * RS; }
+            if constexpr (GPC > 1) {
+                for (int t = 0; t + 1 < nt; ++t, xt += step) tap(RB0{}, acc[r], xt, xt + step);
+                tap(RB0{}, acc[r], xt, xlast);
+            } else {                                  // GPC == 1, RING == 2: ring and operand set alternate per tap -> taps in pairs
+                int t = 0;
+                for (; t + 1 < nt; t += 2, xt += 2 * step) {
+                    tap(RB0{}, acc[r], xt, xt + step);
+                    tap(RB1{}, acc[r], xt + step, t + 2 < nt ? xt + 2 * step : xlast);
                 }
-                if (m < nt) {                         // odd count: the in-flight fragment sits in slot 1; hand it over
+                if (t < nt) {                         // odd count: the in-flight fragment / operands sit in slot 1; hand them over
                     tap(RB0{}, acc[r], xt, xlast);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) ar[0][i] = ar[1][i];
+                    if constexpr (DB) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) bb[0][j] = bb[1][j];
+                    }
                 }
             }
         }
 
+        if (ch < 6) V2W_STAMP(3 + 4 * ch);
         if (more) {
             if (p.vec4) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
+            if (ch < 6) V2W_STAMP(4 + 4 * ch);
             __syncthreads();   // Xn complete for the next iteration; everyone done with Xs before it is overwritten again
+            if (ch < 6) V2W_STAMP(5 + 4 * ch);
         }
     }
+    V2W_STAMP(26);
 
     // ---- epilogue: + bias [+ residual] [+ out] [/ out_div]; the U phases of one (co, q) are U consecutive floats.
     const int Lout = L * U;
+    if constexpr (U == 1) {
+        // The accumulator tile of a wave (one 32- / 16-row block at a time) goes through a wave-private LDS scratch (the signal
+        // buffers are dead) and comes back as float4s ALONG positions: 16-byte loads of the residual / addends and 16-byte stores, a
+        // quarter of the memory instructions of a row-per-register epilogue, all loads of a group in flight together, and - as
+        // important - a ROLLED loop: the fully unrolled row-per-register form made this kernel 66 KB of code against a 64 KB
+        // instruction cache shared by two CUs, and its once-per-tile straight-line code ran at instruction-fetch speed (15-45 % of a
+        // tile's time in the tools/tile_timeline.py stamps).
+        constexpr bool MASK = EPI == 1;
+        constexpr int ERS = MF * NI;               // floats per scratch row (the float4 read-back is conflict-free unpadded)
+        constexpr int C4 = ERS / 4;                // float4s per row
+        constexpr int NIT = MF * C4 / 64;          // float4s per lane and row block
+        constexpr int GV = NIT < 4 ? NIT : 4;      // float4s per lane processed together
+        static_assert(NIT % GV == 0 && (MF * C4) % 64 == 0, "row block must split evenly over the wave");
+        __syncthreads();                           // every wave is done with the signal tiles
+        float* const scr = smem + wave * (MF * ERS);
+        // the common forward cases - no addend or only the residual - request ALL their residual float4s of a row block before the
+        // block's LDS transposition, so one memory round trip per row block overlaps the LDS traffic; the rarer combinations
+        // (running sum, two addends, mask) go GV float4s at a time
+        const bool simple = p.evec && !p.accumulate && !p.add0 && !p.add1 && !(MASK && p.mask_src);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if constexpr (U == 1) {
-            // gather the residual / running-sum values of EG accumulator rows first (all loads in flight together), then
-            // combine and store; EG bounds the registers this takes
-            constexpr int EG = (MI == 1 && F::NREG >= 8) ? 8 : 4;
+        for (int i = 0; i < MI; ++i) {
+            const size_t gbase = ((size_t)b * p.CoutT + m0 + wm0 + i * MF) * L + n0 + wn0;
+            const int cbase = wm0 + i * MF;
+            f32x4 rall[NIT];
+            if (simple) {
 #pragma unroll
-            for (int e0 = 0; e0 < F::NREG; e0 += EG) {
-                constexpr bool MASK = EPI == 1;
-                float rv[EG][NI], ov[EG][NI], o2[EG][NI], mv[MASK ? EG : 1][MASK ? NI : 1];
-#pragma unroll
-                for (int ee = 0; ee < EG; ++ee) {
-                    const int co = m0 + wm0 + i * MF + F::row(e0 + ee, hk);
-                    const size_t orow = ((size_t)b * p.CoutT + co) * Lout;
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int q = n0 + wn0 + j * MF + lr;
-                        rv[ee][j] = (p.res && q < L) ? p.res[orow + q] : 0.f;
-                        ov[ee][j] = (p.accumulate && q < L) ? p.out[orow + q] : ((p.add0 && q < L) ? p.add0[orow + q] : 0.f);
-                        o2[ee][j] = (p.add1 && q < L) ? p.add1[orow + q] : 0.f;
-                        if constexpr (MASK) mv[ee][j] = (p.mask_src && q < L) ? p.mask_src[orow + q] : 1.f;
-                    }
-                }
-#pragma unroll
-                for (int ee = 0; ee < EG; ++ee) {
-                    const int e = e0 + ee;
-                    const int col = wm0 + i * MF + F::row(e, hk);
-                    const size_t orow = ((size_t)b * p.CoutT + m0 + col) * Lout;
-                    const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int q = n0 + wn0 + j * MF + lr;
-                        if (q >= L) continue;
-                        float v = acc[0][i][j][e];
-                        if constexpr (MASK)   // backward through the leaky_relu in front of the forward conv: d/dx lrelu = 1 or slope
-                            if (p.mask_src) v = fmaf(etab[3 * MT + col], mv[ee][j], etab[4 * MT + col]) > 0.f ? v : v * p.mask_slope;
-                        v += bias;
-                        if (p.res) v += fmaf(ra, rv[ee][j], rs);
-                        if (p.add1) v += ov[ee][j] + o2[ee][j];          // (add0 + add1) + value: the reference's `xs += ...` order
-                        else if (p.accumulate || p.add0) v += ov[ee][j];
-                        if (p.out_div != 0.f) v = v / p.out_div;
-                        if constexpr (EPI != 0)   // (not in the EPI = 0 instantiations: the forward kernels keep their exact code)
-                            if (p.out_slope != 1.f) v = v > 0.f ? v : v * p.out_slope;
-                        p.out[orow + q] = v;
-                    }
+                for (int g = 0; g < NIT; ++g) {
+                    const int idx = lane + 64 * g;
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    rall[g] = zero4;
+                    if (p.res && n0 + wn0 + 4 * c4 < L) rall[g] = *reinterpret_cast<const f32x4*>(p.res + gbase + (size_t)row * L + 4 * c4);
                 }
             }
-        } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < F::NREG; ++e) scr[F::row(e, hk) * ERS + j * MF + lr] = acc[0][i][j][e];
+            // (wave-private scratch: the wave's own LDS writes are ordered before its reads by the waitcnt hipcc emits)
+            __builtin_amdgcn_sched_barrier(0);
+            if (simple) {
+#pragma unroll
+                for (int g = 0; g < NIT; ++g) {
+                    const int idx = lane + 64 * g;
+                    const int row = idx / C4, c4 = idx - row * C4;
+                    const int col = cbase + row;
+                    const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
+                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * ERS + 4 * c4);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        float t = v[x] + bias;
+                        if (p.res) t += fmaf(ra, rall[g][x], rs);
+                        if (p.out_div != 0.f) t = t / p.out_div;
+                        if constexpr (EPI != 0)
+                            if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
+                        v[x] = t;
+                    }
+                    if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                }
+            } else if (p.evec) {
+#pragma unroll 1
+                for (int g0 = 0; g0 < NIT; g0 += GV) {
+                    f32x4 rv[GV], ov[GV], o2[GV], mv[MASK ? GV : 1];
+#pragma unroll
+                    for (int g = 0; g < GV; ++g) {
+                        const int idx = lane + 64 * (g0 + g);
+                        const int row = idx / C4, c4 = idx - row * C4;
+                        const bool ok = n0 + wn0 + 4 * c4 < L;             // L % 4 == 0: a float4 is inside or outside as a whole
+                        const size_t goff = gbase + (size_t)row * L + 4 * c4;
+                        rv[g] = ov[g] = o2[g] = zero4;
+                        if (ok) {
+                            if (p.res) rv[g] = *reinterpret_cast<const f32x4*>(p.res + goff);
+                            if (p.accumulate) ov[g] = *reinterpret_cast<const f32x4*>(p.out + goff);
+                            else if (p.add0) ov[g] = *reinterpret_cast<const f32x4*>(p.add0 + goff);
+                            if (p.add1) o2[g] = *reinterpret_cast<const f32x4*>(p.add1 + goff);
+                        }
+                        if constexpr (MASK) {
+                            mv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (ok && p.mask_src) mv[g] = *reinterpret_cast<const f32x4*>(p.mask_src + goff);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GV; ++g) {
+                        const int idx = lane + 64 * (g0 + g);
+                        const int row = idx / C4, c4 = idx - row * C4;
+                        const int col = cbase + row;
+                        const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
+                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * ERS + 4 * c4);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            float t = v[x];
+                            if constexpr (MASK)
+                                if (p.mask_src) t = fmaf(etab[3 * MT + col], mv[g][x], etab[4 * MT + col]) > 0.f ? t : t * p.mask_slope;
+                            t += bias;
+                            if (p.res) t += fmaf(ra, rv[g][x], rs);
+                            if (p.add1) t += ov[g][x] + o2[g][x];      // (add0 + add1) + value: the reference's `xs += ...` order
+                            else if (p.accumulate || p.add0) t += ov[g][x];
+                            if (p.out_div != 0.f) t = t / p.out_div;
+                            if constexpr (EPI != 0)
+                                if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
+                            v[x] = t;
+                        }
+                        if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                    }
+                }
+            } else {                               // ragged L / unaligned operands: the same walk, one element at a time
+#pragma unroll 1
+                for (int idx = lane; idx < MF * ERS; idx += 64) {
+                    const int row = idx / ERS, c = idx - row * ERS;
+                    if (n0 + wn0 + c >= L) continue;
+                    const int col = cbase + row;
+                    const size_t goff = gbase + (size_t)row * L + c;
+                    float t = scr[idx];
+                    if constexpr (MASK)
+                        if (p.mask_src) t = fmaf(etab[3 * MT + col], p.mask_src[goff], etab[4 * MT + col]) > 0.f ? t : t * p.mask_slope;
+                    t += etab[col];
+                    if (p.res) t += fmaf(etab[MT + col], p.res[goff], etab[2 * MT + col]);
+                    if (p.add1) t += p.add0[goff] + p.add1[goff];
+                    else if (p.accumulate) t += p.out[goff];
+                    else if (p.add0) t += p.add0[goff];
+                    if (p.out_div != 0.f) t = t / p.out_div;
+                    if constexpr (EPI != 0)
+                        if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
+                    p.out[goff] = t;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int e = 0; e < F::NREG; ++e) {
                 const int co = m0 + wm0 + i * MF + F::row(e, hk);
@@ -345,6 +493,7 @@ conv_tile_kernel(const MultiArgs m) {
             }
         }
     }
+    V2W_STAMP(27);
 
     // ---- fused BatchNorm statistics of the transposed-conv output (modules.py:23): per tile and channel (sum, sumsq),
     // lanes -> wavefront shuffles -> the WN waves through LDS in fixed order -> one slot per (tile, channel); the slots are
@@ -393,10 +542,11 @@ conv_tile_kernel(const MultiArgs m) {
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int HMAX = 32>
 int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     constexpr int MT = MF * MI * WM, NT = MF * NI * WN, NTHREADS = 64 * WM * WN;
-    constexpr int NPF = (CK * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int RS = TileGeom<MF, CK>::RS;
+    constexpr int NPF = ((CK / 2) * (((NT + 2 * HMAX) / 4 + 7) / 8 * 8) + NTHREADS - 1) / NTHREADS;   // staging items (channel pair x 4 positions) per thread, quads padded to groups of 8
     constexpr int KSTEP = MF == 32 ? 2 : 4;
-    constexpr int RING = (U == 1 && CK / (4 * KSTEP) == 4) ? 4 : 2;
-    static_assert(NTHREADS * NPF < 8192, "slot index range of the magic division");
+    constexpr int RING = (CK / (4 * KSTEP) == 4) ? 4 : 2;
+    static_assert(NTHREADS * NPF < 8 * 8192, "item index range of the magic division");
     if (nprob < 1 || nprob > V2W_MAX_MULTI) return V2W_E_ARG;
     MultiArgs m{};
     size_t lds = 0;
@@ -413,15 +563,21 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
         p.ntl = (p.L + NT - 1) / NT;
         p.ntiles = p.B * p.ntl;
-        p.xcols = (p.hla + NT + p.hr + 3) & ~3;
-        int xw = p.xcols;
-        if (MF == 16) xw += ((16 - xw % 32) + 32) % 32;  // xw % 32 == 16: the two 16-lane k-groups of a half-wave hit disjoint banks
-        p.xw = xw;
+        p.xrows = (p.hla + NT + p.hr + 3) & ~3;
+        p.xcols = p.xrows; p.xw = RS;
         if (p.in_stride < 1) p.in_stride = 1;
         p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0) && p.in_stride == 1;
         const int nbuf = p.Cin / CK > 1 ? 2 : 1;
-        p.atab_off = nbuf * CK * xw;
-        const size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        p.atab_off = nbuf * p.xrows * RS;
+        // vector epilogue (conv only): float4 I/O along positions through a wave-private LDS scratch that overlays the signal buffers
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        p.evec = U == 1 && p.L % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
+        if (U == 1 && p.atab_off < WM * WN * MF * MF * NI) p.atab_off = WM * WN * MF * MF * NI;   // room for the epilogue scratch
+        size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        if (U > 1 && p.stats_part) {                  // the fused BatchNorm partials reuse the signal buffers as [WN][MT][2] scratch
+            const size_t need = (size_t)WN * MT * 2 * sizeof(float);
+            if ((size_t)p.atab_off * sizeof(float) < need) return V2W_E_SHAPE;
+        }
         if (l > lds) lds = l;
         m.p[i] = p;
         m.start[i] = grid;

@@ -16,6 +16,10 @@
 //   from L2 through a two-deep register ping-pong.
 #include "v2w_common.h"
 
+#ifdef V2W_TIMELINE   // diagnostic build only (see v2w_common.h)
+V2W_TL_SETTER(v2w_timeline_set)
+#endif
+
 namespace {
 
 struct PairArgs {
@@ -145,20 +149,30 @@ struct FusedConv {
                                         const float* xt, const float* xn, int sw, float slope) {
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
+#ifndef V2W_TL_NOGLOAD    // (diagnostic what-if builds: V2W_TL_NOGLOAD / _NODSREAD / _NOLRELU drop one operand stream; results are wrong)
             if ((q & 3) == 0) ar[(RB + (q >> 2) + RING - 1) % RING] = frag(ap, ap_next, nfrag, g0 + (q >> 2) + RING - 1);
+#endif
             const int qa = q + LOOK;
             const float* src = qa < QT ? xt + qa * KSTEP * sw : xn + (qa - QT) * KSTEP * sw;
+#ifndef V2W_TL_NODSREAD
 #pragma unroll
             for (int j = 0; j < NI; ++j) bq[qa % NB][j] = src[j * MF];
+#else
+            (void)src;
+#endif
             __builtin_amdgcn_sched_barrier(0);      // reads and weight prefetch stay AHEAD of this k-step's MFMAs
 #pragma unroll
             for (int j = 0; j < NI; ++j)
+#ifdef V2W_TL_NOLRELU
+                acc[j] = F::mfma(ar[(RB + (q >> 2)) % RING][q & 3], bq[q % NB][j], acc[j]);
+#else
                 acc[j] = F::mfma(ar[(RB + (q >> 2)) % RING][q & 3], v2w_lrelu(bq[q % NB][j], slope), acc[j]);
+#endif
         }
     }
     // the whole phase; x0 = src + hk*sw + (this lane's column of tap 0).  Zeroes acc first.
     __device__ __forceinline__ void run(acc_t (&acc)[NI], const f32x4* ap, const f32x4* ap_next, int K, const float* x0, int sw,
-                                        int dil, float slope) {
+                                        int dil, float slope, int tl = -1) {   // tl: first timeline slot of the per-tap stamps (diagnostic builds)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -167,8 +181,10 @@ struct FusedConv {
         prime(x0, sw);
         const float* xt = x0;
         if constexpr (GPC % RING == 0) {
-            for (int t = 0; t < K; ++t, xt += dil)
+            for (int t = 0; t < K; ++t, xt += dil) {
                 tap<0>(acc, ap, ap_next, nfrag, t * GPC, xt, t + 1 < K ? xt + dil : xt, sw, slope);
+                if (tl >= 0) V2W_STAMP(tl + t);
+            }
         } else {                                    // GPC == 1, RING == 2: slot parity carried across taps and phases
             int t = 0;
             if (rb) { tap<1>(acc, ap, ap_next, nfrag, 0, xt, K > 1 ? xt + dil : xt, sw, slope); ++t; xt += dil; }
@@ -335,6 +351,18 @@ int launch_pair(const v2w_pair_args* a, int n, hipStream_t stream) {
 //   out = ( sum_j [ t1_j + conv_{k_j,d2_j}(lrelu(t1_j)) + b2_j ] ) / nk ,   t1_j = x + conv_{k_j,d1_j}(lrelu(x)) + b1_j
 // The x tile is staged ONCE for all nk branches, every t1_j lives only in LDS, the branch sum lives in registers and is
 // added in the reference's order ((r0 + r1) + r2); HBM sees one read of x and one write of out per stage.
+//
+// What shapes this kernel (tools/stage_timeline.py, in-kernel stamps on MI355X): the f32 MFMA shares the SIMD's vector ALU, so
+// EVERY vector instruction issued inside the MFMA loop costs matrix time - an operand leaky_relu in registers (3 VALU per
+// product) took 26 cycles per 64-cycle MFMA, a v_add + ds_read2_b32 pair per k-step another 10.  Hence:
+//   * LDS tiles hold the ACTIVATED operands lrelu(x), lrelu(t1); the residuals (raw x, raw t1) live in registers: conv1 and conv2
+//     are computed on the SAME window of W positions, so a lane's conv2 accumulator meets its own t1 (valid outputs: the window
+//     minus h2max columns on each side);
+//   * tiles are position-major, [position][C + pad] with the channels of a row permuted so that the four k-steps of one packed
+//     weight fragment are 16 contiguous bytes: ONE ds_read_b128 (immediate offsets, no address arithmetic) feeds four MFMAs per
+//     column block; row stride 36 / 24 floats makes those reads bank-conflict free;
+//   * the next unit's operands (LDS) and the weight fragments (L2, scalar base + lane offset) are requested one unit / three
+//     fragments ahead of the MFMAs that use them.
 #define V2W_STAGE_MAXB 4
 struct StageArgs {
     const float* in; const float* in_a; const float* in_s;
@@ -344,9 +372,91 @@ struct StageArgs {
     float* out;
     int nk, B, L;
     int h1max, h2max;
-    int xoff, xw, tw, xcols, nto, ntl;
+    int xoff;          // X row of position (n0 - h2max - h1max); X row 0 sits at a position that is a multiple of 4
+    int xrows;         // staged X rows (multiple of 4)
+    int nto, ntl;      // valid outputs per tile, tiles per batch item
     int vec4;
     float slope, out_div;
+};
+
+template <int MF> struct StageGeom {
+    static constexpr int RS = MF == 32 ? 36 : 24;      // floats per position row: 16-byte aligned, conflict-free ds_read_b128
+    static constexpr int HMAX = 32;                    // largest conv1 halo the staging slots cover
+    // LDS slot of channel c inside a position row.  The packed weight fragment (v2w_pack_mfma) pairs k-step kk, lane half hk with
+    // channel 8g + 2kk + hk (32x32x2) / 4kk + hk (16x16x4); the slot order puts a lane's four k-steps side by side.
+    __host__ __device__ static constexpr int slot(int c) {
+        return MF == 32 ? ((c & ~7) + 4 * (c & 1) + ((c & 7) >> 1)) : (4 * (c & 3) + (c >> 2));
+    }
+};
+
+// One conv phase: acc[j] = sum over taps and channels of W * (activated tile).  `x0` = this lane's float4 of tap 0, column block 0,
+// unit 0; a tap advances `dil` rows, a column block MF rows, a unit 8 floats.
+template <int MF, int NI>
+struct StageConv {
+    typedef Frag<MF> F;
+    typedef typename F::acc_t acc_t;
+    static constexpr int KSTEP = F::KSTEP, GPC = MF / (4 * KSTEP), RING = MF == 32 ? 4 : 2, RS = StageGeom<MF>::RS;
+    static_assert(GPC % RING == 0 || (GPC == 1 && RING == 2), "ring slot of a tap's first fragment must be static");
+    f32x4 ar[RING];        // weight fragments, RING - 1 in flight
+    f32x4 bb[2][NI];       // operand float4s of the running and of the next unit
+    int rb;                // GPC == 1: ring / operand slot of the next tap (alternates per tap, carried across phases)
+
+    __device__ __forceinline__ void start(const f32x4* w, int lane) {
+#pragma unroll
+        for (int g = 0; g + 1 < RING; ++g) ar[g] = w[(size_t)g * 64 + lane];
+        rb = 0;
+    }
+    template <int RB>
+    __device__ __forceinline__ void tap(acc_t (&acc)[NI], const f32x4* wa, const f32x4* wnext, int nfrag, int g0, int lane,
+                                        const float* xt, const float* xn) {
+#pragma unroll
+        for (int gg = 0; gg < GPC; ++gg) {
+            const int g = g0 + gg + RING - 1;                                   // uniform: the stream select stays scalar
+            const f32x4* wsrc = g < nfrag ? wa + (size_t)g * 64 : wnext + (size_t)(g - nfrag) * 64;
+            ar[(RB + gg + RING - 1) % RING] = wsrc[lane];
+            const float* src = gg + 1 < GPC ? xt + 8 * (gg + 1) : xn;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bb[(RB + gg + 1) & 1][j] = *reinterpret_cast<const f32x4*>(src + j * MF * RS);
+            __builtin_amdgcn_sched_barrier(0);      // operand requests stay AHEAD of this unit's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[j] = F::mfma(ar[(RB + gg) % RING][kk], bb[(RB + gg) & 1][j][kk], acc[j]);
+        }
+    }
+    __device__ __forceinline__ void run(acc_t (&acc)[NI], const f32x4* wa, const f32x4* wnext, int K, int lane, const float* x0,
+                                        int dil, int tl = -1) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < F::NREG; ++e) acc[j][e] = 0.f;
+        const int nfrag = K * GPC, step = dil * RS;
+        const float* xt = x0;
+        if constexpr (GPC % RING == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bb[0][j] = *reinterpret_cast<const f32x4*>(x0 + j * MF * RS);
+            for (int t = 0; t + 1 < K; ++t, xt += step) {
+                tap<0>(acc, wa, wnext, nfrag, t * GPC, lane, xt, xt + step);
+                if (tl >= 0) V2W_STAMP(tl + t);
+            }
+            tap<0>(acc, wa, wnext, nfrag, (K - 1) * GPC, lane, xt, xt);      // (the run-on reads of the last tap are never used)
+        } else {                                    // GPC == 1, RING == 2: slot parity carried across taps and phases
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x0 + j * MF * RS);
+                if (rb) bb[1][j] = v; else bb[0][j] = v;
+            }
+            int t = 0;
+            if (rb) { tap<1>(acc, wa, wnext, nfrag, 0, lane, xt, K > 1 ? xt + step : xt); ++t; xt += step; }
+            for (; t + 1 < K; t += 2, xt += 2 * step) {
+                tap<0>(acc, wa, wnext, nfrag, t, lane, xt, xt + step);
+                tap<1>(acc, wa, wnext, nfrag, t + 1, lane, xt + step, t + 2 < K ? xt + 2 * step : xt);
+            }
+            rb = 0;
+            if (t < K) { tap<0>(acc, wa, wnext, nfrag, t, lane, xt, xt); rb = 1; }
+        }
+    }
 };
 
 template <int MF, int NI, int WN>
@@ -354,102 +464,210 @@ __global__ void __launch_bounds__(64 * WN)
 resblock2_stage_kernel(const StageArgs p) {
     typedef Frag<MF> F;
     typedef typename F::acc_t acc_t;
+    typedef StageGeom<MF> G;
     constexpr int NTHREADS = 64 * WN;
     constexpr int C = MF;
-    constexpr int KSTEP = F::KSTEP;
-    constexpr int CKG = 4 * KSTEP;
-    constexpr int GPC = C / CKG;
+    constexpr int W = MF * NI * WN;         // positions each conv phase computes
+    constexpr int RS = G::RS;
+    constexpr int NR = F::NREG;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
     const int b = tile / p.ntl;
-    const int n0 = (tile % p.ntl) * p.nto;
+    const int n0 = (tile % p.ntl) * p.nto;  // first valid output position of the tile (multiple of 4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & (MF - 1), hk = lane / MF;
     const int wn0 = wave * (MF * NI);
-    const int L = p.L, xw = p.xw, tw = p.tw;
+    const int L = p.L;
     const float slope = p.slope;
-    float* const Xs = smem;                 // [C][xw]
-    float* const Ts = smem + C * xw;        // [C][tw]
-    float* const etab = Ts + C * tw;        // bias1[nk][C], bias2[nk][C]
-
-    const int pos0 = n0 - p.h2max - p.h1max - p.xoff;
+    float* const Xa = smem;                          // [xrows][RS]  lrelu(x), exactly 0 outside the sequence
+    float* const Ta = smem + p.xrows * RS;           // [W][RS]      raw x of the window at first, then lrelu(t1_j); conv2's taps reach h2max rows
+                                                     //              past either end (X's tail / the pad below): read-only, feeds discarded columns
+    float* const etab = Ta + (W + p.h2max) * RS;     // bias1[nk][C], bias2[nk][C]
+    const int pos0 = n0 - p.h2max - p.h1max - p.xoff;   // position of X row 0
+    const int xc0 = p.xoff + p.h1max;                // X row of window column 0 (position n0 - h2max)
+    V2W_STAMP(0);
     for (int i = tid; i < p.nk * C; i += NTHREADS) {
         const int j = i / C, c = i - j * C;
         etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
         etab[V2W_STAGE_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
     }
-    if (p.vec4) XStage<C, NTHREADS>::vec4(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, tid);
-    else XStage<C, NTHREADS>::scalar(p.in, p.in_a, p.in_s, Xs, b, L, pos0, p.xcols, xw, wave, lane);
 
-    typedef FusedConv<MF, NI, MF == 32 ? 4 : 2, 3> FC;
-    FC fc;
-    fc.start(reinterpret_cast<const f32x4*>(p.wp1[0]) + lane);
-    __syncthreads();
-
-    acc_t acc[NI], oacc[NI];
-    for (int jb = 0; jb < p.nk; ++jb) {
-        const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
-        const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
-        const f32x4* ap1 = reinterpret_cast<const f32x4*>(p.wp1[jb]) + lane;
-        const f32x4* ap2 = reinterpret_cast<const f32x4*>(p.wp2[jb]) + lane;
-        const f32x4* ap_after = jb + 1 < p.nk ? reinterpret_cast<const f32x4*>(p.wp1[jb + 1]) + lane : ap2;   // last: a harmless re-read
-
-        // ---- conv1_j -> t1_j on positions [n0 - h2max, n0 - h2max + W)
-        fc.run(acc, ap1, ap2, K, Xs + hk * xw + wn0 + lr + p.xoff + (p.h1max - h1), xw, d1, slope);
+    // ---- stage x = a*in + s: lrelu(x) into Xa (all rows), raw x of the window into Ta (the residual of every branch).
+    // A thread takes 4 channels x 4 positions at a time (all its loads are issued before the first is consumed); the channel
+    // permutation turns its 4 x 4 block into two 8-byte stores per position (32 channels) / four dword stores (16 channels).
+    auto put = [&](float* row, int cg, const float (&v)[4]) {     // v[i] = channel 4*cg + i at one position
+        if constexpr (MF == 32) {
+            float* d = row + 8 * (cg >> 1) + 2 * (cg & 1);
+            *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[2]};
+            *reinterpret_cast<f32x2*>(d + 4) = f32x2{v[1], v[3]};
+        } else {
 #pragma unroll
-        for (int e = 0; e < F::NREG; ++e) {
-            const int co = F::row(e, hk);
-            const float bias = etab[jb * C + co];
+            for (int i = 0; i < 4; ++i) row[4 * i + cg] = v[i];
+        }
+    };
+    if (p.vec4) {
+        constexpr int NPF = ((C / 4) * ((W + 2 * G::HMAX + 8) / 4) + NTHREADS - 1) / NTHREADS;
+        const int xr4 = p.xrows >> 2;
+        const unsigned magic = (unsigned)(((1ull << 32) + xr4 - 1) / xr4);
+        f32x4 g[NPF][4];
+        float av[NPF][4], sv[NPF][4];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = wn0 + j * MF + lr;
-                const int pos = n0 - p.h2max + col;
-                const float v = acc[j][e] + bias + Xs[co * xw + col + p.xoff + p.h1max];
-                acc[j][e] = (pos >= 0 && pos < L) ? v : 0.f;
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            const int cg = (int)__umulhi((unsigned)idx, magic);
+            const int pos = pos0 + (idx - cg * xr4) * 4;
+            const bool ok = idx < (C / 4) * xr4 && pos >= 0 && pos < L;      // L % 4 == 0, pos % 4 == 0: whole float4 inside
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s][i] = 1.f; sv[s][i] = 0.f;
+                if (ok) {
+                    const int ch = b * C + 4 * cg + i;
+                    g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
+                    if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
+                }
             }
         }
-        if (jb > 0) __syncthreads();          // conv2 of the previous branch has finished reading T1
 #pragma unroll
-        for (int e = 0; e < F::NREG; ++e) {
-            const int co = F::row(e, hk);
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            if (idx >= (C / 4) * xr4) continue;
+            const int cg = (int)__umulhi((unsigned)idx, magic);
+            const int r0 = (idx - cg * xr4) * 4;
+            const bool ok = pos0 + r0 >= 0 && pos0 + r0 < L;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) Ts[co * tw + wn0 + j * MF + lr] = acc[j][e];
-        }
-        __syncthreads();
-
-        // ---- conv2_j ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        fc.run(acc, ap2, ap_after, K, Ts + hk * tw + wn0 + lr + (p.h2max - h2), tw, d2, slope);
+            for (int e = 0; e < 4; ++e) {
+                float raw[4], act[4];
 #pragma unroll
-        for (int e = 0; e < F::NREG; ++e) {
-            const int co = F::row(e, hk);
-            const float bias = etab[V2W_STAGE_MAXB * C + jb * C + co];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const float r = (acc[j][e] + bias) + Ts[co * tw + wn0 + j * MF + lr + p.h2max];
-                oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
+                for (int i = 0; i < 4; ++i) {
+                    raw[i] = ok ? fmaf(av[s][i], g[s][i][e], sv[s][i]) : 0.f;
+                    act[i] = v2w_lrelu(raw[i], slope);
+                }
+                const int r = r0 + e;
+                put(Xa + r * RS, cg, act);
+                if (r >= xc0 && r < xc0 + W) put(Ta + (r - xc0) * RS, cg, raw);
             }
+        }
+    } else {                                    // any L / alignment: one element at a time
+        for (int i = tid; i < C * p.xrows; i += NTHREADS) {
+            const int c = i / p.xrows, r = i - c * p.xrows, pos = pos0 + r;
+            float raw = 0.f;
+            if (pos >= 0 && pos < L) {
+                const int ch = b * C + c;
+                raw = fmaf(p.in_a ? p.in_a[ch] : 1.f, p.in[(size_t)ch * L + pos], p.in_s ? p.in_s[ch] : 0.f);
+            }
+            Xa[r * RS + G::slot(c)] = v2w_lrelu(raw, slope);
+            if (r >= xc0 && r < xc0 + W) Ta[(r - xc0) * RS + G::slot(c)] = raw;
         }
     }
 
+    typedef StageConv<MF, NI> SC;
+    SC sc;
+    sc.start(reinterpret_cast<const f32x4*>(p.wp1[0]), lane);
+    V2W_STAMP(1);
+    __syncthreads();
+    V2W_STAMP(2);
+
+    // accumulator row `reg` of this lane = channel co = F::row(reg, hk); its slot in a position row:
+    //   32 channels: co = 8g + 4hk + r  ->  slot 8g + 2hk + (r >> 1) + 4(r & 1): (r0, r2) and (r1, r3) are 8-byte pairs
+    //   16 channels: co = 4hk + reg     ->  slot 4reg + hk
+    auto row_get = [&](const float* row, float (&v)[NR]) {
+        if constexpr (MF == 32) {
 #pragma unroll
-    for (int e = 0; e < F::NREG; ++e) {
+            for (int g = 0; g < 4; ++g) {
+                const f32x2 a = *reinterpret_cast<const f32x2*>(row + 8 * g + 2 * hk);
+                const f32x2 c = *reinterpret_cast<const f32x2*>(row + 8 * g + 2 * hk + 4);
+                v[4 * g] = a[0]; v[4 * g + 2] = a[1]; v[4 * g + 1] = c[0]; v[4 * g + 3] = c[1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = row[4 * r + hk];
+        }
+    };
+    auto row_put = [&](float* row, const float (&v)[NR]) {
+        if constexpr (MF == 32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x2*>(row + 8 * g + 2 * hk) = f32x2{v[4 * g], v[4 * g + 2]};
+                *reinterpret_cast<f32x2*>(row + 8 * g + 2 * hk + 4) = f32x2{v[4 * g + 1], v[4 * g + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) row[4 * r + hk] = v[r];
+        }
+    };
+
+    float xres[NI][NR];                       // raw x at this lane's outputs: the residual of conv1 in every branch
+#pragma unroll
+    for (int j = 0; j < NI; ++j) row_get(Ta + (wn0 + j * MF + lr) * RS, xres[j]);
+
+    acc_t acc[NI];
+    float t1r[NI][NR], oacc[NI][NR];
+    const float* const xl = Xa + (wn0 + lr) * RS + 4 * hk;     // this lane's float4 in X / T1 row (window column) 0
+    const float* const tl = Ta + (wn0 + lr) * RS + 4 * hk;
+    for (int jb = 0; jb < p.nk; ++jb) {
+        const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
+        const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
+        const f32x4* w1 = reinterpret_cast<const f32x4*>(p.wp1[jb]);
+        const f32x4* w2 = reinterpret_cast<const f32x4*>(p.wp2[jb]);
+        const f32x4* wafter = jb + 1 < p.nk ? reinterpret_cast<const f32x4*>(p.wp1[jb + 1]) : w2;   // last: a harmless re-read
+
+        // ---- conv1_j on the window: column col <-> position n0 - h2max + col
+        sc.run(acc, w1, w2, K, lane, xl + (xc0 - h1) * RS, d1, jb == 0 ? 16 : (jb == 2 ? 19 : -1));
+        V2W_STAMP(3 + 4 * jb);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int pos = n0 - p.h2max + wn0 + j * MF + lr;
+            const bool in_seq = pos >= 0 && pos < L;            // conv2 zero-pads t1 outside the sequence
+#pragma unroll
+            for (int e = 0; e < NR; ++e)
+                t1r[j][e] = in_seq ? (acc[j][e] + etab[jb * C + F::row(e, hk)]) + xres[j][e] : 0.f;
+        }
+        __syncthreads();                      // everyone is done reading Ta (raw x at jb == 0, the previous branch's t1 after)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float a[NR];
+#pragma unroll
+            for (int e = 0; e < NR; ++e) a[e] = v2w_lrelu(t1r[j][e], slope);
+            row_put(Ta + (wn0 + j * MF + lr) * RS, a);
+        }
+        __syncthreads();
+        V2W_STAMP(4 + 4 * jb);
+
+        // ---- conv2_j on the same window ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
+        sc.run(acc, w2, wafter, K, lane, tl - h2 * RS, d2);
+        V2W_STAMP(5 + 4 * jb);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const float r = (acc[j][e] + etab[V2W_STAGE_MAXB * C + jb * C + F::row(e, hk)]) + t1r[j][e];
+                oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
+            }
+        V2W_STAMP(6 + 4 * jb);
+    }
+
+    // valid outputs: window columns [h2max, h2max + nto)
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
         const int co = F::row(e, hk);
         const size_t orow = ((size_t)b * C + co) * L;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int col = wn0 + j * MF + lr, pos = n0 + col;
-            if (col >= p.nto || pos >= L) continue;
+            const int col = wn0 + j * MF + lr, pos = n0 - p.h2max + col;
+            if (col < p.h2max || col >= p.h2max + p.nto || pos >= L) continue;
             float v = oacc[j][e];
             if (p.out_div != 0.f) v = v / p.out_div;
             p.out[orow + pos] = v;
         }
     }
+    V2W_STAMP(15);
 }
 
 template <int MF, int NI, int WN>
 int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
+    typedef StageGeom<MF> G;
     constexpr int W = MF * NI * WN;
     StageArgs p{};
     p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.out = q->out;
@@ -457,22 +675,23 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     for (int j = 0; j < q->nk; ++j) {
         p.wp1[j] = q->wp1[j]; p.bias1[j] = q->bias1[j]; p.wp2[j] = q->wp2[j]; p.bias2[j] = q->bias2[j];
         p.K[j] = q->k[j]; p.d1[j] = q->dil1[j]; p.d2[j] = q->dil2[j];
+        if (q->k[j] < 3) return V2W_E_SHAPE;             // the weight ring runs three fragments ahead into the next stream
         const int h1 = q->dil1[j] * (q->k[j] - 1) / 2, h2 = q->dil2[j] * (q->k[j] - 1) / 2;
         if (h1 > p.h1max) p.h1max = h1;
         if (h2 > p.h2max) p.h2max = h2;
     }
     p.nto = (W - 2 * p.h2max) & ~3;
-    if (p.nto < W / 2) return V2W_E_SHAPE;
+    if (p.nto < W / 2 || p.h1max > G::HMAX) return V2W_E_SHAPE;
     const int hsum = p.h1max + p.h2max;
     p.xoff = ((hsum + 3) & ~3) - hsum;
-    p.xcols = (p.xoff + W + 2 * p.h1max + 3) & ~3;
-    int xw = p.xcols, tw = (W + 2 * p.h2max + 3) & ~3;
-    if (MF == 16) { xw += ((16 - xw % 32) + 32) % 32; tw += ((16 - tw % 32) + 32) % 32; }
-    p.xw = xw; p.tw = tw;
+    p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
+    if (p.xrows < p.h2max) return V2W_E_SHAPE;
     p.ntl = (q->L + p.nto - 1) / p.nto;
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
-    if (!XStage<MF, 64 * WN>::fits(p.xcols)) return V2W_E_SHAPE;
-    const size_t lds = ((size_t)MF * (xw + tw) + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
+    size_t lds = ((size_t)(p.xrows + W + p.h2max) * G::RS + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
+#ifdef V2W_TIMELINE
+    if (const char* e = getenv("V2W_TL_LDSPAD")) lds += (size_t)atoi(e);      // fewer workgroups per CU: what does ONE wave per SIMD reach?
+#endif
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     auto kern = resblock2_stage_kernel<MF, NI, WN>;
     if (lds > 64 * 1024) {

@@ -22,8 +22,9 @@ struct TileArgs {
     int pad;      // convT only: (K-U)/2
     int hl, hr;   // halo (input positions) left / right of the tile
     int hla;      // hl rounded up to a multiple of 4: LDS column 0 <-> position n0 - hla (16-B aligned rows)
-    int xw;       // LDS row stride of the input tile (floats)
-    int xcols;    // columns actually staged (multiple of 4)
+    int xw;       // split kernel: unused (0)
+    int xcols;    // split kernel: positions actually staged (multiple of 4)
+    int xrows;    // f32 kernel: position rows of the LDS signal tile (multiple of 4): hla + NT + hr rounded up
     int vec4;     // 1: L % 4 == 0 and 16-B aligned base -> float4 staging
     int evec;     // split kernel: 1 = float4 epilogue (L % 4 == 0, every epilogue operand 16-B aligned)
     int atab_off; // LDS offset (floats) of the affine table: after the 1 or 2 signal buffers

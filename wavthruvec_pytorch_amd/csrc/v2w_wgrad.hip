@@ -300,7 +300,7 @@ static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t s
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
     if (dev == 63 || !((attr_set >> dev) & 1ull)) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set |= 1ull << dev;
     }
     hipLaunchKernelGGL(kern, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
@@ -521,10 +521,10 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
                 const size_t lds = set_strides(128);
                 if (lds > 160 * 1024) return V2W_E_SHAPE;
                 if (mf == 32) {
-                    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 } else {
-                    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 }
             }
