@@ -528,7 +528,8 @@ def test_resblock_pair_fused_equals_two_convs(dev, C, L, k, d1, d2, mode):
 
 @pytest.mark.parametrize('C,L', [(32, 1000), (16, 3000), (16, 4), (32, 252)])
 def test_resblock2_stage_fused_equals_branchwise(dev, C, L):
-    """One kernel for the whole ResBlock2 residual section of a stage vs the per-branch launches (bit-identical sum order)."""
+    """One kernel for the whole ResBlock2 residual section of a stage vs the per-branch launches: same branch-sum order; the fused
+    kernel starts its accumulators AT the bias (the per-layer kernel adds it last), so the two differ by a few ulps of O(5) values."""
     from wavthruvec_pytorch_amd import hipops
     r = _rng(12)
     B = 2
@@ -551,7 +552,7 @@ def test_resblock2_stage_fused_equals_branchwise(dev, C, L):
     got = torch.full((B, C, L), float('nan'), device=dev)
     assert hipops.resblock2_stage(x, aff, branches, got, slope=0.1, out_div=3.0)
     assert torch.isfinite(got).all()
-    assert (got - outs[2]).abs().max().item() <= 1e-6
+    assert (got - outs[2]).abs().max().item() <= 4e-6
     xin = (aff[0][:, :, None] * x + aff[1][:, :, None]).cpu()
     want = None
     for br in branches:

@@ -352,6 +352,7 @@ conv_tile_kernel(const MultiArgs m) {
         static_assert(NIT % GV == 0 && (MF * C4) % 64 == 0, "row block must split evenly over the wave");
         __syncthreads();                           // every wave is done with the signal tiles
         float* const scr = smem + wave * (MF * ERS);
+        const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
         // the common forward cases - no addend or only the residual - request ALL their residual float4s of a row block before the
         // block's LDS transposition, so one memory round trip per row block overlaps the LDS traffic; the rarer combinations
         // (running sum, two addends, mask) go GV float4s at a time
@@ -389,7 +390,7 @@ conv_tile_kernel(const MultiArgs m) {
                     for (int x = 0; x < 4; ++x) {
                         float t = v[x] + bias;
                         if (p.res) t += fmaf(ra, rall[g][x], rs);
-                        if (p.out_div != 0.f) t = t / p.out_div;
+                        if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
                         if constexpr (EPI != 0)
                             if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                         v[x] = t;
@@ -434,7 +435,7 @@ conv_tile_kernel(const MultiArgs m) {
                             if (p.res) t += fmaf(ra, rv[g][x], rs);
                             if (p.add1) t += ov[g][x] + o2[g][x];      // (add0 + add1) + value: the reference's `xs += ...` order
                             else if (p.accumulate || p.add0) t += ov[g][x];
-                            if (p.out_div != 0.f) t = t / p.out_div;
+                            if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
                             if constexpr (EPI != 0)
                                 if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                             v[x] = t;
@@ -457,7 +458,7 @@ conv_tile_kernel(const MultiArgs m) {
                     if (p.add1) t += p.add0[goff] + p.add1[goff];
                     else if (p.accumulate) t += p.out[goff];
                     else if (p.add0) t += p.add0[goff];
-                    if (p.out_div != 0.f) t = t / p.out_div;
+                    if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
                     if constexpr (EPI != 0)
                         if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                     p.out[goff] = t;

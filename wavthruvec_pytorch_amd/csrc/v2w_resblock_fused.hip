@@ -425,12 +425,13 @@ struct StageConv {
                     acc[j] = F::mfma(ar[(RB + gg) % RING][kk], bb[(RB + gg) & 1][j][kk], acc[j]);
         }
     }
-    __device__ __forceinline__ void run(acc_t (&acc)[NI], const f32x4* wa, const f32x4* wnext, int K, int lane, const float* x0,
-                                        int dil, int tl = -1) {
+    // `brow`: this lane's NREG bias values (bias[F::row(e, hk)]): the accumulators START at the bias, so no epilogue add is needed
+    __device__ __forceinline__ void run(acc_t (&acc)[NI], const float (&brow)[F::NREG], const f32x4* wa, const f32x4* wnext, int K,
+                                        int lane, const float* x0, int dil, int tl = -1) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < F::NREG; ++e) acc[j][e] = 0.f;
+            for (int e = 0; e < F::NREG; ++e) acc[j][e] = brow[e];
         const int nfrag = K * GPC, step = dil * RS;
         const float* xt = x0;
         if constexpr (GPC % RING == 0) {
@@ -598,6 +599,21 @@ resblock2_stage_kernel(const StageArgs p) {
         }
     };
 
+    // bias of this lane's accumulator rows: F::row(e, hk) is 4 consecutive channels per register quad (32 ch.) / all of them (16)
+    auto bias_rows = [&](const float* tab, float (&v)[NR]) {
+        if constexpr (MF == 32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(tab + 8 * g + 4 * hk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * g + r] = q[r];
+            }
+        } else {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(tab + 4 * hk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = q[r];
+        }
+    };
     float xres[NI][NR];                       // raw x at this lane's outputs: the residual of conv1 in every branch
 #pragma unroll
     for (int j = 0; j < NI; ++j) row_get(Ta + (wn0 + j * MF + lr) * RS, xres[j]);
@@ -614,15 +630,16 @@ resblock2_stage_kernel(const StageArgs p) {
         const f32x4* wafter = jb + 1 < p.nk ? reinterpret_cast<const f32x4*>(p.wp1[jb + 1]) : w2;   // last: a harmless re-read
 
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col
-        sc.run(acc, w1, w2, K, lane, xl + (xc0 - h1) * RS, d1, jb == 0 ? 16 : (jb == 2 ? 19 : -1));
+        float brow[NR];
+        bias_rows(etab + jb * C, brow);
+        sc.run(acc, brow, w1, w2, K, lane, xl + (xc0 - h1) * RS, d1, jb == 0 ? 16 : (jb == 2 ? 19 : -1));
         V2W_STAMP(3 + 4 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int pos = n0 - p.h2max + wn0 + j * MF + lr;
             const bool in_seq = pos >= 0 && pos < L;            // conv2 zero-pads t1 outside the sequence
 #pragma unroll
-            for (int e = 0; e < NR; ++e)
-                t1r[j][e] = in_seq ? (acc[j][e] + etab[jb * C + F::row(e, hk)]) + xres[j][e] : 0.f;
+            for (int e = 0; e < NR; ++e) t1r[j][e] = in_seq ? acc[j][e] + xres[j][e] : 0.f;
         }
         __syncthreads();                      // everyone is done reading Ta (raw x at jb == 0, the previous branch's t1 after)
 #pragma unroll
@@ -636,30 +653,54 @@ resblock2_stage_kernel(const StageArgs p) {
         V2W_STAMP(4 + 4 * jb);
 
         // ---- conv2_j on the same window ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        sc.run(acc, w2, wafter, K, lane, tl - h2 * RS, d2);
+        bias_rows(etab + V2W_STAGE_MAXB * C + jb * C, brow);
+        sc.run(acc, brow, w2, wafter, K, lane, tl - h2 * RS, d2);
         V2W_STAMP(5 + 4 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < NR; ++e) {
-                const float r = (acc[j][e] + etab[V2W_STAGE_MAXB * C + jb * C + F::row(e, hk)]) + t1r[j][e];
+                const float r = acc[j][e] + t1r[j][e];
                 oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
             }
         V2W_STAMP(6 + 4 * jb);
     }
 
-    // valid outputs: window columns [h2max, h2max + nto)
-#pragma unroll
-    for (int e = 0; e < NR; ++e) {
-        const int co = F::row(e, hk);
-        const size_t orow = ((size_t)b * C + co) * L;
+    // ---- store: the branch sums go through an LDS scratch [C][W + 4] (T1 is dead) laid out so that the first valid output
+    // (window column h2max = position n0, a multiple of 4) sits at a 16-byte aligned scratch column; all threads then store float4s
+    // along positions: a quarter of the store instructions of the row-per-register form, 256-byte segments.
+    __syncthreads();                          // every wave is done reading T1
+    {
+        constexpr int SRS = W + 4;
+        float* const scr = Ta;
+        const int soff = (p.h2max + 3) & ~3;          // scratch column of window column h2max: 16-byte aligned
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int col = wn0 + j * MF + lr, pos = n0 - p.h2max + col;
-            if (col < p.h2max || col >= p.h2max + p.nto || pos >= L) continue;
-            float v = oacc[j][e];
-            if (p.out_div != 0.f) v = v / p.out_div;
-            p.out[orow + pos] = v;
+            const int sc = wn0 + j * MF + lr - p.h2max + soff;      // scratch column of this lane's window column
+#pragma unroll
+            for (int e = 0; e < NR; ++e) scr[F::row(e, hk) * SRS + sc] = oacc[j][e];
+        }
+        __syncthreads();
+        const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
+        const int nq = p.nto >> 2;
+        const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
+        for (int idx = tid; idx < C * nq; idx += NTHREADS) {
+            const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
+            const int pos = n0 + 4 * q;
+            if (pos >= L) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
+            if (p.out_div != 0.f) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], p.out_div, dinv);
+            }
+            float* dst = p.out + ((size_t)b * C + row) * L + pos;
+            if (p.vec4) {
+                *reinterpret_cast<f32x4*>(dst) = v;              // L % 4 == 0: whole float4 inside
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (pos + x < L) dst[x] = v[x];
+            }
         }
     }
     V2W_STAMP(15);
@@ -686,6 +727,7 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     p.xoff = ((hsum + 3) & ~3) - hsum;
     p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
     if (p.xrows < p.h2max) return V2W_E_SHAPE;
+    if (MF * (W + 4) > (W + p.h2max) * G::RS) return V2W_E_SHAPE;    // the store scratch [C][W + 4] overlays the T1 tile
     p.ntl = (q->L + p.nto - 1) / p.nto;
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
     size_t lds = ((size_t)(p.xrows + W + p.h2max) * G::RS + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
