@@ -305,13 +305,16 @@ def main():
         # bytes as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process: the committed summary
         # of the same command is used when its kernel name matches, else null.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_cfg2_hbm_traffic.json')
-        if os.path.exists(tpath) and (B, T) == (32, 256):
-            with open(tpath) as f:
+        tpaths = sorted(p for p in os.listdir(os.path.join(ROOT, 'profiles')) if p.endswith('_cfg2_hbm_traffic.json')) \
+            if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+        if tpaths and (B, T) == (32, 256):
+            with open(os.path.join(ROOT, 'profiles', tpaths[-1])) as f:      # the latest round's PMC pass
                 tj = json.load(f)
             if dom in tj:
+                meta = tj.get('_meta', {})
                 traffic = tj[dom]['hbm_bytes_per_launch']
-                traffic_src = 'profiles/r01_cfg2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
+                traffic_src = (f'profiles/{tpaths[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 per the gfx950 '
+                               f'correction; collected {meta.get("date", "?")} at commit {meta.get("commit", "?")})')
         roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_tags,
                     achieved=dom_f / dom_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,

@@ -665,3 +665,53 @@ def test_bench_self_launches_the_ranks_it_was_asked_for(dev):
     assert d1['n_gpus'] == 1 and d1['rccl_ranks'] == 1 and d1['metric'] == d['metric']
     too_many = _run_bench(['--gpus', str(ngpu + 1)] + small)
     assert too_many.returncode != 0 and not [l for l in too_many.stdout.splitlines() if l.startswith('{')]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['1', 1])
+def test_standalone_resblock_forward_matches_the_oracle(dev, kind):
+    """`ResBlock1(h, C, k, d)(x)` / `ResBlock2(...)(x)` are callable in the reference (models.py:37-44, 65-70); here they run their
+    convs through the C ABI.  Checked against the oracle's block restatement."""
+    from wavthruvec_pytorch_amd.models import ResBlock1, ResBlock2
+    h = synthetic.make_hparams(num_wv_feat=768, resblock=kind)
+    rng = np.random.default_rng(5)
+    C, L, k = 32, 500, 7
+    rb = (ResBlock1(h, C, k, (1, 3, 5)) if kind == '1' else ResBlock2(h, C, k, (1, 3))).to(dev)
+    sd = {n: v.detach().cpu() for n, v in rb.state_dict().items()}
+    x = torch.from_numpy(rng.standard_normal((2, C, L)).astype(np.float32))
+    want = O._resblock({'rb.' + n: v for n, v in sd.items()}, 'rb', x, k, (1, 3, 5) if kind == '1' else (1, 3), kind == '1', torch.float32)
+    with torch.no_grad():
+        got = rb(x.to(dev))
+    assert (got.cpu() - want).abs().max().item() <= 2e-5
+    with pytest.raises(NotImplementedError):
+        rb(x.to(dev).requires_grad_(True))
+
+
+def test_backward_uses_the_spectral_norm_state_of_its_own_forward(dev):
+    """Two train-mode forwards, then backward through the FIRST: the spectral-norm u / v advanced in between, and the gradient of
+    `weight_orig` must be the one of the first forward's sigma = u^T W v (the live buffers were read at backward time)."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = to_dev(synthetic.make_inputs(h, 2, 6, seed=8), dev)
+    dy = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 1, 6 * 320)).astype(np.float32)).to(dev)
+    g1 = build_generator(h, sd, dev, training=True)
+    y = g1(*inp)
+    (y * dy).sum().backward()
+    ref = {n: p.grad.clone() for n, p in g1.named_parameters() if 'cbns' in n}
+    g2 = build_generator(h, sd, dev, training=True)
+    y = g2(*inp)
+    with torch.no_grad():
+        g2(*inp)                      # a second forward before the backward of the first: u, v move on
+    (y * dy).sum().backward()
+    for n, p in g2.named_parameters():
+        if 'cbns' in n:
+            assert torch.equal(p.grad, ref[n]), n
+
+
+def test_direct_kernels_refuse_autograd_with_a_clear_message(dev):
+    from wavthruvec_pytorch_amd import hipops
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = build_generator(h, synthetic.make_state_dict(h, seed=0), dev, training=True)
+    g.algo = hipops.ALGO_DIRECT
+    with pytest.raises(NotImplementedError, match='ALGO_AUTO'):
+        g(*to_dev(synthetic.make_inputs(h, 1, 4, seed=1), dev))

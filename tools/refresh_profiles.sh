@@ -1,24 +1,26 @@
 #!/bin/bash
-# Regenerates profiles/ on a GPU box (run from the repo root): bench line, rocprofv3 kernel stats, per-layer view, PMC HBM traffic,
-# the kernel stats of the f16x3 / bf16 precision modes and of the generator training step, the discriminator forwards and the full
-# GAN iteration.  Outputs land in gpurun_out/profiles_new/.
-R=$PWD; O=$R/gpurun_out/profiles_new; mkdir -p $O
+# Regenerates the round's profiles on a GPU box (run from the repo root): bench line, rocprofv3 kernel stats, per-layer view,
+# PMC HBM traffic, SQ counters, kernel stats of the precision modes / training step.  Outputs land in gpurun_out/profiles_new/;
+# usage: V2W_COMMIT=<hash> V2W_DATE=<date> tools/refresh_profiles.sh rNN
+R=$PWD; TAG=${1:-r02}; O=$R/gpurun_out/profiles_new; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt"
+B3="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- $B > $O/ks.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pf -- $B > $O/pf.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pw -- $B > $O/pw.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pf -- $B3 > $O/pf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pw -- $B3 > $O/pw.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/sq_a -o sa -- $B3 > $O/sa.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq_b -o sb -- $B3 > $O/sb.log 2>&1
 for prec in f16x3 bf16; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$prec -o ks -- $B --precision $prec > $O/ks_$prec.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_train -o ks -- python3 $R/tools/train_step_bench.py 32 256 5 > $O/ks_train.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_disc -o ks -- python3 $R/tools/disc_bench.py 32 81920 3 > $O/ks_disc.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_gan -o ks -- python3 $R/tools/gan_step_bench.py 32 256 1 > $O/ks_gan.log 2>&1
 cd $R
-timeout 300 python3 tools/gan_step_bench.py 32 256 3 > $O/gan_iteration.txt 2>&1
 python3 tools/trace_layers.py $O/ks > $O/per_layer.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/hbm_traffic.json 2> $O/pmc.err
-cp $O/hbm_traffic.json profiles/r01_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
-timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 tools/pmc_sq.py $O/sq_a $O/sq_b > $O/sq_counters.json 2> $O/sq.err
+cp $O/hbm_traffic.json profiles/${TAG}_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
+timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 tools/config_bench.py > $O/all_configs.txt 2>&1
 tail -c 600 $O/bench.json; grep ms/step $O/ks_train.log
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete

@@ -152,7 +152,8 @@ def generator_backward(gen, sv, dy):
         dxr, dgb = hipops.cbn_backward(dx, xr, ws[f'gb.{i}'], ws.get(f'bn.stats{i}'), bn.running_mean, bn.running_var,
                                        training=training, eps=bn.eps, sync=gen.stat_sync)
         ly, fc = cbn.layer, gen.fcs[i]
-        d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), ly.weight_u, ly.weight_v,
+        sn_u, sn_v = sv['sn_uv'][i]               # the vectors the forward of THIS graph used (ly.weight_u/_v may have moved on)
+        d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), sn_u, sn_v,
                                                     ws['sigma_ws'][i:i + 1], spk, nz)
         grads[f'cbns.{i}.layer.weight_orig'], grads[f'cbns.{i}.layer.bias'] = d_w, d_b
         grads[f'fcs.{i}.weight'], grads[f'fcs.{i}.bias'] = d_fw, d_fb

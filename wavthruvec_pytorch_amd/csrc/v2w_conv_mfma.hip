@@ -555,13 +555,13 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     for (int i = 0; i < nprob; ++i) {
         TileArgs p = ps[i];
         if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
+        p.hla = (p.hl + 3) & ~3;
+        if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;   // (before the configuration query answers: a probe must see it too)
         if (p.cfg_out) {
             const int c[10] = {MF, U, MI, NI, WM, WN, CK, NPF, RING, p.B * ((p.L + NT - 1) / NT)};
             for (int k = 0; k < 10; ++k) p.cfg_out[k] = c[k];   // [9] = number of position tiles (rows of stats_part)
             return 0;
         }
-        p.hla = (p.hl + 3) & ~3;
-        if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
         p.ntl = (p.L + NT - 1) / NT;
         p.ntiles = p.B * p.ntl;
         p.xrows = (p.hla + NT + p.hr + 3) & ~3;

@@ -20,13 +20,6 @@
 // Sync       : one workgroup barrier per tap; the async copies are fenced with explicit s_waitcnt vmcnt (see the loop).
 #include "v2w_tile.h"
 
-#ifdef V2W_EXP_TIMELINE
-__device__ unsigned long long v2w_dbg[8192];
-extern "C" int v2w_debug_read(void* dst, int bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2w_dbg), bytes); }
-#define V2W_TICK(k) do { if (dbg_on && st < 64) { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) v2w_dbg[(wave * 64 + st) * 8 + (k)] = t_; } } while (0)
-#else
-#define V2W_TICK(k) do {} while (0)
-#endif
 
 namespace {
 
@@ -277,9 +270,6 @@ conv_split_kernel(const MultiArgs m) {
     V2W_BARRIER();
 
     const int rowbase = wn0 + lr + p.hla - p.hl;                 // LDS row of this lane's column for tap 0
-#ifdef V2W_EXP_STAGGER
-    if ((blockIdx.x >> V2W_EXP_STAGGER_SHIFT) & 1) __builtin_amdgcn_s_sleep(V2W_EXP_STAGGER);
-#endif
     int st = 0;
     // One stage = one (chunk, tap): 3 * MI * NI MFMAs per wave between two workgroup barriers.
     // Issue order inside a stage: the weight copy of stage st+NAB-1, then (first tap of a chunk) the signal prefetch of the
@@ -294,9 +284,6 @@ conv_split_kernel(const MultiArgs m) {
     // A fragments, which the barrier publishes, are read after it.
     raw16 bh[NI], bl[BF ? 1 : NI];
     auto mma = [&](acc_t c, raw16 a, raw16 b) __attribute__((always_inline)) {
-#ifdef V2W_EXP_NOMMA
-        c[0] += __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, b[3]); return c;
-#endif
         if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
     };
@@ -314,9 +301,6 @@ conv_split_kernel(const MultiArgs m) {
     // alternate between two register sets (A0 / A1); K is odd, so a chunk starts and ends on the same set and the next
     // chunk starts on the other one: the two chunk bodies below keep every register index static.
     int ring = 0;                                                // ring slot of the stage being computed
-#ifdef V2W_EXP_TIMELINE
-    const bool dbg_on = blockIdx.x == 300;
-#endif
     auto read_a = [&](raw16 (&h)[MI], raw16 (&l)[BF ? 1 : MI], int slot) __attribute__((always_inline)) {
         const unsigned char* Ab = As0 + slot * ASTAGE + (wmi * MI) * V2W_SPLIT_UNIT + lane * 16;
 #pragma unroll
@@ -327,33 +311,19 @@ conv_split_kernel(const MultiArgs m) {
     };
     auto stage = [&](raw16 (&ah)[MI], raw16 (&al)[BF ? 1 : MI], raw16 (&nh)[MI], raw16 (&nl)[BF ? 1 : MI],
                      const bool SIG, const bool COMMIT, int ch, int t) __attribute__((always_inline)) {
-        V2W_TICK(0);
-#ifdef V2W_EXP_TIMELINE
-        if (dbg_on && st < 64 && lane == 0) v2w_dbg[(wave * 64 + st) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-#endif
         const unsigned char* Xs = Xs0 + (ch & 1) * xbytes;
         const bool more = ch + 1 < nch;
-#ifdef V2W_EXP_NODMA
-        const bool dma = false;
-#else
         const bool dma = st + (NAB - 1) < nst;
-#endif
         if (dma) dma_next();
-#ifdef V2W_EXP_NOSIG
-        const bool sig = false;
-#else
         const bool sig = SIG && VEC && more;
-#endif
         if (sig) prefetch((ch + 1) * CK);
         __builtin_amdgcn_sched_barrier(0);
-        V2W_TICK(1);
 
         if (SIG) read_b(Xs, t);                                  // first tap of a chunk: its tile was committed just before the barrier
         const int nslot = ring + 1 == NAB ? 0 : ring + 1;
         if (st + 1 < nst) read_a(nh, nl, nslot);                 // next stage's weights: published by the previous barrier
         ring = nslot;
         __builtin_amdgcn_sched_barrier(0);
-        V2W_TICK(2);
         // term order al*bh, ah*bh, ah*bl: bh has its last use after the second group and bl after the third, so the next tap's
         // fragments are read into the SAME registers right there (no copies) and their LDS latency hides under the
         // remaining MFMAs, the wait and the barrier
@@ -383,24 +353,19 @@ conv_split_kernel(const MultiArgs m) {
             }
         }
 
-#ifndef V2W_EXP_NOSIG
         if (COMMIT && more) {
             unsigned char* Xn = Xs0 + ((ch + 1) & 1) * xbytes;
             if constexpr (VEC) commit((ch + 1) * CK, Xn);        // K >= 3: the tap-1 wait already covered the raw chunk
             else stage_scalar((ch + 1) * CK, Xn);
         }
-#endif
-        V2W_TICK(4);
         // vmcnt retires in order.  The stage two ahead must have landed before this barrier publishes it: it was issued a stage
         // ago, so only what THIS stage issued may stay outstanding (its copy, and the signal copies of a SIG stage; an older
         // signal copy has landed by then as well).  Once no copy is issued any more the counts no longer hold: vmcnt(0).
         if (!dma) V2W_WAIT_VM(0);
         else if (sig) V2W_WAIT_VM(ADMA + NSIG);
         else V2W_WAIT_VM(ADMA);
-        V2W_TICK(5);
         // LDS reads in flight (next operands) need not drain before the barrier; the LDS WRITES of a commit must
         if (COMMIT) V2W_BARRIER(); else asm volatile("s_barrier" ::: "memory");
-        V2W_TICK(6);
         ++st;
     };
     raw16 a0h[MI], a0l[BF ? 1 : MI], a1h[MI], a1l[BF ? 1 : MI];

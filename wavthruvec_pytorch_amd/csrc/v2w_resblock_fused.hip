@@ -513,21 +513,22 @@ resblock2_stage_kernel(const StageArgs p) {
         const int xr4 = p.xrows >> 2;
         const unsigned magic = (unsigned)(((1ull << 32) + xr4 - 1) / xr4);
         f32x4 g[NPF][4];
-        float av[NPF][4], sv[NPF][4];
+        f32x4 av[NPF], sv[NPF];                   // the affine of the block's four channels: one 16-byte load each
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTHREADS;
             const int cg = (int)__umulhi((unsigned)idx, magic);
             const int pos = pos0 + (idx - cg * xr4) * 4;
             const bool ok = idx < (C / 4) * xr4 && pos >= 0 && pos < L;      // L % 4 == 0, pos % 4 == 0: whole float4 inside
+            av[s] = f32x4{1.f, 1.f, 1.f, 1.f}; sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && p.in_a) {
+                av[s] = *reinterpret_cast<const f32x4*>(p.in_a + b * C + 4 * cg);
+                sv[s] = *reinterpret_cast<const f32x4*>(p.in_s + b * C + 4 * cg);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s][i] = 1.f; sv[s][i] = 0.f;
-                if (ok) {
-                    const int ch = b * C + 4 * cg + i;
-                    g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
-                    if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
-                }
+                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)(b * C + 4 * cg + i) * L + pos);
             }
         }
 #pragma unroll
@@ -729,7 +730,8 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     if (p.xrows < p.h2max) return V2W_E_SHAPE;
     if (MF * (W + 4) > (W + p.h2max) * G::RS) return V2W_E_SHAPE;    // the store scratch [C][W + 4] overlays the T1 tile
     p.ntl = (q->L + p.nto - 1) / p.nto;
-    p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
+    p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(q->out) & 15) == 0) &&
+             ((reinterpret_cast<uintptr_t>(q->in_a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(q->in_s) & 15) == 0);
     size_t lds = ((size_t)(p.xrows + W + p.h2max) * G::RS + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
 #ifdef V2W_TIMELINE
     if (const char* e = getenv("V2W_TL_LDSPAD")) lds += (size_t)atoi(e);      // fewer workgroups per CU: what does ONE wave per SIMD reach?

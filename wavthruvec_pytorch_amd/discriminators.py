@@ -85,12 +85,18 @@ class _DiscConv(nn.Module):
         self._last_sn = (sigma, self.weight_u.clone(), self.weight_v.clone())
         return hipops.fold_conv_weight((w / sigma).reshape(co, cig, k), None, out=out)
 
+    def invalidate_weight_cache(self):
+        self._cache = None
+
     def kernel_weights(self):
         """Per-group stride-1 weights: dict(wf=[G] of [k'][s * C_in/G][C_out/G], wp=[G] packed or None, kp, pad_left_taps).
         With j - P = s*q + r:  wf'[q + Q][r * cig + c][o] = wf[s*q + r + P][c][o]  (0 where the tap does not exist)."""
         params = list(self.parameters()) + list(self.buffers())
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._cache is not None and self._cache[0] == key and not (self.spectral and self.training):
+        # train mode refolds every call, as the reference's weight-norm / spectral-norm hooks do (and as the generator does): a
+        # `.data` mutation (EMA swap, re-initialisation) bumps neither the pointer nor the version counter, so the cache is an
+        # eval-mode optimisation only (`invalidate_weight_cache()` after a `.data` edit in eval mode)
+        if self._cache is not None and self._cache[0] == key and not self.training:
             return self._cache[1]
         k, s, P, G = self.k, self.stride, self.padding, self.groups
         cig, cog = self.c_in // G, self.c_out // G

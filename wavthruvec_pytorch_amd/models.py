@@ -21,6 +21,7 @@ from .modules import ConditionalBatchNorm1d
 from .utils import get_padding, init_weights  # noqa: F401  (re-exported like the reference's models.py)
 
 LRELU_SLOPE = 0.1  # models.py:10
+_SIDE_STREAMS: Dict[str, 'torch.cuda.Stream'] = {}
 _Z_CHANNEL = 128   # models.py:110
 
 
@@ -77,6 +78,36 @@ class ConvTranspose1d(_WNConvBase):
     transposed = True
 
 
+def _fold_one(m, device):
+    v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+    wf = hipops.fold_conv_weight(v, g)
+    return wf, hipops.pack_mfma(wf)
+
+
+def _resblock_forward(rb, x, pairs):
+    """Standalone residual block (the reference's are callable: models.py:37-44, 65-70): x (B, C, L) fp32 on the GPU.
+    pairs: [(conv_a, conv_b | None)]: x = x + conv_b(lrelu(conv_a(lrelu(x))))  or  x = x + conv_a(lrelu(x))."""
+    if not x.is_cuda:
+        raise RuntimeError('ResBlock (HIP): GPU tensors only; there is no CPU fallback')
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rb.parameters())):
+        raise NotImplementedError('ResBlock (HIP): standalone blocks run without autograd; back-propagate through Generator.forward')
+    with torch.no_grad():
+        cur = x.detach().contiguous().float()
+        for ca, cb in pairs:
+            wfa, wpa = _fold_one(ca, cur.device)
+            if cb is None:
+                out = torch.empty_like(cur)
+                hipops.conv1d(cur, wfa, ca.bias.detach(), out, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE, res=cur, wp=wpa)
+            else:
+                t = torch.empty_like(cur)
+                hipops.conv1d(cur, wfa, ca.bias.detach(), t, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE, wp=wpa)
+                wfb, wpb = _fold_one(cb, cur.device)
+                out = torch.empty_like(cur)
+                hipops.conv1d(t, wfb, cb.bias.detach(), out, k=cb.kernel_size, dil=cb.dilation, slope=LRELU_SLOPE, res=cur, wp=wpb)
+            cur = out
+        return cur
+
+
 class ResBlock1(nn.Module):
     """models.py:13-50: three (dilated conv, conv) pairs with residuals."""
 
@@ -91,8 +122,10 @@ class ResBlock1(nn.Module):
             Conv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1))
             for _ in range(3)])
 
+    @_hip.on_tensor_device
     def forward(self, x):
-        raise RuntimeError('ResBlock1 only holds parameters here; it runs fused inside Generator.forward (HIP)')
+        """models.py:37-44 as HIP launches (no-grad; inside `Generator.forward` the block runs merged with its siblings)."""
+        return _resblock_forward(self, x, [(c1, c2) for c1, c2 in zip(self.convs1, self.convs2)])
 
     def remove_weight_norm(self):
         for l in self.convs1:
@@ -112,8 +145,10 @@ class ResBlock2(nn.Module):
             Conv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d))
             for d in dilation[:2]])
 
+    @_hip.on_tensor_device
     def forward(self, x):
-        raise RuntimeError('ResBlock2 only holds parameters here; it runs fused inside Generator.forward (HIP)')
+        """models.py:65-70 as HIP launches (no-grad; inside `Generator.forward` the block runs merged with its siblings)."""
+        return _resblock_forward(self, x, [(c, None) for c in self.convs])
 
     def remove_weight_norm(self):
         for l in self.convs:
@@ -218,6 +253,13 @@ class Generator(nn.Module):
         self.conv_post.remove_weight_norm()
 
     # -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _side_stream(device):
+        st = _SIDE_STREAMS.get(str(device))      # per process and device, not per module: modules stay deep-copyable / picklable
+        if st is None:
+            st = _SIDE_STREAMS[str(device)] = torch.cuda.Stream(device=device)
+        return st
+
     def _buf(self, name, shape, dtype=torch.float32, device=None):
         t = self._ws.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
@@ -251,6 +293,11 @@ class Generator(nn.Module):
                     yield f'resblocks.{i}.convs.{n}', m
         yield 'conv_post', self.conv_post
 
+    def invalidate_weight_cache(self):
+        """Forget the folded / packed weights.  The eval-mode cache follows the parameters' storage pointers and in-place version
+        counters; a `.data` mutation (`p.data.copy_(ema)`, `m.weight.data.normal_()`) changes neither - call this after one."""
+        self._fold_key.clear()
+
     def _fold_weights(self, device, need_wf=False):
         """K0: weight-norm fold of every conv.  Layers with an MFMA tile configuration are folded AND packed into their
         fragment stream `wp` by one batched call (two launches for the whole generator); the others (conv_post, odd
@@ -270,7 +317,8 @@ class Generator(nn.Module):
             v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
             u = m.stride if m.transposed else 1
             mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
-                       hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size, 1, u) is not None)
+                       hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size,
+                                               1 if m.transposed else m.dilation, u) is not None)
             if mfma_ok and need_wf:     # a forward that will be back-propagated: dgrad / wgrad also read the plain layout
                 wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
                 scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
@@ -371,6 +419,9 @@ class Generator(nn.Module):
         if spk.shape != (x.shape[0], self.h.spk_dim) or nz.shape != (x.shape[0], self.h.noise_dim):
             raise RuntimeError('spk_emb / noise must be (B, spk_dim) / (B, noise_dim)')
         if needs_grad:
+            if self.algo == hipops.ALGO_DIRECT:
+                raise NotImplementedError('Generator (HIP): the scalar cross-check kernels (algo = ALGO_DIRECT) serve no-grad forwards only; '
+                                          'back-propagation needs the MFMA schedule (algo = ALGO_AUTO)')
             from .backward import GeneratorFunction
             names, params = zip(*[(n, q) for n, q in self.named_parameters()])
             return GeneratorFunction.apply(self, names, x, spk, nz, *params)
@@ -405,12 +456,19 @@ class Generator(nn.Module):
             gbs = [self._buf(f'gb.{i}', (B, 2 * self.cbns[i].num_features), device=dev) for i in range(ns)]
             z_ws = self._buf('z_ws', (ns * B * _Z_CHANNEL,), device=dev)
             sigma_ws = self._buf('sigma_ws', (ns,), device=dev)
-            hipops.cond_gamma_beta(
-                spk, nz,
-                [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
-                [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
-                [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
-                gbs, z_ws, sigma_ws, training)
+            # (depends on spk / noise and the conditioning weights only: three latency-bound launches, ~70 us, that run on a side
+            # stream beside the weight fold, conv_pre and the first upsampler; joined before the first bn_finalize reads gb)
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                hipops.cond_gamma_beta(
+                    spk, nz,
+                    [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                    [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
+                    [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
+                    gbs, z_ws, sigma_ws, training)
+            cond_joined = False
 
             # ---- K1: conv_pre (no activation in front of it)
             cur = self._buf('act.pre', (B, c0, T), device=dev)
@@ -447,6 +505,9 @@ class Generator(nn.Module):
                         self.stat_sync(stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
                 s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
+                if not cond_joined:
+                    main.wait_stream(side)
+                    cond_joined = True
                 hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                    training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
@@ -578,12 +639,17 @@ class Generator(nn.Module):
                                 src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
+            if not cond_joined:
+                main.wait_stream(side)
             # ---- K8: leaky_relu(0.01) -> conv_post -> tanh
             y = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
             self._timed('conv_post', hipops.conv_post_tanh, cur, wf['conv_post'], self.conv_post.bias.detach(), y, k=7,
                         slope=0.01)
 
         if save is not None:
+            # the spectral-norm vectors AS THIS FORWARD LEFT THEM: the backward of sigma = u^T W v must not see a later forward's
+            # power-iteration step (two micro-batches before one backward, a DDP buffer broadcast)
+            save['sn_uv'] = [(c.layer.weight_u.detach().clone(), c.layer.weight_v.detach().clone()) for c in self.cbns]
             save.update(ws=self._ws, wf=wf, wp=wp, y=y, x=x, spk=spk, nz=nz, training=training, B=B, T=T)
             self._ws = keep_ws
             self._fold_key.pop('state', None)     # the cached fold pointed into the handed-over buffers
