@@ -496,59 +496,51 @@ resblock2_stage_kernel(const StageArgs p) {
     }
 
     // ---- stage x = a*in + s: lrelu(x) into Xa (all rows), raw x of the window into Ta (the residual of every branch).
-    // A thread takes 4 channels x 4 positions at a time (all its loads are issued before the first is consumed); the channel
-    // permutation turns its 4 x 4 block into two 8-byte stores per position (32 channels) / four dword stores (16 channels).
-    auto put = [&](float* row, int cg, const float (&v)[4]) {     // v[i] = channel 4*cg + i at one position
-        if constexpr (MF == 32) {
-            float* d = row + 8 * (cg >> 1) + 2 * (cg & 1);
-            *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[2]};
-            *reinterpret_cast<f32x2*>(d + 4) = f32x2{v[1], v[3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) row[4 * i + cg] = v[i];
-        }
-    };
+    // A thread takes 4 channels x 4 positions at a time (all its loads are issued before the first is consumed).  The 4 channels are
+    // the ones whose slots are ADJACENT in a position row - 8g + h + {0, 2, 4, 6} (32 channels) / b + {0, 4, 8, 12} (16) - so a block
+    // is one 16-byte LDS store per position; consecutive lanes take the channel quads of one position quad first (a full row =
+    // conflict-free stores, 128-byte pieces of 8 / 4 rows on the global side), then the next position quad.
+    constexpr int NCQ = C / 4;                      // channel quads
+    auto quad_ch = [&](int cq, int i) { return MF == 32 ? 8 * (cq >> 1) + (cq & 1) + 2 * i : cq + 4 * i; };   // i-th channel of quad cq
     if (p.vec4) {
-        constexpr int NPF = ((C / 4) * ((W + 2 * G::HMAX + 8) / 4) + NTHREADS - 1) / NTHREADS;
+        constexpr int NPF = (NCQ * ((W + 2 * G::HMAX + 8) / 4) + NTHREADS - 1) / NTHREADS;
         const int xr4 = p.xrows >> 2;
-        const unsigned magic = (unsigned)(((1ull << 32) + xr4 - 1) / xr4);
         f32x4 g[NPF][4];
-        f32x4 av[NPF], sv[NPF];                   // the affine of the block's four channels: one 16-byte load each
+        float av[NPF][4], sv[NPF][4];
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTHREADS;
-            const int cg = (int)__umulhi((unsigned)idx, magic);
-            const int pos = pos0 + (idx - cg * xr4) * 4;
-            const bool ok = idx < (C / 4) * xr4 && pos >= 0 && pos < L;      // L % 4 == 0, pos % 4 == 0: whole float4 inside
-            av[s] = f32x4{1.f, 1.f, 1.f, 1.f}; sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok && p.in_a) {
-                av[s] = *reinterpret_cast<const f32x4*>(p.in_a + b * C + 4 * cg);
-                sv[s] = *reinterpret_cast<const f32x4*>(p.in_s + b * C + 4 * cg);
-            }
+            const int cq = idx % NCQ, pq = idx / NCQ;
+            const int pos = pos0 + pq * 4;
+            const bool ok = pq < xr4 && pos >= 0 && pos < L;      // L % 4 == 0, pos % 4 == 0: whole float4 inside
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)(b * C + 4 * cg + i) * L + pos);
+                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s][i] = 1.f; sv[s][i] = 0.f;
+                if (ok) {
+                    const int ch = b * C + quad_ch(cq, i);
+                    g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
+                    if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
+                }
             }
         }
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTHREADS;
-            if (idx >= (C / 4) * xr4) continue;
-            const int cg = (int)__umulhi((unsigned)idx, magic);
-            const int r0 = (idx - cg * xr4) * 4;
+            const int cq = idx % NCQ, pq = idx / NCQ;
+            if (pq >= xr4) continue;
+            const int r0 = pq * 4;
             const bool ok = pos0 + r0 >= 0 && pos0 + r0 < L;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float raw[4], act[4];
+                f32x4 raw, act;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     raw[i] = ok ? fmaf(av[s][i], g[s][i][e], sv[s][i]) : 0.f;
                     act[i] = v2w_lrelu(raw[i], slope);
                 }
                 const int r = r0 + e;
-                put(Xa + r * RS, cg, act);
-                if (r >= xc0 && r < xc0 + W) put(Ta + (r - xc0) * RS, cg, raw);
+                *reinterpret_cast<f32x4*>(Xa + r * RS + 4 * cq) = act;       // slots 4cq .. 4cq + 3 = the quad's channels, in order
+                if (r >= xc0 && r < xc0 + W) *reinterpret_cast<f32x4*>(Ta + (r - xc0) * RS + 4 * cq) = raw;
             }
         }
     } else {                                    // any L / alignment: one element at a time
