@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 21
+#define V2W_ABI_VERSION 22
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -219,6 +219,16 @@ typedef struct {
     int32_t algo;
 } v2w_convt1d_args;
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
+
+/* bf16 counterpart (V2W_ALGO_BF16 arithmetic: bf16 operands, fp32 accumulate - BASELINE configs[2]) of v2w_convt1d_fwd for the
+ * transposed convs of models.py:128-129.  The transposed conv runs as a Conv1d over UP * C_out virtual output channels on the bf16
+ * matrix pipe (csrc/v2w_conv_bf16.hip); `a->wp` must point at the fragments of v2w_pack_bf16_convt (a->wf is ignored), `a->stats_part`
+ * (optional) receives [v2w_convt1d_bf16_tiles(a)][C_out][2] partial (sum, sumsq) for v2w_bn_reduce_partials.
+ * C_in % 32 == 0, u in 2..8, (k - u) even; V2W_E_SHAPE otherwise. */
+int       v2w_pack_bf16_convt(const float* wf, void* wps, int k, int c_in, int c_out, int u, void* stream);
+long long v2w_pack_bf16_convt_bytes(int k, int c_in, int c_out, int u);   /* size of `wps`; 0 = unsupported shape */
+int       v2w_convt1d_bf16_fwd(const v2w_convt1d_args* a, void* stream);
+int       v2w_convt1d_bf16_tiles(const v2w_convt1d_args* a);               /* rows of stats_part (host-only query) */
 
 /* Introspection for profiling: which conv_tile_kernel<MF,U,MI,NI,WM,WN,CK,NPF,RING> instantiation the MFMA path uses for
  * this problem (only the sizes of `a` are read).  0 and cfg[10] filled (cfg[9] = number of position tiles), or V2W_E_SHAPE

@@ -166,6 +166,38 @@ def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+@pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 512, 256, 50, 11, 5), (2, 256, 128, 264, 8, 4), (3, 128, 64, 1000, 8, 4),
+                                              (2, 64, 32, 2052, 4, 2), (2, 32, 16, 4100, 4, 2), (1, 64, 32, 37, 4, 2),
+                                              (2, 1024, 512, 40, 16, 8)])
+def test_convt1d_bf16_operands(dev, B, cin, cout, L, k, u):
+    """The transposed conv of BASELINE configs[2] (bf16 operands, fp32 accumulate: v2w_convt1d_bf16_fwd, run as a Conv1d over
+    UP * C_out virtual channels) == an fp64 ConvTranspose1d of the bf16-rounded operands (models.py:128-129 incl. the leaky_relu in
+    front), plus the fused BatchNorm partial sums of modules.py:23 against the sums of its own output."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(21)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((cin, cout, k)) / np.sqrt(cin * k / u)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    xa = F.leaky_relu(torch.from_numpy(x), 0.1).bfloat16().double()
+    wb = torch.from_numpy(w).bfloat16().double()
+    want = F.conv_transpose1d(xa, wb, torch.from_numpy(bias).double(), stride=u, padding=(k - u) // 2)
+    wf = _t(np.ascontiguousarray(w.transpose(2, 0, 1)), dev)                    # [k][C_in][C_out]
+    wps = hipops.pack_bf16_convt(wf, u)
+    assert wps is not None
+    out = torch.full((B, cout, L * u), float('nan'), device=dev)
+    nt = hipops.convt_bf16_stats_tiles(_t(x, dev), out, k, u)
+    assert nt > 0
+    part = torch.full((nt * cout * 2,), float('nan'), device=dev)
+    hipops.convt1d_bf16(_t(x, dev), wps, _t(bias, dev), out, k=k, u=u, slope=0.1, stats_part=part)
+    assert want.shape == out.shape
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5, f'max err {err}'
+    sums = part.view(nt, cout, 2).double().sum(0).cpu()
+    o = out.cpu().double()
+    assert (sums[:, 0] - o.sum((0, 2))).abs().max().item() <= 1e-3 * max(1.0, o.sum((0, 2)).abs().max().item())
+    assert (sums[:, 1] - (o * o).sum((0, 2))).abs().max().item() <= 1e-4 * (o * o).sum((0, 2)).max().item()
+
+
 @pytest.mark.parametrize('C', [32, 16])
 @pytest.mark.parametrize('B,L,bf16', [(2, 1000, False), (3, 4099, False), (1, 300, False), (2, 1000, True)])
 def test_resblock2_stage_split(dev, B, L, bf16, C):

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -128,6 +128,10 @@ SIGNATURES = {
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
     'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
+    'v2w_pack_bf16_convt': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_bf16_convt_bytes': (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'v2w_convt1d_bf16_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
+    'v2w_convt1d_bf16_tiles': (C.c_int, [C.POINTER(ConvT1dArgs)]),
     'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
     'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),

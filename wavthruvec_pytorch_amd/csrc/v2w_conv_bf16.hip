@@ -13,6 +13,12 @@
 //                 covers 128 positions (NI = 4), so a fragment feeds four MFMAs: 32 B/clk/CU of L2 -> CU traffic at full MFMA rate.
 //   unit        : one tap of one chunk = 2 k-steps x MI x NI MFMAs; the next tap's fragments are requested a unit ahead, each column
 //                 block's operand register is refilled right after its last use.
+// ConvTranspose1d(k, stride U, pad (k-U)/2) runs on the SAME kernel (EPI = 2) as a Conv1d over UP * C_out "virtual" output channels
+// (row = co * UP + phase, UP = U rounded up to a power of two): output phase r of position q reads inputs q + c_r - m, i.e. offsets
+// -1, 0, +1 for every upsampler of the generator, so the transposed conv IS a 3-tap conv whose virtual weights hold the polyphase
+// taps (zeros where a phase has no tap at an offset: 27-33 % of the MFMAs, on a pipe this path does not saturate).  The epilogue
+// interleaves the phases back into (B, C_out, U*L) through an LDS scratch laid out like the output, stores float4s along positions and
+// emits the BatchNorm partial sums (modules.py:23) of its tile.
 // The older split kernel (v2w_conv_split.hip, one workgroup barrier per (16-channel chunk, tap) stage) stays the f16x3 path; in bf16
 // mode a stage of it was 128 cycles of MFMA issue in ~1300 cycles.
 #include "v2w_tile.h"
@@ -182,7 +188,7 @@ conv_bf16_kernel(const MultiArgs m) {
 
     // ---- prologue
     for (int c = tid; c < MT; c += NTHREADS) {
-        etab[c] = p.bias ? p.bias[m0 + c] : 0.f;
+        etab[c] = p.bias ? p.bias[EPI == 2 ? (m0 + c) / p.up_p : m0 + c] : 0.f;
         etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
         etab[2 * MT + c] = p.res_a ? p.res_s[b * p.Cout + m0 + c] : 0.f;
         etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
@@ -227,6 +233,77 @@ conv_bf16_kernel(const MultiArgs m) {
             else stage_scalar((ch + 1) * CK, Xn);
             __syncthreads();
         }
+    }
+
+    if constexpr (EPI == 2) {
+        // ---- transposed-conv epilogue: 64 input positions of one 32-row block at a time -> scratch [32 / UP channels][U * 64 output
+        // positions] (the output's own layout) -> + bias, float4 stores along positions, per-channel (sum, sumsq) of what was stored.
+        const int U = p.up_u, UP = p.up_p;
+        const int CoutR = p.Cout / UP;                     // real output channels
+        const int nco = 32 / UP;                           // channels per 32-row block
+        const int ORS = U * 64, C4 = U * 16;               // scratch row (floats), float4s per row
+        const int Lout = L * U;
+        float* const red = atab + (p.in_a ? 2 * p.Cin : 0);    // [WN][MT / UP][2] partial sums of this workgroup's waves
+        __syncthreads();
+        float* const scr = reinterpret_cast<float*>(smem_b) + wave * 2048;
+        for (int c = lane; c < (MI * 32 / UP) * 2; c += 64) red[((wave % WN) * (MT / UP) + (wm0 / UP)) * 2 + c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += 2) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int R = F::row(e, hk), r = R % UP;
+                        if (r < U) scr[(R / UP) * ORS + U * (jj * 32 + lr) + r] = acc[i][jh + jj][e];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                const int q0 = n0 + wn0 + jh * 32;         // first input position of this pass
+#pragma unroll 1
+                for (int cl = 0; cl < nco; ++cl) {
+                    const int col = wm0 + i * 32 + cl * UP;             // virtual row of the channel's phase 0 inside the tile
+                    const int co = (m0 + col) / UP;
+                    const float bias = etab[col];
+                    float* dst = p.out + ((size_t)b * CoutR + co) * Lout + (size_t)U * q0;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int c4 = lane; c4 < C4; c4 += 64) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + cl * ORS + 4 * c4);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            v[x] += bias;
+                            if (U * q0 + 4 * c4 + x < Lout) { s1 += v[x]; s2 = fmaf(v[x], v[x], s2); }
+                        }
+                        if (p.evec) {
+                            if (U * q0 + 4 * c4 < Lout) *reinterpret_cast<f32x4*>(dst + 4 * c4) = v;
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x)
+                                if (U * q0 + 4 * c4 + x < Lout) dst[4 * c4 + x] = v[x];
+                        }
+                    }
+                    if (p.stats_part) {
+                        s1 = v2w_wave_sum(s1); s2 = v2w_wave_sum(s2);
+                        if (lane == 0) {
+                            float* rd = red + ((wave % WN) * (MT / UP) + col / UP) * 2;
+                            rd[0] += s1; rd[1] += s2;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.stats_part) {
+            __syncthreads();
+            for (int c = tid; c < MT / UP; c += NTHREADS) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { t1 += red[(w * (MT / UP) + c) * 2]; t2 += red[(w * (MT / UP) + c) * 2 + 1]; }
+                p.stats_part[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
+                p.stats_part[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
+            }
+        }
+        return;
     }
 
     // ---- epilogue (as in v2w_conv_mfma.hip): 64 columns of one 32-row block at a time through a wave-private LDS scratch, back as
@@ -387,6 +464,94 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     return v2w_launch_status();
 }
 
+// Virtual 3-tap (in general hl + hr + 1 tap) conv weights of a transposed conv, as bf16 fragments in the layout of pack_bf16_kernel:
+// Wv[tv][ci][co * UP + r] = wf[t0_r + m * U][ci][co] with m = c_r - (tv - hl), t0_r = (r + pad) % U, c_r = (r + pad) / U (0 where the
+// phase has no such tap, and for the padding phases r >= U).
+__global__ void __launch_bounds__(256)
+pack_bf16_convt_kernel(const float* __restrict__ wf, b8* __restrict__ wps, int K, int Cin, int Cout, int U, int UP, int hl, int KV) {
+    const int nch = Cin / 16, pad = (K - U) / 2;
+    const size_t total = (size_t)(Cout * UP / 32) * nch * KV * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = o & 63;
+        size_t rest = o >> 6;
+        const int tv = rest % KV; rest /= KV;
+        const int ch = rest % nch;
+        const int mb = rest / nch;
+        const int R = mb * 32 + (lane & 31), co = R / UP, r = R % UP;
+        const int c0 = ch * 16 + 8 * (lane >> 5);
+        const int rp = r + pad, t0 = rp % U, cr = rp / U, mm = cr - (tv - hl), t = t0 + mm * U;
+        const bool ok = r < U && mm >= 0 && t < K;
+        b8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi[j] = (__bf16)(ok ? wf[((size_t)t * Cin + c0 + j) * Cout + co] : 0.f);
+        wps[(((size_t)(mb * nch + ch) * KV + tv) * 2) * 64 + lane] = hi;
+    }
+}
+
+struct ConvtGeom { int UP, hl, hr, KV; };
+static ConvtGeom convt_geom(int k, int u) {
+    ConvtGeom g{1, 0, 0, 0};
+    while (g.UP < u) g.UP *= 2;
+    const int pad = (k - u) / 2;
+    for (int r = 0; r < u; ++r) {
+        const int rp = r + pad, t0 = rp % u, c = rp / u, nt = (k - t0 + u - 1) / u;
+        if (c > g.hr) g.hr = c;
+        if (nt - 1 - c > g.hl) g.hl = nt - 1 - c;
+    }
+    g.KV = g.hl + g.hr + 1;
+    return g;
+}
+
+template <int MI, int NI, int WM, int WN>
+int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
+    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32;
+    constexpr int NPF = (8 * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    if (p.Cout % MT != 0 || p.Cin % V2W_BF_CK != 0) return V2W_E_SHAPE;
+    p.hla = (p.hl + 3) & ~3;
+    if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
+    p.ntl = (p.L + NT - 1) / NT;
+    p.ntiles = p.B * p.ntl;
+    if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
+    p.xrows = (p.hla + NT + p.hr + 3) & ~3;
+    p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+    p.evec = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    const int nbuf = p.Cin / V2W_BF_CK > 1 ? 2 : 1;
+    int tab = nbuf * p.xrows * V2W_BF_ROWB / 4;
+    if (tab < WM * WN * 2048) tab = WM * WN * 2048;
+    p.atab_off = tab;
+    const size_t lds = ((size_t)tab + 5 * MT + WN * (MT / p.up_p) * 2) * sizeof(float);
+    if (lds > 160 * 1024) return V2W_E_SHAPE;
+    MultiArgs m{};
+    m.p[0] = p;
+    m.start[0] = 0;
+    const int grid = ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
+    m.start[1] = grid;
+    for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
+    auto kern = conv_bf16_kernel<MI, NI, WM, WN, NPF, 2>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    return v2w_launch_status();
+}
+
+static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, int* ntiles_out) {
+    if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 1) return V2W_E_ARG;
+    if (a->k < a->u || ((a->k - a->u) & 1) || a->u > 8) return V2W_E_SHAPE;
+    if (a->C_in % V2W_BF_CK != 0) return V2W_E_SHAPE;
+    const ConvtGeom g = convt_geom(a->k, a->u);
+    TileArgs p{};
+    p.in = a->in; p.wps = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
+    p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out * g.UP; p.L = a->L; p.K = g.KV; p.dil = 1;
+    p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP;
+    const int rows = p.Cout;
+    if (rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512) return launch_bf16_convt<2, 4, 2, 2>(p, stream, ntiles_out);
+    if (rows % 64 == 0) return launch_bf16_convt<1, 4, 2, 2>(p, stream, ntiles_out);
+    if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4>(p, stream, ntiles_out);
+    return V2W_E_SHAPE;
+}
+
 }  // namespace
 
 // Called by v2w_conv1d_split for V2W_ALGO_BF16.  V2W_E_SHAPE: the caller falls back to the split kernel's bf16 form.
@@ -415,4 +580,35 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
     if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream);     // 128 x 256
     if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream);                                 // 64 x 256
     return launch_bf16<1, 2, 2, 2>(ps, n, stream);                                                   // 64 x 128: latency sizes
+}
+
+// ---- bf16 transposed conv (V2W_ALGO_BF16 counterpart of v2w_convt1d_fwd); a->wp = the fragments of v2w_pack_bf16_convt
+extern "C" int v2w_pack_bf16_convt(const float* wf, void* wps, int k, int c_in, int c_out, int u, void* stream) {
+    if (!wf || !wps || k <= 0 || c_in <= 0 || c_out <= 0 || u <= 1) return V2W_E_ARG;
+    if (k < u || ((k - u) & 1) || u > 8 || c_in % 16 != 0) return V2W_E_SHAPE;
+    const ConvtGeom g = convt_geom(k, u);
+    if ((c_out * g.UP) % 32 != 0) return V2W_E_SHAPE;
+    const size_t total = (size_t)(c_out * g.UP / 32) * (c_in / 16) * g.KV * 64;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_bf16_convt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), k, c_in, c_out, u,
+                       g.UP, g.hl, g.KV);
+    return v2w_launch_status();
+}
+// bytes of the fragment buffer of v2w_pack_bf16_convt (0: shape not supported)
+extern "C" long long v2w_pack_bf16_convt_bytes(int k, int c_in, int c_out, int u) {
+    if (k <= 0 || c_in <= 0 || c_out <= 0 || u <= 1 || k < u || ((k - u) & 1) || u > 8 || c_in % 32 != 0) return 0;
+    const ConvtGeom g = convt_geom(k, u);
+    if ((c_out * g.UP) % 32 != 0) return 0;
+    return (long long)(c_out * g.UP / 32) * (c_in / 16) * g.KV * V2W_BF_UNIT;
+}
+extern "C" int v2w_convt1d_bf16_fwd(const v2w_convt1d_args* a, void* stream) {
+    if (!a || !a->in || !a->wp || !a->out) return V2W_E_ARG;
+    return convt_bf16_dispatch(a, (hipStream_t)stream, nullptr);
+}
+// rows of `stats_part` ([rows][C_out][2]) that v2w_convt1d_bf16_fwd fills for this problem; < 0: error / unsupported shape
+extern "C" int v2w_convt1d_bf16_tiles(const v2w_convt1d_args* a) {
+    if (!a) return V2W_E_ARG;
+    int n = 0;
+    const int rc = convt_bf16_dispatch(a, nullptr, &n);
+    return rc == 0 ? n : rc;
 }

@@ -33,6 +33,7 @@ struct TileArgs {
     float slope;
     int accumulate;
     float out_div;
+    int up_u, up_p;   // bf16 transposed conv run as a 3-tap conv over up_p * C_out virtual rows (row = co * up_p + phase): stride, padded phase count
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
 };
 

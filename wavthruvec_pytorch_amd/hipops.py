@@ -203,6 +203,42 @@ def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats
     return out
 
 
+def pack_bf16_convt(wf, u, out=None):
+    """ConvTranspose1d weights wf [k][C_in][C_out] -> bf16 fragments of the virtual 3-tap conv v2w_convt1d_bf16_fwd runs, or None when
+    the shape is not served."""
+    k, ci, co = wf.shape
+    nbytes = int(_hip.load().v2w_pack_bf16_convt_bytes(k, ci, co, u))
+    if nbytes == 0:
+        return None
+    if out is None or out.numel() * out.element_size() < nbytes:
+        out = torch.empty((nbytes // 2,), device=wf.device, dtype=torch.bfloat16)
+    _hip.check(_hip.load().v2w_pack_bf16_convt(wf.data_ptr(), out.data_ptr(), k, ci, co, u, _stream(wf)), 'v2w_pack_bf16_convt')
+    return out
+
+
+def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part):
+    B, ci, L = x.shape
+    a = _hip.ConvT1dArgs()
+    a.in_ = x.data_ptr(); a.wf = None; a.wp = _hip.ptr(wps); a.bias = _hip.ptr(bias); a.out = _hip.ptr(out)
+    a.stats_part = _hip.ptr(stats_part)
+    a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
+    a.slope = slope; a.algo = ALGO_BF16
+    return a
+
+
+def convt_bf16_stats_tiles(x, out, k, u):
+    """Rows of `stats_part` the bf16 transposed conv fills (0: shape not served)."""
+    n = _hip.load().v2w_convt1d_bf16_tiles(C.byref(_convt_bf16_args(x, None, None, out, k, u, 1.0, None)))
+    return n if n > 0 else 0
+
+
+def convt1d_bf16(x, wps, bias, out, *, k, u, slope=1.0, stats_part=None):
+    """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias on the bf16 matrix pipe (fp32 accumulate)."""
+    _hip.check(_hip.load().v2w_convt1d_bf16_fwd(C.byref(_convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part)), _stream(x)),
+               'v2w_convt1d_bf16_fwd')
+    return out
+
+
 def cond_gamma_beta(spk, noise, fc_w: Sequence, fc_b: Sequence, sn_w: Sequence, sn_b: Sequence,
                     sn_u: Sequence, sn_v: Sequence, gb: Sequence, z_ws, sigma_ws, training: bool):
     """All stages' [gamma|beta] in one call; sn_u / sn_v are updated in place when training."""

@@ -391,6 +391,18 @@ class Generator(nn.Module):
                 plan.key = key
                 self._fold_key['split_plan'] = plan
             plan.run()
+        if self.precision == 'bf16':      # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd)
+            for i, m in enumerate(self.ups):
+                if m.out_channels < 64:       # the narrow upsamplers are memory-side: the f32 kernel's epilogue moves their bytes faster
+                    continue
+                v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+                wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
+                hipops.fold_convt_weight(v, g, wfb, scratch)
+                w = hipops.pack_bf16_convt(wfb, m.stride, out=self._ws.get(f'wpsbf.ups.{i}'))
+                if w is not None:
+                    self._ws[f'wpsbf.ups.{i}'] = w
+                    out[f'ups.{i}'] = w
         self._fold_key['wps'] = (gen, out)
         return out
 
@@ -488,12 +500,18 @@ class Generator(nn.Module):
                 if training:
                     stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
                     # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
-                    if algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
+                    if f'ups.{i}' in wps:
+                        nt_stats = hipops.convt_bf16_stats_tiles(cur, xr, up.kernel_size, up.stride)
+                    elif algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
                         nt_stats = hipops.convt_stats_tiles(B, up.in_channels, C, L, up.kernel_size, up.stride)
                     if nt_stats:
                         part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
-                self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
-                            u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
+                if f'ups.{i}' in wps and (nt_stats or not training):
+                    self._timed(f'ups.{i}', hipops.convt1d_bf16, cur, wps[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
+                                u=up.stride, slope=LRELU_SLOPE, stats_part=part)
+                else:
+                    self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
+                                u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 if training:
                     if nt_stats:
