@@ -1,0 +1,309 @@
+// Whole residual section of a narrow ResBlock2 stage (C = 32 / 16) in ONE kernel on the bf16 matrix pipe (bf16 operands, fp32
+// accumulate: BASELINE configs[2]); models.py:135-141 with ResBlock2.forward inlined:
+//   out = ( sum_j [ t1_j + conv_{k_j,d2_j}(lrelu(t1_j)) + b2_j ] ) / nk ,   t1_j = x + conv_{k_j,d1_j}(lrelu(x)) + b1_j
+//
+// The structure of the exact-fp32 stage kernel (v2w_resblock_fused.hip) with everything that a 16x faster matrix pipe changes:
+//   * the MFMAs of a whole tile are ~5 000 cycles of issue, an L2 round trip is ~600: the weight fragments of a conv (<= 11 taps x
+//     2 k-steps x 1 KiB) are requested ALL AT ONCE when its phase starts and live in registers through it - the tap loop holds only
+//     ds_read_b128s and MFMAs;
+//   * LDS tiles are position-major bf16 rows of the ACTIVATED operands lrelu(x), lrelu(t1) (80 / 48 bytes per position: one
+//     conflict-free ds_read_b128 = the 8 k-values a lane feeds to one v_mfma_f32_32x32x16_bf16); conv1 and conv2 run on the same window
+//     of 256 positions so the residuals (x, t1: fp32) stay in the lane that produced them;
+//   * C = 16 uses the 32-row MFMA with the packed fragments' rows 16-31 zero (the pipe is idle most of the time anyway).
+// Weights: the bf16 fragments of v2w_pack_bf16 / v2w_split_pack_batch, [16-channel k-step][tap][2 KiB, first KiB used].
+#include "v2w_common.h"
+
+namespace {
+
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define V2W_SB_MAXB 4
+#define V2W_SB_KMAX 11
+#define V2W_SB_UNIT 2048
+
+struct StageBfArgs {
+    const float* in; const float* in_a; const float* in_s;
+    const unsigned char* w1[V2W_SB_MAXB]; const float* bias1[V2W_SB_MAXB];
+    const unsigned char* w2[V2W_SB_MAXB]; const float* bias2[V2W_SB_MAXB];
+    int K[V2W_SB_MAXB], d1[V2W_SB_MAXB], d2[V2W_SB_MAXB];
+    float* out;
+    int nk, B, L;
+    int h1max, h2max;
+    int xoff, xrows, nto, ntl;
+    int vec4;
+    float slope, out_div;
+};
+
+__device__ __forceinline__ unsigned int sb_pack2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256, C == 32 ? 2 : 3)
+stage_bf16_kernel(const StageBfArgs p) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int NTHREADS = 256, NI = 2, WN = 4, W = 32 * NI * WN;
+    constexpr int ROWB = C == 32 ? 80 : 48;      // bytes per position: C bf16 + 16 B pad
+    constexpr int KS = C / 16;                   // k-steps per tap
+    constexpr int NR = C == 32 ? 16 : 8;         // accumulator registers that hold real output channels (rows < C)
+    constexpr int NCQ = C / 4;                   // channel quads
+    constexpr int KMAX = V2W_SB_KMAX;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tile = blockIdx.x;
+    const int b = tile / p.ntl;
+    const int n0 = (tile % p.ntl) * p.nto;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, hk = lane >> 5;
+    const int wn0 = wave * (32 * NI);
+    const int L = p.L;
+    const float slope = p.slope;
+    unsigned char* const Xa = smem_b;                                  // [xrows][ROWB]  lrelu(x) as bf16, exactly 0 outside the sequence
+    unsigned char* const Ta = smem_b + p.xrows * ROWB;                 // [W][ROWB]      lrelu(t1_j); conv2's taps reach h2max rows past either end
+    float* const etab = reinterpret_cast<float*>(Ta + (W + p.h2max) * ROWB);   // bias1[nk][C], bias2[nk][C]
+    const int pos0 = n0 - p.h2max - p.h1max - p.xoff;                  // position of X row 0 (multiple of 4)
+    const int xc0 = p.xoff + p.h1max;                                  // X row of window column 0 (position n0 - h2max)
+
+    for (int i = tid; i < p.nk * C; i += NTHREADS) {
+        const int j = i / C, c = i - j * C;
+        etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
+        etab[V2W_SB_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
+    }
+
+    // ---- stage lrelu(a*x + s) as bf16: a thread takes 4 channels x 4 positions (8 bytes per position), the channel quads of one
+    // position quad on consecutive lanes (whole rows per 8 / 4 lanes: conflict-free stores)
+    if (p.vec4) {
+        constexpr int NPF = (NCQ * ((W + 2 * 32 + 8) / 4) + NTHREADS - 1) / NTHREADS;
+        const int xr4 = p.xrows >> 2;
+        f32x4 g[NPF][4];
+        float av[NPF][4], sv[NPF][4];
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            const int cq = idx % NCQ, pq = idx / NCQ;
+            const int pos = pos0 + pq * 4;
+            const bool ok = pq < xr4 && pos >= 0 && pos < L;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s][i] = 1.f; sv[s][i] = 0.f;
+                if (ok) {
+                    const int ch = b * C + 4 * cq + i;
+                    g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
+                    if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTHREADS;
+            const int cq = idx % NCQ, pq = idx / NCQ;
+            if (pq >= xr4) continue;
+            const bool ok = pos0 + pq * 4 >= 0 && pos0 + pq * 4 < L;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ok ? v2w_lrelu(fmaf(av[s][i], g[s][i][e], sv[s][i]), slope) : 0.f;
+                *reinterpret_cast<u32x2*>(Xa + (pq * 4 + e) * ROWB + cq * 8) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
+            }
+        }
+    } else {
+        for (int i = tid; i < C * p.xrows; i += NTHREADS) {
+            const int c = i / p.xrows, r = i - c * p.xrows, pos = pos0 + r;
+            float v = 0.f;
+            if (pos >= 0 && pos < L) {
+                const int ch = b * C + c;
+                v = v2w_lrelu(fmaf(p.in_a ? p.in_a[ch] : 1.f, p.in[(size_t)ch * L + pos], p.in_s ? p.in_s[ch] : 0.f), slope);
+            }
+            reinterpret_cast<__bf16*>(Xa + r * ROWB)[c] = (__bf16)v;
+        }
+    }
+
+    // ---- the residual of conv1 in every branch: raw x = a*in + s at this lane's outputs (accumulator row e <-> channel F::row(e, hk),
+    // its two columns), re-read from global memory (L2-resident: this workgroup has just fetched the lines); consumed after conv1 of
+    // branch 0, so the round trip hides behind it
+    float xres[NI][NR];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
+        const bool in_seq = pos >= 0 && pos < L;
+#pragma unroll
+        for (int e = 0; e < NR; ++e) {
+            const int ch = b * C + F::row(e, hk);
+            float v = 0.f;
+            if (in_seq) v = fmaf(p.in_a ? p.in_a[ch] : 1.f, p.in[(size_t)ch * L + pos], p.in_s ? p.in_s[ch] : 0.f);
+            xres[j][e] = v;
+        }
+    }
+
+    // ---- one conv phase.  All K * KS weight fragments are requested up front and stay in registers; the tap loop is unrolled to KMAX
+    // with uniform guards.  `x0`: this lane's 16 bytes in the row of (its column, tap 0), k-step 0.
+    acc_t acc[NI];
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto conv = [&](const unsigned char* wbase, int K, const unsigned char* x0, int step, const float* bias) {
+        u32x4 wr[KMAX][KS];
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (t < K) wr[t][s] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(s * K + t) * V2W_SB_UNIT + l16);
+        // accumulators start at the bias (rows >= C of the 32-row MFMA are padding: they start, and stay, at 0)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float bv = e < NR ? bias[F::row(e, hk)] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[j][e] = bv;
+        }
+        u32x4 bb[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(x0 + j * 32 * ROWB);
+        const unsigned char* xt = x0;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t < K) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const unsigned char* nxt = s + 1 < KS ? xt + 32 : (t + 1 < K ? xt + step : xt);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wr[t][s]), __builtin_bit_cast(b8, bb[j]), acc[j], 0, 0, 0);
+                        bb[j] = *reinterpret_cast<const u32x4*>(nxt + j * 32 * ROWB);
+                    }
+                }
+                xt += step;
+            }
+        }
+    };
+
+    float t1r[NI][NR], oacc[NI][NR];
+    const unsigned char* const xl = Xa + (wn0 + lr) * ROWB + 16 * hk;
+    const unsigned char* const tl = Ta + (wn0 + lr) * ROWB + 16 * hk;
+    __syncthreads();
+    for (int jb = 0; jb < p.nk; ++jb) {
+        const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
+        const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
+
+        // ---- conv1_j on the window: column col <-> position n0 - h2max + col
+        conv(p.w1[jb], K, xl + (xc0 - h1) * ROWB, d1 * ROWB, etab + jb * C);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
+            const bool in_seq = pos >= 0 && pos < L;            // conv2 zero-pads t1 outside the sequence
+#pragma unroll
+            for (int e = 0; e < NR; ++e) t1r[j][e] = in_seq ? acc[j][e] + xres[j][e] : 0.f;
+        }
+        if (jb > 0) __syncthreads();          // conv2 of the previous branch has finished reading T1
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            unsigned char* row = Ta + (wn0 + j * 32 + lr) * ROWB;
+#pragma unroll
+            for (int g4 = 0; g4 < NR / 4; ++g4) {   // accumulator registers 4g .. 4g + 3 = channels 8g + 4hk + {0..3}: 8 contiguous bytes
+                float a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = v2w_lrelu(t1r[j][4 * g4 + r], slope);
+                *reinterpret_cast<u32x2*>(row + 2 * (8 * g4 + 4 * hk)) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2_j on the same window ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
+        conv(p.w2[jb], K, tl - h2 * ROWB, d2 * ROWB, etab + V2W_SB_MAXB * C + jb * C);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const float r = acc[j][e] + t1r[j][e];
+                oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
+            }
+    }
+
+    // ---- store through an aligned fp32 LDS scratch [C][W + 4] (both tiles are dead), float4s along positions
+    __syncthreads();
+    {
+        constexpr int SRS = W + 4;
+        float* const scr = reinterpret_cast<float*>(smem_b);
+        const int soff = (p.h2max + 3) & ~3;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int sc = wn0 + j * 32 + lr - p.h2max + soff;
+#pragma unroll
+            for (int e = 0; e < NR; ++e) scr[F::row(e, hk) * SRS + sc] = oacc[j][e];
+        }
+        __syncthreads();
+        const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
+        const int nq = p.nto >> 2;
+        const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
+        for (int idx = tid; idx < C * nq; idx += NTHREADS) {
+            const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
+            const int pos = n0 + 4 * q;
+            if (pos >= L) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
+            if (p.out_div != 0.f) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], p.out_div, dinv);
+            }
+            float* dst = p.out + ((size_t)b * C + row) * L + pos;
+            if (p.vec4) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (pos + x < L) dst[x] = v[x];
+            }
+        }
+    }
+}
+
+template <int C>
+int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
+    constexpr int W = 256, ROWB = C == 32 ? 80 : 48;
+    StageBfArgs p{};
+    p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.out = q->out;
+    p.nk = q->nk; p.B = q->B; p.L = q->L; p.slope = q->slope; p.out_div = q->out_div;
+    for (int j = 0; j < q->nk; ++j) {
+        p.w1[j] = static_cast<const unsigned char*>(q->wps1[j]); p.bias1[j] = q->bias1[j];
+        p.w2[j] = static_cast<const unsigned char*>(q->wps2[j]); p.bias2[j] = q->bias2[j];
+        p.K[j] = q->k[j]; p.d1[j] = q->dil1[j]; p.d2[j] = q->dil2[j];
+        if (q->k[j] > V2W_SB_KMAX) return V2W_E_SHAPE;
+        const int h1 = q->dil1[j] * (q->k[j] - 1) / 2, h2 = q->dil2[j] * (q->k[j] - 1) / 2;
+        if (h1 > p.h1max) p.h1max = h1;
+        if (h2 > p.h2max) p.h2max = h2;
+    }
+    p.nto = (W - 2 * p.h2max) & ~3;
+    if (p.nto < W / 2 || p.h1max > 32) return V2W_E_SHAPE;
+    const int hsum = p.h1max + p.h2max;
+    p.xoff = ((hsum + 3) & ~3) - hsum;
+    p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
+    if (p.xrows < p.h2max) return V2W_E_SHAPE;
+    p.ntl = (q->L + p.nto - 1) / p.nto;
+    auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+    p.vec4 = (q->L % 4 == 0) && al16(q->in) && al16(q->out);
+    size_t lds = (size_t)(p.xrows + W + p.h2max) * ROWB + 2 * V2W_SB_MAXB * C * sizeof(float);
+    const size_t scr = (size_t)C * (W + 4) * sizeof(float);           // the store scratch overlays the tiles
+    if (lds < scr) lds = scr;
+    if (lds > 160 * 1024) return V2W_E_SHAPE;
+    auto kern = stage_bf16_kernel<C>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(q->B * p.ntl), dim3(256), lds, stream, p);
+    return v2w_launch_status();
+}
+
+}  // namespace
+
+// Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
+int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
+    if (a->C == 32) return launch_stage_bf16<32>(a, stream);
+    if (a->C == 16) return launch_stage_bf16<16>(a, stream);
+    return V2W_E_SHAPE;
+}

@@ -382,6 +382,8 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
 
 }  // namespace
 
+int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16.hip
+
 extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream) {
     if (!a || !a->in || !a->out || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
@@ -389,6 +391,10 @@ extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void
     for (int j = 0; j < a->nk; ++j) {
         if (!a->wps1[j] || !a->wps2[j] || !a->sc1[j] || !a->sc2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
+    }
+    if (a->bf16) {     // bf16 operands: the weights-in-registers kernel of v2w_stage_bf16.hip; shapes it does not take fall through
+        const int rc = v2w_resblock2_stage_bf16(a, (hipStream_t)stream);
+        if (rc != V2W_E_SHAPE) return rc;
     }
     if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
     if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
