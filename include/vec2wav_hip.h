@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 22
+#define V2W_ABI_VERSION 23
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -132,6 +132,9 @@ typedef struct {
                                    * Not combined with the per-(b, channel) affines; f32 MFMA and direct kernels only */
     float   out_slope;            /* 0 or 1: none.  Else leaky_relu(value, out_slope) on what is stored (applied last): the
                                    * discriminators keep the ACTIVATED feature maps (models.py:184-186, 236-238) */
+    int32_t io_bf16;              /* V2W_ALGO_BF16 only (else must be 0): activation STORAGE in bf16 - BASELINE configs[2] priced at 2 bytes
+                                   * per activation.  bit 0: `in` is bf16; bit 1: `out`, `res`, `add0`, `add1` are bf16.
+                                   * Accumulation, bias, affines and the residual arithmetic stay fp32; one rounding at the store. */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
@@ -204,7 +207,8 @@ typedef struct {
     float* out;
     int32_t nk, B, C, L;
     float slope, out_div;
-    int32_t bf16, _pad;
+    int32_t bf16;
+    int32_t io_bf16;   /* bf16 != 0 only: bit 0 `in` is bf16, bit 1 `out` is bf16 (see v2w_conv1d_args) */
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 
@@ -217,6 +221,8 @@ typedef struct {
     int32_t B, C_in, C_out, L, k, u;
     float   slope;
     int32_t algo;
+    int32_t io_bf16;    /* v2w_convt1d_bf16_fwd only (else 0): bit 0 `in` is bf16, bit 1 `out` is bf16 (see v2w_conv1d_args) */
+    int32_t _pad;
 } v2w_convt1d_args;
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
 
@@ -320,6 +326,9 @@ int v2w_cond_bwd(const float* dgb, const float* z, const float* sn_w, const floa
 
 /* ---- K8: leaky_relu(slope) -> Conv1d(C_in -> 1, k, pad (k-1)/2) -> +bias -> tanh  (models.py:143-145).
  * in (B, C_in, L) -> out (B, 1, L); wf [k][C_in][1]. */
+/* the same with a bf16 input tensor (bf16 activation storage of BASELINE configs[2]); output stays fp32 */
+int v2w_conv_post_tanh_bf16in(const void* x_bf16, const float* wf, const float* bias, float* out,
+                              int B, int c_in, int L, int k, float slope, void* stream);
 int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
                        int B, int C_in, int L, int k, float slope, void* stream);
 

@@ -142,8 +142,9 @@ def test_generator_bf16_operand_mode(dev):
 
 
 def test_generator_cfg3_bf16_full_size(dev):
-    """BASELINE configs[2] at its full size (B=64, T=512, bf16 compute / fp32 accumulate): the bf16 precision mode against the
-    exact-fp32 HIP path on the same inputs (the oracle cannot finish this size in seconds): finite, within the 4e-3 bf16 bar;
+    """BASELINE configs[2] at its full size (B=64, T=512, bf16 compute / fp32 accumulate, bf16 activation storage) against the
+    exact-fp32 HIP path on the same inputs, without the oracle (test_generator_cfg3_full_size_vs_oracle_train holds the real bar:
+    the reference's own bf16 autocast deviation, 7e-3 max / 7.5e-4 rms at this size): finite, max <= 1e-2 and rms <= 7.5e-4;
     and the HIP-graph replay of the f16x3 mode is bit-identical to its eager run."""
     h = synthetic.make_hparams(num_wv_feat=768)
     sd = synthetic.make_state_dict(h, seed=0)
@@ -155,7 +156,8 @@ def test_generator_cfg3_bf16_full_size(dev):
         yb = g(*inp)
     assert yb.shape == (64, 1, 512 * 320) and torch.isfinite(yb).all()
     d = (y32 - yb).abs().max().item()
-    assert 1e-6 < d <= 4e-3, f'max|y_bf16 - y_f32| = {d}'
+    rms = (y32 - yb).pow(2).mean().sqrt().item()
+    assert 1e-6 < d <= 1e-2 and rms <= 7.5e-4, f'max|y_bf16 - y_f32| = {d}, rms {rms}'
     del y32, yb
     ge = build_generator(h, sd, dev, training=False)
     ge.precision = 'f16x3'
@@ -498,9 +500,21 @@ def test_generator_weights_follow_the_optimizer(dev, precision):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Full-size parity against the pinned oracle (one CPU forward each: cfg2 ~12 s, cfg5 ~12 s, cfg3 ~1 min on the box's cores)
+def _reference_bf16_deviation(sd, h, inp, want):
+    """How far the REFERENCE's own bf16 arithmetic (the oracle's modules under torch.autocast(bfloat16), the only bf16 mode the
+    reference's stack offers; inference.py / train.py run fp32) lands from its fp32 result on these inputs: (max, rms).  The
+    deviation grows with the number of samples the max runs over (2e-3 at B=2 x T=50, 7e-3 at B=64 x T=512), so a bf16 bar is
+    only meaningful at the same size on the same inputs."""
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        yb, _ = O.generator_forward(dict(sd), h, *inp, training=True)
+    e = yb.float() - want
+    return e.abs().max().item(), e.pow(2).mean().sqrt().item()
+
+
 def _full_size_case(dev, h, B, T, seed, precisions):
     """HIP train-mode forward at a BASELINE configuration's full size vs ONE oracle forward: y (per precision mode with its
-    bar), BatchNorm running statistics, num_batches_tracked and the spectral-norm u / v after the step (f32 path)."""
+    bar), BatchNorm running statistics, num_batches_tracked and the spectral-norm u / v after the step (f32 path).  A bar of
+    'ref-bf16' means: no farther (max AND rms) from the fp32 oracle than the reference's own bf16 autocast run is."""
     sd = synthetic.make_state_dict(h, seed=0)
     inp = synthetic.make_inputs(h, B, T, seed=seed)
     want, nb = O.generator_forward(sd, h, *inp, training=True)
@@ -508,13 +522,26 @@ def _full_size_case(dev, h, B, T, seed, precisions):
     out = {}
     for prec, bar in precisions:
         g = build_generator(h, sd, dev, training=True)
+        storage = True
+        if prec == 'bf16-operands':
+            prec, storage = 'bf16', False
         g.precision = prec
+        g.bf16_storage = storage
         with torch.no_grad():
             y = g(*xin)
         assert y.shape == want.shape and torch.isfinite(y).all()
-        d = (y.cpu() - want).abs().max().item()
-        out[prec] = d
-        assert d <= bar, f'{prec}: max|dy| = {d} > {bar}'
+        e = y.cpu() - want
+        d = e.abs().max().item()
+        out[prec if storage else 'bf16-operands'] = d
+        if bar == 'ref-bf16':
+            if 'ref' not in out:
+                out['ref'] = _reference_bf16_deviation(sd, h, inp, want)
+            rmax, rrms = out['ref']
+            rms = e.pow(2).mean().sqrt().item()
+            print(f'[bf16 vs fp32 oracle @ B={B} T={T}] storage={storage}: max {d:.2e} rms {rms:.2e}; reference autocast: max {rmax:.2e} rms {rrms:.2e}')
+            assert d <= rmax and rms <= rrms, f'{prec} (storage={storage}): max {d} rms {rms} vs reference autocast max {rmax} rms {rrms}'
+        else:
+            assert d <= bar, f'{prec}: max|dy| = {d} > {bar}'
         if prec == 'f32':
             ref = dict(sd)
             O.apply_buffers(ref, nb)
@@ -549,11 +576,14 @@ def test_generator_cfg5_full_size_vs_oracle_train(dev):
 @pytest.mark.timeout(1800)
 def test_generator_cfg3_full_size_vs_oracle_train(dev):
     """BASELINE configs[2]: B=64, T=512 (10.5 M samples).  The fp32 oracle is the reference for BOTH the exact-fp32 path (1e-4)
-    and the configuration's own arithmetic, bf16 compute / fp32 accumulate, at the separately stated 4e-3 bar (bf16
-    autocast of the reference itself sits 4e-3 from its fp64 result; the reference defines no bf16 tolerance)."""
+    and the configuration's own arithmetic - bf16 compute / fp32 accumulate, with bf16 activation storage (the default of
+    precision='bf16') and with fp32 storage (bf16_storage=False).  The reference defines no bf16 tolerance, so the bar is the
+    reference's own bf16 behaviour measured here on the same inputs: both modes must sit no farther from the fp32 oracle (max and
+    rms) than the oracle run under bf16 autocast does (7e-3 max / 7.5e-4 rms at this size)."""
     h = synthetic.make_hparams(num_wv_feat=768)
-    d = _full_size_case(dev, h, 64, 512, 4, [('f32', TOL), ('bf16', 4e-3)])
-    assert d['bf16'] > 1e-6     # the bf16 mode really ran in bf16
+    d = _full_size_case(dev, h, 64, 512, 4, [('f32', TOL), ('bf16', 'ref-bf16'), ('bf16-operands', 'ref-bf16')])
+    assert d['bf16'] > 1e-6 and d['bf16-operands'] > 1e-6     # the bf16 modes really ran in bf16
+    assert d['bf16-operands'] <= 4e-3                           # operand-only rounding keeps the small-size bar even here
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -28,13 +28,14 @@ class Conv1dArgs(C.Structure):
                 ('k', C.c_int32), ('dil', C.c_int32), ('slope', C.c_float), ('accumulate', C.c_int32),
                 ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
                 ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32),
-                ('wps', _fp), ('winv', _fp), ('in_ct', C.c_int32), ('out_ct', C.c_int32), ('out_slope', C.c_float)]
+                ('wps', _fp), ('winv', _fp), ('in_ct', C.c_int32), ('out_ct', C.c_int32), ('out_slope', C.c_float),
+                ('io_bf16', C.c_int32)]
 
 
 class ConvT1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
-                ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32)]
+                ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32), ('io_bf16', C.c_int32), ('_pad', C.c_int32)]
 
 
 class PairArgs(C.Structure):
@@ -67,7 +68,7 @@ class StageSplitArgs(C.Structure):
                 ('wps1', _P4), ('sc1', _P4), ('bias1', _P4), ('wps2', _P4), ('sc2', _P4), ('bias2', _P4),
                 ('k', _I4), ('dil1', _I4), ('dil2', _I4), ('out', _fp),
                 ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
-                ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('_pad', C.c_int32)]
+                ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32)]
 
 
 class SplitDesc(C.Structure):
@@ -148,6 +149,7 @@ SIGNATURES = {
     'v2w_tail_bwd': (C.c_int, [_fp] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     'v2w_wn_bwd': (C.c_int, [_fp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_cond_bwd': (C.c_int, [_fp] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_conv_post_tanh_bf16in': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     'v2w_conv_post_tanh': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
 }
 

@@ -28,6 +28,7 @@ static int check_conv1d(const v2w_conv1d_args* a) {
     if (((a->in_ct > 0 && a->in_ct != a->C_in) && a->in_a) || ((a->out_ct > 0 && a->out_ct != a->C_out) && (a->res_a || a->mask_a)))
         return V2W_E_ARG;                                          // the affine tables are indexed by the slice's own channel count
     if (a->out_slope < 0.f) return V2W_E_ARG;
+    if (a->io_bf16 != 0 && (a->algo != V2W_ALGO_BF16 || a->io_bf16 < 0 || a->io_bf16 > 3)) return V2W_E_ARG;   // bf16 storage: bf16 kernels only
     const bool ext = (a->in_ct > 0 && a->in_ct != a->C_in) || (a->out_ct > 0 && a->out_ct != a->C_out) || (a->out_slope != 0.f && a->out_slope != 1.f);
     if (ext && (a->algo == V2W_ALGO_SPLIT || a->algo == V2W_ALGO_BF16)) return V2W_E_SHAPE;
     return 0;
@@ -50,7 +51,7 @@ extern "C" int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream) {
 }
 
 extern "C" int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream) {
-    if (!a || !a->in || (!a->wf && !a->wp) || !a->out) return V2W_E_ARG;
+    if (!a || !a->in || (!a->wf && !a->wp) || !a->out || a->io_bf16 != 0) return V2W_E_ARG;
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 0) return V2W_E_ARG;
     if (a->k < a->u || ((a->k - a->u) & 1)) return V2W_E_SHAPE;    // L_out = u*L needs k-u even
     hipStream_t st = (hipStream_t)stream;

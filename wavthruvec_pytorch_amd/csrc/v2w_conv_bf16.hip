@@ -21,6 +21,7 @@
 // emits the BatchNorm partial sums (modules.py:23) of its tile.
 // The older split kernel (v2w_conv_split.hip, one workgroup barrier per (16-channel chunk, tap) stage) stays the f16x3 path; in bf16
 // mode a stage of it was 128 cycles of MFMA issue in ~1300 cycles.
+#include <type_traits>
 #include "v2w_tile.h"
 
 namespace {
@@ -39,8 +40,15 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, v);
 }
 
-template <int MI, int NI, int WM, int WN, int NPF, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN, MI * NI >= 8 ? 2 : 1)      // (128 x 256: two workgroups per CU = at most 256 registers)
+// bf16 <-> fp32 on raw words: element 0 of a packed pair is the low half
+__device__ __forceinline__ float bf_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ f32x4 bf4_to_f32(u32x2 w) { return f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])}; }
+__device__ __forceinline__ u32x2 f32_to_bf4(f32x4 v) { return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; }
+
+// IN_BF / OUT_BF: activation STORAGE in bf16 (`in`; `out`, `res`, `add0`, `add1`): 8-byte loads / stores of 4 positions instead of 16.
+template <int MI, int NI, int WM, int WN, int NPF, int EPI, bool IN_BF, bool OUT_BF>
+__global__ void __launch_bounds__(64 * WM * WN, MI * NI >= 8 ? 2 : 3)      // (128 x 256: two workgroups per CU = at most 256 registers; else three)
 conv_bf16_kernel(const MultiArgs m) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -88,7 +96,8 @@ conv_bf16_kernel(const MultiArgs m) {
     // position are 8 contiguous bytes of its row).  Consecutive lanes take the 8 channel quads of one position quad (a whole 64-byte
     // row per 8 lanes: conflict-free stores; 128-byte pieces of 8 x 4 rows on the global side), then the next position quad.
     const int nq = p.xrows >> 2;
-    f32x4 pf[NPF][4];
+    typedef typename std::conditional<IN_BF, u32x2, f32x4>::type pf_t;       // 4 positions of one channel as loaded
+    pf_t pf[NPF][4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto item = [&](int s, int& cq, int& row, bool& in_img, bool& in_seq) {
         int t = tid;
@@ -101,15 +110,20 @@ conv_bf16_kernel(const MultiArgs m) {
         in_seq = in_img && pos >= 0 && pos < L;         // L % 4 == 0 and pos % 4 == 0: a float4 is inside or outside as a whole
     };
     auto prefetch = [&](int ci0) {
-        const float* src = p.in + (size_t)(b * p.Cin + ci0) * L + pos0;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             int cq, row; bool in_img, in_seq;
             item(s, cq, row, in_img, in_seq);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pf[s][i] = zero4;
-                if (in_seq) pf[s][i] = *reinterpret_cast<const f32x4*>(src + (size_t)(4 * cq + i) * L + row);
+                const size_t off = (size_t)(b * p.Cin + ci0 + 4 * cq + i) * L + pos0 + row;
+                if constexpr (IN_BF) {
+                    pf[s][i] = u32x2{0u, 0u};
+                    if (in_seq) pf[s][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.in) + off);
+                } else {
+                    pf[s][i] = zero4;
+                    if (in_seq) pf[s][i] = *reinterpret_cast<const f32x4*>(p.in + off);
+                }
             }
         }
     };
@@ -132,7 +146,12 @@ conv_bf16_kernel(const MultiArgs m) {
                 if (in_seq) {
                     float a[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = v2w_lrelu(fmaf(av[i], pf[s][i][e], sv[i]), slope);
+                    for (int i = 0; i < 4; ++i) {
+                        float xv;
+                        if constexpr (IN_BF) xv = (e & 1) ? bf_hi(pf[s][i][e >> 1]) : bf_lo(pf[s][i][e >> 1]);
+                        else xv = pf[s][i][e];
+                        a[i] = v2w_lrelu(fmaf(av[i], xv, sv[i]), slope);
+                    }
                     v[0] = pack_bf16x2(a[0], a[1]); v[1] = pack_bf16x2(a[2], a[3]);
                 }
                 *reinterpret_cast<u32x2*>(dst + e * ROWB) = v;
@@ -142,12 +161,14 @@ conv_bf16_kernel(const MultiArgs m) {
     auto stage_scalar = [&](int ci0, unsigned char* Xs) {   // any L / alignment: one element at a time
         for (int c = wave; c < CK; c += WM * WN) {
             const int ch = b * p.Cin + ci0 + c;
-            const float* src = p.in + (size_t)ch * L;
             const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_s ? p.in_s[ch] : 0.f;
             for (int j = lane; j < p.xrows; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
-                if (l >= 0 && l < L) v = v2w_lrelu(fmaf(av, src[l], sv), slope);
+                if (l >= 0 && l < L) {
+                    const float xv = IN_BF ? bf_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + l]) : p.in[(size_t)ch * L + l];
+                    v = v2w_lrelu(fmaf(av, xv, sv), slope);
+                }
                 reinterpret_cast<__bf16*>(Xs + j * ROWB)[c] = (__bf16)v;
             }
         }
@@ -184,6 +205,24 @@ conv_bf16_kernel(const MultiArgs m) {
             bb[j] = *reinterpret_cast<const u32x4*>(nxt + j * 32 * ROWB);
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- typed access to the output-side tensors (out, res, add0, add1): fp32, or bf16 storage (OUT_BF) with fp32 arithmetic
+    auto ld4 = [&](const float* base, size_t off) {
+        if constexpr (OUT_BF) return bf4_to_f32(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + off));
+        else return *reinterpret_cast<const f32x4*>(base + off);
+    };
+    auto st4 = [&](float* base, size_t off, f32x4 v) {
+        if constexpr (OUT_BF) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + off) = f32_to_bf4(v);
+        else *reinterpret_cast<f32x4*>(base + off) = v;
+    };
+    auto ld1 = [&](const float* base, size_t off) {
+        if constexpr (OUT_BF) return bf_lo(reinterpret_cast<const unsigned short*>(base)[off]);
+        else return base[off];
+    };
+    auto st1 = [&](float* base, size_t off, float v) {
+        if constexpr (OUT_BF) reinterpret_cast<__bf16*>(base)[off] = (__bf16)v;
+        else base[off] = v;
     };
 
     // ---- prologue
@@ -265,7 +304,7 @@ conv_bf16_kernel(const MultiArgs m) {
                     const int col = wm0 + i * 32 + cl * UP;             // virtual row of the channel's phase 0 inside the tile
                     const int co = (m0 + col) / UP;
                     const float bias = etab[col];
-                    float* dst = p.out + ((size_t)b * CoutR + co) * Lout + (size_t)U * q0;
+                    const size_t dsto = ((size_t)b * CoutR + co) * Lout + (size_t)U * q0;
                     float s1 = 0.f, s2 = 0.f;
                     for (int c4 = lane; c4 < C4; c4 += 64) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(scr + cl * ORS + 4 * c4);
@@ -275,11 +314,11 @@ conv_bf16_kernel(const MultiArgs m) {
                             if (U * q0 + 4 * c4 + x < Lout) { s1 += v[x]; s2 = fmaf(v[x], v[x], s2); }
                         }
                         if (p.evec) {
-                            if (U * q0 + 4 * c4 < Lout) *reinterpret_cast<f32x4*>(dst + 4 * c4) = v;
+                            if (U * q0 + 4 * c4 < Lout) st4(p.out, dsto + 4 * c4, v);
                         } else {
 #pragma unroll
                             for (int x = 0; x < 4; ++x)
-                                if (U * q0 + 4 * c4 + x < Lout) dst[4 * c4 + x] = v[x];
+                                if (U * q0 + 4 * c4 + x < Lout) st1(p.out, dsto + 4 * c4 + x, v[x]);
                         }
                     }
                     if (p.stats_part) {
@@ -328,7 +367,7 @@ conv_bf16_kernel(const MultiArgs m) {
                     const int idx = lane + 64 * g;
                     const int row = idx / C4, c4 = idx - row * C4;
                     rall[g] = zero4;
-                    if (p.res && qb + 4 * c4 < L) rall[g] = *reinterpret_cast<const f32x4*>(p.res + gbase + (size_t)row * L + 4 * c4);
+                    if (p.res && qb + 4 * c4 < L) rall[g] = ld4(p.res, gbase + (size_t)row * L + 4 * c4);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +391,7 @@ conv_bf16_kernel(const MultiArgs m) {
                         if (p.out_div != 0.f) t2 = v2w_div_by(t2, p.out_div, dinv);
                         v[x] = t2;
                     }
-                    if (qb + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                    if (qb + 4 * c4 < L) st4(p.out, gbase + (size_t)row * L + 4 * c4, v);
                 }
             } else if (p.evec) {
 #pragma unroll 1
@@ -366,10 +405,10 @@ conv_bf16_kernel(const MultiArgs m) {
                         const size_t goff = gbase + (size_t)row * L + 4 * c4;
                         rv[g] = ov[g] = o2[g] = zero4;
                         if (ok) {
-                            if (p.res) rv[g] = *reinterpret_cast<const f32x4*>(p.res + goff);
-                            if (p.accumulate) ov[g] = *reinterpret_cast<const f32x4*>(p.out + goff);
-                            else if (p.add0) ov[g] = *reinterpret_cast<const f32x4*>(p.add0 + goff);
-                            if (p.add1) o2[g] = *reinterpret_cast<const f32x4*>(p.add1 + goff);
+                            if (p.res) rv[g] = ld4(p.res, goff);
+                            if (p.accumulate) ov[g] = ld4(p.out, goff);
+                            else if (p.add0) ov[g] = ld4(p.add0, goff);
+                            if (p.add1) o2[g] = ld4(p.add1, goff);
                         }
                         if constexpr (MASK) {
                             mv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -395,7 +434,7 @@ conv_bf16_kernel(const MultiArgs m) {
                             if (p.out_div != 0.f) t2 = v2w_div_by(t2, p.out_div, dinv);
                             v[x] = t2;
                         }
-                        if (qb + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                        if (qb + 4 * c4 < L) st4(p.out, gbase + (size_t)row * L + 4 * c4, v);
                     }
                 }
             } else {                                  // ragged L / unaligned operands: one element at a time
@@ -409,12 +448,12 @@ conv_bf16_kernel(const MultiArgs m) {
                     if constexpr (MASK)
                         if (p.mask_src) t2 = fmaf(etab[3 * MT + col], p.mask_src[goff], etab[4 * MT + col]) > 0.f ? t2 : t2 * p.mask_slope;
                     t2 += etab[col];
-                    if (p.res) t2 += fmaf(etab[MT + col], p.res[goff], etab[2 * MT + col]);
-                    if (p.add1) t2 += p.add0[goff] + p.add1[goff];
-                    else if (p.accumulate) t2 += p.out[goff];
-                    else if (p.add0) t2 += p.add0[goff];
+                    if (p.res) t2 += fmaf(etab[MT + col], ld1(p.res, goff), etab[2 * MT + col]);
+                    if (p.add1) t2 += ld1(p.add0, goff) + ld1(p.add1, goff);
+                    else if (p.accumulate) t2 += ld1(p.out, goff);
+                    else if (p.add0) t2 += ld1(p.add0, goff);
                     if (p.out_div != 0.f) t2 = v2w_div_by(t2, p.out_div, dinv);
-                    p.out[goff] = t2;
+                    st1(p.out, goff, t2);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +494,13 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     m.start[nprob] = grid;
     for (int i = nprob + 1; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
-    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0>;
+    const int io = m.p[0].io_bf16;
+    for (int i = 1; i < nprob; ++i) if (m.p[i].io_bf16 != io) return V2W_E_ARG;      // one instantiation per launch
+    if (io == 1 || (epi && io != 0)) return V2W_E_SHAPE;     // bf16 in with fp32 out does not occur on the path; the mask epilogue is fp32-only
+    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false>
+              : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false>
+              : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true>
+                        : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -527,7 +572,8 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
     const int grid = ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
     m.start[1] = grid;
     for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
-    auto kern = conv_bf16_kernel<MI, NI, WM, WN, NPF, 2>;
+    if (p.io_bf16 != 0 && p.io_bf16 != 3) return V2W_E_SHAPE;
+    auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -544,7 +590,7 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     TileArgs p{};
     p.in = a->in; p.wps = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out * g.UP; p.L = a->L; p.K = g.KV; p.dil = 1;
-    p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP;
+    p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP; p.io_bf16 = a->io_bf16;
     const int rows = p.Cout;
     if (rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512) return launch_bf16_convt<2, 4, 2, 2>(p, stream, ntiles_out);
     if (rows % 64 == 0) return launch_bf16_convt<1, 4, 2, 2>(p, stream, ntiles_out);
@@ -574,6 +620,7 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
         p.hl = p.hr = q->dil * (q->k - 1) / 2;
         if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
+        p.io_bf16 = q->io_bf16;
         ps[i] = p;
         tiles += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 64);
     }

@@ -736,6 +736,7 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
     if (bf) {      // bf16 operands: the chunk-per-barrier kernel of v2w_conv_bf16.hip; shapes it does not take fall through to this file's
         const int rc = v2w_conv1d_bf16(a, n, stream);
         if (rc != V2W_E_SHAPE) return rc;
+        for (int i = 0; i < n; ++i) if (a[i].io_bf16) return V2W_E_SHAPE;      // this file's kernels read and write fp32 only
     }
     TileArgs ps[V2W_MAX_MULTI];
     long tiles256 = 0;

@@ -104,11 +104,22 @@ convt1d_direct_kernel(const v2w_convt1d_args a) {
     a.out[((size_t)b * a.C_out + co) * Lout + n] = acc + (a.bias ? a.bias[co] : 0.f);
 }
 
+// bf16 activation storage (BASELINE configs[2]): the tail can read a bf16 input tensor; everything after the load is fp32
+struct InF32 { typedef float elem_t; static __device__ __forceinline__ float get(const float* p, size_t i) { return p[i]; }
+               static __device__ __forceinline__ f32x4 get4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); } };
+struct InBf16 { typedef unsigned short elem_t;
+                static __device__ __forceinline__ float get(const unsigned short* p, size_t i) { return __builtin_bit_cast(float, (unsigned)p[i] << 16); }
+                static __device__ __forceinline__ f32x4 get4(const unsigned short* p, size_t i) {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(p + i);
+                    return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                                 __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)}; } };
+
 // Tail: each thread produces 4 consecutive samples from a register window of 4 + (k-1) inputs per channel.
 // HBM-bound (3.3 FLOP/B): the input is read once (neighbour overlap is served by L1/L2), the output written once.
-template <int KMAX>
+template <int KMAX, typename IN = InF32>
 __global__ void __launch_bounds__(256)
-conv_post_tanh_kernel(const float* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
+conv_post_tanh_kernel(const typename IN::elem_t* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
                       float* __restrict__ out, int B, int Cin, int L, int k, float slope) {
     extern __shared__ float w_s[];   // [k][Cin]
     for (int i = threadIdx.x; i < k * Cin; i += blockDim.x) w_s[i] = wf[i];
@@ -119,12 +130,12 @@ conv_post_tanh_kernel(const float* __restrict__ in, const float* __restrict__ wf
     if (l0 >= L) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* src = in + ((size_t)b * Cin + ci) * L;
+        const size_t src = ((size_t)b * Cin + ci) * L;
         float win[4 + KMAX - 1];
 #pragma unroll
         for (int j = 0; j < 4 + KMAX - 1; ++j) {
             const int li = l0 - pad + j;
-            win[j] = (j < 4 + k - 1 && li >= 0 && li < L) ? v2w_lrelu(src[li], slope) : 0.f;
+            win[j] = (j < 4 + k - 1 && li >= 0 && li < L) ? v2w_lrelu(IN::get(in, src + li), slope) : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < KMAX; ++t) {
@@ -144,8 +155,9 @@ conv_post_tanh_kernel(const float* __restrict__ in, const float* __restrict__ wf
 
 // Vectorised tail for L % 4 == 0 and k <= 9: per channel three aligned float4 loads cover the 4 outputs' window
 // [l0-4, l0+8); every load is a full 16 B/lane coalesced access.
+template <typename IN = InF32>
 __global__ void __launch_bounds__(256)
-conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
+conv_post_tanh_vec4_kernel(const typename IN::elem_t* __restrict__ in, const float* __restrict__ wf, const float* __restrict__ bias,
                            float* __restrict__ out, int B, int Cin, int L, int k, float slope) {
     extern __shared__ float w_s[];   // [k][Cin]
     for (int i = threadIdx.x; i < k * Cin; i += blockDim.x) w_s[i] = wf[i];
@@ -158,10 +170,10 @@ conv_post_tanh_vec4_kernel(const float* __restrict__ in, const float* __restrict
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* src = in + ((size_t)b * Cin + ci) * L + l0;
-        const f32x4 lo = l0 >= 4 ? *reinterpret_cast<const f32x4*>(src - 4) : zero4;
-        const f32x4 mid = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 hi = l0 + 4 < L ? *reinterpret_cast<const f32x4*>(src + 4) : zero4;
+        const size_t src = ((size_t)b * Cin + ci) * L + l0;
+        const f32x4 lo = l0 >= 4 ? IN::get4(in, src - 4) : zero4;
+        const f32x4 mid = IN::get4(in, src);
+        const f32x4 hi = l0 + 4 < L ? IN::get4(in, src + 4) : zero4;
         float win[12];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { win[e] = v2w_lrelu(lo[e], slope); win[4 + e] = v2w_lrelu(mid[e], slope); win[8 + e] = v2w_lrelu(hi[e], slope); }
@@ -200,8 +212,9 @@ int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream) {
     return v2w_launch_status();
 }
 
-extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
-                                  int B, int C_in, int L, int k, float slope, void* stream) {
+template <typename IN>
+static int conv_post_tanh_impl(const typename IN::elem_t* in, const float* wf, const float* bias, float* out,
+                               int B, int C_in, int L, int k, float slope, void* stream) {
     if (!in || !wf || !out || B <= 0 || C_in <= 0 || L <= 0 || k <= 0 || (k & 1) == 0) return V2W_E_ARG;
     if (k > 15) return V2W_E_SHAPE;
     dim3 grid((L + 1023) / 1024, B);
@@ -209,10 +222,20 @@ extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float*
     hipStream_t s = (hipStream_t)stream;
     const bool aligned = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (aligned && k <= 9) {
-        hipLaunchKernelGGL(conv_post_tanh_vec4_kernel, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+        hipLaunchKernelGGL(conv_post_tanh_vec4_kernel<IN>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
         return v2w_launch_status();
     }
-    if (k <= 7) hipLaunchKernelGGL(conv_post_tanh_kernel<7>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
-    else hipLaunchKernelGGL(conv_post_tanh_kernel<15>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    if (k <= 7) hipLaunchKernelGGL((conv_post_tanh_kernel<7, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    else hipLaunchKernelGGL((conv_post_tanh_kernel<15, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
     return v2w_launch_status();
+}
+
+extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float* bias, float* out,
+                                  int B, int C_in, int L, int k, float slope, void* stream) {
+    return conv_post_tanh_impl<InF32>(in, wf, bias, out, B, C_in, L, k, slope, stream);
+}
+
+extern "C" int v2w_conv_post_tanh_bf16in(const void* x_bf16, const float* wf, const float* bias, float* out,
+                                         int B, int C_in, int L, int k, float slope, void* stream) {
+    return conv_post_tanh_impl<InBf16>(static_cast<const unsigned short*>(x_bf16), wf, bias, out, B, C_in, L, k, slope, stream);
 }

@@ -11,6 +11,7 @@
 //     of 256 positions so the residuals (x, t1: fp32) stay in the lane that produced them;
 //   * C = 16 uses the 32-row MFMA with the packed fragments' rows 16-31 zero (the pipe is idle most of the time anyway).
 // Weights: the bf16 fragments of v2w_pack_bf16 / v2w_split_pack_batch, [16-channel k-step][tap][2 KiB, first KiB used].
+#include <type_traits>
 #include "v2w_common.h"
 
 namespace {
@@ -42,7 +43,11 @@ __device__ __forceinline__ unsigned int sb_pack2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, v);
 }
 
-template <int C>
+__device__ __forceinline__ float sb_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float sb_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// IO_BF: `in` and `out` are bf16 tensors (activation storage of BASELINE configs[2]); arithmetic stays fp32
+template <int C, bool IO_BF>
 __global__ void __launch_bounds__(256, C == 32 ? 2 : 3)
 stage_bf16_kernel(const StageBfArgs p) {
     typedef Frag<32> F;
@@ -81,7 +86,8 @@ stage_bf16_kernel(const StageBfArgs p) {
     if (p.vec4) {
         constexpr int NPF = (NCQ * ((W + 2 * 32 + 8) / 4) + NTHREADS - 1) / NTHREADS;
         const int xr4 = p.xrows >> 2;
-        f32x4 g[NPF][4];
+        typedef typename std::conditional<IO_BF, u32x2, f32x4>::type ld_t;
+        ld_t g[NPF][4];
         float av[NPF][4], sv[NPF][4];
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
@@ -91,10 +97,11 @@ stage_bf16_kernel(const StageBfArgs p) {
             const bool ok = pq < xr4 && pos >= 0 && pos < L;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[s][i] = 1.f; sv[s][i] = 0.f;
+                g[s][i] = ld_t{}; av[s][i] = 1.f; sv[s][i] = 0.f;
                 if (ok) {
                     const int ch = b * C + 4 * cq + i;
-                    g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
+                    if constexpr (IO_BF) g[s][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.in) + (size_t)ch * L + pos);
+                    else g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
                     if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
                 }
             }
@@ -109,7 +116,12 @@ stage_bf16_kernel(const StageBfArgs p) {
             for (int e = 0; e < 4; ++e) {
                 float a[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = ok ? v2w_lrelu(fmaf(av[s][i], g[s][i][e], sv[s][i]), slope) : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    float xv;
+                    if constexpr (IO_BF) xv = (e & 1) ? sb_hi(g[s][i][e >> 1]) : sb_lo(g[s][i][e >> 1]);
+                    else xv = g[s][i][e];
+                    a[i] = ok ? v2w_lrelu(fmaf(av[s][i], xv, sv[s][i]), slope) : 0.f;
+                }
                 *reinterpret_cast<u32x2*>(Xa + (pq * 4 + e) * ROWB + cq * 8) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
             }
         }
@@ -119,7 +131,8 @@ stage_bf16_kernel(const StageBfArgs p) {
             float v = 0.f;
             if (pos >= 0 && pos < L) {
                 const int ch = b * C + c;
-                v = v2w_lrelu(fmaf(p.in_a ? p.in_a[ch] : 1.f, p.in[(size_t)ch * L + pos], p.in_s ? p.in_s[ch] : 0.f), slope);
+                const float xv = IO_BF ? sb_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + pos]) : p.in[(size_t)ch * L + pos];
+                v = v2w_lrelu(fmaf(p.in_a ? p.in_a[ch] : 1.f, xv, p.in_s ? p.in_s[ch] : 0.f), slope);
             }
             reinterpret_cast<__bf16*>(Xa + r * ROWB)[c] = (__bf16)v;
         }
@@ -137,7 +150,10 @@ stage_bf16_kernel(const StageBfArgs p) {
         for (int e = 0; e < NR; ++e) {
             const int ch = b * C + F::row(e, hk);
             float v = 0.f;
-            if (in_seq) v = fmaf(p.in_a ? p.in_a[ch] : 1.f, p.in[(size_t)ch * L + pos], p.in_s ? p.in_s[ch] : 0.f);
+            if (in_seq) {
+                const float xv = IO_BF ? sb_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + pos]) : p.in[(size_t)ch * L + pos];
+                v = fmaf(p.in_a ? p.in_a[ch] : 1.f, xv, p.in_s ? p.in_s[ch] : 0.f);
+            }
             xres[j][e] = v;
         }
     }
@@ -250,13 +266,25 @@ stage_bf16_kernel(const StageBfArgs p) {
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], p.out_div, dinv);
             }
-            float* dst = p.out + ((size_t)b * C + row) * L + pos;
-            if (p.vec4) {
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else {
+            const size_t doff = ((size_t)b * C + row) * L + pos;
+            if constexpr (IO_BF) {
+                unsigned short* dst = reinterpret_cast<unsigned short*>(p.out) + doff;
+                if (p.vec4) {
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{sb_pack2(v[0], v[1]), sb_pack2(v[2], v[3])};
+                } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    if (pos + x < L) dst[x] = v[x];
+                    for (int x = 0; x < 4; ++x)
+                        if (pos + x < L) reinterpret_cast<__bf16*>(dst)[x] = (__bf16)v[x];
+                }
+            } else {
+                float* dst = p.out + doff;
+                if (p.vec4) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (pos + x < L) dst[x] = v[x];
+                }
             }
         }
     }
@@ -290,7 +318,8 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
     const size_t scr = (size_t)C * (W + 4) * sizeof(float);           // the store scratch overlays the tiles
     if (lds < scr) lds = scr;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
-    auto kern = stage_bf16_kernel<C>;
+    if (q->io_bf16 != 0 && q->io_bf16 != 3) return V2W_E_ARG;
+    auto kern = q->io_bf16 ? stage_bf16_kernel<C, true> : stage_bf16_kernel<C, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

@@ -396,6 +396,7 @@ extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void
         const int rc = v2w_resblock2_stage_bf16(a, (hipStream_t)stream);
         if (rc != V2W_E_SHAPE) return rc;
     }
+    if (a->io_bf16) return V2W_E_SHAPE;       // this file's kernels read and write fp32 only
     if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
     if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
     return V2W_E_SHAPE;

@@ -33,6 +33,7 @@ struct TileArgs {
     float slope;
     int accumulate;
     float out_div;
+    int io_bf16;      // bf16 kernels: bit 0 `in` is bf16, bit 1 `out` / `res` / `add0` / `add1` are bf16 (pointers are typed float* regardless)
     int up_u, up_p;   // bf16 transposed conv run as a 3-tap conv over up_p * C_out virtual rows (row = co * up_p + phase): stride, padded phase count
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
 };

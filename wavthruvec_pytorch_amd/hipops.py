@@ -135,11 +135,12 @@ def pack_split(wf, out=None, sc=None, bf16=False):
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
                  accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None):
+                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None, io_bf16=0):
     B, ci, Lx = x.shape
     L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
     co = out.shape[1]
     a.out_slope = out_slope
+    a.io_bf16 = io_bf16        # ALGO_BF16 only: bit 0 x is bf16, bit 1 out / res / add are bf16 (activation storage of BASELINE configs[2])
     xoff = ooff = 0
     if group is not None:             # (g, C_in per group, C_out per group): this call computes ONE group of a grouped conv
         g, cig, cog = group
@@ -216,13 +217,13 @@ def pack_bf16_convt(wf, u, out=None):
     return out
 
 
-def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part):
+def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16=0):
     B, ci, L = x.shape
     a = _hip.ConvT1dArgs()
     a.in_ = x.data_ptr(); a.wf = None; a.wp = _hip.ptr(wps); a.bias = _hip.ptr(bias); a.out = _hip.ptr(out)
     a.stats_part = _hip.ptr(stats_part)
     a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
-    a.slope = slope; a.algo = ALGO_BF16
+    a.slope = slope; a.algo = ALGO_BF16; a.io_bf16 = io_bf16
     return a
 
 
@@ -232,9 +233,10 @@ def convt_bf16_stats_tiles(x, out, k, u):
     return n if n > 0 else 0
 
 
-def convt1d_bf16(x, wps, bias, out, *, k, u, slope=1.0, stats_part=None):
-    """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias on the bf16 matrix pipe (fp32 accumulate)."""
-    _hip.check(_hip.load().v2w_convt1d_bf16_fwd(C.byref(_convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part)), _stream(x)),
+def convt1d_bf16(x, wps, bias, out, *, k, u, slope=1.0, stats_part=None, io_bf16=0):
+    """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias on the bf16 matrix pipe (fp32 accumulate).
+    io_bf16 = 3: x and out are bf16 tensors."""
+    _hip.check(_hip.load().v2w_convt1d_bf16_fwd(C.byref(_convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16)), _stream(x)),
                'v2w_convt1d_bf16_fwd')
     return out
 
@@ -284,6 +286,10 @@ def affine_apply(x, a, s, out):
 
 def conv_post_tanh(x, wf, bias, out, *, k, slope):
     B, ci, L = x.shape
+    if x.dtype == torch.bfloat16:        # bf16 activation storage: the tail reads bf16, computes and writes fp32
+        _hip.check(_hip.load().v2w_conv_post_tanh_bf16in(x.data_ptr(), wf.data_ptr(), _hip.ptr(bias), out.data_ptr(),
+                                                         B, ci, L, k, slope, _stream(x)), 'v2w_conv_post_tanh_bf16in')
+        return out
     _hip.check(_hip.load().v2w_conv_post_tanh(x.data_ptr(), wf.data_ptr(), _hip.ptr(bias), out.data_ptr(),
                                               B, ci, L, k, slope, _stream(x)), 'v2w_conv_post_tanh')
     return out
@@ -408,7 +414,7 @@ def resblock_pair_multi(problems):
     return True
 
 
-def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False):
+def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0):
     """Split-operand (f16x3 / bf16) form of resblock2_stage for C == 32.  `branches`: list of dicts(wps1, b1, wps2, b2, k, dil1, dil2)
     with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken."""
     B, Cc, L = x.shape
@@ -422,6 +428,7 @@ def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=F
     a.out = out.data_ptr()
     a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
     a.slope, a.out_div, a.bf16 = slope, out_div, int(bf16)
+    a.io_bf16 = io_bf16
     rc = _hip.load().v2w_resblock2_stage_split_fwd(C.byref(a), _stream(x))
     if rc == -2:
         return False

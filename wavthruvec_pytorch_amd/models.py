@@ -203,6 +203,7 @@ class Generator(nn.Module):
                                               # C_out >= split_min_channels run on the f16 matrix pipe with split operands
                                               # (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulate; hipops.ALGO_SPLIT)
         self.split_min_channels = 64
+        self.bf16_storage = True              # precision == 'bf16': keep activations in bf16 between layers (no-grad forwards)
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
@@ -344,14 +345,14 @@ class Generator(nn.Module):
         self._fold_key.update(state=state, wf=wf, wp=wp, gen=self._fold_key.get('gen', 0) + 1)
         return wf, wp
 
-    def _split_weights(self, device):
+    def _split_weights(self, device, all_ups=False):
         """precision == 'f16x3': (hi, lo) half-precision fragments + scale record of every Conv1d layer the split kernel
         serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward)."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
         if self.precision not in ('f16x3', 'bf16'):
             raise ValueError(f"Generator.precision must be 'f32', 'f16x3' or 'bf16', got {self.precision!r}")
-        gen = (self._fold_key.get('gen', 0), self.precision)
+        gen = (self._fold_key.get('gen', 0), self.precision, all_ups)
         cached = self._fold_key.get('wps')
         if cached is not None and cached[0] == gen:
             return cached[1]
@@ -393,8 +394,8 @@ class Generator(nn.Module):
             plan.run()
         if self.precision == 'bf16':      # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd)
             for i, m in enumerate(self.ups):
-                if m.out_channels < 64:       # the narrow upsamplers are memory-side: the f32 kernel's epilogue moves their bytes faster
-                    continue
+                if m.out_channels < 64 and not all_ups:   # the narrow upsamplers are memory-side: with fp32 tensors the f32 kernel's epilogue
+                    continue                              # moves their bytes faster; with bf16 storage every upsampler runs here
                 v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
                 wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
                 scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
@@ -453,14 +454,28 @@ class Generator(nn.Module):
             keep_ws, self._ws = self._ws, {}
         fuse_stage = () if save is not None else self.fuse_stage
         fuse_pairs = () if save is not None else self.fuse_pairs
+        # bf16 activation STORAGE (BASELINE configs[2] priced at 2 bytes per activation): every layer of the no-grad bf16 forward reads
+        # and writes bf16 tensors when all of them run on the bf16 kernels - default ResBlock2 generator, wide stages C % 32 == 0
+        # (>= 64), narrow stages 32 / 16 fused.  fp32 accumulate, fp32 BatchNorm statistics from the accumulators, fp32 output.
+        adt = torch.float32
+        if (self.precision == 'bf16' and self.bf16_storage and save is None and algo == hipops.ALGO_AUTO and nk <= 3
+                and all(isinstance(rb, ResBlock2) for rb in self.resblocks) and x.shape[2] % 4 == 0 and self.h.num_wv_feat % 32 == 0
+                and all((up.out_channels >= 64 and up.out_channels % 64 == 0) or up.out_channels in fuse_stage for up in self.ups)
+                and all(up.in_channels % 32 == 0 and 2 <= up.stride <= 8 for up in self.ups)):
+            adt = torch.bfloat16
+        st = adt == torch.bfloat16
 
         with torch.no_grad():
             wf, wp = self._fold_weights(dev, need_wf=save is not None)
-            wps = self._split_weights(dev)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
+            wps = self._split_weights(dev, all_ups=st)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
 
-            def ck(nm):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
+            def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
                 if nm in wps and nm in self._split_wide:
+                    if st:       # bf16 storage: io bit 0 = the input tensor is bf16, bit 1 = out / res / addends are bf16
+                        return dict(algo=hipops.ALGO_BF16, wps=wps[nm], io_bf16=io)
                     return dict(algo=hipops.ALGO_BF16 if self.precision == 'bf16' else hipops.ALGO_SPLIT, wps=wps[nm])
+                if st:
+                    raise RuntimeError(f'bf16 storage: layer {nm} has no bf16 kernel (set generator.bf16_storage = False)')
                 return dict(algo=algo, wp=wp[nm])
 
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
@@ -483,16 +498,16 @@ class Generator(nn.Module):
             cond_joined = False
 
             # ---- K1: conv_pre (no activation in front of it)
-            cur = self._buf('act.pre', (B, c0, T), device=dev)
+            cur = self._buf('act.pre', (B, c0, T), dtype=adt, device=dev)
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
-                        slope=1.0, **ck('conv_pre'))
+                        slope=1.0, **ck('conv_pre', io=2))        # (the latents arrive as fp32)
             L = T
             for i in range(ns):
                 up = self.ups[i]
                 C = up.out_channels
                 Lo = L * up.stride
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
-                xr = self._buf(f'act.up{i}', (B, C, Lo), device=dev)
+                xr = self._buf(f'act.up{i}', (B, C, Lo), dtype=adt, device=dev)
                 cbn = self.cbns[i]
                 bn = cbn.batch_nrom
                 stats = part = None
@@ -508,7 +523,9 @@ class Generator(nn.Module):
                         part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
                 if f'ups.{i}' in wps and (nt_stats or not training):
                     self._timed(f'ups.{i}', hipops.convt1d_bf16, cur, wps[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
-                                u=up.stride, slope=LRELU_SLOPE, stats_part=part)
+                                u=up.stride, slope=LRELU_SLOPE, stats_part=part, io_bf16=3 if st else 0)
+                elif st:
+                    raise RuntimeError(f'bf16 storage: ups.{i} has no bf16 kernel (set generator.bf16_storage = False)')
                 else:
                     self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
                                 u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
@@ -533,13 +550,13 @@ class Generator(nn.Module):
                 # The branches are independent until the final sum, so conv n of ALL branches goes out as one launch
                 # (heaviest kernel size first); the first nk-1 branches end in their own buffers o_j and the last branch's
                 # final conv adds them in the reference's order ((r0 + r1) + r2) / nk  (models.py:135-141).
-                xs = self._buf(f'act.rb{i}', (B, C, Lo), device=dev)
+                xs = self._buf(f'act.rb{i}', (B, C, Lo), dtype=adt, device=dev)
                 rbs = [self.resblocks[i * nk + j] for j in range(nk)]
                 names = [f'resblocks.{i * nk + j}' for j in range(nk)]
                 merged = algo != hipops.ALGO_DIRECT and nk <= 3
                 if merged:
-                    t1s = [self._buf(f'act.t1_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
-                    outs = [self._buf(f'act.o_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk - 1)] + [xs]
+                    t1s = [self._buf(f'act.t1_{i}_{j}', (B, C, Lo), dtype=adt, device=dev) for j in range(nk)]
+                    outs = [self._buf(f'act.o_{i}_{j}', (B, C, Lo), dtype=adt, device=dev) for j in range(nk - 1)] + [xs]
                     heavy_first = sorted(range(nk), key=lambda j: -rbs[j].kernel_size)
 
                     def launch(tag_sfx, probs):
@@ -574,7 +591,10 @@ class Generator(nn.Module):
                                                    wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                                    dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
                                               for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
-                                             bf16=self.precision == 'bf16')
+                                             bf16=self.precision == 'bf16', io_bf16=3 if st else 0)
+                        if st and not ok and C in (16, 32):
+                            raise RuntimeError('bf16 storage: the fused narrow-stage kernel did not take this shape '
+                                               '(set generator.bf16_storage = False)')
                         if not ok and C in fuse_stage and all(wp[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1)):
                             # the whole residual section of the stage in ONE kernel: x read once, t1_j in LDS, sum in registers
                             ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
