@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wavthruvec_pytorch_amd import workmodel, synthetic  # noqa: E402
 
 
-def main(path, B=32, T=256, which=-2):
+def main(path, B=32, T=256, which=-2, act_bytes=4):
     f = glob.glob(os.path.join(path, '**', '*_kernel_trace.csv'), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -17,7 +17,7 @@ def main(path, B=32, T=256, which=-2):
     idx = [i for i, n in enumerate(names) if 'cond_fc' in n]
     s, e = idx[which - 1], idx[which]
     h = synthetic.make_hparams(num_wv_feat=768)
-    by_name = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
+    by_name = {l['name']: l for l in workmodel.conv_layers(h, B, T, act_bytes)}
     # launch groups as Generator.forward issues them: the residual branches of a stage share launches (heaviest first)
     groups = [['conv_pre']]
     nk = len(h.resblock_kernel_sizes)
@@ -39,12 +39,13 @@ def main(path, B=32, T=256, which=-2):
         n = r['Kernel_Name']
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += d
-        if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n or 'resblock2_stage' in n:
+        if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n or 'resblock2_stage' in n or 'conv_bf16' in n or 'stage_bf16' in n\
+                or 'conv_split' in n or 'stage_split' in n:
             grp = groups[li]; li += 1
             l = dict(name='+'.join(g.replace('resblocks.', 'rb') for g in grp), flops=sum(by_name[g]['flops'] for g in grp),
                      bytes=sum(by_name[g]['bytes'] for g in grp))
-            short = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:46]
-            print(f"{l['name']:20s} {short:46s} {d:8.1f} us {l['flops'] / d / 1e6:7.1f} TF {l['bytes'] / d / 1e3:7.0f} GB/s "
+            short = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:52]
+            print(f"{l['name']:20s} {short:52s} {d:8.1f} us {l['flops'] / d / 1e6:7.1f} TF {l['bytes'] / d / 1e3:7.0f} GB/s "
                   f"grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']} agpr={r['Accum_VGPR_Count']}")
         else:
             k = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]

@@ -60,7 +60,7 @@ conv_bf16_kernel(const MultiArgs m) {
     int pq = 0;
 #pragma unroll
     for (int i = 1; i < V2W_MAX_MULTI; ++i) pq += (int)blockIdx.x >= m.start[i] ? 1 : 0;
-    const TileArgs& p = m.p[pq];
+    const TileArgs p = pinned_tile_args(m.p[pq]);
     const int mtiles = p.Cout / MT;
     const int id = blockIdx.x - m.start[pq];
     const int grp = id / (8 * mtiles), rem = id % (8 * mtiles);
@@ -91,6 +91,7 @@ conv_bf16_kernel(const MultiArgs m) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    V2W_STAMP(0);
 
     // ---- staging: an item = 4 consecutive channels x 4 positions: four float4 loads, four 8-byte LDS stores (the 4 channels of one
     // position are 8 contiguous bytes of its row).  Consecutive lanes take the 8 channel quads of one position quad (a whole 64-byte
@@ -109,21 +110,17 @@ conv_bf16_kernel(const MultiArgs m) {
         const int pos = pos0 + row;
         in_seq = in_img && pos >= 0 && pos < L;         // L % 4 == 0 and pos % 4 == 0: a float4 is inside or outside as a whole
     };
-    auto prefetch = [&](int ci0) {
+    auto prefetch = [&](int ci0) {            // unconditional loads (positions outside the sequence read position 0 and are zeroed in commit)
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             int cq, row; bool in_img, in_seq;
             item(s, cq, row, in_img, in_seq);
+            const int pos = in_seq ? pos0 + row : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const size_t off = (size_t)(b * p.Cin + ci0 + 4 * cq + i) * L + pos0 + row;
-                if constexpr (IN_BF) {
-                    pf[s][i] = u32x2{0u, 0u};
-                    if (in_seq) pf[s][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.in) + off);
-                } else {
-                    pf[s][i] = zero4;
-                    if (in_seq) pf[s][i] = *reinterpret_cast<const f32x4*>(p.in + off);
-                }
+                const size_t off = (size_t)(b * p.Cin + ci0 + 4 * cq + i) * L + pos;
+                if constexpr (IN_BF) pf[s][i] = *gptr<const u32x2>(reinterpret_cast<const unsigned short*>(p.in) + off);
+                else pf[s][i] = *gptr<const f32x4>(p.in + off);
             }
         }
     };
@@ -142,18 +139,16 @@ conv_bf16_kernel(const MultiArgs m) {
             unsigned char* dst = Xs + row * ROWB + cq * 8;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                u32x2 v = {0u, 0u};                     // padding stays exactly 0 (it pads the ACTIVATED signal)
-                if (in_seq) {
-                    float a[4];
+                float a[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float xv;
-                        if constexpr (IN_BF) xv = (e & 1) ? bf_hi(pf[s][i][e >> 1]) : bf_lo(pf[s][i][e >> 1]);
-                        else xv = pf[s][i][e];
-                        a[i] = v2w_lrelu(fmaf(av[i], xv, sv[i]), slope);
-                    }
-                    v[0] = pack_bf16x2(a[0], a[1]); v[1] = pack_bf16x2(a[2], a[3]);
+                for (int i = 0; i < 4; ++i) {
+                    float xv;
+                    if constexpr (IN_BF) xv = (e & 1) ? bf_hi(pf[s][i][e >> 1]) : bf_lo(pf[s][i][e >> 1]);
+                    else xv = pf[s][i][e];
+                    a[i] = v2w_lrelu(fmaf(av[i], xv, sv[i]), slope);
                 }
+                u32x2 v = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+                if (!in_seq) v = u32x2{0u, 0u};             // padding stays exactly 0 (it pads the ACTIVATED signal)
                 *reinterpret_cast<u32x2*>(dst + e * ROWB) = v;
             }
         }
@@ -161,12 +156,12 @@ conv_bf16_kernel(const MultiArgs m) {
     auto stage_scalar = [&](int ci0, unsigned char* Xs) {   // any L / alignment: one element at a time
         for (int c = wave; c < CK; c += WM * WN) {
             const int ch = b * p.Cin + ci0 + c;
-            const float av = p.in_a ? p.in_a[ch] : 1.f, sv = p.in_s ? p.in_s[ch] : 0.f;
+            const float av = p.in_a ? gptr<const float>(p.in_a)[ch] : 1.f, sv = p.in_s ? p.in_s[ch] : 0.f;
             for (int j = lane; j < p.xrows; j += 64) {
                 const int l = pos0 + j;
                 float v = 0.f;
                 if (l >= 0 && l < L) {
-                    const float xv = IN_BF ? bf_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + l]) : p.in[(size_t)ch * L + l];
+                    const float xv = IN_BF ? bf_lo(gptr<const unsigned short>(p.in)[(size_t)ch * L + l]) : gptr<const float>(p.in)[(size_t)ch * L + l];
                     v = v2w_lrelu(fmaf(av, xv, sv), slope);
                 }
                 reinterpret_cast<__bf16*>(Xs + j * ROWB)[c] = (__bf16)v;
@@ -188,7 +183,7 @@ conv_bf16_kernel(const MultiArgs m) {
         const int chc = ch < nch ? ch : nch - 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            a[i] = *reinterpret_cast<const u32x4*>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_BF_UNIT + l16);
+            a[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_BF_UNIT + l16);
     };
 
     // ---- B operands: one 16-byte fragment per column block, refilled right after its last use in the running k-step
@@ -209,20 +204,20 @@ conv_bf16_kernel(const MultiArgs m) {
 
     // ---- typed access to the output-side tensors (out, res, add0, add1): fp32, or bf16 storage (OUT_BF) with fp32 arithmetic
     auto ld4 = [&](const float* base, size_t off) {
-        if constexpr (OUT_BF) return bf4_to_f32(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + off));
-        else return *reinterpret_cast<const f32x4*>(base + off);
+        if constexpr (OUT_BF) return bf4_to_f32(*gptr<const u32x2>(reinterpret_cast<const unsigned short*>(base) + off));
+        else return *gptr<const f32x4>(base + off);
     };
     auto st4 = [&](float* base, size_t off, f32x4 v) {
-        if constexpr (OUT_BF) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + off) = f32_to_bf4(v);
-        else *reinterpret_cast<f32x4*>(base + off) = v;
+        if constexpr (OUT_BF) *gptr<u32x2>(reinterpret_cast<unsigned short*>(base) + off) = f32_to_bf4(v);
+        else *gptr<f32x4>(base + off) = v;
     };
     auto ld1 = [&](const float* base, size_t off) {
-        if constexpr (OUT_BF) return bf_lo(reinterpret_cast<const unsigned short*>(base)[off]);
-        else return base[off];
+        if constexpr (OUT_BF) return bf_lo(gptr<const unsigned short>(base)[off]);
+        else return gptr<const float>(base)[off];
     };
     auto st1 = [&](float* base, size_t off, float v) {
-        if constexpr (OUT_BF) reinterpret_cast<__bf16*>(base)[off] = (__bf16)v;
-        else base[off] = v;
+        if constexpr (OUT_BF) gptr<__bf16>(base)[off] = (__bf16)v;
+        else gptr<float>(base)[off] = v;
     };
 
     // ---- prologue
@@ -235,7 +230,7 @@ conv_bf16_kernel(const MultiArgs m) {
     }
     if (p.in_a) {
         for (int c = tid; c < p.Cin; c += NTHREADS) {
-            atab[c] = p.in_a[b * p.Cin + c];
+            atab[c] = gptr<const float>(p.in_a)[b * p.Cin + c];
             atab[p.Cin + c] = p.in_s[b * p.Cin + c];
         }
         __syncthreads();
@@ -245,6 +240,7 @@ conv_bf16_kernel(const MultiArgs m) {
     load_frag(ar[0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    V2W_STAMP(1);
 
     const int lbase = (wn0 + lr + p.hla - p.hl) * ROWB + 16 * hk;     // this lane's 16 bytes in the row of (its column, tap 0), k-step 0
     const int step = p.dil * ROWB;
@@ -252,27 +248,56 @@ conv_bf16_kernel(const MultiArgs m) {
         const unsigned char* Xs = smem_b + (ch & 1) * bufsz;
         unsigned char* Xn = smem_b + ((ch + 1) & 1) * bufsz;
         const bool more = ch + 1 < nch;
+#ifndef V2W_BF_ABL_NOCOMMIT
         if (more && p.vec4) prefetch((ch + 1) * CK);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+        if (ch < 6) V2W_STAMP(2 + 4 * ch);
         const unsigned char* xt = Xs + lbase;
 #pragma unroll
         for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(xt + j * 32 * ROWB);
         // a tap = k-step 0 (channels 0-15 of the chunk: bytes 0-31 of a row) from ring slot 0, then k-step 1 (bytes 32-63) from slot 1;
         // each slot's next fragment is requested while the other slot computes; the chunk's last request is tap 0 of the next chunk
         for (int t = 0; t < K; ++t, xt += step) {
+#ifdef V2W_BF_ABL_NOFRAG
+            if (ch == 0 && t == 0) load_frag(ar[1], ch, 1, t);
+#else
             load_frag(ar[1], ch, 1, t);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             kstep(ar[0], xt + 32);
+#ifndef V2W_BF_ABL_NOFRAG
             if (t + 1 < K) load_frag(ar[0], ch, 0, t + 1); else load_frag(ar[0], ch + 1, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             kstep(ar[1], t + 1 < K ? xt + step : xt);
         }
+        if (ch < 6) V2W_STAMP(3 + 4 * ch);
         if (more) {
+#ifndef V2W_BF_ABL_NOCOMMIT
             if (p.vec4) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
+#endif
+            if (ch < 6) V2W_STAMP(4 + 4 * ch);
             __syncthreads();
+            if (ch < 6) V2W_STAMP(5 + 4 * ch);
         }
     }
+    V2W_STAMP(26);
+#ifdef V2W_BF_ABL_NOEPI
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+        if (sacc == 12345.678f) gptr<float>(p.out)[tid] = sacc;
+        V2W_STAMP(27);
+        return;
+    }
+#endif
 
     if constexpr (EPI == 2) {
         // ---- transposed-conv epilogue: 64 input positions of one 32-row block at a time -> scratch [32 / UP channels][U * 64 output
@@ -338,10 +363,11 @@ conv_bf16_kernel(const MultiArgs m) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < WN; ++w) { t1 += red[(w * (MT / UP) + c) * 2]; t2 += red[(w * (MT / UP) + c) * 2 + 1]; }
-                p.stats_part[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
-                p.stats_part[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
+                gptr<float>(p.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
+                gptr<float>(p.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
             }
         }
+        V2W_STAMP(27);
         return;
     }
 
@@ -353,6 +379,107 @@ conv_bf16_kernel(const MultiArgs m) {
     float* const scr = reinterpret_cast<float*>(smem_b) + wave * (32 * ERS);
     const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
     const bool simple = p.evec && !p.accumulate && !p.add0 && !p.add1 && !(MASK && p.mask_src);
+
+    // Pipelined form: a pass's residual / addend loads are requested NB passes ahead (the first NB before any store), held as loaded
+    // (bf16 pairs stay packed) and converted when used.  vmcnt counts loads and stores in issue order, so a pass that requests its
+    // operands after the previous pass's stores waits for a load round trip AND those stores' acknowledgements: at 2 workgroups per
+    // CU that was 40 k of the 129 k cycles of a 128 x 256 tile (C = 128, k = 7).
+    typedef typename std::conditional<OUT_BF, u32x2, f32x4>::type raw_t;
+    constexpr int NPASS = MI * (NI / 2);
+    const bool extra = p.accumulate || p.add0 || p.add1;
+    auto pipelined = [&](auto ns_c, auto nb_c) {
+        constexpr int NS = decltype(ns_c)::value, NB = decltype(nb_c)::value < NPASS ? decltype(nb_c)::value : NPASS;
+        const float* const sp[3] = {p.res, p.accumulate ? p.out : p.add0, p.add1};
+        raw_t rr[NB][NS][NIT];
+        // addresses: element g of a pass is row (lane >> 4) + 4 g, positions 4 (lane & 15) .. + 3 of the pass's 32 x 64 block, i.e. a
+        // wave-uniform base (scalar registers, scalar arithmetic) + ONE per-lane byte offset that does not depend on g
+        constexpr int ES = OUT_BF ? 2 : 4;
+        const int lrow = lane >> 4, lc4 = lane & 15;
+        auto pass_base = [&](int ps) {                           // element offset of (row 0, position 0) of pass ps: uniform
+            const int i = ps / (NI / 2), jh = (ps % (NI / 2)) * 2;
+            return ((size_t)b * p.Cout + m0 + wm0 + i * 32) * L + n0 + wn0 + jh * 32;
+        };
+        auto lane_off = [&](int ps) {                            // bytes; lanes past the end of the sequence re-read position 0 of the pass
+            const int jh = (ps % (NI / 2)) * 2;
+            const int qb = n0 + wn0 + jh * 32;
+            unsigned o = (unsigned)(lrow * L + (qb + 4 * lc4 < L ? 4 * lc4 : 0)) * ES;
+            asm volatile("" : "+v"(o));
+            return o;
+        };
+        auto pass_live = [&](int ps) { return n0 + wn0 + (ps % (NI / 2)) * 64 < L; };     // (uniform) the pass has positions inside L
+        auto request = [&](raw_t (&dst)[NS][NIT], int ps, int g) {        // element g of pass ps, every stream
+            if (!pass_live(ps)) return;
+            const size_t eb = pass_base(ps) + (size_t)(4 * g) * L;
+            const unsigned vo = lane_off(ps);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!sp[s]) continue;                                     // (uniform)
+                const unsigned char* base = reinterpret_cast<const unsigned char*>(sp[s]) + eb * ES;
+                dst[s][g] = *gptr<const raw_t>(base + vo);
+            }
+        };
+        auto widen = [&](raw_t r) { if constexpr (OUT_BF) return bf4_to_f32(r); else return r; };
+#pragma unroll
+        for (int ps = 0; ps < NB; ++ps)
+#pragma unroll
+            for (int g = 0; g < NIT; ++g) request(rr[ps], ps, g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int i = ps / (NI / 2), jh = (ps % (NI / 2)) * 2;
+            const int cbase = wm0 + i * 32;
+            const int qb = n0 + wn0 + jh * 32;
+            if (!pass_live(ps)) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) scr[F::row(e, hk) * ERS + jj * 32 + lr] = acc[i][jh + jj][e];
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned vo = lane_off(ps);
+            const bool ok = qb + 4 * lc4 < L;
+#pragma unroll
+            for (int g = 0; g < NIT; ++g) {
+                const int row = lrow + 4 * g;
+                const int col = cbase + row;
+                const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
+                f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * ERS + 4 * lc4);
+                f32x4 r0 = zero4, r1 = zero4, r2 = zero4;
+                if (sp[0]) r0 = widen(rr[ps % NB][0][g]);
+                if constexpr (NS > 1) {
+                    if (sp[1]) r1 = widen(rr[ps % NB][1][g]);
+                    if (sp[2]) r2 = widen(rr[ps % NB][2][g]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ps + NB < NPASS) request(rr[ps % NB], ps + NB, g);     // the slot's next occupant, ahead of this element's store
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float t2 = v[x] + bias;
+                    if (sp[0]) t2 += fmaf(ra, r0[x], rs);
+                    if constexpr (NS > 1) {
+                        if (sp[2]) t2 += r1[x] + r2[x];
+                        else if (sp[1]) t2 += r1[x];
+                    }
+                    if (p.out_div != 0.f) t2 = v2w_div_by(t2, p.out_div, dinv);
+                    v[x] = t2;
+                }
+                if (ok) {
+                    unsigned char* ob = reinterpret_cast<unsigned char*>(p.out) + (pass_base(ps) + (size_t)(4 * g) * L) * ES;
+                    if constexpr (OUT_BF) *gptr<u32x2>(ob + vo) = f32_to_bf4(v);
+                    else *gptr<f32x4>(ob + vo) = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef std::integral_constant<int, 1> one_t;
+    typedef std::integral_constant<int, 3> three_t;
+    if (p.evec && !(MASK && p.mask_src) && (!extra || OUT_BF)) {
+        if (!extra) pipelined(one_t{}, std::integral_constant<int, OUT_BF ? 4 : 2>{});
+        else pipelined(three_t{}, std::integral_constant<int, 1>{});
+        V2W_STAMP(27);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int cbase = wm0 + i * 32;
@@ -412,7 +539,7 @@ conv_bf16_kernel(const MultiArgs m) {
                         }
                         if constexpr (MASK) {
                             mv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-                            if (ok && p.mask_src) mv[g] = *reinterpret_cast<const f32x4*>(p.mask_src + goff);
+                            if (ok && p.mask_src) mv[g] = *gptr<const f32x4>(p.mask_src + goff);
                         }
                     }
 #pragma unroll
@@ -446,7 +573,7 @@ conv_bf16_kernel(const MultiArgs m) {
                     const size_t goff = gbase + (size_t)row * L + c;
                     float t2 = scr[idx];
                     if constexpr (MASK)
-                        if (p.mask_src) t2 = fmaf(etab[3 * MT + col], p.mask_src[goff], etab[4 * MT + col]) > 0.f ? t2 : t2 * p.mask_slope;
+                        if (p.mask_src) t2 = fmaf(etab[3 * MT + col], gptr<const float>(p.mask_src)[goff], etab[4 * MT + col]) > 0.f ? t2 : t2 * p.mask_slope;
                     t2 += etab[col];
                     if (p.res) t2 += fmaf(etab[MT + col], ld1(p.res, goff), etab[2 * MT + col]);
                     if (p.add1) t2 += ld1(p.add0, goff) + ld1(p.add1, goff);
@@ -459,6 +586,7 @@ conv_bf16_kernel(const MultiArgs m) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    V2W_STAMP(27);
 }
 
 template <int MI, int NI, int WM, int WN>
@@ -599,6 +727,10 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
 }
 
 }  // namespace
+
+#ifdef V2W_TIMELINE
+V2W_TL_SETTER(v2w_timeline_set_bf16)
+#endif
 
 // Called by v2w_conv1d_split for V2W_ALGO_BF16.  V2W_E_SHAPE: the caller falls back to the split kernel's bf16 form.
 int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {

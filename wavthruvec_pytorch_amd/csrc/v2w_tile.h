@@ -38,6 +38,32 @@ struct TileArgs {
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
 };
 
+// The tile kernels pick their problem with a per-workgroup index into MultiArgs::p, so every `p.field` is a scalar load from the
+// kernel-argument segment - which the register allocator treats as free to repeat: short of SGPRs it re-issues the load at each use,
+// inside the staging and epilogue loops, each time followed by an s_waitcnt lgkmcnt(0) that also drains the wave's LDS queue
+// (conv_bf16_kernel: 341 s_loads, 12 of them serialised in front of the 12 loads of a chunk prefetch).  pinned_tile_args() returns a
+// copy whose hot fields went through an opaque asm and therefore live in registers (SGPRs, or VGPR lanes when those run out).
+// A pointer that went through the asm is a GENERIC pointer to the compiler (flat_load: counts against vmcnt AND lgkmcnt); every
+// access through a pinned pointer goes through gptr<T>(), which names the global address space again.
+template <typename T> __device__ __forceinline__ void pin_s(T& v) { asm volatile("" : "+s"(v)); }
+template <typename T> using global_ptr = T __attribute__((address_space(1)))*;
+template <typename T, typename U> __device__ __forceinline__ global_ptr<T> gptr(U* q) { return (global_ptr<T>)q; }
+__device__ __forceinline__ void pin_s(float& v) {
+    int t = __builtin_bit_cast(int, v);
+    asm volatile("" : "+s"(t));
+    v = __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ TileArgs pinned_tile_args(const TileArgs& g) {
+    TileArgs p = g;
+    pin_s(p.in); pin_s(p.in_a); pin_s(p.wp); pin_s(p.wps); pin_s(p.res); pin_s(p.add0); pin_s(p.add1); pin_s(p.mask_src); pin_s(p.out);
+    pin_s(p.stats_part);
+    pin_s(p.Cin); pin_s(p.Cout); pin_s(p.L); pin_s(p.K); pin_s(p.dil); pin_s(p.CinT); pin_s(p.CoutT); pin_s(p.in_stride); pin_s(p.in_phase);
+    pin_s(p.hl); pin_s(p.hla); pin_s(p.xrows); pin_s(p.xcols); pin_s(p.vec4); pin_s(p.evec); pin_s(p.atab_off); pin_s(p.ntl); pin_s(p.ntiles);
+    pin_s(p.accumulate); pin_s(p.up_u); pin_s(p.up_p); pin_s(p.pad);
+    pin_s(p.slope); pin_s(p.out_div); pin_s(p.mask_slope); pin_s(p.out_slope);
+    return p;
+}
+
 #define V2W_MAX_MULTI 4
 // Up to V2W_MAX_MULTI problems of identical tile configuration in one launch (the residual branches of a stage):
 // blocks [start[q], start[q+1]) belong to problem q; heaviest problem first so the tail of the launch is made of light tiles.

@@ -10,20 +10,22 @@ from __future__ import annotations
 from typing import Dict, List
 
 
-def conv_layers(h, batch: int, n_frame: int) -> List[Dict]:
-    """One dict per conv/convT launch of a forward: name, kind, shape, flops, bytes (fp32)."""
+def conv_layers(h, batch: int, n_frame: int, act_bytes: int = 4) -> List[Dict]:
+    """One dict per conv/convT launch of a forward: name, kind, shape, flops, bytes.  act_bytes is the size of an element of
+    the activations BETWEEN layers (4: fp32; 2: the bf16 storage mode of precision='bf16'); the latents read by conv_pre, the
+    audio written by conv_post and the weights are fp32 in every mode."""
     resblock1 = h.resblock == '1'
     es = 4
     layers = []
     c0 = h.upsample_initial_channel
     L = n_frame
 
-    def act(c, l):
-        return batch * c * l * es
+    def act(c, l, e=None):
+        return batch * c * l * (act_bytes if e is None else e)
 
     layers.append(dict(name='conv_pre', kind='conv', cin=h.num_wv_feat, cout=c0, k=7, d=1, L=L,
                        flops=2.0 * h.num_wv_feat * c0 * 7 * L * batch,
-                       bytes=act(h.num_wv_feat, L) + act(c0, L) + h.num_wv_feat * c0 * 7 * es))
+                       bytes=act(h.num_wv_feat, L, 4) + act(c0, L) + h.num_wv_feat * c0 * 7 * es))
     nk = len(h.resblock_kernel_sizes)
     cout = c0
     for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
@@ -41,10 +43,10 @@ def conv_layers(h, batch: int, n_frame: int) -> List[Dict]:
                                    flops=2.0 * cout * cout * rk * L * batch,
                                    bytes=2 * act(cout, L) + extra + cout * cout * rk * es))
     layers.append(dict(name='conv_post', kind='conv', cin=cout, cout=1, k=7, d=1, L=L,
-                       flops=2.0 * cout * 7 * L * batch, bytes=act(cout, L) + act(1, L) + cout * 7 * es))
+                       flops=2.0 * cout * 7 * L * batch, bytes=act(cout, L) + act(1, L, 4) + cout * 7 * es))
     return layers
 
 
-def totals(h, batch: int, n_frame: int):
-    ls = conv_layers(h, batch, n_frame)
+def totals(h, batch: int, n_frame: int, act_bytes: int = 4):
+    ls = conv_layers(h, batch, n_frame, act_bytes)
     return sum(l['flops'] for l in ls), sum(l['bytes'] for l in ls)
