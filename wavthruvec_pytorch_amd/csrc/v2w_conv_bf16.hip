@@ -110,18 +110,23 @@ conv_bf16_kernel(const MultiArgs m) {
         const int pos = pos0 + row;
         in_seq = in_img && pos >= 0 && pos < L;         // L % 4 == 0 and pos % 4 == 0: a float4 is inside or outside as a whole
     };
-    auto prefetch = [&](int ci0) {            // unconditional loads (positions outside the sequence read position 0 and are zeroed in commit)
+    // item s of a chunk always reads (channel quad cq, positions row .. row + 3) of the chunk's 32 channels: the address is a wave-
+    // uniform base (batch item, chunk, channel i of the quad: scalar arithmetic) + a per-lane byte offset that never changes
+    constexpr int ESI = IN_BF ? 2 : 4;
+    unsigned poff[NPF];
 #pragma unroll
-        for (int s = 0; s < NPF; ++s) {
-            int cq, row; bool in_img, in_seq;
-            item(s, cq, row, in_img, in_seq);
-            const int pos = in_seq ? pos0 + row : 0;
+    for (int s = 0; s < NPF; ++s) {
+        int cq, row; bool in_img, in_seq;
+        item(s, cq, row, in_img, in_seq);
+        poff[s] = (unsigned)(4 * cq * L + (in_seq ? pos0 + row : 0)) * ESI;       // outside the sequence: position 0, zeroed in commit
+        asm volatile("" : "+v"(poff[s]));
+    }
+    auto prefetch = [&](int ci0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const size_t off = (size_t)(b * p.Cin + ci0 + 4 * cq + i) * L + pos;
-                if constexpr (IN_BF) pf[s][i] = *gptr<const u32x2>(reinterpret_cast<const unsigned short*>(p.in) + off);
-                else pf[s][i] = *gptr<const f32x4>(p.in + off);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(p.in) + (size_t)(b * p.Cin + ci0 + i) * L * ESI;
+#pragma unroll
+            for (int s = 0; s < NPF; ++s) pf[s][i] = *gptr<const pf_t>(base + poff[s]);
         }
     };
     auto commit = [&](int ci0, unsigned char* Xs) {
@@ -220,7 +225,10 @@ conv_bf16_kernel(const MultiArgs m) {
         else gptr<float>(base)[off] = v;
     };
 
-    // ---- prologue
+    // ---- prologue: the loads that do not depend on LDS go out first (chunk 0 of the signal, the first fragments)
+    if (p.vec4) prefetch(0);
+    load_frag(ar[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     for (int c = tid; c < MT; c += NTHREADS) {
         etab[c] = p.bias ? p.bias[EPI == 2 ? (m0 + c) / p.up_p : m0 + c] : 0.f;
         etab[MT + c] = p.res_a ? p.res_a[b * p.Cout + m0 + c] : 1.f;
@@ -235,9 +243,8 @@ conv_bf16_kernel(const MultiArgs m) {
         }
         __syncthreads();
     }
-    if (p.vec4) { prefetch(0); commit(0, smem_b); }
+    if (p.vec4) commit(0, smem_b);
     else stage_scalar(0, smem_b);
-    load_frag(ar[0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     V2W_STAMP(1);
@@ -311,6 +318,98 @@ conv_bf16_kernel(const MultiArgs m) {
         __syncthreads();
         float* const scr = reinterpret_cast<float*>(smem_b) + wave * 2048;
         for (int c = lane; c < (MI * 32 / UP) * 2; c += 64) red[((wave % WN) * (MT / UP) + (wm0 / UP)) * 2 + c] = 0.f;
+
+        // Fast form (whole tile inside the sequence, float4-aligned output, a stride the generator uses): compile-time U / UP, so
+        //   - the accumulators go to the scratch as 8- / 16-byte LDS stores where the phases of a channel are adjacent registers,
+        //   - the scratch IS the output block ([channel][U * 64 positions], contiguous): float4 number lane + 64 g of it is one
+        //     ds_read_b128 at a constant offset, all 64 lanes busy for every stride,
+        //   - the BatchNorm partial sums stay in registers (a float4 of running sums per g) across the passes of a row block and are
+        //     reduced once per row block, through the scratch, in a fixed order (the older form: two 64-lane shuffle reductions per
+        //     channel and pass - 2 x 16 per pass at stride 2 - and half-empty waves for U = 2).
+        auto fast = [&](auto u_c, auto up_c) {
+            constexpr int U = decltype(u_c)::value, UP = decltype(up_c)::value;
+            constexpr int NCO = 32 / UP, RW = 16 * U, G = NCO * U / 4, ORS = U * 64, ES = OUT_BF ? 2 : 4;
+            constexpr int PARTS = 64 / (2 * NCO), NPER = RW / PARTS;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int Lout = L * U;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f32x4 sa[G], sq[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) sa[g] = sq[g] = zero4;
+                const int co0 = (m0 + wm0 + i * 32) / UP;
+#pragma unroll
+                for (int jh = 0; jh < NI; jh += 2) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const acc_t& a = acc[i][jh + jj];
+                        float* const sc = scr + U * (jj * 32 + lr);
+#pragma unroll
+                        for (int eg = 0; eg < 4; ++eg) {
+                            if constexpr (UP == 2) {                 // rows 8 eg + 4 hk + {0..3}: channels 4 eg + 2 hk + {0, 1}, phases {0, 1}
+                                *reinterpret_cast<f32x2*>(sc + (4 * eg + 2 * hk) * ORS) = f32x2{a[4 * eg], a[4 * eg + 1]};
+                                *reinterpret_cast<f32x2*>(sc + (4 * eg + 2 * hk + 1) * ORS) = f32x2{a[4 * eg + 2], a[4 * eg + 3]};
+                            } else if constexpr (UP == 4) {          // channel 2 eg + hk, phases 0..3
+                                *reinterpret_cast<f32x4*>(sc + (2 * eg + hk) * ORS) = f32x4{a[4 * eg], a[4 * eg + 1], a[4 * eg + 2], a[4 * eg + 3]};
+                            } else if constexpr (U == 8) {           // channel eg, phases 4 hk .. 4 hk + 3
+                                *reinterpret_cast<f32x4*>(sc + eg * ORS + 4 * hk) = f32x4{a[4 * eg], a[4 * eg + 1], a[4 * eg + 2], a[4 * eg + 3]};
+                            } else {                                 // UP = 8, U = 5: channel eg, phases 4 hk + {0..3} < 5
+                                sc[eg * ORS + 4 * hk] = a[4 * eg];
+                                if (hk == 0) { sc[eg * ORS + 1] = a[4 * eg + 1]; sc[eg * ORS + 2] = a[4 * eg + 2]; sc[eg * ORS + 3] = a[4 * eg + 3]; }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const size_t ub = ((size_t)b * CoutR + co0) * Lout + (size_t)U * (n0 + wn0 + jh * 32);     // (uniform)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int idx = lane + 64 * g;
+                        int cl, c4;
+                        if constexpr (RW == 32) { cl = 2 * g + (lane >> 5); c4 = lane & 31; }
+                        else if constexpr (RW == 64) { cl = g; c4 = lane; }
+                        else if constexpr (RW == 128) { cl = g >> 1; c4 = lane + 64 * (g & 1); }
+                        else { cl = (idx >= RW) + (idx >= 2 * RW) + (idx >= 3 * RW); c4 = idx - cl * RW; }
+                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + 4 * idx);
+                        const float bias = etab[wm0 + i * 32 + cl * UP];
+                        v += f32x4{bias, bias, bias, bias};
+                        if (p.stats_part) { sa[g] += v; sq[g] += v * v; }
+                        unsigned vo = (unsigned)(cl * Lout + 4 * c4) * ES;
+                        unsigned char* ob = reinterpret_cast<unsigned char*>(p.out) + ub * ES;
+                        if constexpr (OUT_BF) *gptr<u32x2>(ob + vo) = f32_to_bf4(v);
+                        else *gptr<f32x4>(ob + vo) = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (p.stats_part) {
+                    // per-lane sums -> scratch[g * 64 + lane] = (sum, sumsq): slot k of it belongs to channel k / RW; lane = (channel,
+                    // part, stat) adds NPER slots in order, the parts of a channel meet in a fixed shuffle tree
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        *reinterpret_cast<f32x2*>(scr + 2 * (g * 64 + lane)) =
+                            f32x2{(sa[g][0] + sa[g][1]) + (sa[g][2] + sa[g][3]), (sq[g][0] + sq[g][1]) + (sq[g][2] + sq[g][3])};
+                    const int stat = lane & 1, part = (lane >> 1) % PARTS, c = lane / (2 * PARTS);
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NPER; ++k) t += scr[2 * (c * RW + part * NPER + k) + stat];
+#pragma unroll
+                    for (int off = 2; off < 2 * PARTS; off <<= 1) t += __shfl_xor(t, off, 64);
+                    if (part == 0) red[((wave % WN) * (MT / UP) + (wm0 + i * 32) / UP + c) * 2 + stat] += t;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        bool done = false;
+        if (p.evec && n0 + NT <= L && (long long)L * U * 16 * 4 < (1ll << 31)) {
+            typedef std::integral_constant<int, 2> c2; typedef std::integral_constant<int, 4> c4t;
+            typedef std::integral_constant<int, 5> c5; typedef std::integral_constant<int, 8> c8;
+            done = true;
+            if (U == 2 && UP == 2) fast(c2{}, c2{});
+            else if (U == 4 && UP == 4) fast(c4t{}, c4t{});
+            else if (U == 5 && UP == 8) fast(c5{}, c8{});
+            else if (U == 8 && UP == 8) fast(c8{}, c8{});
+            else done = false;
+        }
+        if (!done)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
