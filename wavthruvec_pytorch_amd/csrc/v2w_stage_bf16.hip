@@ -71,14 +71,20 @@ stage_bf16_kernel(const StageBfArgs p) {
     const float slope = p.slope;
     unsigned char* const Xa = smem_b;                                  // [xrows][ROWB]  lrelu(x) as bf16, exactly 0 outside the sequence
     unsigned char* const Ta = smem_b + p.xrows * ROWB;                 // [W][ROWB]      lrelu(t1_j); conv2's taps reach h2max rows past either end
-    float* const etab = reinterpret_cast<float*>(Ta + (W + p.h2max) * ROWB);   // bias1[nk][C], bias2[nk][C]
+    float* const etab = reinterpret_cast<float*>(Ta + (W + p.h2max) * ROWB);   // bias1[nk][C], bias2[nk][C], then in_a[C], in_s[C] of this batch item
+    float* const atab = etab + 2 * V2W_SB_MAXB * C;
     const int pos0 = n0 - p.h2max - p.h1max - p.xoff;                  // position of X row 0 (multiple of 4)
     const int xc0 = p.xoff + p.h1max;                                  // X row of window column 0 (position n0 - h2max)
 
+    V2W_STAMP(0);
     for (int i = tid; i < p.nk * C; i += NTHREADS) {
         const int j = i / C, c = i - j * C;
         etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
         etab[V2W_SB_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
+    }
+    for (int c = tid; c < C; c += NTHREADS) {
+        atab[c] = p.in_a ? p.in_a[b * C + c] : 1.f;
+        atab[C + c] = p.in_s ? p.in_s[b * C + c] : 0.f;
     }
 
     // ---- stage lrelu(a*x + s) as bf16: a thread takes 4 channels x 4 positions (8 bytes per position), the channel quads of one
@@ -88,28 +94,29 @@ stage_bf16_kernel(const StageBfArgs p) {
         const int xr4 = p.xrows >> 2;
         typedef typename std::conditional<IO_BF, u32x2, f32x4>::type ld_t;
         ld_t g[NPF][4];
-        float av[NPF][4], sv[NPF][4];
+        // (NTHREADS is a multiple of NCQ: a thread keeps its channel quad for every item) affine of its 4 channels, loaded once
+        const int cq = tid % NCQ;
+        float av[4], sv[4];
 #pragma unroll
-        for (int s = 0; s < NPF; ++s) {
-            const int idx = tid + s * NTHREADS;
-            const int cq = idx % NCQ, pq = idx / NCQ;
+        for (int i = 0; i < 4; ++i) {
+            av[i] = p.in_a ? p.in_a[b * C + 4 * cq + i] : 1.f;
+            sv[i] = p.in_s ? p.in_s[b * C + 4 * cq + i] : 0.f;
+        }
+        constexpr int ESI = IO_BF ? 2 : 4;
+        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(p.in) + (size_t)(b * C) * L * ESI;     // (uniform)
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {                         // unconditional loads: outside the sequence position 0, zeroed below
+            const int pq = (tid + s * NTHREADS) / NCQ;
             const int pos = pos0 + pq * 4;
             const bool ok = pq < xr4 && pos >= 0 && pos < L;
+            unsigned vo = (unsigned)(4 * cq * L + (ok ? pos : 0)) * ESI;
+            asm volatile("" : "+v"(vo));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                g[s][i] = ld_t{}; av[s][i] = 1.f; sv[s][i] = 0.f;
-                if (ok) {
-                    const int ch = b * C + 4 * cq + i;
-                    if constexpr (IO_BF) g[s][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.in) + (size_t)ch * L + pos);
-                    else g[s][i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)ch * L + pos);
-                    if (p.in_a) { av[s][i] = p.in_a[ch]; sv[s][i] = p.in_s[ch]; }
-                }
-            }
+            for (int i = 0; i < 4; ++i) g[s][i] = *reinterpret_cast<const ld_t*>(inb + (size_t)i * L * ESI + vo);
         }
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
-            const int idx = tid + s * NTHREADS;
-            const int cq = idx % NCQ, pq = idx / NCQ;
+            const int pq = (tid + s * NTHREADS) / NCQ;
             if (pq >= xr4) continue;
             const bool ok = pos0 + pq * 4 >= 0 && pos0 + pq * 4 < L;
 #pragma unroll
@@ -120,9 +127,27 @@ stage_bf16_kernel(const StageBfArgs p) {
                     float xv;
                     if constexpr (IO_BF) xv = (e & 1) ? sb_hi(g[s][i][e >> 1]) : sb_lo(g[s][i][e >> 1]);
                     else xv = g[s][i][e];
-                    a[i] = ok ? v2w_lrelu(fmaf(av[s][i], xv, sv[s][i]), slope) : 0.f;
+                    a[i] = v2w_lrelu(fmaf(av[i], xv, sv[i]), slope);
                 }
-                *reinterpret_cast<u32x2*>(Xa + (pq * 4 + e) * ROWB + cq * 8) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
+                u32x2 v = {sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
+                if (!ok) v = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2*>(Xa + (pq * 4 + e) * ROWB + cq * 8) = v;
+                if constexpr (IO_BF) {
+                    // the stored (bf16) input itself, position-major, for the window's 256 columns: parked in the T1 tile (unused until
+                    // conv1 of branch 0 is done), where the residual x of every lane's outputs is read back with 8-byte LDS loads
+                    const int col = pq * 4 + e - xc0;
+                    if (col >= 0 && col < W) {
+                        unsigned w0, w1;
+                        if (e & 1) {
+                            w0 = __builtin_amdgcn_perm(g[s][1][e >> 1], g[s][0][e >> 1], 0x07060302u);
+                            w1 = __builtin_amdgcn_perm(g[s][3][e >> 1], g[s][2][e >> 1], 0x07060302u);
+                        } else {
+                            w0 = __builtin_amdgcn_perm(g[s][1][e >> 1], g[s][0][e >> 1], 0x05040100u);
+                            w1 = __builtin_amdgcn_perm(g[s][3][e >> 1], g[s][2][e >> 1], 0x05040100u);
+                        }
+                        *reinterpret_cast<u32x2*>(Ta + col * ROWB + cq * 8) = u32x2{w0, w1};
+                    }
+                }
             }
         }
     } else {
@@ -138,39 +163,46 @@ stage_bf16_kernel(const StageBfArgs p) {
         }
     }
 
+    V2W_STAMP(1);
     // ---- the residual of conv1 in every branch: raw x = a*in + s at this lane's outputs (accumulator row e <-> channel F::row(e, hk),
-    // its two columns), re-read from global memory (L2-resident: this workgroup has just fetched the lines); consumed after conv1 of
-    // branch 0, so the round trip hides behind it
+    // its two columns).  bf16 storage: read back from the raw tile after the first barrier (below); otherwise re-read from global
+    // memory, one element per load (L2-resident: this workgroup has just fetched the lines).
+    const bool raw_tile = IO_BF && p.vec4;
     float xres[NI][NR];
+    if (!raw_tile) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
-        const bool in_seq = pos >= 0 && pos < L;
+        for (int j = 0; j < NI; ++j) {
+            const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
+            const bool in_seq = pos >= 0 && pos < L;
 #pragma unroll
-        for (int e = 0; e < NR; ++e) {
-            const int ch = b * C + F::row(e, hk);
-            float v = 0.f;
-            if (in_seq) {
-                const float xv = IO_BF ? sb_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + pos]) : p.in[(size_t)ch * L + pos];
-                v = fmaf(p.in_a ? p.in_a[ch] : 1.f, xv, p.in_s ? p.in_s[ch] : 0.f);
+            for (int e = 0; e < NR; ++e) {
+                const int ch = b * C + F::row(e, hk);
+                float v = 0.f;
+                if (in_seq) {
+                    const float xv = IO_BF ? sb_lo(reinterpret_cast<const unsigned short*>(p.in)[(size_t)ch * L + pos]) : p.in[(size_t)ch * L + pos];
+                    v = fmaf(p.in_a ? p.in_a[ch] : 1.f, xv, p.in_s ? p.in_s[ch] : 0.f);
+                }
+                xres[j][e] = v;
             }
-            xres[j][e] = v;
         }
     }
 
-    // ---- one conv phase.  All K * KS weight fragments are requested up front and stay in registers; the tap loop is unrolled to KMAX
-    // with uniform guards.  `x0`: this lane's 16 bytes in the row of (its column, tap 0), k-step 0.
+    // ---- one conv phase.  The K * KS weight fragments of a conv live in registers through it; the NEXT conv's fragments are requested
+    // into the same registers as they fall free - tap t right after the MFMAs of tap t, taps past this conv's K at its start - so that
+    // a conv never starts with an L2 round trip in front of its first MFMA (6 x ~2 k cycles of a 62 k-cycle tile).  The tap loop is
+    // unrolled to KMAX with uniform guards.  `x0`: this lane's 16 bytes in the row of (its column, tap 0), k-step 0.
     acc_t acc[NI];
     const unsigned lane16 = (unsigned)lane * 16u;
-    auto conv = [&](const unsigned char* wbase, int K, const unsigned char* x0, int step, const float* bias) {
-        u32x4 wr[KMAX][KS];
+    u32x4 wr[KMAX][KS];
+    auto request = [&](int t, const unsigned char* wbase, int K) {          // tap t of a conv with K taps -> wr[t]
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t)
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                if (t < K) wr[t][s] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(s * K + t) * V2W_SB_UNIT + l16);
+        for (int s = 0; s < KS; ++s) wr[t][s] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(s * K + t) * V2W_SB_UNIT + l16);
+    };
+    // B operands two k-steps ahead (an LDS read issued one k-step = NI MFMAs = 64 cycles ahead is not back when it is needed).
+    auto conv = [&](int K, const unsigned char* x0, int step, const float* bias, const unsigned char* wnext, int Knext,
+                    const unsigned char* wextra, int Kextra) {
         // accumulators start at the bias (rows >= C of the 32-row MFMA are padding: they start, and stay, at 0)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -178,37 +210,73 @@ stage_bf16_kernel(const StageBfArgs p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[j][e] = bv;
         }
-        u32x4 bb[NI];
+        // k-step q = t * KS + s reads rows x0 + t * step at byte 32 s; bb[q & 1] holds it, refilled with k-step q + 2 after its MFMAs
+        auto rows = [&](int q) {
+            const int t = q / KS, sq = q % KS;
+            const int tc = t < K ? t : K - 1;                 // past the end: a valid (unused) address
+            return x0 + tc * step + 32 * sq;
+        };
+        u32x4 bb[2][NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(x0 + j * 32 * ROWB);
-        const unsigned char* xt = x0;
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bb[q][j] = *reinterpret_cast<const u32x4*>(rows(q) + j * 32 * ROWB);
 #pragma unroll
         for (int t = 0; t < KMAX; ++t) {
             if (t < K) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const unsigned char* nxt = s + 1 < KS ? xt + 32 : (t + 1 < K ? xt + step : xt);
+                    const int q = t * KS + s;
+                    const unsigned char* nxt = rows(q + 2);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wr[t][s]), __builtin_bit_cast(b8, bb[j]), acc[j], 0, 0, 0);
-                        bb[j] = *reinterpret_cast<const u32x4*>(nxt + j * 32 * ROWB);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wr[t][s]), __builtin_bit_cast(b8, bb[q & 1][j]), acc[j], 0, 0, 0);
+                        bb[q & 1][j] = *reinterpret_cast<const u32x4*>(nxt + j * 32 * ROWB);
                     }
                 }
-                xt += step;
+                if (t < Knext) request(t, wnext, Knext);
             }
         }
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (t >= K && t < Kextra) request(t, wextra, Kextra);      // (registers this conv and the next do not use)
     };
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < p.K[0]) request(t, p.w1[0], p.K[0]);
 
     float t1r[NI][NR], oacc[NI][NR];
     const unsigned char* const xl = Xa + (wn0 + lr) * ROWB + 16 * hk;
     const unsigned char* const tl = Ta + (wn0 + lr) * ROWB + 16 * hk;
+    V2W_STAMP(2);
     __syncthreads();
+    V2W_STAMP(3);
+    if (raw_tile) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
+            const bool in_seq = pos >= 0 && pos < L;
+            const unsigned char* row = Ta + (wn0 + j * 32 + lr) * ROWB;
+#pragma unroll
+            for (int g4 = 0; g4 < NR / 4; ++g4) {   // accumulator registers 4g .. 4g + 3 = channels 8g + 4hk + {0..3}: 8 contiguous bytes
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(row + 2 * (8 * g4 + 4 * hk));
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(atab + 8 * g4 + 4 * hk);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(atab + C + 8 * g4 + 4 * hk);
+                xres[j][4 * g4 + 0] = in_seq ? fmaf(a4[0], sb_lo(raw[0]), s4[0]) : 0.f;
+                xres[j][4 * g4 + 1] = in_seq ? fmaf(a4[1], sb_hi(raw[0]), s4[1]) : 0.f;
+                xres[j][4 * g4 + 2] = in_seq ? fmaf(a4[2], sb_lo(raw[1]), s4[2]) : 0.f;
+                xres[j][4 * g4 + 3] = in_seq ? fmaf(a4[3], sb_hi(raw[1]), s4[3]) : 0.f;
+            }
+        }
+    }
     for (int jb = 0; jb < p.nk; ++jb) {
         const int K = p.K[jb], d1 = p.d1[jb], d2 = p.d2[jb];
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
+        const bool more = jb + 1 < p.nk;
 
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col
-        conv(p.w1[jb], K, xl + (xc0 - h1) * ROWB, d1 * ROWB, etab + jb * C);
+        conv(K, xl + (xc0 - h1) * ROWB, d1 * ROWB, etab + jb * C, p.w2[jb], K, more ? p.w1[jb + 1] : p.w1[jb], more ? p.K[jb + 1] : 0);
+        V2W_STAMP(4 + 5 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int pos = n0 - p.h2max + wn0 + j * 32 + lr;
@@ -216,7 +284,8 @@ stage_bf16_kernel(const StageBfArgs p) {
 #pragma unroll
             for (int e = 0; e < NR; ++e) t1r[j][e] = in_seq ? acc[j][e] + xres[j][e] : 0.f;
         }
-        if (jb > 0) __syncthreads();          // conv2 of the previous branch has finished reading T1
+        V2W_STAMP(5 + 5 * jb);
+        __syncthreads();          // conv2 of the previous branch has finished reading T1 (branch 0: every wave has read its residuals)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             unsigned char* row = Ta + (wn0 + j * 32 + lr) * ROWB;
@@ -228,10 +297,13 @@ stage_bf16_kernel(const StageBfArgs p) {
                 *reinterpret_cast<u32x2*>(row + 2 * (8 * g4 + 4 * hk)) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
             }
         }
+        V2W_STAMP(6 + 5 * jb);
         __syncthreads();
+        V2W_STAMP(7 + 5 * jb);
 
         // ---- conv2_j on the same window ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        conv(p.w2[jb], K, tl - h2 * ROWB, d2 * ROWB, etab + V2W_SB_MAXB * C + jb * C);
+        conv(K, tl - h2 * ROWB, d2 * ROWB, etab + V2W_SB_MAXB * C + jb * C, more ? p.w1[jb + 1] : p.w1[jb], more ? p.K[jb + 1] : 0, p.w1[jb], 0);
+        V2W_STAMP(8 + 5 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -242,6 +314,7 @@ stage_bf16_kernel(const StageBfArgs p) {
     }
 
     // ---- store through an aligned fp32 LDS scratch [C][W + 4] (both tiles are dead), float4s along positions
+    V2W_STAMP(20);
     __syncthreads();
     {
         constexpr int SRS = W + 4;
@@ -254,6 +327,7 @@ stage_bf16_kernel(const StageBfArgs p) {
             for (int e = 0; e < NR; ++e) scr[F::row(e, hk) * SRS + sc] = oacc[j][e];
         }
         __syncthreads();
+        V2W_STAMP(21);
         const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
         const int nq = p.nto >> 2;
         const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
@@ -288,6 +362,7 @@ stage_bf16_kernel(const StageBfArgs p) {
             }
         }
     }
+    V2W_STAMP(22);
 }
 
 template <int C>
@@ -314,7 +389,7 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
     p.ntl = (q->L + p.nto - 1) / p.nto;
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
     p.vec4 = (q->L % 4 == 0) && al16(q->in) && al16(q->out);
-    size_t lds = (size_t)(p.xrows + W + p.h2max) * ROWB + 2 * V2W_SB_MAXB * C * sizeof(float);
+    size_t lds = (size_t)(p.xrows + W + p.h2max) * ROWB + (2 * V2W_SB_MAXB + 2) * C * sizeof(float);
     const size_t scr = (size_t)C * (W + 4) * sizeof(float);           // the store scratch overlays the tiles
     if (lds < scr) lds = scr;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
@@ -329,6 +404,10 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef V2W_TIMELINE
+V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
+#endif
 
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
