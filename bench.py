@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # MI355X_MICROARCH.md: dense bf16 MFMA = 16 x the f32 rate (~2.5 PF)
 
 
 def baseline_metric() -> str:
@@ -248,7 +249,10 @@ def main():
                     per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
         g._profile = None
     if rank == 0:
-        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T)}
+        bf16_run = args.precision == 'bf16'
+        act_bytes = 2 if (bf16_run and g.bf16_storage) else 4      # bytes of an activation element between layers in this mode
+        peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16_run else PEAK_FP32_MFMA_TFLOPS
+        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T, act_bytes)}
         # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
         # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
         def kernel_of(l, nprob=1):
@@ -257,6 +261,8 @@ def main():
             direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
             if args.algo == 'direct':
                 return direct
+            if bf16_run and (l['kind'] == 'conv' or act_bytes == 2) and l['cin'] % 32 == 0 and (l['cout'] % 64 == 0 or l['kind'] == 'convt'):
+                return 'conv_bf16_kernel' + (' (transposed-conv epilogue)' if l['kind'] == 'convt' else '')
             if args.precision != 'f32' and l['kind'] == 'conv' and l['cout'] >= g.split_min_channels and l['cout'] % 64 == 0:
                 return 'conv_split_kernel (%s)' % args.precision
             # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
@@ -279,12 +285,12 @@ def main():
                 kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                         ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
                 if staged and args.precision != 'f32':
-                    kname = 'stage_split_kernel<%d, 2, 4, %s>' % (ls[0]['cout'] // 16, 'true' if args.precision == 'bf16' else 'false')
+                    kname = ('stage_bf16_kernel<%d>' % ls[0]['cout']) if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
             nbytes = sum(l['bytes'] for l in ls)
             if fused:                              # the intermediate is neither written nor re-read
-                nbytes -= sum(2 * B * l['cout'] * l['L'] * 4 for l in ls[::2])
+                nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])
             if staged:                             # x read once, no per-branch outputs / running-sum traffic
-                act = B * ls[0]['cout'] * ls[0]['L'] * 4
+                act = B * ls[0]['cout'] * ls[0]['L'] * act_bytes
                 nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
             launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
                                  t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
@@ -299,7 +305,7 @@ def main():
         conv_t = sum(d['t'] for d in launches.values() if d['conv'])
         conv_f = sum(d['flops'] for d in launches.values() if d['conv'])
         all_t = sum(d['t'] for d in launches.values())
-        tot_f, tot_b = workmodel.totals(h, B, T)
+        tot_f, tot_b = workmodel.totals(h, B, T, act_bytes)
         step_s = elapsed / args.steps
         # HBM bytes per launch of that kernel from the PMC passes (tools/pmc_traffic.py; FETCH_SIZE x2 + WRITE_SIZE, KiB ->
         # bytes as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process: the committed summary
@@ -315,20 +321,59 @@ def main():
                 traffic = tj[dom]['hbm_bytes_per_launch']
                 traffic_src = (f'profiles/{tpaths[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 per the gfx950 '
                                f'correction; collected {meta.get("date", "?")} at commit {meta.get("commit", "?")})')
-        roof = dict(bound='mfma', kernel=dom + ' (f32 MFMA implicit-GEMM conv)', launches=dom_tags,
-                    achieved=dom_f / dom_t / 1e12, peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=dom_f / dom_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch_avg=sum(launches[n]['bytes'] for n in dom_tags) / len(dom_tags),
+        dom_b = sum(launches[n]['bytes'] for n in dom_tags)
+        mfma_frac, hbm_frac = dom_f / dom_t / 1e12 / peak_tf, dom_b / dom_t / 1e9 / PEAK_HBM_GBS
+        bound = 'hbm' if hbm_frac > mfma_frac else 'mfma'        # the ceiling the dominant kernel sits closer to
+        roof = dict(bound=bound, kernel=dom + (' (bf16 MFMA implicit-GEMM conv)' if bf16_run else ' (f32 MFMA implicit-GEMM conv)'),
+                    launches=dom_tags,
+                    achieved=(dom_b / dom_t / 1e9) if bound == 'hbm' else (dom_f / dom_t / 1e12),
+                    peak=PEAK_HBM_GBS if bound == 'hbm' else peak_tf, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
+                    frac=max(mfma_frac, hbm_frac), mfma_frac=mfma_frac, hbm_frac=hbm_frac,
+                    traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch_avg=dom_b / len(dom_tags),
                     launches_per_step=len(dom_tags), avg_launch_us=dom_t / len(dom_tags) * 1e6,
-                    flops_per_launch_avg=dom_f / len(dom_tags),
+                    flops_per_launch_avg=dom_f / len(dom_tags), activation_bytes_per_element=act_bytes,
                     per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4), tflops=round(gflops[k] / gtime[k] / 1e12, 2),
                                         algorithmic_gbs=round(sum(launches[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
                                 for k, v in sorted(groups.items(), key=lambda kv: -gtime[kv[0]])},
-                    all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / peak_tf,
                                            launches_per_step=sum(1 for d in launches.values() if d['conv'])),
                     whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
-                                       mfma_frac=tot_f / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                       mfma_frac=tot_f / step_s / 1e12 / peak_tf,
                                        hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))
+
+    # ---- BASELINE configs[2] (B = 64 x T = 512, bf16 compute / fp32 accumulate, bf16 activation storage): reported beside the
+    # headline line as its own workload, priced against BOTH ceilings with ITS byte count (bf16 activations between layers)
+    cfg3 = None
+    if rank == 0 and world == 1 and args.precision == 'f32' and not args.no_alt and (B, T) == (32, 256):
+        del g
+        torch.cuda.empty_cache()
+        B3, T3 = 64, 512
+        g3 = Generator(h)
+        g3.load_state_dict(synthetic.make_state_dict(h, seed=0))
+        g3 = g3.to(dev).train()
+        g3.precision = 'bf16'
+        x3 = synthetic.make_inputs(h, B3, T3, seed=4, device=dev)
+        n3 = max(5, args.steps)
+        with torch.no_grad():
+            for _ in range(max(2, args.warmup)):
+                g3(*x3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n3):
+                g3(*x3)
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t0
+        f3, b3 = workmodel.totals(h, B3, T3, 2)
+        s3 = el3 / n3
+        cfg3 = dict(workload='BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
+                             'bf16 activation storage', dtype='bf16', steps=n3, ms_per_step=s3 * 1e3,
+                    value=B3 * T3 * synthetic.total_upsample(h) / s3, unit='samples/s',
+                    flops=f3, algorithmic_bytes=b3, hbm_frac=b3 / s3 / 1e9 / PEAK_HBM_GBS, mfma_frac=f3 / s3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                    peaks=dict(hbm_gbs=PEAK_HBM_GBS, bf16_mfma_tflops=PEAK_BF16_MFMA_TFLOPS),
+                    parity='tests/test_hip_generator.py::test_generator_cfg3_full_size_vs_oracle_train: no farther from the fp32 oracle than '
+                           "the reference's own bf16 autocast on the same inputs (4.3e-3 vs 8.0e-3 max, 3.4e-4 vs 7.5e-4 rms)")
+        del g3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -346,9 +391,9 @@ def main():
             'dtype': {'f32': 'f32', 'f16x3': 'f32 as f16 hi+lo (3 MFMA per product), f32 accumulate',
                       'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: B={B}/GPU x T={T} frames, 768-d latents, upsample (5,4,4,2,2) x320, '
-                                   'ResBlock2, train-mode CondBN, fp32', 'global_batch': B * world, 'frames': T,
+                                   f'ResBlock2, train-mode CondBN, {args.precision}', 'global_batch': B * world, 'frames': T,
                        'parallelism': f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt,
+            'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'cfg3_bf16': cfg3,
         }
         print(json.dumps(out))
     if world > 1:
