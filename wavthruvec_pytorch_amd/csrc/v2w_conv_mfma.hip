@@ -28,6 +28,7 @@
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
 #include <type_traits>
+#include <mutex>
 #include "v2w_tile.h"
 
 #ifdef V2W_TIMELINE   // diagnostic build only (see v2w_common.h)
@@ -81,7 +82,13 @@ conv_tile_kernel(const MultiArgs m) {
     for (int i = 1; i < V2W_MAX_MULTI; ++i) pq += (int)blockIdx.x >= m.start[i] ? 1 : 0;
     const TileArgs& p = m.p[pq];
     const int mtiles = p.Cout / MT;
-    const int id = blockIdx.x - m.start[pq];
+    int id = blockIdx.x - m.start[pq];
+    int slice = 0;                            // split over C_in chunks (launch_tile): the grid repeats the tiles once per slice
+    if (p.ksplit > 1) {
+        const int per = ((p.ntiles + 7) >> 3) * 8 * mtiles;
+        slice = id / per;
+        id -= slice * per;
+    }
     const int grp = id / (8 * mtiles), rem = id % (8 * mtiles);
     const int mt = rem >> 3;
     const int tile = grp * 8 + (rem & 7);
@@ -100,6 +107,9 @@ conv_tile_kernel(const MultiArgs m) {
     const int L = p.L, K = p.K;
     const float slope = p.slope;
     const int nch = p.Cin / CK;
+    const int nchs = p.ksplit > 1 ? nch / p.ksplit : nch;     // chunks of this workgroup: [ch0, ch1)
+    const int ch0 = slice * nchs, ch1 = ch0 + nchs;
+    float* const outp = p.out + (size_t)slice * p.B * p.CoutT * L * U;
     const int pos0 = n0 - p.hla;           // position of LDS row 0
     const int bufsz = p.xrows * RS;        // floats per signal buffer
     float* const etab = smem + p.atab_off;    // epilogue constants of this M-tile: bias, res_a, res_s, mask_a, mask_s [MT] each
@@ -199,7 +209,7 @@ conv_tile_kernel(const MultiArgs m) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
         ap[i] = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)((m0 + wm0) / MF + i) * nfrag) * 64;
-    int fidx = 0;                           // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
+    int fidx = ch0 * K * GPC;               // fragment the NEXT load fetches (clamped at the end: a harmless re-read)
     f32x4 ar[RING][MI];                     // weight ring: RING - 1 fragments in flight (every index below is a compile-time constant)
     const unsigned lane16 = (unsigned)lane * 16u;
     auto load_next = [&](f32x4 (&a)[MI]) {
@@ -266,8 +276,8 @@ conv_tile_kernel(const MultiArgs m) {
         }
         __syncthreads();
     }
-    if (p.vec4) { prefetch(0); commit(0, smem); }
-    else stage_scalar(0, smem);
+    if (p.vec4) { prefetch(ch0 * CK); commit(ch0 * CK, smem); }
+    else stage_scalar(ch0 * CK, smem);
 #pragma unroll
     for (int g = 0; g + 1 < RING; ++g) load_next(ar[g]);
     __builtin_amdgcn_sched_barrier(0);
@@ -277,13 +287,13 @@ conv_tile_kernel(const MultiArgs m) {
     const int lbase = (wn0 + lr + p.hla) * RS + 4 * hk;   // this lane's float4 in LDS row (position n0 + its column), unit 0
     typedef std::integral_constant<int, 0> RB0;
     typedef std::integral_constant<int, 1> RB1;
-    for (int ch = 0; ch < nch; ++ch) {
-        const float* Xs = smem + (ch & 1) * bufsz;
-        float* Xn = smem + ((ch + 1) & 1) * bufsz;
-        const bool more = ch + 1 < nch;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const float* Xs = smem + ((ch - ch0) & 1) * bufsz;
+        float* Xn = smem + ((ch - ch0 + 1) & 1) * bufsz;
+        const bool more = ch + 1 < ch1;
         if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
         __builtin_amdgcn_sched_barrier(0);
-        if (ch < 6) V2W_STAMP(2 + 4 * ch);
+        if (ch - ch0 < 6) V2W_STAMP(2 + 4 * (ch - ch0));
 
         // per phase r (one phase for a conv): taps at rows d0 + m*dstr, m < nt
         auto phase = [&](int r, int& d0, int& dstr, int& nt) {
@@ -324,13 +334,13 @@ conv_tile_kernel(const MultiArgs m) {
             }
         }
 
-        if (ch < 6) V2W_STAMP(3 + 4 * ch);
+        if (ch - ch0 < 6) V2W_STAMP(3 + 4 * (ch - ch0));
         if (more) {
             if (p.vec4) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
-            if (ch < 6) V2W_STAMP(4 + 4 * ch);
+            if (ch - ch0 < 6) V2W_STAMP(4 + 4 * (ch - ch0));
             __syncthreads();   // Xn complete for the next iteration; everyone done with Xs before it is overwritten again
-            if (ch < 6) V2W_STAMP(5 + 4 * ch);
+            if (ch - ch0 < 6) V2W_STAMP(5 + 4 * (ch - ch0));
         }
     }
     V2W_STAMP(26);
@@ -395,7 +405,7 @@ conv_tile_kernel(const MultiArgs m) {
                             if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                         v[x] = t;
                     }
-                    if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                    if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(outp + gbase + (size_t)row * L + 4 * c4) = v;
                 }
             } else if (p.evec) {
 #pragma unroll 1
@@ -410,7 +420,7 @@ conv_tile_kernel(const MultiArgs m) {
                         rv[g] = ov[g] = o2[g] = zero4;
                         if (ok) {
                             if (p.res) rv[g] = *reinterpret_cast<const f32x4*>(p.res + goff);
-                            if (p.accumulate) ov[g] = *reinterpret_cast<const f32x4*>(p.out + goff);
+                            if (p.accumulate) ov[g] = *reinterpret_cast<const f32x4*>(outp + goff);
                             else if (p.add0) ov[g] = *reinterpret_cast<const f32x4*>(p.add0 + goff);
                             if (p.add1) o2[g] = *reinterpret_cast<const f32x4*>(p.add1 + goff);
                         }
@@ -440,7 +450,7 @@ conv_tile_kernel(const MultiArgs m) {
                                 if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                             v[x] = t;
                         }
-                        if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(p.out + gbase + (size_t)row * L + 4 * c4) = v;
+                        if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(outp + gbase + (size_t)row * L + 4 * c4) = v;
                     }
                 }
             } else {                               // ragged L / unaligned operands: the same walk, one element at a time
@@ -456,12 +466,12 @@ conv_tile_kernel(const MultiArgs m) {
                     t += etab[col];
                     if (p.res) t += fmaf(etab[MT + col], p.res[goff], etab[2 * MT + col]);
                     if (p.add1) t += p.add0[goff] + p.add1[goff];
-                    else if (p.accumulate) t += p.out[goff];
+                    else if (p.accumulate) t += outp[goff];
                     else if (p.add0) t += p.add0[goff];
                     if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
                     if constexpr (EPI != 0)
                         if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
-                    p.out[goff] = t;
+                    outp[goff] = t;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -480,15 +490,15 @@ conv_tile_kernel(const MultiArgs m) {
                     if (q >= L) continue;
                     if constexpr (U == 2) {
                         f32x2 v; v[0] = acc[0][i][j][e] + bias; v[1] = acc[1][i][j][e] + bias;
-                        *reinterpret_cast<f32x2*>(p.out + orow + (size_t)q * 2) = v;
+                        *reinterpret_cast<f32x2*>(outp + orow + (size_t)q * 2) = v;
                     } else if constexpr (U == 4) {
                         f32x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = acc[r][i][j][e] + bias;
-                        *reinterpret_cast<f32x4*>(p.out + orow + (size_t)q * 4) = v;
+                        *reinterpret_cast<f32x4*>(outp + orow + (size_t)q * 4) = v;
                     } else {
 #pragma unroll
-                        for (int r = 0; r < U; ++r) p.out[orow + (size_t)q * U + r] = acc[r][i][j][e] + bias;
+                        for (int r = 0; r < U; ++r) outp[orow + (size_t)q * U + r] = acc[r][i][j][e] + bias;
                     }
                 }
             }
@@ -536,6 +546,96 @@ conv_tile_kernel(const MultiArgs m) {
             }
         }
     }
+}
+
+// ---- split over C_in for launches that cannot fill the chip (inference at B = 1: conv_pre at T = 50 is 64 workgroups walking
+// 24 chunks x 7 taps one after the other, 176 us).  The launch is repeated over `ksplit` slices of the chunks, every slice writes its
+// plain partial sums to its own slab of a per-(device, stream) workspace (same (B, C_out, L_out) layout as the output), and
+// splitk_reduce_kernel adds the slabs in slice order and applies the epilogue - bias, residual, addends, division - in the main
+// kernel's arithmetic order: deterministic, no atomics, visibility from the kernel boundary.
+struct SplitEpi {
+    const float* slab; float* out;
+    const float* bias; const float* res; const float* res_a; const float* res_s; const float* add0; const float* add1;
+    int accumulate; float out_div;
+    int Cout, Lout;
+    size_t slice_stride;      // floats between the slabs of consecutive slices
+};
+struct SplitEpiArgs {
+    SplitEpi e[V2W_MAX_MULTI];
+    long long start[V2W_MAX_MULTI + 1];     // first float4 of problem i in the flat index space
+    int n, S;
+};
+
+// VEC: float4 per thread (every L_out a multiple of 4, every pointer 16-byte aligned); else one element per thread
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const SplitEpiArgs a) {
+    constexpr int W = VEC ? 4 : 1;
+    typedef typename std::conditional<VEC, f32x4, float>::type vec_t;
+    const long long total = a.start[a.n];
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int q = 0;
+#pragma unroll
+        for (int i = 1; i < V2W_MAX_MULTI; ++i) q += (i < a.n && idx >= a.start[i]) ? 1 : 0;
+        const SplitEpi& e = a.e[q];
+        const size_t off = (size_t)(idx - a.start[q]) * W;
+        const size_t row = off / e.Lout;                  // b * Cout + co (VEC: Lout % 4 == 0, a float4 never crosses rows)
+        const int co = (int)(row % e.Cout);
+        float v[W], r[W], ov[W], o2[W];
+        auto ld = [&](const float* src, float (&dst)[W]) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(src + off);
+            if constexpr (VEC) { dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3]; } else dst[0] = t;
+        };
+        ld(e.slab, v);
+        for (int s = 1; s < a.S; ++s) {
+            float t[W];
+            ld(e.slab + (size_t)s * e.slice_stride, t);
+#pragma unroll
+            for (int x = 0; x < W; ++x) v[x] += t[x];
+        }
+        const float bias = e.bias ? e.bias[co] : 0.f;
+#pragma unroll
+        for (int x = 0; x < W; ++x) r[x] = ov[x] = o2[x] = 0.f;
+        float ra = 1.f, rs = 0.f;
+        if (e.res) { ld(e.res, r); if (e.res_a) { ra = e.res_a[row]; rs = e.res_s[row]; } }
+        if (e.accumulate) ld(e.out, ov);
+        else if (e.add0) ld(e.add0, ov);
+        if (e.add1) ld(e.add1, o2);
+        const float dinv = e.out_div != 0.f ? 1.f / e.out_div : 1.f;
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            float t2 = v[x] + bias;
+            if (e.res) t2 += fmaf(ra, r[x], rs);
+            if (e.add1) t2 += ov[x] + o2[x];
+            else if (e.accumulate || e.add0) t2 += ov[x];
+            if (e.out_div != 0.f) t2 = v2w_div_by(t2, e.out_div, dinv);
+            v[x] = t2;
+        }
+        if constexpr (VEC) *reinterpret_cast<f32x4*>(e.out + off) = f32x4{v[0], v[1], v[2], v[3]};
+        else e.out[off] = v[0];
+    }
+}
+
+// One slab workspace per (device, stream) that ever needed one: allocated on first use (never while the stream is capturing - the
+// caller then launches unsplit), kept for the life of the process.
+#define V2W_SPLITK_WS_BYTES (32u << 20)
+static float* splitk_workspace(hipStream_t stream) {
+    struct Entry { int dev; hipStream_t stream; float* buf; };
+    static Entry table[32];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (table[i].dev == dev && table[i].stream == stream) return table[i].buf;
+    if (used == 32) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    void* buf = nullptr;
+    if (hipMalloc(&buf, V2W_SPLITK_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    table[used++] = Entry{dev, stream, static_cast<float*>(buf)};
+    return static_cast<float*>(buf);
 }
 
 // HMAX: largest halo (each side) the staging slots cover: 32 for the generator (k = 11, dilation 5 -> 25); the 48 variants serve
@@ -592,6 +692,52 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         if (m.p[i].mask_src != nullptr) epi = 1;
         else if (m.p[i].out_slope != 1.f && epi == 0) epi = 2;
     }
+    // split over C_in chunks (see splitk_reduce_kernel) when the launch is at most half a workgroup per CU and every problem has the
+    // plain epilogue: S = the largest power of two that divides the chunk count and keeps the grid within two workgroups per CU
+    SplitEpiArgs red{};
+    int S = 1;
+    bool red_vec = true;
+    if (epi == 0 && grid <= 128) {
+        const int nch = m.p[0].Cin / CK;
+        int s2 = 1;
+        while (s2 * 2 <= 8 && nch % (s2 * 2) == 0 && grid * s2 * 2 <= 512) s2 *= 2;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        size_t floats = 0;
+        bool ok = s2 > 1, vec = true;
+        for (int i = 0; i < nprob && ok; ++i) {
+            const TileArgs& p = m.p[i];
+            const size_t n = (size_t)p.B * p.Cout * p.L * U;
+            ok = !p.stats_part && p.CoutT == p.Cout && p.Cin / CK == nch;
+            vec = vec && (p.L * U) % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1);
+            floats += n * s2;
+        }
+        if (ok && floats * sizeof(float) <= V2W_SPLITK_WS_BYTES) {
+            float* ws = splitk_workspace(stream);
+            if (ws) {
+                S = s2;
+                red_vec = vec;
+                size_t off = 0;
+                long long f4 = 0;
+                grid = 0;
+                for (int i = 0; i < nprob; ++i) {
+                    TileArgs& p = m.p[i];
+                    const size_t n = (size_t)p.B * p.Cout * p.L * U;
+                    red.e[i] = SplitEpi{ws + off, p.out, p.bias, p.res, p.res_a, p.res_s, p.add0, p.add1, p.accumulate, p.out_div, p.Cout, p.L * U, n};
+                    red.start[i] = f4;
+                    f4 += vec ? (long long)(n / 4) : (long long)p.B * p.Cout * p.L * U;
+                    p.out = ws + off; p.bias = nullptr; p.res = p.res_a = p.res_s = nullptr; p.add0 = p.add1 = nullptr;
+                    p.accumulate = 0; p.out_div = 0.f; p.ksplit = S;
+                    p.evec = U == 1 && p.L % 4 == 0;
+                    off += n * S;
+                    m.start[i] = grid;
+                    grid += ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT) * S;
+                }
+                m.start[nprob] = grid;
+                red.start[nprob] = f4;
+                red.n = nprob; red.S = S;
+            }
+        }
+    }
     auto kern = epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1>
               : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0>);
     if (lds > 64 * 1024) {
@@ -600,6 +746,14 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    if (S > 1) {
+        const int rc = v2w_launch_status();
+        if (rc != 0) return rc;
+        long long blocks = (red.start[nprob] + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        if (red_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, red);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, red);
+    }
     return v2w_launch_status();
 }
 

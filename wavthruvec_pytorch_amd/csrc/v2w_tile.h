@@ -34,6 +34,8 @@ struct TileArgs {
     int accumulate;
     float out_div;
     int io_bf16;      // bf16 kernels: bit 0 `in` is bf16, bit 1 `out` / `res` / `add0` / `add1` are bf16 (pointers are typed float* regardless)
+    int ksplit;       // f32 tile kernel: > 1 = the launch is the partial pass of a split over C_in chunks: slice s of the grid accumulates chunks
+                      // [s, s + 1) * (C_in / CK / ksplit) and stores its plain sums to out + s * B * CoutT * L * U (see launch_tile)
     int up_u, up_p;   // bf16 transposed conv run as a 3-tap conv over up_p * C_out virtual rows (row = co * up_p + phase): stride, padded phase count
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
 };

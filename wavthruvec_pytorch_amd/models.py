@@ -22,6 +22,7 @@ from .utils import get_padding, init_weights  # noqa: F401  (re-exported like th
 
 LRELU_SLOPE = 0.1  # models.py:10
 _SIDE_STREAMS: Dict[str, 'torch.cuda.Stream'] = {}
+_CAPTURE_STREAMS: Dict[str, 'torch.cuda.Stream'] = {}      # per process and device: the stream HIP graphs are warmed up and captured on
 _Z_CHANNEL = 128   # models.py:110
 
 
@@ -226,14 +227,18 @@ class Generator(nn.Module):
             raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
         sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
         with torch.no_grad():
-            side = torch.cuda.Stream(device=sx.device)
+            # warm-up and capture run on ONE per-device stream: the library keys its split-K slab workspace by (device, stream) and
+            # never allocates while a stream is capturing, so the capture must see the stream the warm-up ran on
+            side = _CAPTURE_STREAMS.get(str(sx.device))
+            if side is None:
+                side = _CAPTURE_STREAMS[str(sx.device)] = torch.cuda.Stream(device=sx.device)
             side.wait_stream(torch.cuda.current_stream(sx.device))
             with torch.cuda.stream(side):
                 for _ in range(max(1, warmup)):     # builds every workspace buffer and the fold plan outside the capture
                     self.forward(sx, ss, sn)
             torch.cuda.current_stream(sx.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 sy = self.forward(sx, ss, sn)
 
         def run(x, spk_emb, noise):
