@@ -15,8 +15,15 @@ for prec in f16x3 bf16; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$prec -o ks -- $B --precision $prec > $O/ks_$prec.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_train -o ks -- python3 $R/tools/train_step_bench.py 32 256 5 > $O/ks_train.log 2>&1
+# BASELINE configs[2] in its own arithmetic (bf16 compute / fp32 accumulate, bf16 activation storage) and the cfg1 inference latency
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_cfg3 -o ks -- $B --precision bf16 --batch 64 --frames 512 > $O/ks_cfg3.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ks_lat -o ks -- python3 $R/tools/latency_bench.py 1 50 > $O/ks_lat.log 2>&1
 cd $R
 python3 tools/trace_layers.py $O/ks > $O/per_layer.txt 2>&1
+python3 tools/trace_layers.py $O/ks_cfg3 64 512 -2 2 > $O/cfg3_bf16_per_layer.txt 2>&1
+python3 tools/trace_timeline.py $O/ks_lat > $O/cfg1_latency_timeline.txt 2>&1
+python3 tools/latency_bench.py > $O/latency.txt 2>&1
+python3 tools/train_step_bench.py 32 256 5 > $O/train_step.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/hbm_traffic.json 2> $O/pmc.err
 python3 tools/pmc_sq.py $O/sq_a $O/sq_b > $O/sq_counters.json 2> $O/sq.err
 cp $O/hbm_traffic.json profiles/${TAG}_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
