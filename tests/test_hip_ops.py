@@ -166,6 +166,95 @@ def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+@pytest.mark.parametrize('B,C,L,k,dil,streams', [(3, 128, 2560, 7, 3, 'res'), (3, 128, 2560, 11, 1, 'res+add2+div'), (2, 64, 1028, 3, 1, 'acc'),
+                                                  (2, 256, 300, 7, 1, 'res+add2+div'), (1, 64, 132, 3, 3, 'plain')])
+def test_conv1d_bf16_activation_storage(dev, B, C, L, k, dil, streams):
+    """io_bf16 = 3 (BASELINE configs[2] with bf16 activations between layers): input, residual, addends and output are bf16 TENSORS,
+    arithmetic stays fp32.  Every operand-stream combination of the pipelined epilogue (residual only; residual + two addends + the
+    division; running sum) against fp64 math on the same bf16 values, to the rounding of the bf16 store."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(31)
+    bf = lambda a: torch.from_numpy(a).bfloat16()
+    x = bf(r.standard_normal((B, C, L), dtype=np.float32))
+    w = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    bias = r.standard_normal(C).astype(np.float32)
+    ia, is_ = (1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), (0.3 * r.standard_normal((B, C))).astype(np.float32)
+    xin = torch.from_numpy(ia)[:, :, None].double() * x.double() + torch.from_numpy(is_)[:, :, None].double()
+    xa = F.leaky_relu(xin.float(), 0.1).bfloat16().double()          # (the kernel's affine + leaky_relu run in fp32, then round)
+    want = F.conv1d(xa, torch.from_numpy(w).bfloat16().double(), torch.from_numpy(bias).double(), padding=dil * (k - 1) // 2, dilation=dil)
+    kw = dict(k=k, dil=dil, slope=0.1, in_affine=(_t(ia, dev), _t(is_, dev)), algo=hipops.ALGO_BF16, io_bf16=3)
+    out = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    if 'res' in streams:
+        res = bf(r.standard_normal((B, C, L), dtype=np.float32))
+        want = want + res.double()
+        kw['res'] = res.to(dev)
+    if 'add2' in streams:
+        a0, a1 = bf(r.standard_normal((B, C, L), dtype=np.float32)), bf(r.standard_normal((B, C, L), dtype=np.float32))
+        want = want + (a0.double() + a1.double())
+        kw['add'] = [a0.to(dev), a1.to(dev)]
+    if 'acc' in streams:
+        prev = bf(r.standard_normal((B, C, L), dtype=np.float32))
+        want = want + prev.double()
+        out = prev.to(dev).clone()
+        kw['accumulate'] = True
+    if 'div' in streams:
+        want = want / 3.0
+        kw['out_div'] = 3.0
+    wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+    hipops.conv1d(x.to(dev), None, _t(bias, dev), out, wps=hipops.pack_split(wf, bf16=True), **kw)
+    assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
+    # the fp32 affine + activation differ from the fp64 reference by 1 bf16 ulp on a few operands; the store rounds to bf16 (2^-9 relative)
+    err = (out.cpu().double() - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 3e-2
+    assert (err <= tol).all(), f'max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    assert err.mean().item() <= 4e-3
+
+
+@pytest.mark.parametrize('C', [32, 16])
+def test_resblock2_stage_bf16_storage(dev, C):
+    """The fused C = 32 / 16 stage with bf16 tensors on both sides (io_bf16 = 3): == the same kernel on fp32 copies of the same values up
+    to the rounding of the bf16 store (the raw-tile residual path vs the global re-read path compute the same fp32 arithmetic)."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(33)
+    B, L = 3, 2052
+    x = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32)).bfloat16().to(dev)
+    a, s_ = _t((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), dev), _t((0.3 * r.standard_normal((B, C))).astype(np.float32), dev)
+    branches = []
+    for k in (3, 7, 11):
+        ws = [_t(_relayout(torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))).numpy(), dev) for _ in range(2)]
+        branches.append(dict(wps1=hipops.pack_split(ws[0], bf16=True), b1=_t(r.standard_normal(C).astype(np.float32) * 0.1, dev),
+                             wps2=hipops.pack_split(ws[1], bf16=True), b2=_t(r.standard_normal(C).astype(np.float32) * 0.1, dev), k=k, dil1=1, dil2=3))
+    o16 = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    o32 = torch.full((B, C, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage_split(x, (a, s_), branches, o16, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
+    assert hipops.resblock2_stage_split(x.float(), (a, s_), branches, o32, slope=0.1, out_div=3.0, bf16=True, io_bf16=0)
+    assert torch.isfinite(o32).all()
+    assert torch.equal(o16, o32.bfloat16()), f'max diff {(o16.float() - o32).abs().max().item()}'
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', [(1, 768, 512, 50, 7, 1), (1, 256, 256, 250, 11, 3), (2, 128, 128, 1000, 3, 1), (1, 512, 512, 64, 7, 1)])
+def test_conv1d_split_over_cin_matches_the_unsplit_kernel(dev, B, cin, cout, L, k, dil):
+    """Launches of at most 128 workgroups are split over C_in chunks (slabs + splitk_reduce_kernel): same result as
+    the direct kernel to fp32 summation order, bitwise identical from run to run, with every epilogue operand (residual affine,
+    running sum, division), for sequence lengths that are and are not multiples of 4."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(41)
+    x = _t(r.standard_normal((B, cin, L), dtype=np.float32), dev)
+    wf = _t(_relayout(torch.from_numpy((r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32))).numpy(), dev)
+    bias = _t(r.standard_normal(cout).astype(np.float32), dev)
+    res = _t(r.standard_normal((B, cout, L), dtype=np.float32), dev)
+    ra, rs = _t((1 + 0.2 * r.standard_normal((B, cout))).astype(np.float32), dev), _t((0.3 * r.standard_normal((B, cout))).astype(np.float32), dev)
+    prev = _t(r.standard_normal((B, cout, L), dtype=np.float32), dev)
+    kw = dict(k=k, dil=dil, slope=0.1, res=res, res_affine=(ra, rs), accumulate=True, out_div=3.0)
+    outs = []
+    for algo, wp in ((hipops.ALGO_AUTO, hipops.pack_mfma(wf)), (hipops.ALGO_AUTO, hipops.pack_mfma(wf)), (hipops.ALGO_DIRECT, None)):
+        o = prev.clone()
+        hipops.conv1d(x, wf, bias, o, algo=algo, wp=wp, **kw)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]), 'split launches are not run-to-run deterministic'
+    assert (outs[0] - outs[2]).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 512, 256, 50, 11, 5), (2, 256, 128, 264, 8, 4), (3, 128, 64, 1000, 8, 4),
                                               (2, 64, 32, 2052, 4, 2), (2, 32, 16, 4100, 4, 2), (1, 64, 32, 37, 4, 2),
                                               (2, 1024, 512, 40, 16, 8)])
