@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 23
+#define V2W_ABI_VERSION 24
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -73,6 +73,9 @@ int v2w_wf_gather_transpose(const float* wf, float* out, int k, int c_in, int c_
  * tile configuration (C_in % 16 != 0, C_out neither 16 nor a multiple of 32, unsupported stride): such layers run on
  * the direct kernel with wp = NULL. */
 int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_out, int u, void* stream);
+/* the stream of the layer's input-gradient conv (== v2w_pack_mfma of v2w_wf_transpose_flip(wf)) straight from wf [k][c_out][c_in]:
+ * c_in / c_out are the GRADIENT conv's channel counts (backward of models.py:65-70: dx = conv(dy; W^T, taps reversed)) */
+int v2w_pack_mfma_dgrad(const float* wf, float* wp, int k, int c_in, int c_out, void* stream);
 /* n matrices back to back -> n packed streams back to back in one launch (the groups of a grouped conv) */
 int v2w_pack_mfma_batch(const float* wf, float* wp, int k, int c_in, int c_out, int u, int n, void* stream);
 

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -97,6 +97,7 @@ SIGNATURES = {
     'v2w_wf_gather_transpose': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_mfma_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_pack_mfma_dgrad': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'v2w_pack_split': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_mel_phases': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -96,8 +96,42 @@ def generator_backward(gen, sv, dy):
         dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
         db2 = hipops.channel_sum(dr)
         dx = torch.empty_like(dr)
-        from .models import ResBlock1
-        for j in range(nk):
+        from .models import ResBlock1, ResBlock2
+        merged = gen.precision == 'f32' and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 and hipops.conv_tile_config(B, C, C, Lo, 3) is not None \
+            and all(isinstance(gen.resblocks[i * nk + j], ResBlock2) for j in range(nk))
+        if merged:
+            # ---- ResBlock2, the forward's launch structure mirrored: the three branches' conv2 input gradients in ONE launch, the conv1
+            # input gradients of branches 0 .. nk-2 in one launch and the last branch adding them (heaviest kernel size first), so the
+            # tile shape is chosen for three problems' worth of tiles instead of one
+            rbs = [gen.resblocks[i * nk + j] for j in range(nk)]
+            names = [f'resblocks.{i * nk + j}' for j in range(nk)]
+            order = sorted(range(nk), key=lambda j: -rbs[j].kernel_size)
+            t1s = [ws[f'act.t1_{i}_{j}'] for j in range(nk)]
+            dt1s = [torch.empty_like(dr) for _ in range(nk)]
+            # fragment streams of the gradient convs straight from the forward-layout weights (no transposed copies: C -> C layers)
+            p2 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1']) for j in range(nk)]
+            p1 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0']) for j in range(nk)]
+            # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
+            hipops.conv1d_multi([(dr, None, None, dt1s[j],
+                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, res=dr, mask=(t1s[j], None),
+                                       mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA)) for j in order])
+            # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx = sum_j dt1_j + lrelu'(x) * conv(dt1_j; W1^T flipped)
+            parts = [torch.empty_like(dr) for _ in range(nk - 1)]
+
+            def dconv1(j, out, **extra):
+                return (dt1s[j], None, None, out,
+                        dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=1.0, res=dt1s[j], mask=(xr, aff), mask_slope=LRELU_SLOPE,
+                             wp=p1[j], algo=hipops.ALGO_MFMA, **extra))
+            hipops.conv1d_multi([dconv1(j, parts[j]) for j in order if j < nk - 1])
+            hipops.conv1d_multi([dconv1(nk - 1, dx, add=parts)])
+            for j in range(nk):
+                c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
+                k = rbs[j].kernel_size
+                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
+                grads[names[j] + '.convs.1.bias'] = db2
+                _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+                grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+        for j in range(nk if not merged else 0):
             rb = gen.resblocks[i * nk + j]
             name = f'resblocks.{i * nk + j}'
             k = rb.kernel_size

@@ -770,7 +770,7 @@ int launch_convt_u(TileArgs p, hipStream_t stream) {
 // where ts runs over the taps in the order the tile kernel consumes them: 0..K-1 for a conv, phase by phase
 // (r = 0..U-1: t = (r+pad)%U, +U, ...) for a transposed conv.
 __global__ void __launch_bounds__(256)
-pack_mfma_kernel(const float* wf, float* wp, int K, int Cin, int Cout, int MF, int CK, int U) {
+pack_mfma_kernel(const float* wf, float* wp, int K, int Cin, int Cout, int MF, int CK, int U, int tflip = 0) {
     const int KSTEP = MF == 32 ? 2 : 4, CKG = 4 * KSTEP, GPC = CK / CKG, nch = Cin / CK;
     const int pad = (K - U) / 2;
     const size_t total = (size_t)K * Cin * Cout;
@@ -794,7 +794,8 @@ pack_mfma_kernel(const float* wf, float* wp, int K, int Cin, int Cout, int MF, i
         }
         const int c = ch * CK + gg * CKG + j * KSTEP + lane / MF;
         const int co = mb * MF + lane % MF;
-        wp[o] = wf[((size_t)t * Cin + c) * Cout + co];
+        // tflip: `wf` is the FORWARD layer's [K][Cout][Cin] and this stream serves its input gradient: tap-reversed, transposed
+        wp[o] = tflip ? wf[((size_t)(K - 1 - t) * Cout + co) * Cin + c] : wf[((size_t)t * Cin + c) * Cout + co];
     }
 }
 
@@ -892,6 +893,19 @@ extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
+    return v2w_launch_status();
+}
+
+// The fragment stream of a conv layer's INPUT-GRADIENT convolution straight from the layer's own wf [k][C][D] (C = its C_in, D = its C_out):
+// the stream v2w_pack_mfma(v2w_wf_transpose_flip(wf), k, D, C, 1) would give, without the transposed copy.  c_in / c_out are the
+// gradient convolution's (c_in = D, c_out = C).
+extern "C" int v2w_pack_mfma_dgrad(const float* wf, float* wp, int k, int c_in, int c_out, void* stream) {
+    if (!wf || !wp || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
+    const LayerCfg cfg = v2w_layer_cfg(c_in, c_out, 1);
+    if (!cfg.mf) return V2W_E_SHAPE;
+    const size_t total = (size_t)k * c_in * c_out;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, 1, 1);
     return v2w_launch_status();
 }
 

@@ -90,6 +90,18 @@ def pack_mfma(wf, out=None, u=1):
     return out
 
 
+def pack_mfma_dgrad(wf):
+    """wf [k][C_in][C_out] of a conv layer -> the MFMA fragment stream of its input-gradient conv (C_out -> C_in channels, taps reversed),
+    or None when that shape has no MFMA tile configuration (then: transpose_flip + the direct kernel)."""
+    k, ci, co = wf.shape
+    out = torch.empty((k * ci * co,), device=wf.device, dtype=torch.float32)
+    rc = _hip.load().v2w_pack_mfma_dgrad(wf.data_ptr(), out.data_ptr(), k, co, ci, _stream(wf))
+    if rc == -2:
+        return None
+    _hip.check(rc, 'v2w_pack_mfma_dgrad')
+    return out
+
+
 def pack_mfma_batch(w4):
     """w4 [n][k][C_in][C_out] contiguous -> the n packed MFMA streams [n][k*C_in*C_out] in one launch."""
     _chk(w4, 'w4')
