@@ -47,13 +47,16 @@ __device__ __forceinline__ f32x4 bf4_to_f32(u32x2 w) { return f32x4{bf_lo(w[0]),
 __device__ __forceinline__ u32x2 f32_to_bf4(f32x4 v) { return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; }
 
 // IN_BF / OUT_BF: activation STORAGE in bf16 (`in`; `out`, `res`, `add0`, `add1`): 8-byte loads / stores of 4 positions instead of 16.
-template <int MI, int NI, int WM, int WN, int NPF, int EPI, bool IN_BF, bool OUT_BF>
+// CKT: channels per chunk.  32 (two k-steps per tap); 64 for the C_in = 64 layers, which then are ONE chunk: no chunk loop, twice the
+// bytes in flight while the tile is staged (a 64-channel layer as two chunks spent 85 % of its tile time outside the MFMA phases).
+template <int MI, int NI, int WM, int WN, int NPF, int EPI, bool IN_BF, bool OUT_BF, int CKT = V2W_BF_CK>
 __global__ void __launch_bounds__(64 * WM * WN, MI * NI >= 8 ? 2 : 3)      // (128 x 256: two workgroups per CU = at most 256 registers; else three)
 conv_bf16_kernel(const MultiArgs m) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int NTHREADS = 64 * WM * WN;
-    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, CK = V2W_BF_CK, ROWB = V2W_BF_ROWB;
+    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, CK = CKT, ROWB = 2 * CK + 16, KS = CK / 16, NCQ = CK / 4;
+    static_assert(CK == 32 || CK == 64, "chunk = 2 or 4 k-steps");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // 2 x [xrows][ROWB] signal tiles, then the float tables
 
@@ -104,9 +107,9 @@ conv_bf16_kernel(const MultiArgs m) {
         int t = tid;
         asm volatile("" : "+v"(t));
         const int idx = t + s * NTHREADS;
-        cq = idx & 7;
-        row = (idx >> 3) * 4;
-        in_img = (idx >> 3) < nq;
+        cq = idx & (NCQ - 1);
+        row = (idx / NCQ) * 4;
+        in_img = (idx / NCQ) < nq;
         const int pos = pos0 + row;
         in_seq = in_img && pos >= 0 && pos < L;         // L % 4 == 0 and pos % 4 == 0: a float4 is inside or outside as a whole
     };
@@ -175,20 +178,22 @@ conv_bf16_kernel(const MultiArgs m) {
     };
 
     // ---- weights: fragment (row block, 16-channel k-step c16, tap t) sits at ((rb * nst + c16 * K + t) * V2W_BF_UNIT) + lane * 16
-    const int nst = 2 * nch * K;                             // fragments per row block
+    const int nst = KS * nch * K;                            // fragments per row block
     const unsigned char* ap[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
         ap[i] = reinterpret_cast<const unsigned char*>(p.wps) + (size_t)((m0 + wm0) / 32 + i) * nst * V2W_BF_UNIT;
     const unsigned lane16 = (unsigned)lane * 16u;
-    u32x4 ar[2][MI];                                         // [k-step of the tap][row block]: one computing, one in flight
+    // ring of fragments: CK = 32 two slots (one computing, one in flight); CK = 64 one slot per k-step of a tap, each refilled with the
+    // NEXT tap's fragment right after its use: three k-steps (3 x 32 MI NI cycles of MFMA issue) ahead of an L2 round trip of 500+
+    u32x4 ar[KS == 4 ? 4 : 2][MI];
     auto load_frag = [&](u32x4 (&a)[MI], int ch, int s, int t) {   // k-step s of (chunk ch, tap t); clamped past the end (harmless re-read)
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));                        // keeps the address scalar base + 32-bit lane offset (see v2w_conv_mfma.hip)
         const int chc = ch < nch ? ch : nch - 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            a[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_BF_UNIT + l16);
+            a[i] = *gptr<const u32x4>(ap[i] + (size_t)((KS * chc + s) * K + t) * V2W_BF_UNIT + l16);
     };
 
     // ---- B operands: one 16-byte fragment per column block, refilled right after its last use in the running k-step
@@ -228,6 +233,7 @@ conv_bf16_kernel(const MultiArgs m) {
     // ---- prologue: the loads that do not depend on LDS go out first (chunk 0 of the signal, the first fragments)
     if (p.vec4) prefetch(0);
     load_frag(ar[0], 0, 0, 0);
+    if constexpr (KS == 4) { load_frag(ar[1], 0, 1, 0); load_frag(ar[2], 0, 2, 0); load_frag(ar[3], 0, 3, 0); }
     __builtin_amdgcn_sched_barrier(0);
     for (int c = tid; c < MT; c += NTHREADS) {
         etab[c] = p.bias ? p.bias[EPI == 2 ? (m0 + c) / p.up_p : m0 + c] : 0.f;
@@ -265,19 +271,38 @@ conv_bf16_kernel(const MultiArgs m) {
         for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(xt + j * 32 * ROWB);
         // a tap = k-step 0 (channels 0-15 of the chunk: bytes 0-31 of a row) from ring slot 0, then k-step 1 (bytes 32-63) from slot 1;
         // each slot's next fragment is requested while the other slot computes; the chunk's last request is tap 0 of the next chunk
-        for (int t = 0; t < K; ++t, xt += step) {
-#ifdef V2W_BF_ABL_NOFRAG
-            if (ch == 0 && t == 0) load_frag(ar[1], ch, 1, t);
-#else
-            load_frag(ar[1], ch, 1, t);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(ar[0], xt + 32);
+        if constexpr (KS == 4) {
+            for (int t = 0; t < K; ++t, xt += step) {
+                const bool last = t + 1 >= K;
+                const int chn = last ? ch + 1 : ch, tn = last ? 0 : t + 1;     // (one load either way: no branch, no join for vmcnt)
+#pragma unroll
+                for (int sq = 0; sq < 4; ++sq) {
+                    kstep(ar[sq], sq < 3 ? xt + 32 * (sq + 1) : (last ? xt : xt + step));
 #ifndef V2W_BF_ABL_NOFRAG
-            if (t + 1 < K) load_frag(ar[0], ch, 0, t + 1); else load_frag(ar[0], ch + 1, 0, 0);
+                    load_frag(ar[sq], chn, sq, tn);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(ar[1], t + 1 < K ? xt + step : xt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else
+        for (int t = 0; t < K; ++t, xt += step) {
+#pragma unroll
+            for (int sp = 0; sp < KS; sp += 2) {             // k-steps sp (ring slot 0) and sp + 1 (slot 1) of the tap
+#ifdef V2W_BF_ABL_NOFRAG
+                if (ch == 0 && t == 0) load_frag(ar[1], ch, sp + 1, t);
+#else
+                load_frag(ar[1], ch, sp + 1, t);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ar[0], xt + 32 * (sp + 1));
+#ifndef V2W_BF_ABL_NOFRAG
+                if (sp + 2 < KS) load_frag(ar[0], ch, sp + 2, t);
+                else if (t + 1 < K) load_frag(ar[0], ch, 0, t + 1);
+                else load_frag(ar[0], ch + 1, 0, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(ar[1], sp + 2 < KS ? xt + 32 * (sp + 2) : (t + 1 < K ? xt + step : xt));
+            }
         }
         if (ch < 6) V2W_STAMP(3 + 4 * ch);
         if (more) {
@@ -688,25 +713,25 @@ conv_bf16_kernel(const MultiArgs m) {
     V2W_STAMP(27);
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, int CK = V2W_BF_CK>
 int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
-    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32;
-    constexpr int NPF = (8 * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32, ROWB = 2 * CK + 16;
+    constexpr int NPF = ((CK / 4) * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
     static_assert(NI % 2 == 0, "the epilogue walks column blocks in pairs");
     MultiArgs m{};
     size_t lds = 0;
     int grid = 0, epi = 0;
     for (int i = 0; i < nprob; ++i) {
         TileArgs p = ps[i];
-        if (p.Cout % MT != 0 || p.Cin % V2W_BF_CK != 0) return V2W_E_SHAPE;
+        if (p.Cout % MT != 0 || p.Cin % CK != 0) return V2W_E_SHAPE;
         p.hla = (p.hl + 3) & ~3;
         if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
         p.ntl = (p.L + NT - 1) / NT;
         p.ntiles = p.B * p.ntl;
         p.xrows = (p.hla + NT + p.hr + 3) & ~3;
         p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
-        const int nbuf = p.Cin / V2W_BF_CK > 1 ? 2 : 1;
-        int tab = nbuf * p.xrows * V2W_BF_ROWB / 4;                        // float index of the tables, after the signal buffers ...
+        const int nbuf = p.Cin / CK > 1 ? 2 : 1;
+        int tab = nbuf * p.xrows * ROWB / 4;                        // float index of the tables, after the signal buffers ...
         if (tab < WM * WN * 32 * 64) tab = WM * WN * 32 * 64;              // ... and after the epilogue scratch that overlays them
         p.atab_off = tab;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -724,10 +749,10 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     const int io = m.p[0].io_bf16;
     for (int i = 1; i < nprob; ++i) if (m.p[i].io_bf16 != io) return V2W_E_ARG;      // one instantiation per launch
     if (io == 1 || (epi && io != 0)) return V2W_E_SHAPE;     // bf16 in with fp32 out does not occur on the path; the mask epilogue is fp32-only
-    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false>
-              : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false>
-              : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true>
-                        : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true>;
+    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false, CK>
+              : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false, CK>
+              : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true, CK>
+                        : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true, CK>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -856,6 +881,7 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
         tiles += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 64);
     }
     if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream);     // 128 x 256
+    if (tiles >= 256 && a->C_in == 64 && a->io_bf16 == 3) return launch_bf16<1, 4, 2, 2, 64>(ps, n, stream);   // 64 x 256, bf16 tensors: the 64 input channels as ONE chunk
     if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream);                                 // 64 x 256
     return launch_bf16<1, 2, 2, 2>(ps, n, stream);                                                   // 64 x 128: latency sizes
 }
