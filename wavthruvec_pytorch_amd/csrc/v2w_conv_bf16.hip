@@ -141,8 +141,8 @@ conv_bf16_kernel(const MultiArgs m) {
             float av[4], sv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                av[i] = p.in_a ? atab[ci0 + 4 * cq + i] : 1.f;
-                sv[i] = p.in_a ? atab[p.Cin + ci0 + 4 * cq + i] : 0.f;
+                av[i] = atab[ci0 + 4 * cq + i];               // (the table is (1, 0) without an affine: no scalar branch in here -
+                sv[i] = atab[p.Cin + ci0 + 4 * cq + i];       //  two inlined copies of this lambda with one ended in a backend error)
             }
             unsigned char* dst = Xs + row * ROWB + cq * 8;
 #pragma unroll
@@ -184,9 +184,11 @@ conv_bf16_kernel(const MultiArgs m) {
     for (int i = 0; i < MI; ++i)
         ap[i] = reinterpret_cast<const unsigned char*>(p.wps) + (size_t)((m0 + wm0) / 32 + i) * nst * V2W_BF_UNIT;
     const unsigned lane16 = (unsigned)lane * 16u;
-    // ring of fragments: CK = 32 two slots (one computing, one in flight); CK = 64 one slot per k-step of a tap, each refilled with the
-    // NEXT tap's fragment right after its use: three k-steps (3 x 32 MI NI cycles of MFMA issue) ahead of an L2 round trip of 500+
-    u32x4 ar[KS == 4 ? 4 : 2][MI];
+    // ring of four fragments, each refilled right after its use with the fragment four k-steps on: three k-steps (3 x 32 MI NI cycles of
+    // MFMA issue) ahead of an L2 round trip of 500+.  CK = 64: a slot per k-step of a tap.  CK = 32 (two k-steps per tap): the taps of the
+    // whole tile are walked in PAIRS - even tap slots 0, 1, odd tap slots 2, 3 - across chunk boundaries (tap counts are odd).
+    constexpr bool PAIRS = KS == 2 && MI >= 2 && IN_BF && EPI != 1;      // (the other instantiations have no registers for it)
+    u32x4 ar[(KS == 4 || PAIRS) ? 4 : 2][MI];
     auto load_frag = [&](u32x4 (&a)[MI], int ch, int s, int t) {   // k-step s of (chunk ch, tap t); clamped past the end (harmless re-read)
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));                        // keeps the address scalar base + 32-bit lane offset (see v2w_conv_mfma.hip)
@@ -234,6 +236,11 @@ conv_bf16_kernel(const MultiArgs m) {
     if (p.vec4) prefetch(0);
     load_frag(ar[0], 0, 0, 0);
     if constexpr (KS == 4) { load_frag(ar[1], 0, 1, 0); load_frag(ar[2], 0, 2, 0); load_frag(ar[3], 0, 3, 0); }
+    else if constexpr (PAIRS) {
+        load_frag(ar[1], 0, 1, 0);
+        const int c1 = K > 1 ? 0 : 1, t1 = K > 1 ? 1 : 0;   // tap 1 of the tile
+        load_frag(ar[2], c1, 0, t1); load_frag(ar[3], c1, 1, t1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     for (int c = tid; c < MT; c += NTHREADS) {
         etab[c] = p.bias ? p.bias[EPI == 2 ? (m0 + c) / p.up_p : m0 + c] : 0.f;
@@ -242,13 +249,11 @@ conv_bf16_kernel(const MultiArgs m) {
         etab[3 * MT + c] = p.mask_a ? p.mask_a[b * p.Cout + m0 + c] : 1.f;
         etab[4 * MT + c] = p.mask_a ? p.mask_s[b * p.Cout + m0 + c] : 0.f;
     }
-    if (p.in_a) {
-        for (int c = tid; c < p.Cin; c += NTHREADS) {
-            atab[c] = gptr<const float>(p.in_a)[b * p.Cin + c];
-            atab[p.Cin + c] = p.in_s[b * p.Cin + c];
-        }
-        __syncthreads();
+    for (int c = tid; c < p.Cin; c += NTHREADS) {
+        atab[c] = p.in_a ? gptr<const float>(p.in_a)[b * p.Cin + c] : 1.f;
+        atab[p.Cin + c] = p.in_a ? p.in_s[b * p.Cin + c] : 0.f;
     }
+    __syncthreads();
     if (p.vec4) commit(0, smem_b);
     else stage_scalar(0, smem_b);
     __builtin_amdgcn_sched_barrier(0);
@@ -257,6 +262,7 @@ conv_bf16_kernel(const MultiArgs m) {
 
     const int lbase = (wn0 + lr + p.hla - p.hl) * ROWB + 16 * hk;     // this lane's 16 bytes in the row of (its column, tap 0), k-step 0
     const int step = p.dil * ROWB;
+    if constexpr (!PAIRS) {
     for (int ch = 0; ch < nch; ++ch) {
         const unsigned char* Xs = smem_b + (ch & 1) * bufsz;
         unsigned char* Xn = smem_b + ((ch + 1) & 1) * bufsz;
@@ -315,6 +321,63 @@ conv_bf16_kernel(const MultiArgs m) {
             if (ch < 6) V2W_STAMP(5 + 4 * ch);
         }
     }
+    } else {
+        // ---- CK = 32: the tile's nch * K taps in pairs
+        int ch = 0, t = 0;                                   // the running tap
+        int qc = 0, qt = 2;                                  // the tap two ahead of it (whose fragments the running tap requests)
+        while (qt >= K) { qt -= K; ++qc; }
+#ifndef V2W_BF_ABL_NOCOMMIT
+        if (nch > 1 && p.vec4) prefetch(CK);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        V2W_STAMP(2);
+        const unsigned char* xt = smem_b + lbase;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(xt + j * 32 * ROWB);
+        auto tap = [&](auto par_c) {
+            constexpr int S0 = 2 * decltype(par_c)::value;
+            const bool last = t + 1 >= K;
+            kstep(ar[S0], xt + 32);
+#ifndef V2W_BF_ABL_NOFRAG
+            load_frag(ar[S0], qc, 0, qt);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(ar[S0 + 1], last ? xt : xt + step);
+#ifndef V2W_BF_ABL_NOFRAG
+            load_frag(ar[S0 + 1], qc, 1, qt);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (++qt >= K) { qt = 0; ++qc; }
+            if (!last) { ++t; xt += step; return; }
+            // ---- chunk boundary (touches neither the accumulators nor the ring)
+            if (ch < 6) V2W_STAMP(3 + 4 * ch);
+            const bool more = ch + 1 < nch;
+            if (more) {
+#ifndef V2W_BF_ABL_NOCOMMIT
+                if (p.vec4) commit((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
+                else stage_scalar((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
+#endif
+                if (ch < 6) V2W_STAMP(4 + 4 * ch);
+                __syncthreads();
+                if (ch < 6) V2W_STAMP(5 + 4 * ch);
+            }
+            ++ch; t = 0;
+            if (ch < nch) {
+#ifndef V2W_BF_ABL_NOCOMMIT
+                if (ch + 1 < nch && p.vec4) prefetch((ch + 1) * CK);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch < 6) V2W_STAMP(2 + 4 * ch);
+                xt = smem_b + (ch & 1) * bufsz + lbase;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(xt + j * 32 * ROWB);
+            }
+        };
+        const int TT = nch * K;
+        int g = 0;
+        for (; g + 1 < TT; g += 2) { tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); }
+        if (g < TT) tap(std::integral_constant<int, 0>{});
+    }
     V2W_STAMP(26);
 #ifdef V2W_BF_ABL_NOEPI
     {
@@ -339,7 +402,7 @@ conv_bf16_kernel(const MultiArgs m) {
         const int nco = 32 / UP;                           // channels per 32-row block
         const int ORS = U * 64, C4 = U * 16;               // scratch row (floats), float4s per row
         const int Lout = L * U;
-        float* const red = atab + (p.in_a ? 2 * p.Cin : 0);    // [WN][MT / UP][2] partial sums of this workgroup's waves
+        float* const red = atab + 2 * p.Cin;                   // [WN][MT / UP][2] partial sums of this workgroup's waves
         __syncthreads();
         float* const scr = reinterpret_cast<float*>(smem_b) + wave * 2048;
         for (int c = lane; c < (MI * 32 / UP) * 2; c += 64) red[((wave % WN) * (MT / UP) + (wm0 / UP)) * 2 + c] = 0.f;
@@ -736,7 +799,7 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
         p.atab_off = tab;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         p.evec = p.L % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
-        const size_t l = ((size_t)tab + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        const size_t l = ((size_t)tab + 5 * MT + 2 * p.Cin) * sizeof(float);
         if (l > lds) lds = l;
         if (p.mask_src) epi = 1;
         m.p[i] = p;
@@ -816,7 +879,7 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
     int tab = nbuf * p.xrows * V2W_BF_ROWB / 4;
     if (tab < WM * WN * 2048) tab = WM * WN * 2048;
     p.atab_off = tab;
-    const size_t lds = ((size_t)tab + 5 * MT + WN * (MT / p.up_p) * 2) * sizeof(float);
+    const size_t lds = ((size_t)tab + 5 * MT + 2 * p.Cin + WN * (MT / p.up_p) * 2) * sizeof(float);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     MultiArgs m{};
     m.p[0] = p;

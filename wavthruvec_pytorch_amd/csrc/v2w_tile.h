@@ -44,17 +44,21 @@ struct TileArgs {
 // kernel-argument segment - which the register allocator treats as free to repeat: short of SGPRs it re-issues the load at each use,
 // inside the staging and epilogue loops, each time followed by an s_waitcnt lgkmcnt(0) that also drains the wave's LDS queue
 // (conv_bf16_kernel: 341 s_loads, 12 of them serialised in front of the 12 loads of a chunk prefetch).  pinned_tile_args() returns a
-// copy whose hot fields went through an opaque asm and therefore live in registers (SGPRs, or VGPR lanes when those run out).
-// A pointer that went through the asm is a GENERIC pointer to the compiler (flat_load: counts against vmcnt AND lgkmcnt); every
+// copy whose hot fields went through v_readfirstlane and therefore live in registers (SGPRs, or VGPR lanes when those run out).
+// A pointer rebuilt from its two halves is a GENERIC pointer to the compiler (flat_load: counts against vmcnt AND lgkmcnt); every
 // access through a pinned pointer goes through gptr<T>(), which names the global address space again.
-template <typename T> __device__ __forceinline__ void pin_s(T& v) { asm volatile("" : "+s"(v)); }
+// (v_readfirstlane of the loaded value: its result is a scalar register the compiler neither re-materialises nor - unlike the
+// result of an opaque asm - treats as possibly divergent)
+__device__ __forceinline__ void pin_s(int& v) { v = __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void pin_s(float& v) { v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <typename T> __device__ __forceinline__ void pin_s(T*& v) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    v = reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 template <typename T> using global_ptr = T __attribute__((address_space(1)))*;
 template <typename T, typename U> __device__ __forceinline__ global_ptr<T> gptr(U* q) { return (global_ptr<T>)q; }
-__device__ __forceinline__ void pin_s(float& v) {
-    int t = __builtin_bit_cast(int, v);
-    asm volatile("" : "+s"(t));
-    v = __builtin_bit_cast(float, t);
-}
 __device__ __forceinline__ TileArgs pinned_tile_args(const TileArgs& g) {
     TileArgs p = g;
     pin_s(p.in); pin_s(p.in_a); pin_s(p.wp); pin_s(p.wps); pin_s(p.res); pin_s(p.add0); pin_s(p.add1); pin_s(p.mask_src); pin_s(p.out);
