@@ -49,7 +49,11 @@ __device__ __forceinline__ u32x2 f32_to_bf4(f32x4 v) { return u32x2{pack_bf16x2(
 // IN_BF / OUT_BF: activation STORAGE in bf16 (`in`; `out`, `res`, `add0`, `add1`): 8-byte loads / stores of 4 positions instead of 16.
 // CKT: channels per chunk.  32 (two k-steps per tap); 64 for the C_in = 64 layers, which then are ONE chunk: no chunk loop, twice the
 // bytes in flight while the tile is staged (a 64-channel layer as two chunks spent 85 % of its tile time outside the MFMA phases).
-template <int MI, int NI, int WM, int WN, int NPF, int EPI, bool IN_BF, bool OUT_BF, int CKT = V2W_BF_CK>
+// VEC: float4-aligned input (L % 4 == 0, 16-byte aligned base) - the vector staging path.  A template parameter, not a run-time flag:
+// with the element-wise fallback in the same kernel its (never taken) loads sit on a path that joins the hot one, and hipcc then waits
+// vmcnt(0) at the join - once in front of every chunk's prefetch (for the fragment loads in flight) and once right after it (for the
+// prefetch itself: a full memory latency per chunk, in the open).
+template <int MI, int NI, int WM, int WN, int NPF, int EPI, bool IN_BF, bool OUT_BF, int CKT = V2W_BF_CK, bool VEC = true>
 __global__ void __launch_bounds__(64 * WM * WN, MI * NI >= 8 ? 2 : 3)      // (128 x 256: two workgroups per CU = at most 256 registers; else three)
 conv_bf16_kernel(const MultiArgs m) {
     typedef Frag<32> F;
@@ -233,7 +237,7 @@ conv_bf16_kernel(const MultiArgs m) {
     };
 
     // ---- prologue: the loads that do not depend on LDS go out first (chunk 0 of the signal, the first fragments)
-    if (p.vec4) prefetch(0);
+    if constexpr (VEC) prefetch(0);
     load_frag(ar[0], 0, 0, 0);
     if constexpr (KS == 4) { load_frag(ar[1], 0, 1, 0); load_frag(ar[2], 0, 2, 0); load_frag(ar[3], 0, 3, 0); }
     else if constexpr (PAIRS) {
@@ -254,7 +258,7 @@ conv_bf16_kernel(const MultiArgs m) {
         atab[p.Cin + c] = p.in_a ? p.in_s[b * p.Cin + c] : 0.f;
     }
     __syncthreads();
-    if (p.vec4) commit(0, smem_b);
+    if constexpr (VEC) commit(0, smem_b);
     else stage_scalar(0, smem_b);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -268,7 +272,7 @@ conv_bf16_kernel(const MultiArgs m) {
         unsigned char* Xn = smem_b + ((ch + 1) & 1) * bufsz;
         const bool more = ch + 1 < nch;
 #ifndef V2W_BF_ABL_NOCOMMIT
-        if (more && p.vec4) prefetch((ch + 1) * CK);
+        if constexpr (VEC) { if (more) prefetch((ch + 1) * CK); }
 #endif
         __builtin_amdgcn_sched_barrier(0);
         if (ch < 6) V2W_STAMP(2 + 4 * ch);
@@ -313,7 +317,7 @@ conv_bf16_kernel(const MultiArgs m) {
         if (ch < 6) V2W_STAMP(3 + 4 * ch);
         if (more) {
 #ifndef V2W_BF_ABL_NOCOMMIT
-            if (p.vec4) commit((ch + 1) * CK, Xn);
+            if constexpr (VEC) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
 #endif
             if (ch < 6) V2W_STAMP(4 + 4 * ch);
@@ -327,7 +331,7 @@ conv_bf16_kernel(const MultiArgs m) {
         int qc = 0, qt = 2;                                  // the tap two ahead of it (whose fragments the running tap requests)
         while (qt >= K) { qt -= K; ++qc; }
 #ifndef V2W_BF_ABL_NOCOMMIT
-        if (nch > 1 && p.vec4) prefetch(CK);
+        if constexpr (VEC) { if (nch > 1) prefetch(CK); }
 #endif
         __builtin_amdgcn_sched_barrier(0);
         V2W_STAMP(2);
@@ -354,7 +358,7 @@ conv_bf16_kernel(const MultiArgs m) {
             const bool more = ch + 1 < nch;
             if (more) {
 #ifndef V2W_BF_ABL_NOCOMMIT
-                if (p.vec4) commit((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
+                if constexpr (VEC) commit((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
                 else stage_scalar((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
 #endif
                 if (ch < 6) V2W_STAMP(4 + 4 * ch);
@@ -364,7 +368,7 @@ conv_bf16_kernel(const MultiArgs m) {
             ++ch; t = 0;
             if (ch < nch) {
 #ifndef V2W_BF_ABL_NOCOMMIT
-                if (ch + 1 < nch && p.vec4) prefetch((ch + 1) * CK);
+                if constexpr (VEC) { if (ch + 1 < nch) prefetch((ch + 1) * CK); }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (ch < 6) V2W_STAMP(2 + 4 * ch);
@@ -776,7 +780,7 @@ conv_bf16_kernel(const MultiArgs m) {
     V2W_STAMP(27);
 }
 
-template <int MI, int NI, int WM, int WN, int CK = V2W_BF_CK>
+template <int MI, int NI, int WM, int WN, int CK = V2W_BF_CK, bool VEC = true>
 int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32, ROWB = 2 * CK + 16;
     constexpr int NPF = ((CK / 4) * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
@@ -793,6 +797,7 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
         p.ntiles = p.B * p.ntl;
         p.xrows = (p.hla + NT + p.hr + 3) & ~3;
         p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
+        if (VEC && !p.vec4) return V2W_E_ARG;                  // (the dispatcher sends unaligned inputs to the VEC = false instantiation)
         const int nbuf = p.Cin / CK > 1 ? 2 : 1;
         int tab = nbuf * p.xrows * ROWB / 4;                        // float index of the tables, after the signal buffers ...
         if (tab < WM * WN * 32 * 64) tab = WM * WN * 32 * 64;              // ... and after the epilogue scratch that overlays them
@@ -812,10 +817,10 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     const int io = m.p[0].io_bf16;
     for (int i = 1; i < nprob; ++i) if (m.p[i].io_bf16 != io) return V2W_E_ARG;      // one instantiation per launch
     if (io == 1 || (epi && io != 0)) return V2W_E_SHAPE;     // bf16 in with fp32 out does not occur on the path; the mask epilogue is fp32-only
-    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false, CK>
-              : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false, CK>
-              : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true, CK>
-                        : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true, CK>;
+    auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false, CK, VEC>
+              : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false, CK, VEC>
+              : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true, CK, VEC>
+                        : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true, CK, VEC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -862,7 +867,7 @@ static ConvtGeom convt_geom(int k, int u) {
     return g;
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, bool VEC = true>
 int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32;
     constexpr int NPF = (8 * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
@@ -888,7 +893,8 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
     m.start[1] = grid;
     for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     if (p.io_bf16 != 0 && p.io_bf16 != 3) return V2W_E_SHAPE;
-    auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false>;
+    if (VEC && !p.vec4) return V2W_E_ARG;
+    auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true, V2W_BF_CK, VEC> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false, V2W_BF_CK, VEC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -907,6 +913,15 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out * g.UP; p.L = a->L; p.K = g.KV; p.dil = 1;
     p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP; p.io_bf16 = a->io_bf16;
     const int rows = p.Cout;
+    // the stats tiling (rows of stats_part) depends on the tile width only: every configuration here is 256 or 512 positions wide, the
+    // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin
+    const bool vec = (a->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->in) & 15) == 0);
+    if (!vec && !ntiles_out) {
+        if (rows % 64 == 0 && !(rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512)) return launch_bf16_convt<1, 4, 2, 2, false>(p, stream, ntiles_out);
+        if (rows % 128 == 0) return launch_bf16_convt<2, 4, 2, 2, false>(p, stream, ntiles_out);
+        if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4, false>(p, stream, ntiles_out);
+        return V2W_E_SHAPE;
+    }
     if (rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512) return launch_bf16_convt<2, 4, 2, 2>(p, stream, ntiles_out);
     if (rows % 64 == 0) return launch_bf16_convt<1, 4, 2, 2>(p, stream, ntiles_out);
     if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4>(p, stream, ntiles_out);
@@ -943,6 +958,8 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
         ps[i] = p;
         tiles += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 64);
     }
+    for (int i = 0; i < n; ++i)          // unaligned input or L % 4 != 0: element-wise staging, one small-tile instantiation serves every shape
+        if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0) return launch_bf16<1, 2, 2, 2, V2W_BF_CK, false>(ps, n, stream);
     if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream);     // 128 x 256
     if (tiles >= 256 && a->C_in == 64 && a->io_bf16 == 3) return launch_bf16<1, 4, 2, 2, 64>(ps, n, stream);   // 64 x 256, bf16 tensors: the 64 input channels as ONE chunk
     if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream);                                 // 64 x 256
