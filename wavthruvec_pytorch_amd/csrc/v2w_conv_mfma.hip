@@ -58,7 +58,10 @@ template <int MF, int CK> struct TileGeom {
 // its own instantiation.  2 = out_slope only (the discriminators' activated feature maps): no extra registers.
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 128 x 128 conv tile runs three
 // workgroups per CU - its LDS footprint allows exactly that - and would otherwise drift to 2 through the epilogue's temporaries)
-template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, int EPI>
+// VEC: every problem of the launch has float4-aligned, unit-stride input (the vector staging path).  A template parameter, not a
+// run-time flag: with the element-wise fallback in the same kernel its (never taken) loads join the hot path, and hipcc then waits
+// vmcnt(0) in front of every chunk's prefetch and again right behind it - the prefetch's memory latency in the open, once per chunk.
+template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int NPF, int RING, int EPI, bool VEC>
 __global__ void __launch_bounds__(64 * WM * WN, (U == 1 && MI * NI >= 4) ? 3 : 1)
 conv_tile_kernel(const MultiArgs m) {
     typedef Frag<MF> F;
@@ -276,7 +279,7 @@ conv_tile_kernel(const MultiArgs m) {
         }
         __syncthreads();
     }
-    if (p.vec4) { prefetch(ch0 * CK); commit(ch0 * CK, smem); }
+    if constexpr (VEC) { prefetch(ch0 * CK); commit(ch0 * CK, smem); }
     else stage_scalar(ch0 * CK, smem);
 #pragma unroll
     for (int g = 0; g + 1 < RING; ++g) load_next(ar[g]);
@@ -291,7 +294,7 @@ conv_tile_kernel(const MultiArgs m) {
         const float* Xs = smem + ((ch - ch0) & 1) * bufsz;
         float* Xn = smem + ((ch - ch0 + 1) & 1) * bufsz;
         const bool more = ch + 1 < ch1;
-        if (more && p.vec4) prefetch((ch + 1) * CK);   // in flight during the MFMA phase below
+        if constexpr (VEC) { if (more) prefetch((ch + 1) * CK); }   // in flight during the MFMA phase below
         __builtin_amdgcn_sched_barrier(0);
         if (ch - ch0 < 6) V2W_STAMP(2 + 4 * (ch - ch0));
 
@@ -336,7 +339,7 @@ conv_tile_kernel(const MultiArgs m) {
 
         if (ch - ch0 < 6) V2W_STAMP(3 + 4 * (ch - ch0));
         if (more) {
-            if (p.vec4) commit((ch + 1) * CK, Xn);
+            if constexpr (VEC) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
             if (ch - ch0 < 6) V2W_STAMP(4 + 4 * (ch - ch0));
             __syncthreads();   // Xn complete for the next iteration; everyone done with Xs before it is overwritten again
@@ -738,8 +741,12 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
             }
         }
     }
-    auto kern = epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1>
-              : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0>);
+    bool vec = true;
+    for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
+    auto kern = vec ? (epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1, true>
+                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, true>))
+                    : (epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1, false>
+                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, false> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, false>));
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
