@@ -319,7 +319,8 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
         rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
     if rc != 0:
         return None
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0>'   # forward instantiation (EPI = 0: no optional epilogue)
+    # forward instantiation (EPI = 0: no optional epilogue) with vector staging (VEC: L % 4 == 0, aligned unit-stride input)
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, ' + ('true' if L % 4 == 0 else 'false') + '>'
 
 
 def convt_stats_tiles(B, c_in, c_out, L, k, u):
