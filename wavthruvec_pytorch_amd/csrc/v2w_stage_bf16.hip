@@ -73,6 +73,7 @@ stage_bf16_kernel(const StageBfArgs p) {
     unsigned char* const Ta = smem_b + p.xrows * ROWB;                 // [W][ROWB]      lrelu(t1_j); conv2's taps reach h2max rows past either end
     float* const etab = reinterpret_cast<float*>(Ta + (W + p.h2max) * ROWB);   // bias1[nk][C], bias2[nk][C], then in_a[C], in_s[C] of this batch item
     float* const atab = etab + 2 * V2W_SB_MAXB * C;
+    unsigned char* const Wl = reinterpret_cast<unsigned char*>(atab + 2 * C);   // [K * KS][1 KiB]: the running conv's weight fragments, in the order it consumes them
     const int pos0 = n0 - p.h2max - p.h1max - p.xoff;                  // position of X row 0 (multiple of 4)
     const int xc0 = p.xoff + p.h1max;                                  // X row of window column 0 (position n0 - h2max)
 
@@ -187,22 +188,34 @@ stage_bf16_kernel(const StageBfArgs p) {
         }
     }
 
-    // ---- one conv phase.  The K * KS weight fragments of a conv live in registers through it; the NEXT conv's fragments are requested
-    // into the same registers as they fall free - tap t right after the MFMAs of tap t, taps past this conv's K at its start - so that
-    // a conv never starts with an L2 round trip in front of its first MFMA (6 x ~2 k cycles of a 62 k-cycle tile).  The tap loop is
-    // unrolled to KMAX with uniform guards.  `x0`: this lane's 16 bytes in the row of (its column, tap 0), k-step 0.
+    // ---- weights.  Every wave of the workgroup - and every workgroup of the launch - needs the same fragments: fetched per wave into
+    // registers (336 KB per tile against 28 KB of signal; 7 TB/s of L2 traffic over the launch) each conv phase began with an L2 round
+    // trip of ~5 k cycles.  Now each wave fetches a QUARTER of the next conv's fragments into registers while the current conv runs,
+    // the workgroup assembles them in LDS between two convs (in consumption order: tap-major) and the MFMA loop reads its A operand
+    // with ds_read_b128 at immediate offsets, two k-steps ahead like the B operand.
     acc_t acc[NI];
     const unsigned lane16 = (unsigned)lane * 16u;
-    u32x4 wr[KMAX][KS];
-    auto request = [&](int t, const unsigned char* wbase, int K) {          // tap t of a conv with K taps -> wr[t]
+    constexpr int NWL = (KMAX * KS + 3) / 4;                 // fragments a wave fetches per conv
+    u32x4 wl[NWL];
+    auto wload = [&](const unsigned char* wbase, int K) {    // unconditional loads (past the end: the last fragment again)
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));
 #pragma unroll
-        for (int s = 0; s < KS; ++s) wr[t][s] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(s * K + t) * V2W_SB_UNIT + l16);
+        for (int i = 0; i < NWL; ++i) {
+            const int v = wave + 4 * i;                      // consumption-order index: tap v / KS, k-step v % KS
+            const int vc = v < K * KS ? v : K * KS - 1;
+            wl[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)((vc % KS) * K + vc / KS) * V2W_SB_UNIT + l16);
+        }
     };
-    // B operands two k-steps ahead (an LDS read issued one k-step = NI MFMAs = 64 cycles ahead is not back when it is needed).
-    auto conv = [&](int K, const unsigned char* x0, int step, const float* bias, const unsigned char* wnext, int Knext,
-                    const unsigned char* wextra, int Kextra) {
+    auto wstore = [&](int K) {
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int v = wave + 4 * i;
+            if (v < K * KS) *reinterpret_cast<u32x4*>(Wl + v * 1024 + lane16) = wl[i];
+        }
+    };
+    // `x0`: this lane's 16 bytes in the row of (its column, tap 0), k-step 0.  The tap loop is unrolled to KMAX with uniform guards.
+    auto conv = [&](int K, const unsigned char* x0, int step, const float* bias) {
         // accumulators start at the bias (rows >= C of the 32-row MFMA are padding: they start, and stay, at 0)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -210,17 +223,21 @@ stage_bf16_kernel(const StageBfArgs p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[j][e] = bv;
         }
-        // k-step q = t * KS + s reads rows x0 + t * step at byte 32 s; bb[q & 1] holds it, refilled with k-step q + 2 after its MFMAs
+        // k-step q = t * KS + s reads rows x0 + t * step at byte 32 s and fragment q; bb[q & 1] / wa[q & 1] hold them, refilled with
+        // k-step q + 2 after its MFMAs (an LDS read issued one k-step = NI MFMAs = 64 cycles ahead is not back when it is needed)
         auto rows = [&](int q) {
             const int t = q / KS, sq = q % KS;
             const int tc = t < K ? t : K - 1;                 // past the end: a valid (unused) address
             return x0 + tc * step + 32 * sq;
         };
-        u32x4 bb[2][NI];
+        const unsigned char* const wq = Wl + lane16;
+        u32x4 bb[2][NI], wa[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q) {
+            wa[q] = *reinterpret_cast<const u32x4*>(wq + q * 1024);
 #pragma unroll
             for (int j = 0; j < NI; ++j) bb[q][j] = *reinterpret_cast<const u32x4*>(rows(q) + j * 32 * ROWB);
+        }
 #pragma unroll
         for (int t = 0; t < KMAX; ++t) {
             if (t < K) {
@@ -230,25 +247,21 @@ stage_bf16_kernel(const StageBfArgs p) {
                     const unsigned char* nxt = rows(q + 2);
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wr[t][s]), __builtin_bit_cast(b8, bb[q & 1][j]), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wa[q & 1]), __builtin_bit_cast(b8, bb[q & 1][j]), acc[j], 0, 0, 0);
                         bb[q & 1][j] = *reinterpret_cast<const u32x4*>(nxt + j * 32 * ROWB);
                     }
+                    wa[q & 1] = *reinterpret_cast<const u32x4*>(wq + (q + 2 < KMAX * KS ? q + 2 : q) * 1024);   // (stale past K * KS: unused)
                 }
-                if (t < Knext) request(t, wnext, Knext);
             }
         }
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t)
-            if (t >= K && t < Kextra) request(t, wextra, Kextra);      // (registers this conv and the next do not use)
     };
-#pragma unroll
-    for (int t = 0; t < KMAX; ++t)
-        if (t < p.K[0]) request(t, p.w1[0], p.K[0]);
+    wload(p.w1[0], p.K[0]);
 
     float t1r[NI][NR], oacc[NI][NR];
     const unsigned char* const xl = Xa + (wn0 + lr) * ROWB + 16 * hk;
     const unsigned char* const tl = Ta + (wn0 + lr) * ROWB + 16 * hk;
     V2W_STAMP(2);
+    wstore(p.K[0]);
     __syncthreads();
     V2W_STAMP(3);
     if (raw_tile) {
@@ -275,7 +288,8 @@ stage_bf16_kernel(const StageBfArgs p) {
         const bool more = jb + 1 < p.nk;
 
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col
-        conv(K, xl + (xc0 - h1) * ROWB, d1 * ROWB, etab + jb * C, p.w2[jb], K, more ? p.w1[jb + 1] : p.w1[jb], more ? p.K[jb + 1] : 0);
+        wload(p.w2[jb], K);                                  // conv2_j's fragments travel while conv1_j computes
+        conv(K, xl + (xc0 - h1) * ROWB, d1 * ROWB, etab + jb * C);
         V2W_STAMP(4 + 5 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -297,12 +311,14 @@ stage_bf16_kernel(const StageBfArgs p) {
                 *reinterpret_cast<u32x2*>(row + 2 * (8 * g4 + 4 * hk)) = u32x2{sb_pack2(a[0], a[1]), sb_pack2(a[2], a[3])};
             }
         }
+        wstore(K);                                           // (every wave is past conv1_j: the barrier above)
         V2W_STAMP(6 + 5 * jb);
         __syncthreads();
         V2W_STAMP(7 + 5 * jb);
 
         // ---- conv2_j on the same window ; r_j = (acc + b2) + t1_j ; branch sum in the reference's order
-        conv(K, tl - h2 * ROWB, d2 * ROWB, etab + V2W_SB_MAXB * C + jb * C, more ? p.w1[jb + 1] : p.w1[jb], more ? p.K[jb + 1] : 0, p.w1[jb], 0);
+        if (more) wload(p.w1[jb + 1], p.K[jb + 1]);
+        conv(K, tl - h2 * ROWB, d2 * ROWB, etab + V2W_SB_MAXB * C + jb * C);
         V2W_STAMP(8 + 5 * jb);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -311,6 +327,11 @@ stage_bf16_kernel(const StageBfArgs p) {
                 const float r = acc[j][e] + t1r[j][e];
                 oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
             }
+        if (more) {                                          // the next branch's conv1 fragments: every wave is done with this conv's
+            __syncthreads();
+            wstore(p.K[jb + 1]);
+            __syncthreads();
+        }
     }
 
     // ---- store through an aligned fp32 LDS scratch [C][W + 4] (both tiles are dead), float4s along positions
@@ -389,7 +410,9 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
     p.ntl = (q->L + p.nto - 1) / p.nto;
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
     p.vec4 = (q->L % 4 == 0) && al16(q->in) && al16(q->out);
-    size_t lds = (size_t)(p.xrows + W + p.h2max) * ROWB + (2 * V2W_SB_MAXB + 2) * C * sizeof(float);
+    int kmax = 0;
+    for (int j = 0; j < q->nk; ++j) if (q->k[j] > kmax) kmax = q->k[j];
+    size_t lds = (size_t)(p.xrows + W + p.h2max) * ROWB + (2 * V2W_SB_MAXB + 2) * C * sizeof(float) + (size_t)kmax * (C / 16) * 1024;
     const size_t scr = (size_t)C * (W + 4) * sizeof(float);           // the store scratch overlays the tiles
     if (lds < scr) lds = scr;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
