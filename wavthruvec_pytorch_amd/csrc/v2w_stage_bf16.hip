@@ -78,15 +78,17 @@ stage_bf16_kernel(const StageBfArgs p) {
     const int xc0 = p.xoff + p.h1max;                                  // X row of window column 0 (position n0 - h2max)
 
     V2W_STAMP(0);
-    for (int i = tid; i < p.nk * C; i += NTHREADS) {
-        const int j = i / C, c = i - j * C;
-        etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
-        etab[V2W_SB_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
-    }
-    for (int c = tid; c < C; c += NTHREADS) {
-        atab[c] = p.in_a ? p.in_a[b * C + c] : 1.f;
-        atab[C + c] = p.in_s ? p.in_s[b * C + c] : 0.f;
-    }
+    auto fill_tables = [&]() {                 // (called AFTER the signal loads are out: a load -> LDS store round trip of its own)
+        for (int i = tid; i < p.nk * C; i += NTHREADS) {
+            const int j = i / C, c = i - j * C;
+            etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
+            etab[V2W_SB_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
+        }
+        for (int c = tid; c < C; c += NTHREADS) {
+            atab[c] = p.in_a ? p.in_a[b * C + c] : 1.f;
+            atab[C + c] = p.in_s ? p.in_s[b * C + c] : 0.f;
+        }
+    };
 
     // ---- stage lrelu(a*x + s) as bf16: a thread takes 4 channels x 4 positions (8 bytes per position), the channel quads of one
     // position quad on consecutive lanes (whole rows per 8 / 4 lanes: conflict-free stores)
@@ -115,6 +117,9 @@ stage_bf16_kernel(const StageBfArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[s][i] = *reinterpret_cast<const ld_t*>(inb + (size_t)i * L * ESI + vo);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fill_tables();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int pq = (tid + s * NTHREADS) / NCQ;
@@ -152,6 +157,7 @@ stage_bf16_kernel(const StageBfArgs p) {
             }
         }
     } else {
+        fill_tables();
         for (int i = tid; i < C * p.xrows; i += NTHREADS) {
             const int c = i / p.xrows, r = i - c * p.xrows, pos = pos0 + r;
             float v = 0.f;
