@@ -138,6 +138,11 @@ typedef struct {
     int32_t io_bf16;              /* V2W_ALGO_BF16 only (else must be 0): activation STORAGE in bf16 - BASELINE configs[2] priced at 2 bytes
                                    * per activation.  bit 0: `in` is bf16; bit 1: `out`, `res`, `add0`, `add1` are bf16.
                                    * Accumulation, bias, affines and the residual arithmetic stay fp32; one rounding at the store. */
+    float*  rowsum_part;          /* optional, masked (mask_src != NULL) f32 MFMA launches with float4-aligned operands only: the launch also
+                                   * writes, per position tile and output channel, (sum of the values it stored, 0) to
+                                   * rowsum_part[tile][C_out][2] - tiles = v2w_conv1d_tile_config()[9] - for v2w_bn_reduce_partials to add up:
+                                   * the bias gradient of the layer whose output gradient this launch produces (backward of models.py:65-70)
+                                   * without another pass over the tensor.  V2W_E_ARG when the launch cannot provide it. */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):

@@ -255,6 +255,39 @@ def test_conv1d_split_over_cin_matches_the_unsplit_kernel(dev, B, cin, cout, L, 
     assert (outs[0] - outs[2]).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize('B,C,L,k,dil,nprob', [(4, 128, 1280, 7, 3, 3), (3, 64, 2052, 3, 1, 2), (2, 256, 520, 11, 1, 1), (4, 32, 4096, 7, 1, 3)])
+def test_conv1d_masked_launch_row_sums(dev, B, C, L, k, dil, nprob):
+    """rowsum_part: a masked (input-gradient) launch also writes per-tile channel sums of what it stores - the bias gradient of the layer
+    whose output gradient it produces (backward of models.py:65-70) - which bn_reduce_partials adds up: == the sum of its own output."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(51)
+    dy = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    ntile = hipops.conv_rowsum_tiles(B, nprob, C, C, L, 3)
+    assert ntile > 0
+    probs, parts, outs = [], [], []
+    for q in range(nprob):
+        wf = _t(_relayout(torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))).numpy(), dev)
+        msk = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+        out = torch.full((B, C, L), float('nan'), device=dev)
+        part = torch.full((ntile * C * 2,), float('nan'), device=dev)
+        probs.append((dy, None, None, out, dict(k=k, dil=dil, slope=1.0, res=dy, mask=(msk, None), mask_slope=0.1, wp=hipops.pack_mfma(wf),
+                                               algo=hipops.ALGO_MFMA, rowsum=part)))
+        parts.append(part); outs.append(out)
+    if nprob > 1:
+        hipops.conv1d_multi(probs)
+    else:
+        hipops.conv1d(*probs[0][:4], **probs[0][4])
+    for part, out in zip(parts, outs):
+        st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
+        hipops.bn_reduce_partials(part, ntile, C, B * L, st)
+        want = out.double().sum((0, 2))
+        assert torch.isfinite(out).all()
+        assert (st[:C] - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()) + 2e-3
+    from wavthruvec_pytorch_amd._hip import HipLibraryError
+    with pytest.raises(HipLibraryError):          # no mask: not an input-gradient launch
+        hipops.conv1d(dy, None, None, outs[0], k=k, dil=dil, wp=probs[0][4]['wp'], algo=hipops.ALGO_MFMA, rowsum=parts[0])
+
+
 @pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 512, 256, 50, 11, 5), (2, 256, 128, 264, 8, 4), (3, 128, 64, 1000, 8, 4),
                                               (2, 64, 32, 2052, 4, 2), (2, 32, 16, 4100, 4, 2), (1, 64, 32, 37, 4, 2),
                                               (2, 1024, 512, 40, 16, 8)])

@@ -29,7 +29,7 @@ class Conv1dArgs(C.Structure):
                 ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
                 ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32),
                 ('wps', _fp), ('winv', _fp), ('in_ct', C.c_int32), ('out_ct', C.c_int32), ('out_slope', C.c_float),
-                ('io_bf16', C.c_int32)]
+                ('io_bf16', C.c_int32), ('rowsum_part', _fp)]
 
 
 class ConvT1dArgs(C.Structure):

@@ -112,9 +112,12 @@ def generator_backward(gen, sv, dy):
             p2 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1']) for j in range(nk)]
             p1 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0']) for j in range(nk)]
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
+            # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
+            ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, 3) if Lo % 4 == 0 else 0
+            rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
             hipops.conv1d_multi([(dr, None, None, dt1s[j],
                                   dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, res=dr, mask=(t1s[j], None),
-                                       mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA)) for j in order])
+                                       mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA, rowsum=rsp[j])) for j in order])
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx = sum_j dt1_j + lrelu'(x) * conv(dt1_j; W1^T flipped)
             parts = [torch.empty_like(dr) for _ in range(nk - 1)]
 
@@ -130,7 +133,12 @@ def generator_backward(gen, sv, dy):
                 _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
                 grads[names[j] + '.convs.1.bias'] = db2
                 _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
-                grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+                if ntile:
+                    st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
+                    hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
+                    grads[names[j] + '.convs.0.bias'] = st[:C].float()
+                else:
+                    grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
         for j in range(nk if not merged else 0):
             rb = gen.resblocks[i * nk + j]
             name = f'resblocks.{i * nk + j}'

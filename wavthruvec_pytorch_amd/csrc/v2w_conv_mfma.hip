@@ -366,6 +366,7 @@ conv_tile_kernel(const MultiArgs m) {
         __syncthreads();                           // every wave is done with the signal tiles
         float* const scr = smem + wave * (MF * ERS);
         const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
+        float* const rsum = atab + (p.in_a ? 2 * p.Cin : 0);      // MASK + stats_part: [WN][MT] row sums of the waves (behind the tables)
         // the common forward cases - no addend or only the residual - request ALL their residual float4s of a row block before the
         // block's LDS transposition, so one memory round trip per row block overlaps the LDS traffic; the rarer combinations
         // (running sum, two addends, mask) go GV float4s at a time
@@ -454,6 +455,16 @@ conv_tile_kernel(const MultiArgs m) {
                             v[x] = t;
                         }
                         if (n0 + wn0 + 4 * c4 < L) *reinterpret_cast<f32x4*>(outp + gbase + (size_t)row * L + 4 * c4) = v;
+                        if constexpr (MASK) {
+                            // per-channel sum of what this launch stores (the bias gradient of the layer whose output gradient it is):
+                            // the C4 lanes that share a row meet in a shuffle tree, the row's first lane parks the sum in LDS
+                            if (p.stats_part) {
+                                float sr = n0 + wn0 + 4 * c4 < L ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+#pragma unroll
+                                for (int off = 1; off < C4; off <<= 1) sr += __shfl_xor(sr, off, 64);
+                                if (c4 == 0) rsum[(wave % WN) * MT + col] = sr;
+                            }
+                        }
                     }
                 }
             } else {                               // ragged L / unaligned operands: the same walk, one element at a time
@@ -478,6 +489,18 @@ conv_tile_kernel(const MultiArgs m) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MASK) {
+            if (p.stats_part) {                   // [tile][Cout][2] = (sum of the stored values over the tile's positions, 0): bn_reduce_partials adds the tiles
+                __syncthreads();
+                for (int c = tid; c < MT; c += NTHREADS) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) t += rsum[w * MT + c];
+                    p.stats_part[((size_t)tile * p.Cout + m0 + c) * 2 + 0] = t;
+                    p.stats_part[((size_t)tile * p.Cout + m0 + c) * 2 + 1] = 0.f;
+                }
+            }
         }
     } else {
 #pragma unroll
@@ -678,6 +701,10 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
         p.evec = U == 1 && p.L % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1) && al16(p.mask_src);
         if (U == 1 && p.atab_off < WM * WN * MF * MF * NI) p.atab_off = WM * WN * MF * MF * NI;   // room for the epilogue scratch
         size_t l = ((size_t)p.atab_off + 5 * MT + (p.in_a ? 2 * p.Cin : 0)) * sizeof(float);
+        if (U == 1 && p.stats_part) {                 // row sums of a masked launch (bias gradients): vector epilogue only, [WN][MT] floats behind the tables
+            if (!p.evec || !p.mask_src || p.CoutT != p.Cout) return V2W_E_ARG;
+            l += (size_t)WN * MT * sizeof(float);
+        }
         if (U > 1 && p.stats_part) {                  // the fused BatchNorm partials reuse the signal buffers as [WN][MT][2] scratch
             const size_t need = (size_t)WN * MT * 2 * sizeof(float);
             if ((size_t)p.atab_off * sizeof(float) < need) return V2W_E_SHAPE;
@@ -946,6 +973,7 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         p.res = q->res; p.res_a = q->res_a; p.res_s = q->res_s; p.out = q->out;
         p.add0 = q->add0; p.add1 = q->add1;
         p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
+        p.stats_part = q->rowsum_part;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
         p.CinT = q->in_ct > 0 ? q->in_ct : q->C_in; p.CoutT = q->out_ct > 0 ? q->out_ct : q->C_out;
         p.out_slope = q->out_slope > 0.f ? q->out_slope : 1.f;

@@ -147,11 +147,12 @@ def pack_split(wf, out=None, sc=None, bf16=False):
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
                  accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None, io_bf16=0):
+                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None, io_bf16=0, rowsum=None):
     B, ci, Lx = x.shape
     L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
     co = out.shape[1]
     a.out_slope = out_slope
+    a.rowsum_part = _hip.ptr(rowsum)   # masked f32 MFMA launches: [tiles][C_out][2] per-tile sums of the stored values (bias gradients)
     a.io_bf16 = io_bf16        # ALGO_BF16 only: bit 0 x is bf16, bit 1 out / res / add are bf16 (activation storage of BASELINE configs[2])
     xoff = ooff = 0
     if group is not None:             # (g, C_in per group, C_out per group): this call computes ONE group of a grouped conv
@@ -321,6 +322,16 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
         return None
     # forward instantiation (EPI = 0: no optional epilogue) with vector staging (VEC: L % 4 == 0, aligned unit-stride input)
     return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, ' + ('true' if L % 4 == 0 else 'false') + '>'
+
+
+def conv_rowsum_tiles(B, nprob, c_in, c_out, L, k, dil=1):
+    """Rows of the `rowsum` array a masked f32 MFMA launch of `nprob` problems of this shape fills per problem (0: no tile configuration)."""
+    cfg = (C.c_int32 * 10)()
+    a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B * nprob, c_in, c_out, L, k, dil
+    a.pad_left = -1
+    if _hip.load().v2w_conv1d_tile_config(C.byref(a), cfg) != 0:
+        return 0
+    return cfg[9] // nprob
 
 
 def convt_stats_tiles(B, c_in, c_out, L, k, u):
