@@ -93,12 +93,18 @@ def generator_backward(gen, sv, dy):
         # ---- mean over the nk residual branches: every branch receives dr = dxs / nk
         inv = torch.full((B, C), 1.0 / nk, device=dev)
         zero = torch.zeros((B, C), device=dev)
-        dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
-        db2 = hipops.channel_sum(dr)
-        dx = torch.empty_like(dr)
         from .models import ResBlock1, ResBlock2
         merged = gen.precision == 'f32' and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 and hipops.conv_tile_config(B, C, C, Lo, 3) is not None \
             and all(isinstance(gen.resblocks[i * nk + j], ResBlock2) for j in range(nk))
+        if merged:
+            # dr is never materialised on this path: the gradient convs read dxs through the per-(b, c) affine (1/nk, 0) - operand and
+            # residual - and the quantities that are linear in dr (conv2's weight and bias gradients) are scaled afterwards
+            dr = dxs
+            db2 = hipops.channel_sum(dxs) * (1.0 / nk)
+        else:
+            dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
+            db2 = hipops.channel_sum(dr)
+        dx = torch.empty_like(dxs)
         if merged:
             # ---- ResBlock2, the forward's launch structure mirrored: the three branches' conv2 input gradients in ONE launch, the conv1
             # input gradients of branches 0 .. nk-2 in one launch and the last branch adding them (heaviest kernel size first), so the
@@ -107,7 +113,7 @@ def generator_backward(gen, sv, dy):
             names = [f'resblocks.{i * nk + j}' for j in range(nk)]
             order = sorted(range(nk), key=lambda j: -rbs[j].kernel_size)
             t1s = [ws[f'act.t1_{i}_{j}'] for j in range(nk)]
-            dt1s = [torch.empty_like(dr) for _ in range(nk)]
+            dt1s = [torch.empty_like(dxs) for _ in range(nk)]
             # fragment streams of the gradient convs straight from the forward-layout weights (no transposed copies: C -> C layers)
             p2 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1']) for j in range(nk)]
             p1 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0']) for j in range(nk)]
@@ -115,11 +121,12 @@ def generator_backward(gen, sv, dy):
             # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
             ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, 3) if Lo % 4 == 0 else 0
             rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
-            hipops.conv1d_multi([(dr, None, None, dt1s[j],
-                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, res=dr, mask=(t1s[j], None),
-                                       mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA, rowsum=rsp[j])) for j in order])
+            hipops.conv1d_multi([(dxs, None, None, dt1s[j],
+                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, in_affine=(inv, zero), res=dxs,
+                                       res_affine=(inv, zero), mask=(t1s[j], None), mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA,
+                                       rowsum=rsp[j])) for j in order])
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx = sum_j dt1_j + lrelu'(x) * conv(dt1_j; W1^T flipped)
-            parts = [torch.empty_like(dr) for _ in range(nk - 1)]
+            parts = [torch.empty_like(dxs) for _ in range(nk - 1)]
 
             def dconv1(j, out, **extra):
                 return (dt1s[j], None, None, out,
@@ -130,7 +137,7 @@ def generator_backward(gen, sv, dy):
             for j in range(nk):
                 c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
                 k = rbs[j].kernel_size
-                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
+                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
                 grads[names[j] + '.convs.1.bias'] = db2
                 _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
                 if ntile:
