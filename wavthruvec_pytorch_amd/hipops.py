@@ -147,7 +147,7 @@ def pack_split(wf, out=None, sc=None, bf16=False):
 
 def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, res=None, res_affine=None,
                  accumulate=False, out_div=0.0, algo=ALGO_AUTO, wp=None, add=None, mask=None, mask_slope=1.0,
-                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None, io_bf16=0, rowsum=None):
+                 in_stride=0, in_phase=0, pad_left=-1, L=None, wps=None, out_slope=0.0, group=None, io_bf16=0, rowsum=None, in_ct=0):
     B, ci, Lx = x.shape
     L = Lx if L is None else L       # strided input: the conv length is Lx / in_stride
     co = out.shape[1]
@@ -160,6 +160,8 @@ def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, re
         a.in_ct, a.out_ct = ci, co
         xoff, ooff = g * cig * Lx * 4, g * cog * out.shape[2] * 4
         ci, co = cig, cog
+    if in_ct:                          # `x` is a C_in-channel slice (a view) of a tensor with in_ct channels per batch item
+        a.in_ct = in_ct
     a.in_stride, a.in_phase, a.pad_left = in_stride, in_phase, pad_left
     a.in_ = x.data_ptr() + xoff
     a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
@@ -504,12 +506,24 @@ def convt1d_dgrad(dy, wf, out, *, k, u, mask=None, mask_slope=1.0, algo=ALGO_AUT
     output phases of a small Conv1d on that phase of dy.  dy (B, C_out, u*L), wf [k][C_in][C_out], out (B, C_in, L)."""
     pad = (k - u) // 2
     L = out.shape[2]
+    B, co = dy.shape[0], dy.shape[1]
+    # float4-aligned lengths: de-interleave dy once into its u phases stacked along the channels (B, u*C_out, L) - one streaming pass -
+    # so that every phase conv reads unit-stride rows through the vector staging path (the strided form stages element by element and
+    # ran at less than half the forward's rate)
+    dyp = None
+    if algo == ALGO_AUTO and L % 4 == 0 and conv_tile_config(B, co, out.shape[1], L, 3) is not None:
+        dyp = torch.empty((B, u * co, L), device=dy.device, dtype=torch.float32)
+        _hip.check(_hip.load().v2w_phase_split(dy.data_ptr(), dyp.data_ptr(), B, co, co, L * u, 1, u, 0, 0, _stream(dy)), 'v2w_phase_split')
     for r in range(u):
         t0, c = (r + pad) % u, (r + pad) // u
         nt = (k - t0 + u - 1) // u
         wr = gather_transpose(wf, t0, u, nt)                   # [nt][C_out][C_in]
-        conv1d(dy, wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask, mask_slope=mask_slope,
-               in_stride=u, in_phase=r, pad_left=c, L=L, algo=algo)
+        if dyp is not None:
+            conv1d(dyp[:, r * co:(r + 1) * co, :], wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask,
+                   mask_slope=mask_slope, pad_left=c, in_ct=u * co, algo=algo)
+        else:
+            conv1d(dy, wr, None, out, k=nt, dil=1, slope=1.0, accumulate=(r > 0), wp=pack_mfma(wr), mask=mask, mask_slope=mask_slope,
+                   in_stride=u, in_phase=r, pad_left=c, L=L, algo=algo)
     return out
 
 
