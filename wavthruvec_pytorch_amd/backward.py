@@ -82,6 +82,7 @@ def generator_backward(gen, sv, dy):
     _wn_grads(grads, 'conv_post', gen.conv_post, dwf_post)
 
     z_all = ws['z_ws'].view(ns, B, 128)
+    side = gen._side_stream(dev)
     for i in reversed(range(ns)):
         up = gen.ups[i]
         C = up.out_channels
@@ -202,8 +203,16 @@ def generator_backward(gen, sv, dy):
                                        training=training, eps=bn.eps, sync=gen.stat_sync)
         ly, fc = cbn.layer, gen.fcs[i]
         sn_u, sn_v = sv['sn_uv'][i]               # the vectors the forward of THIS graph used (ly.weight_u/_v may have moved on)
-        d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), sn_u, sn_v,
-                                                    ws['sigma_ws'][i:i + 1], spk, nz)
+        # the conditioning branch (spectral-norm Linear + fcs[i]: five small latency-bound kernels per stage) hangs off dgb only and
+        # nothing downstream waits for it: it runs on the side stream, beside the convolutions, and is joined at the end
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), sn_u, sn_v,
+                                                        ws['sigma_ws'][i:i + 1], spk, nz)
+        dgb.record_stream(side)
+        for t in (d_w, d_b, d_fw, d_fb):
+            t.record_stream(main)
         grads[f'cbns.{i}.layer.weight_orig'], grads[f'cbns.{i}.layer.bias'] = d_w, d_b
         grads[f'fcs.{i}.weight'], grads[f'fcs.{i}.bias'] = d_fw, d_fb
 
@@ -217,4 +226,5 @@ def generator_backward(gen, sv, dy):
     # ---- conv_pre (models.py:123): no activation in front of it, no input gradient requested
     grads['conv_pre.bias'] = hipops.channel_sum(dxs)
     _wn_grads(grads, 'conv_pre', gen.conv_pre, hipops.wgrad(x, dxs, k=7, dil=1, slope=1.0))
+    torch.cuda.current_stream(dev).wait_stream(side)
     return grads
