@@ -135,18 +135,29 @@ def generator_backward(gen, sv, dy):
                              wp=p1[j], algo=hipops.ALGO_MFMA, **extra))
             hipops.conv1d_multi([dconv1(j, parts[j]) for j in order if j < nk - 1])
             hipops.conv1d_multi([dconv1(nk - 1, dx, add=parts)])
-            for j in range(nk):
-                c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
-                k = rbs[j].kernel_size
-                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
-                grads[names[j] + '.convs.1.bias'] = db2
-                _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
-                if ntile:
-                    st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
-                    hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
-                    grads[names[j] + '.convs.0.bias'] = st[:C].float()
-                else:
-                    grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+            # weight / bias gradients: nothing downstream waits for them - side stream, beside the next stage's gradient convs
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                made = []
+                for j in range(nk):
+                    c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
+                    k = rbs[j].kernel_size
+                    g0 = dict(grads)
+                    _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
+                    grads[names[j] + '.convs.1.bias'] = db2
+                    _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+                    if ntile:
+                        st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
+                        hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
+                        grads[names[j] + '.convs.0.bias'] = st[:C].float()
+                    else:
+                        grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+                    made += [v for kk, v in grads.items() if kk not in g0]
+            for t in [dxs, xr, aff[0], aff[1]] + dt1s + t1s + [r_ for r_ in rsp if r_ is not None]:
+                t.record_stream(side)
+            for t in made:
+                t.record_stream(main)
         for j in range(nk if not merged else 0):
             rb = gen.resblocks[i * nk + j]
             name = f'resblocks.{i * nk + j}'
