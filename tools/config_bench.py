@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Forward time of the BASELINE.json configurations that fit one GPU, in the three precision modes (train-mode CondBN)."""
+"""Forward time (event-timed median of 10 steps) of the BASELINE.json configurations that fit one GPU, in the three precision modes
+(train-mode CondBN)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,11 +22,13 @@ for name, (hp, B, T) in CFGS.items():
         g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train(); g.precision = prec
         with torch.no_grad():
             for _ in range(3): y = g(*inp)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10): y = g(*inp)
-            e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            evs[0].record()
+            for i in range(10):
+                y = g(*inp)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+        ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))[5]       # median step (an allocator stall in one step is not the kernels' time)
         ys[prec] = y
         out.append(f'{prec} {ms:7.3f} ms ({B * T * up / ms / 1e3:6.1f} M/s)')
         del g
