@@ -18,6 +18,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_train 
 # BASELINE configs[2] in its own arithmetic (bf16 compute / fp32 accumulate, bf16 activation storage) and the cfg1 inference latency
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_cfg3 -o ks -- $B --precision bf16 --batch 64 --frames 512 > $O/ks_cfg3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ks_lat -o ks -- python3 $R/tools/latency_bench.py 1 50 > $O/ks_lat.log 2>&1
+B3C="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --precision bf16 --batch 64 --frames 512"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -o pf -- $B3C > $O/c3pf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c3_write -o pw -- $B3C > $O/c3pw.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/c3_sq_a -o sa -- $B3C > $O/c3sa.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/c3_sq_b -o sb -- $B3C > $O/c3sb.log 2>&1
 cd $R
 python3 tools/trace_layers.py $O/ks > $O/per_layer.txt 2>&1
 python3 tools/trace_layers.py $O/ks_cfg3 64 512 -2 2 > $O/cfg3_bf16_per_layer.txt 2>&1
@@ -26,6 +31,8 @@ python3 tools/latency_bench.py > $O/latency.txt 2>&1
 python3 tools/train_step_bench.py 32 256 5 > $O/train_step.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/hbm_traffic.json 2> $O/pmc.err
 python3 tools/pmc_sq.py $O/sq_a $O/sq_b > $O/sq_counters.json 2> $O/sq.err
+python3 tools/pmc_traffic.py $O/c3_fetch $O/c3_write > $O/cfg3_bf16_hbm_traffic.json 2> $O/c3pmc.err
+python3 tools/pmc_sq.py $O/c3_sq_a $O/c3_sq_b > $O/cfg3_bf16_sq_counters.json 2> $O/c3sq.err
 cp $O/hbm_traffic.json profiles/${TAG}_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
 timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/config_bench.py > $O/all_configs.txt 2>&1
