@@ -482,7 +482,8 @@ conv_bf16_kernel(const MultiArgs m) {
                     const int stat = lane & 1, part = (lane >> 1) % PARTS, c = lane / (2 * PARTS);
                     float t = 0.f;
 #pragma unroll
-                    for (int k = 0; k < NPER; ++k) t += scr[2 * (c * RW + part * NPER + k) + stat];
+                    for (int k = 0; k < NPER; ++k)        // (each lane starts at its own slot: same-bank reads of the 32 lanes of a stat otherwise)
+                        t += scr[2 * (c * RW + part * NPER + (k + (lane >> 1)) % NPER) + stat];
 #pragma unroll
                     for (int off = 2; off < 2 * PARTS; off <<= 1) t += __shfl_xor(t, off, 64);
                     if (part == 0) red[((wave % WN) * (MT / UP) + (wm0 + i * 32) / UP + c) * 2 + stat] += t;
