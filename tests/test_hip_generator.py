@@ -141,6 +141,24 @@ def test_generator_bf16_operand_mode(dev):
     assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
 
 
+@pytest.mark.parametrize('B,T', [(2, 33), (1, 7), (3, 50)])
+def test_generator_bf16_storage_ragged_lengths(dev, B, T):
+    """precision='bf16' with bf16 activation storage at lengths that are not multiples of 4 (and a 5-frame input): every bf16 kernel's
+    element-wise staging / epilogue fallback (unaligned rows) against the fp32 oracle, at the small-size bf16 bar."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=5)
+    inp_cpu = synthetic.make_inputs(h, B, T, seed=9)
+    want, _ = O.generator_forward({k: v.clone() for k, v in sd.items()}, h, *inp_cpu, training=True)
+    g = build_generator(h, sd, dev, training=True)
+    g.precision = 'bf16'
+    assert g.bf16_storage
+    with torch.no_grad():
+        y = g(*to_dev(inp_cpu, dev))
+    assert y.shape == want.shape and torch.isfinite(y).all()
+    d = (y.cpu() - want).abs().max().item()
+    assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
+
+
 def test_generator_cfg3_bf16_full_size(dev):
     """BASELINE configs[2] at its full size (B=64, T=512, bf16 compute / fp32 accumulate, bf16 activation storage) against the
     exact-fp32 HIP path on the same inputs, without the oracle (test_generator_cfg3_full_size_vs_oracle_train holds the real bar:
