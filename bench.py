@@ -55,10 +55,11 @@ def usable_cpus() -> int:
     return n
 
 
-def _timed_oracle(O, sd, h, inp, training, threads, reps):
+def _timed_oracle(O, sd, h, inp, training, threads, reps, warmups=1):
     import torch
     torch.set_num_threads(threads)
-    O.generator_forward(sd, h, *inp, training=training)          # warm-up
+    for _ in range(warmups):
+        O.generator_forward(sd, h, *inp, training=training)
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -69,24 +70,25 @@ def _timed_oracle(O, sd, h, inp, training, threads, reps):
 
 def cpu_baseline(h):
     """The oracle (CPU restatement of the reference forward, oracle/vec2wav_oracle.py) timed on this box's host cores: a reported
-    baseline, never the target.  Bounded to ~30 s:
+    baseline, never the target.  Bounded to about a minute:
       * cfg1 (BASELINE configs[0]: B=1, T=50, the reference's own CPU-runnable case): 1 thread and all usable cores, train and eval
-        mode, median of 3 after a warm-up (SURVEY 8(d) / BASELINE.md 4);
+        mode, median of 10 after 3 warm-ups (SURVEY 8(d) / BASELINE.md 4);
       * the cfg2 sample B=4 x T=256 (1/8 of the cfg2 batch, same per-sample work) in train mode: short sweep over thread counts,
-        best median -> `value` / `cores` (more threads than the problem can feed are slower)."""
+        best median of 3 -> `value` / `cores` (more threads than the problem can feed are slower);
+      * cfg2 ITSELF (B=32 x T=256) once at all usable cores after one warm-up: `cfg2_full_samples_per_s`."""
     from oracle import vec2wav_oracle as O
     from wavthruvec_pytorch_amd import synthetic
     sd = synthetic.make_state_dict(h, seed=0)
     ncpu = usable_cpus()
     up = synthetic.total_upsample(h)
-    t_end = time.time() + 40.0
+    t_end = time.time() + 60.0
     cfg1 = {}
     inp1 = synthetic.make_inputs(h, 1, 50, seed=1234)
     for mode, training in (('train', True), ('eval', False)):
         for th in sorted({1, ncpu}):
             if time.time() > t_end:
                 break
-            cfg1[f'{mode}_threads{th}'] = 50 * up / _timed_oracle(O, sd, h, inp1, training, th, 3)
+            cfg1[f'{mode}_threads{th}'] = 50 * up / _timed_oracle(O, sd, h, inp1, training, th, 10, warmups=3)
     B, T = 4, 256
     inp = synthetic.make_inputs(h, B, T, seed=1234)
     cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
@@ -98,10 +100,17 @@ def cpu_baseline(h):
         if time.time() > t_end:
             break
     med, th = best
+    full = None
+    if time.time() < t_end + 30.0:
+        inpf = synthetic.make_inputs(h, 32, 256, seed=1234)
+        tf = _timed_oracle(O, sd, h, inpf, True, ncpu, 1, warmups=1)
+        full = dict(value=32 * 256 * up / tf, unit='samples/s', cores=ncpu, seconds_per_forward=tf,
+                    sample='one full cfg2 forward (B=32, T=256, train mode) after one warm-up')
     return dict(value=B * T * up / med, unit='samples/s', cores=th, kind='port',
                 sample=f'oracle (torch CPU fp32 restatement of the reference forward), train mode, B={B} T={T} 768-d, '
                        f'median of 3 at {th} threads (best of thread counts {cands}; {ncpu} usable CPUs)',
-                cfg1_B1_T50_samples_per_s=cfg1)
+                cfg1_B1_T50_samples_per_s=cfg1, cfg1_protocol='median of 10 after 3 warm-ups (BASELINE.md 4)',
+                cfg2_full_samples_per_s=full)
 
 
 def self_launch(args) -> int:
@@ -122,6 +131,204 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def csrc_hash() -> str:
+    """Hash of the kernel sources and headers (wavthruvec_pytorch_amd.build.sources_hash): a PMC traffic file collected from other
+    sources is stale."""
+    from wavthruvec_pytorch_amd import build
+    return build.sources_hash()
+
+
+def traffic_of(kernel: str, suffix: str):
+    """HBM bytes per launch of `kernel` from the latest committed PMC pass profiles/rNN_<suffix> (tools/pmc_traffic.py: FETCH_SIZE x2 +
+    WRITE_SIZE, KiB -> bytes as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process.  The file records a
+    hash of the kernel sources it was collected from; when csrc/ has changed since, the number is withheld (null + the reason)."""
+    pdir = os.path.join(ROOT, 'profiles')
+    tpaths = sorted(q for q in os.listdir(pdir) if q.endswith(suffix)) if os.path.isdir(pdir) else []
+    if not tpaths:
+        return None, None
+    with open(os.path.join(pdir, tpaths[-1])) as f:
+        tj = json.load(f)
+    meta = tj.get('_meta', {})
+    want = kernel.replace(' ', '')
+    hit = sorted((k for k in tj if k != '_meta' and k.replace(' ', '').startswith(want)), key=lambda k: -tj[k].get('launches', 0))
+    if not hit:
+        return None, f'profiles/{tpaths[-1]}: no entry for {kernel}'
+    if meta.get('csrc_sha') != csrc_hash():
+        return None, (f'stale: csrc changed since profiles/{tpaths[-1]} was collected (commit {meta.get("commit", "?")}, '
+                      f'sources {meta.get("csrc_sha", "unrecorded")}, now {csrc_hash()})')
+    return tj[hit[0]]['hbm_bytes_per_launch'], (f'profiles/{tpaths[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 '
+                                                 f'per the gfx950 correction; collected {meta.get("date", "?")} at commit {meta.get("commit", "?")}, '
+                                                 f'same kernel sources)')
+
+
+def run_steps(g, inp, steps, warmup, barrier=lambda: None):
+    """EXACTLY `steps` forwards between barrier + synchronize pairs (wall clock), HIP events on the launching stream around every
+    step as well (event-timed median).  Returns (elapsed seconds, per-step milliseconds)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    with torch.no_grad():
+        for _ in range(warmup):
+            g(*inp)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            g(*inp)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    return elapsed, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, record=True):
+    """Roofline of the dominant kernel of `g`'s forward: HIP events around every conv launch on the launching stream (3 profiled
+    forwards, run by every rank - they contain the statistics all-reduce; `record` = this rank keeps the numbers), algorithmic
+    FLOPs / bytes of the layers each launch covers (workmodel.py = SURVEY 8(d)), grouped by the kernel instantiation that ran them."""
+    from wavthruvec_pytorch_amd import workmodel, hipops
+    per, sync_t = {}, []
+    with torch.no_grad():
+        for _ in range(3):
+            g._profile = [] if record else None
+            g(*inp)
+            torch.cuda.synchronize()
+            if record:
+                for tag, e0, e1 in g._profile:
+                    (sync_t if tag.startswith('stat_sync.') else per.setdefault(tag, [])).append(e0.elapsed_time(e1) * 1e-3)
+        g._profile = None
+    if not record:
+        return None
+    bf16_run = precision == 'bf16'
+    act_bytes = 2 if (bf16_run and g.bf16_storage) else 4      # bytes of an activation element between layers in this mode
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16_run else PEAK_FP32_MFMA_TFLOPS
+    layers = {l['name']: l for l in workmodel.conv_layers(h, B, T, act_bytes)}
+
+    def kernel_of(l, nprob=1):
+        if l['name'] == 'conv_post':
+            return 'conv_post_tanh_vec4_kernel'
+        direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
+        if algo == 'direct':
+            return direct
+        if bf16_run and (l['kind'] == 'conv' or act_bytes == 2) and l['cin'] % 32 == 0 and (l['cout'] % 64 == 0 or l['kind'] == 'convt'):
+            name = hipops.conv_bf16_config(B, nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1), io_bf16=3 if act_bytes == 2 and l['name'] != 'conv_pre' else (2 if act_bytes == 2 else 0))
+            if name:
+                return name
+        if precision != 'f32' and l['kind'] == 'conv' and l['cout'] >= g.split_min_channels and l['cout'] % 64 == 0:
+            return 'conv_split_kernel (%s)' % precision
+        # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
+        return hipops.conv_tile_config(B * nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
+
+    launches = {}      # tag -> dict(kernel, flops, bytes, t)
+    for tag, ts in per.items():
+        names, fused = [], False
+        staged = tag.startswith('stage:')       # whole residual section of a narrow stage in one kernel
+        for part in tag.replace('stage:', '').split('+'):   # 'resblocks.J.a&b' = convs a and b of block J fused
+            if '&' in part:
+                base, ab = part.rsplit('.', 1)
+                names += [f'{base}.{x}' for x in ab.split('&')]
+                fused = True
+            else:
+                names.append(part)
+        ls = [layers[n] for n in names]
+        kname = kernel_of(ls[0], len(tag.split('+')))
+        if fused:
+            kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
+                    ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
+            if staged and precision != 'f32':
+                kname = ('stage_bf16_kernel<%d' % ls[0]['cout']) if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
+        nbytes = sum(l['bytes'] for l in ls)
+        if fused:                              # the intermediate is neither written nor re-read
+            nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])
+        if staged:                             # x read once, no per-branch outputs / running-sum traffic
+            act = B * ls[0]['cout'] * ls[0]['L'] * act_bytes
+            nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
+        launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
+                             t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
+    groups = {}
+    for tag, d in launches.items():
+        groups.setdefault(d['kernel'], []).append(tag)
+    gtime = {k: sum(launches[n]['t'] for n in v) for k, v in groups.items()}
+    gflops = {k: sum(launches[n]['flops'] for n in v) for k, v in groups.items()}
+    dom = max(gtime, key=gtime.get)
+    dom_tags = groups[dom]
+    dom_t, dom_f = gtime[dom], gflops[dom]
+    conv_t = sum(d['t'] for d in launches.values() if d['conv'])
+    conv_f = sum(d['flops'] for d in launches.values() if d['conv'])
+    all_t = sum(d['t'] for d in launches.values())
+    tot_f, tot_b = workmodel.totals(h, B, T, act_bytes)
+    traffic, traffic_src = traffic_of(dom, traffic_suffix) if traffic_suffix else (None, None)
+    dom_b = sum(launches[n]['bytes'] for n in dom_tags)
+    mfma_frac, hbm_frac = dom_f / dom_t / 1e12 / peak_tf, dom_b / dom_t / 1e9 / PEAK_HBM_GBS
+    bound = 'hbm' if hbm_frac > mfma_frac else 'mfma'        # the ceiling the dominant kernel sits closer to
+    roof = dict(bound=bound, kernel=dom + (' (bf16 MFMA implicit-GEMM conv)' if bf16_run else ' (f32 MFMA implicit-GEMM conv)'),
+                launches=dom_tags,
+                achieved=(dom_b / dom_t / 1e9) if bound == 'hbm' else (dom_f / dom_t / 1e12),
+                peak=PEAK_HBM_GBS if bound == 'hbm' else peak_tf, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
+                frac=max(mfma_frac, hbm_frac), mfma_frac=mfma_frac, hbm_frac=hbm_frac,
+                traffic=traffic, traffic_source=traffic_src,
+                algorithmic_bytes_per_launch_avg=dom_b / len(dom_tags),
+                launches_per_step=len(dom_tags), avg_launch_us=dom_t / len(dom_tags) * 1e6,
+                flops_per_launch_avg=dom_f / len(dom_tags), activation_bytes_per_element=act_bytes,
+                per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4), tflops=round(gflops[k] / gtime[k] / 1e12, 2),
+                                    algorithmic_gbs=round(sum(launches[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
+                            for k, v in sorted(groups.items(), key=lambda kv: -gtime[kv[0]])},
+                all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / peak_tf,
+                                       launches_per_step=sum(1 for d in launches.values() if d['conv'])),
+                whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
+                                   mfma_frac=tot_f / step_s / 1e12 / peak_tf,
+                                   hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))
+    if sync_t:
+        roof['stat_sync_allreduce_us_mean'] = mean(sync_t) * 1e6
+    return roof
+
+
+def single_rank_rccl_group(dev):
+    """A ONE-rank RCCL communicator on this GPU (`init_process_group('nccl', world_size=1, device_id=...)`): the code path a multi-GPU
+    job runs - communicator creation, the device all-reduce on the compute stream, the barrier - executed on a one-GPU box."""
+    if dist.is_initialized():
+        return
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+
+
+def stat_sync_overhead(g, inp, dev, steps):
+    """What the data-parallel CondBN exchange costs per forward, measured on the hardware at hand: the same train-mode step with and
+    without `enable_sync_batchnorm()` over a one-rank RCCL group (five sequentially dependent fp64 all-reduces of [sum | sumsq | count]
+    on the compute stream), interleaved rounds in one process, plus the event-timed duration of each all-reduce.  At one
+    rank the collective moves no data: this is its fixed launch + completion latency, the floor of the per-stage cost at N ranks."""
+    single_rank_rccl_group(dev)
+    keep = g.stat_sync
+    g.stat_sync = None
+    with_ms, without_ms = [], []
+    from wavthruvec_pytorch_amd.distributed import BNStatSync
+    sync = BNStatSync()
+    for _ in range(3):
+        for on in (True, False):
+            g.stat_sync = sync if on else None
+            el, _ms = run_steps(g, inp, steps, 2)
+            (with_ms if on else without_ms).append(el / steps * 1e3)
+    g.stat_sync = sync
+    per = []
+    with torch.no_grad():
+        for _ in range(3):
+            g._profile = []
+            g(*inp)
+            torch.cuda.synchronize()
+            per += [e0.elapsed_time(e1) * 1e3 for tag, e0, e1 in g._profile if tag.startswith('stat_sync.')]
+        g._profile = None
+    g.stat_sync = keep
+    w, wo = median(with_ms), median(without_ms)
+    return dict(backend=sync.backend, ranks=sync.world_size, allreduces_per_forward=g.num_upsamples,
+                ms_per_step_with_sync=w, ms_per_step_without_sync=wo, stat_sync_ms_per_step=w - wo,
+                allreduce_us_event_mean=mean(per) if per else None, allreduce_us_event_max=max(per) if per else None,
+                rounds_with=with_ms, rounds_without=without_ms,
+                note='one-rank RCCL group on one GPU: the fixed cost of the five per-stage all-reduces (no bytes cross a link); '
+                     'at N ranks each adds the xGMI all-reduce latency of <= 4 KiB')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -131,9 +338,12 @@ def main():
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--algo', default='auto', choices=['auto', 'direct'])
-    ap.add_argument('--no-alt', action='store_true', help="skip the additional precision='f16x3' measurement")
+    ap.add_argument('--no-alt', action='store_true', help="skip the additional measurements (f16x3 mode, cfg3, ResBlock1, RCCL sync overhead)")
     ap.add_argument('--precision', default='f32', choices=['f32', 'f16x3', 'bf16'],
                     help="precision mode of the TIMED steps (default: exact fp32; the others are for profiling that mode)")
+    ap.add_argument('--resblock', default='2', choices=['1', '2'], help="'1': the ResBlock1 generator (h.resblock == '1'); default ResBlock2")
+    ap.add_argument('--force-pg', action='store_true',
+                    help='--gpus 1 only: create a ONE-rank RCCL process group and keep the CondBN statistics all-reduces inside the timed region')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -160,45 +370,33 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif args.force_pg:
+        single_rank_rccl_group(dev)
+    grouped = world > 1 or args.force_pg
 
     from wavthruvec_pytorch_amd import Generator, synthetic, workmodel, hipops
 
-    h = synthetic.make_hparams(num_wv_feat=768)
+    h = synthetic.make_hparams(num_wv_feat=768, resblock='1' if args.resblock == '1' else 1)
     B, T = args.batch, args.frames
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).train()
     g.algo = hipops.ALGO_DIRECT if args.algo == 'direct' else hipops.ALGO_AUTO
     g.precision = args.precision
-    if world > 1:
+    if grouped:
         g.enable_sync_batchnorm()
     x, spk, nz = synthetic.make_inputs(h, B, T, seed=1234 + rank, device=dev)
-    samples_per_step = world * B * T * synthetic.total_upsample(h)
+    inp = (x, spk, nz)
+    up = synthetic.total_upsample(h)
+    samples_per_step = world * B * T * up
 
     def barrier():
-        if world > 1:
+        if grouped:
             if backend == 'nccl':
                 dist.barrier(device_ids=[dev_index])
             else:
                 dist.barrier()
 
-    # the timed region: EXACTLY `steps` forwards between barrier + synchronize pairs (wall clock -> `value`); HIP events on the
-    # launching stream bracket every step as well (event-timed median, reported beside the wall-clock mean)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            g(x, spk, nz)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        evs[0].record()
-        for i in range(args.steps):
-            g(x, spk, nz)
-            evs[i + 1].record()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     def max_over_ranks(v):
         if world > 1:
             t = torch.tensor([v], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
@@ -206,30 +404,26 @@ def main():
             return t.item()
         return v
 
+    # ---- the timed region
+    elapsed, step_ms = run_steps(g, inp, args.steps, args.warmup, barrier)
     elapsed = max_over_ranks(elapsed)
     event_median_ms = max_over_ranks(median(step_ms)) if step_ms else None
-    rccl_ranks = dist.get_world_size() if (world > 1 and backend == 'nccl') else (1 if world == 1 else None)
+    rccl_ranks = dist.get_world_size() if (grouped and backend == 'nccl') else (1 if world == 1 else None)
+    extras = world == 1 and rank == 0 and args.algo == 'auto' and not args.no_alt and args.precision == 'f32' and args.resblock == '2' \
+        and (B, T) == (32, 256)
 
     # ---- the same step with Generator.precision = 'f16x3' (wide Conv1d layers on the f16 matrix pipe with split operands,
     # fp32 accumulation; same parity bar).  Reported BESIDE the exact-fp32 `value`, never instead of it.
     alt = None
-    if args.algo == 'auto' and not args.no_alt and args.precision == 'f32':
+    if args.algo == 'auto' and not args.no_alt and args.precision == 'f32' and args.resblock == '2':
         with torch.no_grad():
-            y32 = g(x, spk, nz).clone()
+            y32 = g(*inp).clone()
             g.precision = 'f16x3'
-            for _ in range(args.warmup):
-                ysp = g(x, spk, nz)
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                ysp = g(x, spk, nz)
-            torch.cuda.synchronize()
-            barrier()
-            alt_elapsed = max_over_ranks(time.perf_counter() - t0)
-            diff = max_over_ranks((ysp - y32).abs().max().item())
+            alt_elapsed, _ms = run_steps(g, inp, args.steps, args.warmup, barrier)
+            alt_elapsed = max_over_ranks(alt_elapsed)
+            diff = max_over_ranks((g(*inp) - y32).abs().max().item())
             g.precision = 'f32'
-            g(x, spk, nz)                   # back on the fp32 fragments for the profiling pass below
+            g(*inp)                   # back on the fp32 fragments for the profiling pass below
         alt = dict(precision='f16x3', value=samples_per_step * args.steps / alt_elapsed, unit='samples/s',
                    ms_per_step=alt_elapsed / args.steps * 1e3, max_abs_diff_vs_f32_path=diff, parity_bar=1e-4,
                    arithmetic='Conv1d layers with C_out >= 64 and the fused C = 32 / 16 residual stages: x = x_hi + x_lo (f16), '
@@ -237,117 +431,47 @@ def main():
                               'BatchNorm and conv_post exact fp32')
 
     # ---- roofline of the dominant kernel: events around every conv launch, on the launching stream, live
-    roof = None
-    per = {}
-    with torch.no_grad():          # every rank runs these forwards (they contain the statistics all-reduce); rank 0 records
-        for _ in range(3):
-            g._profile = [] if rank == 0 else None
-            g(x, spk, nz)
-            torch.cuda.synchronize()
-            if rank == 0:
-                for tag, e0, e1 in g._profile:
-                    per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
-        g._profile = None
-    if rank == 0:
-        bf16_run = args.precision == 'bf16'
-        act_bytes = 2 if (bf16_run and g.bf16_storage) else 4      # bytes of an activation element between layers in this mode
-        peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16_run else PEAK_FP32_MFMA_TFLOPS
-        layers = {l['name']: l for l in workmodel.conv_layers(h, B, T, act_bytes)}
-        # group the launches by the kernel instantiation that ran them (same names rocprofv3 --stats prints); a launch tag
-        # is one layer, or several joined by '+' when the residual branches of a stage went out as ONE launch
-        def kernel_of(l, nprob=1):
-            if l['name'] == 'conv_post':
-                return 'conv_post_tanh_vec4_kernel'
-            direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
-            if args.algo == 'direct':
-                return direct
-            if bf16_run and (l['kind'] == 'conv' or act_bytes == 2) and l['cin'] % 32 == 0 and (l['cout'] % 64 == 0 or l['kind'] == 'convt'):
-                return 'conv_bf16_kernel' + (' (transposed-conv epilogue)' if l['kind'] == 'convt' else '')
-            if args.precision != 'f32' and l['kind'] == 'conv' and l['cout'] >= g.split_min_channels and l['cout'] % 64 == 0:
-                return 'conv_split_kernel (%s)' % args.precision
-            # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
-            return hipops.conv_tile_config(B * nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
+    suffix = None
+    if (B, T) == (32, 256) and args.resblock == '2':
+        suffix = {'f32': '_cfg2_hbm_traffic.json', 'bf16': '_cfg2_bf16_hbm_traffic.json'}.get(args.precision)
+    if (B, T) == (64, 512) and args.precision == 'bf16' and args.resblock == '2':
+        suffix = '_cfg3_bf16_hbm_traffic.json'
+    roof = roofline_block(g, h, inp, B, T, args.precision, args.algo, elapsed / args.steps, suffix, record=rank == 0)
 
-        launches = {}      # tag -> dict(kernel, flops, bytes, t)
-        for tag, ts in per.items():
-            names, fused = [], False
-            staged = tag.startswith('stage:')       # whole residual section of a narrow stage in one kernel
-            for part in tag.replace('stage:', '').split('+'):   # 'resblocks.J.a&b' = convs a and b of block J fused
-                if '&' in part:
-                    base, ab = part.rsplit('.', 1)
-                    names += [f'{base}.{x}' for x in ab.split('&')]
-                    fused = True
-                else:
-                    names.append(part)
-            ls = [layers[n] for n in names]
-            kname = kernel_of(ls[0], len(tag.split('+')))
-            if fused:
-                kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
-                        ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
-                if staged and args.precision != 'f32':
-                    kname = ('stage_bf16_kernel<%d>' % ls[0]['cout']) if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
-            nbytes = sum(l['bytes'] for l in ls)
-            if fused:                              # the intermediate is neither written nor re-read
-                nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])
-            if staged:                             # x read once, no per-branch outputs / running-sum traffic
-                act = B * ls[0]['cout'] * ls[0]['L'] * act_bytes
-                nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
-            launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
-                                 t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
-        groups = {}
-        for tag, d in launches.items():
-            groups.setdefault(d['kernel'], []).append(tag)
-        gtime = {k: sum(launches[n]['t'] for n in v) for k, v in groups.items()}
-        gflops = {k: sum(launches[n]['flops'] for n in v) for k, v in groups.items()}
-        dom = max(gtime, key=gtime.get)
-        dom_tags = groups[dom]
-        dom_t, dom_f = gtime[dom], gflops[dom]
-        conv_t = sum(d['t'] for d in launches.values() if d['conv'])
-        conv_f = sum(d['flops'] for d in launches.values() if d['conv'])
-        all_t = sum(d['t'] for d in launches.values())
-        tot_f, tot_b = workmodel.totals(h, B, T, act_bytes)
-        step_s = elapsed / args.steps
-        # HBM bytes per launch of that kernel from the PMC passes (tools/pmc_traffic.py; FETCH_SIZE x2 + WRITE_SIZE, KiB ->
-        # bytes as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process: the committed summary
-        # of the same command is used when its kernel name matches, else null.
-        traffic, traffic_src = None, None
-        tpaths = sorted(p for p in os.listdir(os.path.join(ROOT, 'profiles')) if p.endswith('_cfg2_hbm_traffic.json')) \
-            if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
-        if tpaths and (B, T) == (32, 256):
-            with open(os.path.join(ROOT, 'profiles', tpaths[-1])) as f:      # the latest round's PMC pass
-                tj = json.load(f)
-            if dom in tj:
-                meta = tj.get('_meta', {})
-                traffic = tj[dom]['hbm_bytes_per_launch']
-                traffic_src = (f'profiles/{tpaths[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 per the gfx950 '
-                               f'correction; collected {meta.get("date", "?")} at commit {meta.get("commit", "?")})')
-        dom_b = sum(launches[n]['bytes'] for n in dom_tags)
-        mfma_frac, hbm_frac = dom_f / dom_t / 1e12 / peak_tf, dom_b / dom_t / 1e9 / PEAK_HBM_GBS
-        bound = 'hbm' if hbm_frac > mfma_frac else 'mfma'        # the ceiling the dominant kernel sits closer to
-        roof = dict(bound=bound, kernel=dom + (' (bf16 MFMA implicit-GEMM conv)' if bf16_run else ' (f32 MFMA implicit-GEMM conv)'),
-                    launches=dom_tags,
-                    achieved=(dom_b / dom_t / 1e9) if bound == 'hbm' else (dom_f / dom_t / 1e12),
-                    peak=PEAK_HBM_GBS if bound == 'hbm' else peak_tf, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
-                    frac=max(mfma_frac, hbm_frac), mfma_frac=mfma_frac, hbm_frac=hbm_frac,
-                    traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch_avg=dom_b / len(dom_tags),
-                    launches_per_step=len(dom_tags), avg_launch_us=dom_t / len(dom_tags) * 1e6,
-                    flops_per_launch_avg=dom_f / len(dom_tags), activation_bytes_per_element=act_bytes,
-                    per_kernel={k: dict(launches=len(v), ms=round(gtime[k] * 1e3, 4), tflops=round(gflops[k] / gtime[k] / 1e12, 2),
-                                        algorithmic_gbs=round(sum(launches[n]['bytes'] for n in v) / gtime[k] / 1e9, 1))
-                                for k, v in sorted(groups.items(), key=lambda kv: -gtime[kv[0]])},
-                    all_conv_launches=dict(achieved=conv_f / conv_t / 1e12, frac=conv_f / conv_t / 1e12 / peak_tf,
-                                           launches_per_step=sum(1 for d in launches.values() if d['conv'])),
-                    whole_forward=dict(flops=tot_f, algorithmic_bytes=tot_b, sum_conv_kernel_ms=all_t * 1e3,
-                                       mfma_frac=tot_f / step_s / 1e12 / peak_tf,
-                                       hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))
+    # ---- what the data-parallel statistics exchange costs per forward, on a one-rank RCCL group (the only RCCL run a one-GPU box allows)
+    sync = None
+    if extras or (args.force_pg and rank == 0 and world == 1):
+        try:
+            sync = stat_sync_overhead(g, inp, dev, max(5, args.steps // 2))
+        except Exception as e:            # a box without a usable RCCL must not lose the bench line
+            sync = dict(error=f'{type(e).__name__}: {e}')
 
-    # ---- BASELINE configs[2] (B = 64 x T = 512, bf16 compute / fp32 accumulate, bf16 activation storage): reported beside the
-    # headline line as its own workload, priced against BOTH ceilings with ITS byte count (bf16 activations between layers)
-    cfg3 = None
-    if rank == 0 and world == 1 and args.precision == 'f32' and not args.no_alt and (B, T) == (32, 256):
+    # ---- the ResBlock1 generator (h.resblock == '1', models.py:13-44) at the cfg2 shape: SURVEY 8(d) "ResBlock1 reported additionally"
+    rb1 = None
+    if extras:
         del g
         torch.cuda.empty_cache()
+        h1 = synthetic.make_hparams(num_wv_feat=768, resblock='1')
+        g1 = Generator(h1)
+        g1.load_state_dict(synthetic.make_state_dict(h1, seed=0))
+        g1 = g1.to(dev).train()
+        n1 = max(5, args.steps // 2)
+        el1, ms1 = run_steps(g1, inp, n1, max(2, args.warmup // 2))
+        f1, b1 = workmodel.totals(h1, B, T, 4)
+        s1 = el1 / n1
+        r1 = roofline_block(g1, h1, inp, B, T, 'f32', 'auto', s1, None)
+        rb1 = dict(workload=f'Generator.forward with ResBlock1 (h.resblock == \'1\'), B={B} x T={T}, 768-d, x320, train mode, exact fp32',
+                   dtype='f32', steps=n1, ms_per_step=s1 * 1e3, ms_per_step_event_median=median(ms1), value=B * T * up / s1, unit='samples/s',
+                   flops=f1, algorithmic_bytes=b1, mfma_frac=f1 / s1 / 1e12 / PEAK_FP32_MFMA_TFLOPS, hbm_frac=b1 / s1 / 1e9 / PEAK_HBM_GBS,
+                   roofline={k: r1[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_per_step', 'per_kernel')},
+                   parity='tests/test_hip_generator.py::test_generator_resblock1_full_size_vs_oracle_train (|dy| <= 1e-4 at this size)')
+        del g1
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE configs[2] (B = 64 x T = 512, bf16 compute / fp32 accumulate, bf16 activation storage): its own workload, priced
+    # against BOTH ceilings with ITS byte count (bf16 activations between layers), with its own dominant-kernel roofline
+    cfg3 = None
+    if extras:
         B3, T3 = 64, 512
         g3 = Generator(h)
         g3.load_state_dict(synthetic.make_state_dict(h, seed=0))
@@ -355,32 +479,26 @@ def main():
         g3.precision = 'bf16'
         x3 = synthetic.make_inputs(h, B3, T3, seed=4, device=dev)
         n3 = max(5, args.steps)
-        with torch.no_grad():
-            for _ in range(max(2, args.warmup)):
-                g3(*x3)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n3):
-                g3(*x3)
-            torch.cuda.synchronize()
-            el3 = time.perf_counter() - t0
+        el3, ms3 = run_steps(g3, x3, n3, max(3, args.warmup))
         f3, b3 = workmodel.totals(h, B3, T3, 2)
         s3 = el3 / n3
+        r3 = roofline_block(g3, h, x3, B3, T3, 'bf16', 'auto', s3, '_cfg3_bf16_hbm_traffic.json')
         cfg3 = dict(workload='BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
-                             'bf16 activation storage', dtype='bf16', steps=n3, ms_per_step=s3 * 1e3,
-                    value=B3 * T3 * synthetic.total_upsample(h) / s3, unit='samples/s',
+                             'bf16 activation storage', dtype='bf16', steps=n3, ms_per_step=s3 * 1e3, ms_per_step_event_median=median(ms3),
+                    value=B3 * T3 * up / s3, unit='samples/s',
                     flops=f3, algorithmic_bytes=b3, hbm_frac=b3 / s3 / 1e9 / PEAK_HBM_GBS, mfma_frac=f3 / s3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                    peaks=dict(hbm_gbs=PEAK_HBM_GBS, bf16_mfma_tflops=PEAK_BF16_MFMA_TFLOPS),
+                    peaks=dict(hbm_gbs=PEAK_HBM_GBS, bf16_mfma_tflops=PEAK_BF16_MFMA_TFLOPS), roofline=r3,
                     parity='tests/test_hip_generator.py::test_generator_cfg3_full_size_vs_oracle_train: no farther from the fp32 oracle than '
-                           "the reference's own bf16 autocast on the same inputs (4.3e-3 vs 8.0e-3 max, 3.4e-4 vs 7.5e-4 rms)")
+                           "the reference's own bf16 autocast on the same inputs (max and rms)")
         del g3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(h)
+        cpu = cpu_baseline(synthetic.make_hparams(num_wv_feat=768))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        rbname = 'ResBlock1' if args.resblock == '1' else 'ResBlock2'
         out = {
             'metric': baseline_metric(),
             'value': samples_per_step * args.steps / elapsed,
@@ -391,12 +509,13 @@ def main():
             'dtype': {'f32': 'f32', 'f16x3': 'f32 as f16 hi+lo (3 MFMA per product), f32 accumulate',
                       'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: B={B}/GPU x T={T} frames, 768-d latents, upsample (5,4,4,2,2) x320, '
-                                   f'ResBlock2, train-mode CondBN, {args.precision}', 'global_batch': B * world, 'frames': T,
-                       'parallelism': f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'cfg3_bf16': cfg3,
+                                   f'{rbname}, train-mode CondBN, {args.precision}', 'global_batch': B * world, 'frames': T,
+                       'parallelism': (f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else
+                                       'single GPU' + (', one-rank RCCL group: the CondBN all-reduces are inside the timed region' if args.force_pg else ''))},
+            'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 24
+#define V2W_ABI_VERSION 25
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -249,6 +249,11 @@ int       v2w_convt1d_bf16_tiles(const v2w_convt1d_args* a);               /* ro
  * when the direct kernel would run. */
 int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg);
 int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg);
+/* The same for the V2W_ALGO_BF16 kernels: cfg[10] = MI, NI, WM, WN, NPF, EPI, IN_BF, OUT_BF, CK, VEC of the conv_bf16_kernel
+ * instantiation a launch of these n (<= 4) problems / this transposed conv would run (sizes, io_bf16 and the alignment of `in` are
+ * read; nothing is dereferenced).  V2W_E_SHAPE when the bf16 kernels do not take the shape. */
+int v2w_conv1d_bf16_config(const v2w_conv1d_args* a, int n, int32_t* cfg);
+int v2w_convt1d_bf16_config(const v2w_convt1d_args* a, int32_t* cfg);
 
 /* ---- K3: per-stage conditioning  z = fcs[i](cat(spk, noise))  (models.py:120,131), legacy
  * spectral_norm power iteration on cbns[i].layer (modules.py:16,24) and [gamma|beta] = (W/sigma) z + b.

@@ -159,6 +159,23 @@ def test_generator_bf16_storage_ragged_lengths(dev, B, T):
     assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
 
 
+def test_generator_bf16_storage_falls_back_when_a_layer_has_no_bf16_kernel(dev):
+    """precision='bf16' with the default bf16 activation storage on a configuration the bf16-tensor kernels do not cover (a residual
+    kernel of 13 taps: the fused narrow-stage kernel stops at 11): the forward must run - with fp32 tensors between the layers -
+    instead of raising in the middle, and stay at the bf16-operand bar against the fp32 oracle."""
+    h = synthetic.make_hparams(num_wv_feat=768, resblock_kernel_sizes=[3, 7, 13])
+    sd = synthetic.make_state_dict(h, seed=5)
+    inp_cpu = synthetic.make_inputs(h, 2, 16, seed=9)
+    want, _ = O.generator_forward({k: v.clone() for k, v in sd.items()}, h, *inp_cpu, training=True)
+    g = build_generator(h, sd, dev, training=True)
+    g.precision = 'bf16'
+    assert g.bf16_storage and not g._bf16_storage_kernels_exist(2, 16)
+    with torch.no_grad():
+        y = g(*to_dev(inp_cpu, dev))
+    d = (y.cpu() - want).abs().max().item()
+    assert torch.isfinite(y).all() and 1e-6 < d <= 4e-3, f'max|dy| = {d}'
+
+
 def test_generator_cfg3_bf16_full_size(dev):
     """BASELINE configs[2] at its full size (B=64, T=512, bf16 compute / fp32 accumulate, bf16 activation storage) against the
     exact-fp32 HIP path on the same inputs, without the oracle (test_generator_cfg3_full_size_vs_oracle_train holds the real bar:
@@ -484,6 +501,30 @@ def test_generator_backward_matches_oracle_autograd(dev, training, B, T, resbloc
     assert (y2 - y.detach()).abs().max().item() <= (1e-6 if precision == 'f32' else 5e-6)
 
 
+def test_generator_backward_wide_halo_resblock2(dev):
+    """ResBlock2 with kernel 11 x dilation 7: halo 35 > the 32 positions the f32 tile kernel's staging slots cover, so those convs have
+    no tile configuration and run on the direct kernel - in the forward AND in the backward, whose merged-branch launches
+    (ALGO_MFMA, no fallback) must not be chosen for such a stage (the probe used k = 3, dilation 1)."""
+    h = synthetic.make_hparams(num_wv_feat=768, resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 7, 5]])
+    sd = synthetic.make_state_dict(h, seed=0)
+    B, T = 2, 8
+    inp = synthetic.make_inputs(h, B, T, seed=21)
+    dy = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 1, T * 320)).astype(np.float32))
+    y_ref, g_ref, _ = O.generator_gradients(sd, h, *inp, dy, training=True)
+    g = build_generator(h, sd, dev, training=True)
+    y = g(*to_dev(inp, dev))
+    assert (y.detach().cpu() - y_ref).abs().max().item() <= TOL
+    (y * dy.to(dev)).sum().backward()
+    bad = {}
+    for n, p in g.named_parameters():
+        ref = g_ref[n]
+        floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
+        if err > 4e-3:
+            bad[n] = err
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_generator_weights_follow_the_optimizer(dev, precision):
     """The folded / packed weights are cached per parameter version: after `optim_g.step()` (train.py:215) the next forward - train
@@ -529,17 +570,21 @@ def _reference_bf16_deviation(sd, h, inp, want):
     return e.abs().max().item(), e.pow(2).mean().sqrt().item()
 
 
-def _full_size_case(dev, h, B, T, seed, precisions):
-    """HIP train-mode forward at a BASELINE configuration's full size vs ONE oracle forward: y (per precision mode with its
+def _full_size_case(dev, h, B, T, seed, precisions, training=True):
+    """HIP forward at a BASELINE configuration's full size vs ONE oracle forward: y (per precision mode with its
     bar), BatchNorm running statistics, num_batches_tracked and the spectral-norm u / v after the step (f32 path).  A bar of
-    'ref-bf16' means: no farther (max AND rms) from the fp32 oracle than the reference's own bf16 autocast run is."""
+    'ref-bf16' means: no farther (max AND rms) from the fp32 oracle than the reference's own bf16 autocast run is.
+    training=False: calibrated eval (running statistics := the batch statistics of these inputs, SURVEY 8(c): a fresh-init eval
+    forward is ill-conditioned), buffers must stay untouched."""
     sd = synthetic.make_state_dict(h, seed=0)
     inp = synthetic.make_inputs(h, B, T, seed=seed)
-    want, nb = O.generator_forward(sd, h, *inp, training=True)
+    if not training:
+        O.calibrate_running_stats(sd, h, *inp)
+    want, nb = O.generator_forward(sd, h, *inp, training=training)
     xin = to_dev(inp, dev)
     out = {}
     for prec, bar in precisions:
-        g = build_generator(h, sd, dev, training=True)
+        g = build_generator(h, sd, dev, training=training)
         storage = True
         if prec == 'bf16-operands':
             prec, storage = 'bf16', False
@@ -582,6 +627,22 @@ def test_generator_cfg2_full_size_vs_oracle_train(dev):
     exact-fp32 path AND the split-f16 mode; running statistics and spectral-norm state equal the oracle's."""
     h = synthetic.make_hparams(num_wv_feat=768)
     _full_size_case(dev, h, 32, 256, 1234, [('f32', TOL), ('f16x3', TOL)])
+
+
+@pytest.mark.timeout(900)
+def test_generator_cfg2_full_size_vs_oracle_eval(dev):
+    """The same configuration in EVAL mode at full size (the inference pipeline's mode: running statistics, no spectral-norm step,
+    weights folded once): every sample of the batch against the oracle's calibrated-eval forward, buffers unchanged."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    _full_size_case(dev, h, 32, 256, 1234, [('f32', TOL), ('f16x3', TOL)], training=False)
+
+
+@pytest.mark.timeout(1200)
+def test_generator_resblock1_full_size_vs_oracle_train(dev):
+    """The ResBlock1 generator (h.resblock == '1', models.py:13-44: 2 665 GFLOP at this size) at the cfg2 shape
+    B=32 x T=256, fp32, train mode: |dy| <= 1e-4 against the pinned oracle, buffers equal (bench.py reports it as resblock1_f32)."""
+    h = synthetic.make_hparams(num_wv_feat=768, resblock='1')
+    _full_size_case(dev, h, 32, 256, 1234, [('f32', TOL)])
 
 
 @pytest.mark.timeout(900)
@@ -651,6 +712,90 @@ def test_data_parallel_condbn_two_ranks_rccl(dev, tmp_path):
     assert (got - want).abs().max().item() <= TOL
     for k, v in parts[0]['sd'].items():
         assert torch.equal(v, parts[1]['sd'][k]), k          # both ranks end with identical buffers
+
+
+def _rccl_single_rank_worker(rank, port, B, T, out_dir, use_ddp):
+    """ONE rank over RCCL on the one GPU of a test box: `init_process_group('nccl', world_size=1, device_id=cuda:0)` creates a real
+    communicator, and `BNStatSync` issues its all-reduces on it (distributed.py: one-rank RCCL groups run the collective)."""
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = synthetic.make_inputs(h, B, T, seed=1234)
+    dy = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 1, T * 320)).astype(np.float32))
+    # the un-synchronised run of the same global batch (world 1: the shard IS the batch)
+    g0 = build_generator(h, sd, dev, training=True)
+    with torch.no_grad():
+        y0 = g0(*to_dev(inp, dev))
+    g = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    assert g.stat_sync.backend == 'nccl' and g.stat_sync.world_size == 1 and g.stat_sync.single_rank_collective
+    with torch.no_grad():
+        y = g(*to_dev(inp, dev))
+    assert g.stat_sync.calls == g.num_upsamples                      # one all-reduce per stage really went out
+    assert torch.equal(y, y0)                                        # a one-rank sum changes nothing, bit for bit
+    for k, v in g.state_dict().items():
+        if 'cbns' in k:
+            assert torch.equal(v, g0.state_dict()[k]), k
+    # forward + backward under autograd (train.py:167-214), optionally through DistributedDataParallel (train.py:92)
+    g2 = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    model = g2
+    if use_ddp:
+        from torch.nn.parallel import DistributedDataParallel
+        model = DistributedDataParallel(g2, device_ids=[0])
+    yb = model(*to_dev(inp, dev))
+    (yb * dy.to(dev)).sum().backward()
+    assert g2.stat_sync.calls == 2 * g2.num_upsamples                # + one all-reduce of the CondBN backward sums per stage
+    torch.cuda.synchronize()
+    torch.save({'y': y.cpu(), 'yb': yb.detach().cpu(), 'grads': {n: p.grad.cpu() for n, p in g2.named_parameters()},
+                'sd': {k: v.cpu() for k, v in g.state_dict().items() if 'cbns' in k}}, os.path.join(out_dir, 'rank0.pt'))
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('use_ddp', [False, True])
+def test_rccl_single_rank_condbn_forward_backward(dev, tmp_path, use_ddp):
+    """The RCCL (`backend='nccl'`) branch of the data-parallel CondBN on real hardware: a one-rank communicator on the box's one
+    GPU (BASELINE configs[3] needs 8; the driver runs that).  Executes `init_process_group(device_id=...)`, the fp64 device
+    all-reduce of `[sum | sumsq | count]` on the compute stream between the transposed conv and `bn_finalize` (with the
+    conditioning side stream joined around it), the backward's all-reduce of the CondBN sums, and DDP's own bucket all-reduce -
+    and checks forward, every parameter gradient and the post-forward buffers against the pinned oracle (train.py:58-60, 91-94)."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    B, T = 5, 12
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_single_rank_worker, args=(port, B, T, str(tmp_path), use_ddp), nprocs=1, join=True)
+    got = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = synthetic.make_inputs(h, B, T, seed=1234)
+    dy = torch.from_numpy(np.random.default_rng(7).standard_normal((B, 1, T * 320)).astype(np.float32))
+    want, nb = O.generator_forward(sd, h, *inp, training=True)
+    assert (got['y'] - want).abs().max().item() <= TOL
+    assert (got['yb'] - want).abs().max().item() <= TOL
+    ref = dict(sd)
+    O.apply_buffers(ref, nb)
+    for k, v in got['sd'].items():
+        if v.dtype == torch.long:
+            assert v.item() == ref[k].item(), k
+        else:
+            assert (v - ref[k]).abs().max().item() <= 2e-5 * max(1.0, ref[k].abs().max().item()), k
+    _, g_ref, _ = O.generator_gradients(sd, h, *inp, dy, training=True)
+    bad = {}
+    for n, gr in got['grads'].items():
+        floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6
+        err = (gr - g_ref[n]).abs().max().item() / max(g_ref[n].abs().max().item(), floor)
+        if err > 4e-3:
+            bad[n] = err
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
 
 
 def test_generator_on_a_non_current_device():

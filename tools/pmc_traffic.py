@@ -30,7 +30,10 @@ def per_kernel(path, counter):
 
 def main(fetch_dir, write_dir):
     fe, wr = per_kernel(fetch_dir, 'FETCH_SIZE'), per_kernel(write_dir, 'WRITE_SIZE')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from wavthruvec_pytorch_amd import build
     out = {'_meta': dict(commit=os.environ.get('V2W_COMMIT', 'unknown'), date=os.environ.get('V2W_DATE', 'unknown'),
+                         csrc_sha=build.sources_hash(),
                          command='bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}
     for k in sorted(set(fe) | set(wr)):
         nf, f = fe.get(k, [0, 0.0])

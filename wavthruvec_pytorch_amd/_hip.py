@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -136,6 +136,8 @@ SIGNATURES = {
     'v2w_convt1d_bf16_tiles': (C.c_int, [C.POINTER(ConvT1dArgs)]),
     'v2w_conv1d_tile_config': (C.c_int, [C.POINTER(Conv1dArgs), C.POINTER(C.c_int32)]),
     'v2w_convt1d_tile_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
+    'v2w_conv1d_bf16_config': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, C.POINTER(C.c_int32)]),
+    'v2w_convt1d_bf16_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
     'v2w_bn_stats': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),

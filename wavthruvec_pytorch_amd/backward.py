@@ -95,8 +95,12 @@ def generator_backward(gen, sv, dy):
         inv = torch.full((B, C), 1.0 / nk, device=dev)
         zero = torch.zeros((B, C), device=dev)
         from .models import ResBlock1, ResBlock2
-        merged = gen.precision == 'f32' and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 and hipops.conv_tile_config(B, C, C, Lo, 3) is not None \
-            and all(isinstance(gen.resblocks[i * nk + j], ResBlock2) for j in range(nk))
+        # the merged launches run on ALGO_MFMA, which has no direct-kernel fallback: every gradient conv of every branch must have a
+        # tile configuration at ITS kernel size and dilation (a wide halo, e.g. k = 11 with dilation 7, has none: per-branch path)
+        merged = gen.precision == 'f32' and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 \
+            and all(isinstance(gen.resblocks[i * nk + j], ResBlock2) for j in range(nk)) \
+            and all(hipops.conv_tile_config(B * nk, C, C, Lo, gen.resblocks[i * nk + j].kernel_size, c.dilation) is not None
+                    for j in range(nk) for c in gen.resblocks[i * nk + j].convs)
         if merged:
             # dr is never materialised on this path: the gradient convs read dxs through the per-(b, c) affine (1/nk, 0) - operand and
             # residual - and the quantities that are linear in dr (conv2's weight and bias gradients) are scaled afterwards

@@ -5,6 +5,9 @@ newer), then one link.  The objects and the library are build artefacts (git-ign
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -49,31 +52,66 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def sources_hash() -> str:
+    """sha256 (16 hex digits) over every kernel source and header the library is built from: profiles record it so that a counter
+    file collected from other sources is recognised as stale (bench.py `roofline.traffic`)."""
+    hsh = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            hsh.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return hsh.hexdigest()[:16]
+
+
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout: N ranks importing the package after a source edit (torchrun, bench.py --gpus N) would
+    otherwise compile and link into the same paths at once."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, '.lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
-    """Compile every HIP source for gfx950 into one shared library next to the package."""
+    """Compile every HIP source for gfx950 into one shared library next to the package.  Objects and the library are written under a
+    temporary name and renamed into place (an interrupted compile never leaves a truncated file that looks fresh)."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = find_hipcc()
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    todo = list(SOURCES) if force else _stale_sources()
+    with _build_lock():
+        if not force and not needs_build():       # another process built it while this one waited for the lock
+            return LIB_PATH
+        todo = list(SOURCES) if force else _stale_sources()
 
-    def compile_one(s):
-        cmd = [hipcc] + FLAGS + ['-c', '-o', _obj(s), os.path.join(CSRC, s)]
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f'hipcc failed on {s}:\n' + r.stdout + r.stderr)
+        def run(cmd, what):
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'{what}:\n' + r.stdout + r.stderr)
 
-    jobs = jobs or max(1, min(len(todo) or 1, (os.cpu_count() or 2)))
-    with ThreadPoolExecutor(max_workers=jobs) as ex:
-        list(ex.map(compile_one, todo))
-    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + [_obj(s) for s in SOURCES]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('hipcc link failed:\n' + r.stdout + r.stderr)
+        def compile_one(s):
+            tmp = _obj(s) + f'.tmp{os.getpid()}'
+            try:
+                run([hipcc] + FLAGS + ['-c', '-o', tmp, os.path.join(CSRC, s)], f'hipcc failed on {s}')
+                os.replace(tmp, _obj(s))
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+
+        jobs = jobs or max(1, min(len(todo) or 1, (os.cpu_count() or 2)))
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(compile_one, todo))
+        tmp = LIB_PATH + f'.tmp{os.getpid()}'
+        try:
+            run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', tmp] + [_obj(s) for s in SOURCES], 'hipcc link failed')
+            os.replace(tmp, LIB_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB_PATH
 
 

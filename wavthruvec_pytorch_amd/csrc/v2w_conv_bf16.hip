@@ -782,7 +782,7 @@ conv_bf16_kernel(const MultiArgs m) {
 }
 
 template <int MI, int NI, int WM, int WN, int CK = V2W_BF_CK, bool VEC = true>
-int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
+int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream, int32_t* cfg = nullptr) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32, ROWB = 2 * CK + 16;
     constexpr int NPF = ((CK / 4) * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
     static_assert(NI % 2 == 0, "the epilogue walks column blocks in pairs");
@@ -818,6 +818,11 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream) {
     const int io = m.p[0].io_bf16;
     for (int i = 1; i < nprob; ++i) if (m.p[i].io_bf16 != io) return V2W_E_ARG;      // one instantiation per launch
     if (io == 1 || (epi && io != 0)) return V2W_E_SHAPE;     // bf16 in with fp32 out does not occur on the path; the mask epilogue is fp32-only
+    if (cfg) {      // configuration query: the template arguments of the instantiation this launch would run
+        const int32_t c[10] = {MI, NI, WM, WN, NPF, epi, io == 3, io >= 2, CK, VEC};
+        for (int i = 0; i < 10; ++i) cfg[i] = c[i];
+        return 0;
+    }
     auto kern = epi ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 1, false, false, CK, VEC>
               : io == 0 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, false, CK, VEC>
               : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true, CK, VEC>
@@ -869,9 +874,13 @@ static ConvtGeom convt_geom(int k, int u) {
 }
 
 template <int MI, int NI, int WM, int WN, bool VEC = true>
-int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
+int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg = nullptr) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32;
     constexpr int NPF = (8 * ((NT + 2 * HMAX) / 4) + NTHREADS - 1) / NTHREADS;
+    if (cfg) {
+        const int32_t c[10] = {MI, NI, WM, WN, NPF, 2, p.io_bf16 != 0, p.io_bf16 != 0, V2W_BF_CK, VEC};
+        for (int i = 0; i < 10; ++i) cfg[i] = c[i];
+    }
     if (p.Cout % MT != 0 || p.Cin % V2W_BF_CK != 0) return V2W_E_SHAPE;
     p.hla = (p.hl + 3) & ~3;
     if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
@@ -904,7 +913,7 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out) {
     return v2w_launch_status();
 }
 
-static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, int* ntiles_out) {
+static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, int* ntiles_out, int32_t* cfg = nullptr) {
     if (a->B <= 0 || a->C_in <= 0 || a->C_out <= 0 || a->L <= 0 || a->k <= 0 || a->u <= 1) return V2W_E_ARG;
     if (a->k < a->u || ((a->k - a->u) & 1) || a->u > 8) return V2W_E_SHAPE;
     if (a->C_in % V2W_BF_CK != 0) return V2W_E_SHAPE;
@@ -918,14 +927,14 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin
     const bool vec = (a->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->in) & 15) == 0);
     if (!vec && !ntiles_out) {
-        if (rows % 64 == 0 && !(rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512)) return launch_bf16_convt<1, 4, 2, 2, false>(p, stream, ntiles_out);
-        if (rows % 128 == 0) return launch_bf16_convt<2, 4, 2, 2, false>(p, stream, ntiles_out);
-        if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4, false>(p, stream, ntiles_out);
+        if (rows % 64 == 0 && !(rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512)) return launch_bf16_convt<1, 4, 2, 2, false>(p, stream, ntiles_out, cfg);
+        if (rows % 128 == 0) return launch_bf16_convt<2, 4, 2, 2, false>(p, stream, ntiles_out, cfg);
+        if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4, false>(p, stream, ntiles_out, cfg);
         return V2W_E_SHAPE;
     }
-    if (rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512) return launch_bf16_convt<2, 4, 2, 2>(p, stream, ntiles_out);
-    if (rows % 64 == 0) return launch_bf16_convt<1, 4, 2, 2>(p, stream, ntiles_out);
-    if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4>(p, stream, ntiles_out);
+    if (rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512) return launch_bf16_convt<2, 4, 2, 2>(p, stream, ntiles_out, cfg);
+    if (rows % 64 == 0) return launch_bf16_convt<1, 4, 2, 2>(p, stream, ntiles_out, cfg);
+    if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4>(p, stream, ntiles_out, cfg);
     return V2W_E_SHAPE;
 }
 
@@ -936,7 +945,7 @@ V2W_TL_SETTER(v2w_timeline_set_bf16)
 #endif
 
 // Called by v2w_conv1d_split for V2W_ALGO_BF16.  V2W_E_SHAPE: the caller falls back to the split kernel's bf16 form.
-int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
+int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t* cfg) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
     if (a->C_in % V2W_BF_CK != 0 || a->C_out % 64 != 0 || a->k < 1) return V2W_E_SHAPE;
     TileArgs ps[V2W_MAX_MULTI];
@@ -944,7 +953,7 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
     for (int i = 0; i < n; ++i) {
         const v2w_conv1d_args* q = a + i;
         if (q->B != a->B || q->C_in != a->C_in || q->C_out != a->C_out || q->L != a->L) return V2W_E_SHAPE;
-        if (!q->wps) return V2W_E_ARG;
+        if (!q->wps && !cfg) return V2W_E_ARG;
         if (q->in_stride > 1 || q->in_ct > 0 || q->out_ct > 0) return V2W_E_SHAPE;
         TileArgs p{};
         p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wps = q->wps; p.winv = q->winv; p.bias = q->bias;
@@ -960,11 +969,11 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream) {
         tiles += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 64);
     }
     for (int i = 0; i < n; ++i)          // unaligned input or L % 4 != 0: element-wise staging, one small-tile instantiation serves every shape
-        if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0) return launch_bf16<1, 2, 2, 2, V2W_BF_CK, false>(ps, n, stream);
-    if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream);     // 128 x 256
-    if (tiles >= 256 && a->C_in == 64 && a->io_bf16 == 3) return launch_bf16<1, 4, 2, 2, 64>(ps, n, stream);   // 64 x 256, bf16 tensors: the 64 input channels as ONE chunk
-    if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream);                                 // 64 x 256
-    return launch_bf16<1, 2, 2, 2>(ps, n, stream);                                                   // 64 x 128: latency sizes
+        if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0) return launch_bf16<1, 2, 2, 2, V2W_BF_CK, false>(ps, n, stream, cfg);
+    if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream, cfg);     // 128 x 256
+    if (tiles >= 256 && a->C_in == 64 && a->io_bf16 == 3) return launch_bf16<1, 4, 2, 2, 64>(ps, n, stream, cfg);   // 64 x 256, bf16 tensors: the 64 input channels as ONE chunk
+    if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream, cfg);                                 // 64 x 256
+    return launch_bf16<1, 2, 2, 2>(ps, n, stream, cfg);                                                   // 64 x 128: latency sizes
 }
 
 // ---- bf16 transposed conv (V2W_ALGO_BF16 counterpart of v2w_convt1d_fwd); a->wp = the fragments of v2w_pack_bf16_convt
@@ -991,6 +1000,17 @@ extern "C" int v2w_convt1d_bf16_fwd(const v2w_convt1d_args* a, void* stream) {
     return convt_bf16_dispatch(a, (hipStream_t)stream, nullptr);
 }
 // rows of `stats_part` ([rows][C_out][2]) that v2w_convt1d_bf16_fwd fills for this problem; < 0: error / unsupported shape
+// cfg[10] = MI, NI, WM, WN, NPF, EPI, IN_BF, OUT_BF, CK, VEC of the conv_bf16_kernel instantiation the call would launch (host-only
+// queries, no pointer is dereferenced beyond the alignment test of the vector staging path)
+extern "C" int v2w_convt1d_bf16_config(const v2w_convt1d_args* a, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    int n = 0;
+    return convt_bf16_dispatch(a, nullptr, &n, cfg);
+}
+extern "C" int v2w_conv1d_bf16_config(const v2w_conv1d_args* a, int n, int32_t* cfg) {
+    if (!a || !cfg) return V2W_E_ARG;
+    return v2w_conv1d_bf16(a, n, nullptr, cfg);
+}
 extern "C" int v2w_convt1d_bf16_tiles(const v2w_convt1d_args* a) {
     if (!a) return V2W_E_ARG;
     int n = 0;

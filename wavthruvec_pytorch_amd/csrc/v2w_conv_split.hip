@@ -727,14 +727,14 @@ extern "C" int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c
     return v2w_launch_status();
 }
 
-int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream);   // v2w_conv_bf16.hip
+int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t* cfg);   // v2w_conv_bf16.hip
 
 // Called by v2w_api.hip for algo == V2W_ALGO_SPLIT (bf = false) and V2W_ALGO_BF16 (bf = true).  n problems sharing B, C_in, C_out, L in one launch.
 int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool bf) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
     if (!v2w_split_supported(a->C_in, a->C_out, 1)) return V2W_E_SHAPE;
     if (bf) {      // bf16 operands: the chunk-per-barrier kernel of v2w_conv_bf16.hip; shapes it does not take fall through to this file's
-        const int rc = v2w_conv1d_bf16(a, n, stream);
+        const int rc = v2w_conv1d_bf16(a, n, stream, nullptr);
         if (rc != V2W_E_SHAPE) return rc;
         for (int i = 0; i < n; ++i) if (a[i].io_bf16) return V2W_E_SHAPE;      // this file's kernels read and write fp32 only
     }

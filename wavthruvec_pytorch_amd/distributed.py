@@ -35,15 +35,21 @@ def shard_batch(tensors, rank: int, world_size: int):
 class BNStatSync:
     """Callable handed to the generator: sums the per-stage statistics array over the process group in place."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, single_rank_collective: Optional[bool] = None):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised: call init_process_group first')
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        # A one-rank group needs no exchange.  Over RCCL the collective is issued all the same (a legal one-rank all-reduce): it is
+        # the code a multi-GPU job runs, and on a one-GPU box the only way to execute and time it (bench.py --force-pg, the -m gpu
+        # tests).  gloo groups of one rank skip it unless asked.
+        self.single_rank_collective = (self.backend == 'nccl') if single_rank_collective is None else bool(single_rank_collective)
+        self.calls = 0
 
     def __call__(self, stats: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.world_size > 1 or self.single_rank_collective:
+            self.calls += 1
             if stats.is_cuda and self.backend == 'gloo':
                 # gloo has no device collectives: bounce the <= 4 KiB array through the host (tests / single-GPU multi-rank)
                 host = stats.cpu()

@@ -311,7 +311,9 @@ def conv_post_tanh(x, wf, bias, out, *, k, slope):
 
 
 def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
-    """Name of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel)."""
+    """Name PREFIX of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel).  The
+    instantiation's last template argument (VEC: vector staging) depends on the alignment and stride of the actual input, which a
+    shape query cannot know: kernel names of a trace are matched with `startswith`."""
     cfg = (C.c_int32 * 10)()
     if u == 1:
         a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
@@ -322,8 +324,29 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
         rc = _hip.load().v2w_convt1d_tile_config(C.byref(a), cfg)
     if rc != 0:
         return None
-    # forward instantiation (EPI = 0: no optional epilogue) with vector staging (VEC: L % 4 == 0, aligned unit-stride input)
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, ' + ('true' if L % 4 == 0 else 'false') + '>'
+    # forward instantiation (EPI = 0: no optional epilogue)
+    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, '
+
+
+def conv_bf16_config(B, nprob, c_in, c_out, L, k, dil=1, u=1, io_bf16=3):
+    """Name of the conv_bf16_kernel instantiation a V2W_ALGO_BF16 launch of `nprob` such problems runs (aligned tensors), or None."""
+    cfg = (C.c_int32 * 10)()
+    if u == 1:
+        arr = (_hip.Conv1dArgs * nprob)()
+        for a in arr:
+            a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
+            a.pad_left = -1
+            a.io_bf16 = io_bf16
+        rc = _hip.load().v2w_conv1d_bf16_config(arr, nprob, cfg)
+    else:
+        a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
+        a.io_bf16 = io_bf16
+        rc = _hip.load().v2w_convt1d_bf16_config(C.byref(a), cfg)
+    if rc != 0:
+        return None
+    v = list(cfg)
+    tf = lambda b: 'true' if b else 'false'
+    return 'conv_bf16_kernel<' + ', '.join(str(x) for x in v[:6]) + f', {tf(v[6])}, {tf(v[7])}, {v[8]}, {tf(v[9])}>'
 
 
 def conv_rowsum_tiles(B, nprob, c_in, c_out, L, k, dil=1):

@@ -222,7 +222,10 @@ class Generator(nn.Module):
 
         The forward is ~40-60 kernel launches; at inference sizes (B=1, T~50) it is launch-bound, and replaying one graph
         removes the per-launch host cost.  Inputs are copied into static buffers, the returned tensor is the graph's static
-        output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured."""
+        output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured.
+        Graphs captured on one device share its capture stream and with it the library's split-over-C_in slab workspace (one
+        32 MiB slab per (device, stream), csrc/v2w_conv_mfma.hip): replays of DIFFERENT captured generators on that device must
+        be serialised on one stream - replaying two of them concurrently on different streams would race on the slab."""
         if self.stat_sync is not None:
             raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
         sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
@@ -412,6 +415,31 @@ class Generator(nn.Module):
         self._fold_key['wps'] = (gen, out)
         return out
 
+    def _bf16_storage_kernels_exist(self, B, T) -> bool:
+        """bf16 activation storage needs a bf16-tensor kernel for EVERY layer: asked of the library before the forward starts (shape
+        queries only), so that a configuration one of them declines - a residual kernel size > 11 or a halo > 32 positions in a
+        narrow stage, a conv the bf16 tile kernel has no configuration for - runs with fp32 tensors between the layers (bf16
+        operands, the `bf16_storage = False` arithmetic) instead of failing in the middle of the forward."""
+        key = (B, T, self.num_kernels, tuple(self.fuse_stage))
+        hit = self._fold_key.get('bf16_storage_ok')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ok = hipops.conv_bf16_config(B, 1, self.conv_pre.in_channels, self.conv_pre.out_channels, T, 7, 1, 1, io_bf16=2) is not None
+        L, nk = T, self.num_kernels
+        for i, up in enumerate(self.ups):
+            ok = ok and hipops.conv_bf16_config(B, 1, up.in_channels, up.out_channels, L, up.kernel_size, 1, up.stride, io_bf16=3) is not None
+            L *= up.stride
+            C = up.out_channels
+            for rb in self.resblocks[i * nk:(i + 1) * nk]:
+                for c in rb.convs:
+                    if C in (16, 32):       # the fused narrow-stage kernel (v2w_stage_bf16.hip: V2W_SB_KMAX taps, halo <= 32)
+                        ok = ok and rb.kernel_size <= 11 and rb.kernel_size % 2 == 1 and c.dilation * (rb.kernel_size - 1) // 2 <= 32
+                    else:
+                        ok = ok and rb.kernel_size % 2 == 1 and rb.kernel_size >= 3 and \
+                            hipops.conv_bf16_config(B, 1, C, C, L, rb.kernel_size, c.dilation, 1, io_bf16=3) is not None
+        self._fold_key['bf16_storage_ok'] = (key, bool(ok))
+        return bool(ok)
+
     # -------------------------------------------------------------------------------------------
     @_hip.on_tensor_device
     def forward(self, x, spk_emb=None, noise=None):
@@ -466,7 +494,8 @@ class Generator(nn.Module):
         if (self.precision == 'bf16' and self.bf16_storage and save is None and algo == hipops.ALGO_AUTO and nk <= 3
                 and all(isinstance(rb, ResBlock2) for rb in self.resblocks) and x.shape[2] % 4 == 0 and self.h.num_wv_feat % 32 == 0
                 and all((up.out_channels >= 64 and up.out_channels % 64 == 0) or up.out_channels in fuse_stage for up in self.ups)
-                and all(up.in_channels % 32 == 0 and 2 <= up.stride <= 8 for up in self.ups)):
+                and all(up.in_channels % 32 == 0 and 2 <= up.stride <= 8 for up in self.ups)
+                and self._bf16_storage_kernels_exist(B, T)):
             adt = torch.bfloat16
         st = adt == torch.bfloat16
 
@@ -542,7 +571,7 @@ class Generator(nn.Module):
                         pws = self._buf('bn.partial', (2 * max(C, 256) * 64,), dtype=torch.float64, device=dev)
                         hipops.bn_stats(xr, stats, pws)
                     if self.stat_sync is not None:
-                        self.stat_sync(stats)
+                        self._timed(f'stat_sync.{i}', self.stat_sync, stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
                 s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
                 if not cond_joined:
