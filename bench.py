@@ -294,6 +294,20 @@ def single_rank_rccl_group(dev):
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
 
 
+class stdout_to_stderr:
+    """RCCL prints its version banner to the C-level stdout when a communicator is created; rank 0's stdout carries ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+
+
 def stat_sync_overhead(g, inp, dev, steps):
     """What the data-parallel CondBN exchange costs per forward, measured on the hardware at hand: the same train-mode step with and
     without `enable_sync_batchnorm()` over a one-rank RCCL group (five sequentially dependent fp64 all-reduces of [sum | sumsq | count]
@@ -364,6 +378,8 @@ def main():
     backend = os.environ.get('V2W_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    redirect = stdout_to_stderr()
+    redirect.__enter__()          # everything until the JSON line (RCCL's banner included) goes to stderr
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -514,9 +530,11 @@ def main():
                                        'single GPU' + (', one-rank RCCL group: the CondBN all-reduces are inside the timed region' if args.force_pg else ''))},
             'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
         }
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    redirect.__exit__()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

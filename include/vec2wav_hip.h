@@ -220,6 +220,28 @@ typedef struct {
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 
+/* ---- the residual convolutions of a WIDE ResBlock2 stage (C % 64 == 0) on bf16 tensors (BASELINE configs[2]: bf16 compute / fp32
+ * accumulate, bf16 activation storage), one launch per conv position of the block instead of one per branch group
+ * (csrc/v2w_conv_bf16_res.hip; models.py:135-141 with ResBlock2.forward, models.py:65-70, inlined):
+ *   mode 0  t1_j = x + conv_{k_j,dil_j}(lrelu(x)) + bias_j  for j < nbr, x = in_a * in[0] + in_s (per (b, c); NULL: x = in[0]):
+ *           in[0] is read ONCE for all branches, out[j] receives t1_j;
+ *   mode 1  out[0] = ( sum_j [ in[j] + conv_{k_j,dil_j}(lrelu(in[j])) + bias_j ] ) / out_div   (out_div == 0: no division):
+ *           one accumulator across the branches, nothing but out[0] is written.
+ * in / out are bf16 (B, C, L) tensors, 16-byte aligned, L % 4 == 0; wps[j] = the fragments of v2w_pack_bf16 / v2w_split_pack_batch of
+ * the (k_j, C, C) layer; k odd, dil * (k - 1) / 2 <= 32.  The residual is rebuilt from the staged (activated, bf16) operand: exact for
+ * values >= 0, to 2^-9 relative below.  V2W_E_SHAPE: shape not served (the caller issues the per-layer launches instead). */
+typedef struct {
+    const void* in[3];
+    const float* in_a; const float* in_s;
+    const void* wps[3]; const float* bias[3];
+    void* out[3];
+    int32_t k[3], dil[3];
+    int32_t nbr, mode, B, C, L;
+    float slope, out_div;
+    int32_t _pad;
+} v2w_branch_convs_args;
+int v2w_branch_convs_bf16_fwd(const v2w_branch_convs_args* a, void* stream);
+
 /* ---- K2: fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)/2) -> +bias
  * (models.py:128-129).  in (B, C_in, L) -> out (B, C_out, L*u); requires (k-u) even and >= 0. */
 typedef struct {

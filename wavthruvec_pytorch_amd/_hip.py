@@ -71,6 +71,13 @@ class StageSplitArgs(C.Structure):
                 ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32)]
 
 
+class BranchConvsArgs(C.Structure):
+    _fields_ = [('in_', _fp * 3), ('in_a', _fp), ('in_s', _fp), ('wps', _fp * 3), ('bias', _fp * 3), ('out', _fp * 3),
+                ('k', C.c_int32 * 3), ('dil', C.c_int32 * 3),
+                ('nbr', C.c_int32), ('mode', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
+                ('slope', C.c_float), ('out_div', C.c_float), ('_pad', C.c_int32)]
+
+
 class SplitDesc(C.Structure):
     _fields_ = [('v', _fp), ('g', _fp), ('wps', _fp), ('sc', _fp), ('rowscale', _fp),
                 ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32)]
@@ -129,6 +136,7 @@ SIGNATURES = {
     'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
     'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
+    'v2w_branch_convs_bf16_fwd': (C.c_int, [C.POINTER(BranchConvsArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_pack_bf16_convt': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_pack_bf16_convt_bytes': (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -124,7 +124,9 @@ def generator_backward(gen, sv, dy):
             p1 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0']) for j in range(nk)]
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
             # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
-            ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, 3) if Lo % 4 == 0 else 0
+            # (the launch's tile shape follows its WIDEST halo - the wide-halo tile variants are other shapes: probe with that branch)
+            kw, dw = max(((rb.kernel_size, rb.convs[1].dilation) for rb in rbs), key=lambda kd: kd[1] * (kd[0] - 1))
+            ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, kw, dw) if Lo % 4 == 0 else 0
             rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
             hipops.conv1d_multi([(dxs, None, None, dt1s[j],
                                   dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, in_affine=(inv, zero), res=dxs,

@@ -485,6 +485,32 @@ def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=F
     return True
 
 
+def branch_convs_bf16(mode, ins, in_affine, wps, biases, outs, ks, dils, *, slope, out_div=0.0):
+    """The first (mode 0) or second (mode 1) convs of the residual branches of a wide ResBlock2 stage on bf16 tensors in ONE launch
+    (v2w_branch_convs_bf16_fwd).  mode 0: ins = [x], outs = [t1_j]; mode 1: ins = [t1_j], outs = [out].  False: shape not served."""
+    a = _hip.BranchConvsArgs()
+    n = len(wps)
+    x = ins[0]
+    for t in list(ins) + list(outs):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.shape != x.shape:
+            raise ValueError('branch_convs_bf16: contiguous bf16 (B, C, L) tensors of one shape')
+    B, Cc, L = x.shape
+    for j in range(n):
+        a.wps[j] = wps[j].data_ptr(); a.bias[j] = _hip.ptr(biases[j]); a.k[j] = ks[j]; a.dil[j] = dils[j]
+    for j, t in enumerate(ins):
+        a.in_[j] = t.data_ptr()
+    for j, t in enumerate(outs):
+        a.out[j] = t.data_ptr()
+    a.in_a, a.in_s = (_hip.ptr(in_affine[0]), _hip.ptr(in_affine[1])) if in_affine is not None else (None, None)
+    a.nbr, a.mode, a.B, a.C, a.L = n, mode, B, Cc, L
+    a.slope, a.out_div = slope, out_div
+    rc = _hip.load().v2w_branch_convs_bf16_fwd(C.byref(a), _stream(x))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_branch_convs_bf16_fwd')
+    return True
+
+
 def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
     """Whole ResBlock2 residual section of a narrow stage in one kernel.  `branches`: list of dicts(wp1, b1, wp2, b2, k, dil1, dil2).
     Returns False (nothing launched) when the shape is not taken."""

@@ -205,6 +205,7 @@ class Generator(nn.Module):
                                               # (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulate; hipops.ALGO_SPLIT)
         self.split_min_channels = 64
         self.bf16_storage = True              # precision == 'bf16': keep activations in bf16 between layers (no-grad forwards)
+        self.fuse_wide = True                 # bf16 storage: the residual convs of the wide stages (C >= 64) as one launch per conv position
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
@@ -642,6 +643,24 @@ class Generator(nn.Module):
                                                               b2=rbs[j].convs[1].bias.detach(), out=outs[j], k=rbs[j].kernel_size,
                                                               dil1=rbs[j].convs[0].dilation, dil2=rbs[j].convs[1].dilation,
                                                               res_mode=0, slope=LRELU_SLOPE, **final_kw(j)) for j in range(nk)})
+                        if not ok and st and self.fuse_wide and C >= 64 and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
+                            # wide stage on bf16 tensors: the first convs of all branches in ONE launch (x staged once), then the second
+                            # convs in one launch on one accumulator (v2w_branch_convs_bf16_fwd; o_j never written)
+                            ks = [rb.kernel_size for rb in rbs]
+                            ok = self._timed('bconv0:' + '+'.join(f'{nm}.0' for nm in names), hipops.branch_convs_bf16, 0, [xr], aff,
+                                             [wps[nm + '.convs.0'][0] for nm in names], [rb.convs[0].bias.detach() for rb in rbs], t1s,
+                                             ks, [rb.convs[0].dilation for rb in rbs], slope=LRELU_SLOPE)
+                            if ok:
+                                ok2 = self._timed('bconv1:' + '+'.join(f'{nm}.1' for nm in names), hipops.branch_convs_bf16, 1, t1s, None,
+                                                  [wps[nm + '.convs.1'][0] for nm in names], [rb.convs[1].bias.detach() for rb in rbs], [xs],
+                                                  ks, [rb.convs[1].dilation for rb in rbs], slope=LRELU_SLOPE, out_div=float(nk))
+                                if not ok2:
+                                    conv2 = {j: (j, (t1s[j], wf[names[j] + '.convs.1'], rbs[j].convs[1].bias.detach(), outs[j],
+                                                     dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=LRELU_SLOPE,
+                                                          res=t1s[j], **ck(names[j] + '.convs.1'), **final_kw(j)))) for j in range(nk)}
+                                    if nk > 1:
+                                        launch('1', {j: conv2[j] for j in range(nk - 1)})
+                                    launch('1', {nk - 1: conv2[nk - 1]})
                         if not ok:
                             launch('0', {j: (j, (xr, wf[names[j] + '.convs.0'], rbs[j].convs[0].bias.detach(), t1s[j],
                                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=LRELU_SLOPE,
