@@ -136,10 +136,16 @@ conv_bf16_res_kernel(const ResArgs a) {
             for (int s = 0; s < NPF; ++s) pf[s][i] = *gptr<const u32x2>(base + poff[s]);
         }
     };
-    auto commit = [&](int ch, const u32x2 (&pf)[NPF][4]) {
+    auto prefetch1 = [&](const unsigned short* in, int ch, int s, u32x2 (&pf)[4]) {       // item s of plane ch alone
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            pf[i] = *gptr<const u32x2>(reinterpret_cast<const unsigned char*>(in) + (size_t)(b * C + 32 * ch + i) * L * 2 + poff[s]);
+    };
+    auto commit = [&](int ch, const u32x2 (&pf)[NPF][4], int only = -1) {
         unsigned char* const plane = smem_r + ch * psz;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
+            if (only >= 0 && s != only) continue;
             if (!in_img[s]) continue;
             const int cq = scq[s], row = srow[s];
             float av[4], sv[4];
@@ -164,7 +170,24 @@ conv_bf16_res_kernel(const ResArgs a) {
             }
         }
     };
+    // mode 1 stages under live accumulators: ONE plane of registers, item s of plane ch + 1 requested as soon as item s of plane ch is
+    // committed (two buffers of a plane each spilled 17 registers)
+    auto stage_rot = [&](const unsigned short* in) {
+        u32x2 pf[NPF][4];
+        prefetch(in, 0, pf);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int ch = 0; ch + 1 < nch; ++ch) {
+#pragma unroll
+            for (int s = 0; s < NPF; ++s) {
+                commit(ch, pf, s);
+                prefetch1(in, ch + 1, s, pf[s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        commit(nch - 1, pf);
+    };
     auto stage = [&](const unsigned short* in) {              // every plane of the tile; two planes of loads in flight
+        if constexpr (MODE == 1) { stage_rot(in); return; }
         u32x2 pf0[NPF][4], pf1[NPF][4];
         prefetch(in, 0, pf0);
         prefetch(in, 1, pf1);
@@ -201,17 +224,23 @@ conv_bf16_res_kernel(const ResArgs a) {
 
     acc_t acc[MI][NI];
     const unsigned lane16 = (unsigned)lane * 16u;
-    u32x4 bb[NI];
+#ifdef V2W_RS_BB2
+    u32x4 bb[2][NI];                 // one operand set per k-step of a tap, each refilled for the NEXT tap: an LDS read has a whole k-step to land
+#else
+    u32x4 bb[1][NI];
+#endif
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
     };
-    // one k-step: MI x NI MFMAs; `nxt` = this lane's 16 bytes of the NEXT k-step in column block 0 (the blocks are 2 KiB apart)
-    auto kstep = [&](const u32x4 (&av)[MI], unsigned nxt) {
+    // one k-step: MI x NI MFMAs; `nxt` = this lane's 16 bytes, in column block 0 (the blocks are 2 KiB apart), of the k-step that operand
+    // set `bs` serves next
+    auto kstep = [&](auto bs_c, const u32x4 (&av)[MI], unsigned nxt) {
+        constexpr int bs = decltype(bs_c)::value;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[j]);
-            bb[j] = *reinterpret_cast<const u32x4*>(smem_r + nxt + j * 2048);
+            for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[bs][j]);
+            bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_r + nxt + j * 2048);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -253,6 +282,7 @@ conv_bf16_res_kernel(const ResArgs a) {
                     residual4(i, j, g, r);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) acc[i][j][4 * g + x] += r[x];
+                    if (g == 3) __builtin_amdgcn_sched_barrier(0);      // (block by block: all 32 reads at once cost 64 registers)
                 }
     };
 
@@ -286,7 +316,18 @@ conv_bf16_res_kernel(const ResArgs a) {
         const int r0 = hla - hl + wn0 + lr;                  // LDS row of (column lr of block 0, tap 0)
         unsigned xt = baddr(0, r0);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const u32x4*>(smem_r + xt + j * 2048);
+        for (int j = 0; j < NI; ++j) {
+            bb[0][j] = *reinterpret_cast<const u32x4*>(smem_r + xt + j * 2048);
+#ifdef V2W_RS_BB2
+            bb[1][j] = *reinterpret_cast<const u32x4*>(smem_r + (xt ^ 32u) + j * 2048);
+#endif
+        }
+        typedef std::integral_constant<int, 0> set0;
+#ifdef V2W_RS_BB2
+        typedef std::integral_constant<int, 1> set1;
+#else
+        typedef std::integral_constant<int, 0> set1;
+#endif
         auto tap = [&](auto par_c) {
             constexpr int S0 = 2 * decltype(par_c)::value;
             // the next tap: same chunk one dilation step on, or tap 0 of the next chunk (past the end: this tap again - unused)
@@ -294,10 +335,17 @@ conv_bf16_res_kernel(const ResArgs a) {
             if (nt_ >= K) { nt_ = 0; ++nch_; }
             if (nch_ >= nch) { nch_ = ch; nt_ = t; }
             const unsigned xn = baddr(nch_, r0 + nt_ * dil);
-            kstep(ar[S0], xt ^ 32u);                         // k-step 1 of the tap: slot ^ 2
+#ifdef V2W_RS_BB2
+            kstep(set0{}, ar[S0], xn);                       // k-step 0 of the next tap
             load_frag(ar[S0], qc, 0, qt);
             __builtin_amdgcn_sched_barrier(0);
-            kstep(ar[S0 + 1], xn);
+            kstep(set1{}, ar[S0 + 1], xn ^ 32u);             // k-step 1 of the next tap: slot ^ 2
+#else
+            kstep(set0{}, ar[S0], xt ^ 32u);                 // k-step 1 of the tap: slot ^ 2
+            load_frag(ar[S0], qc, 0, qt);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(set1{}, ar[S0 + 1], xn);
+#endif
             load_frag(ar[S0 + 1], qc, 1, qt);
             __builtin_amdgcn_sched_barrier(0);
             if (++qt >= K) { qt = 0; ++qc; }
@@ -316,6 +364,7 @@ conv_bf16_res_kernel(const ResArgs a) {
         const float dinv = div != 0.f ? 1.f / div : 1.f;
         unsigned vo = (unsigned)((4 * hk + qp) * L + 4 * qm) * 2u;             // lane part of the address: channel 4hk + qp, positions 4 qm ..
         asm volatile("" : "+v"(vo));
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(out) + (size_t)b * C * L * 2;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -339,31 +388,53 @@ conv_bf16_res_kernel(const ResArgs a) {
                     }
                     rs_quad_transpose(v, q0, q1);
                     const u32x2 w = {rs_pack2(v[0], v[1]), rs_pack2(v[2], v[3])};
-                    unsigned char* ob = reinterpret_cast<unsigned char*>(out) + ((size_t)(b * C + m0 + wm0 + 32 * i + 8 * g) * L + q) * 2;
-                    if (ok) *gptr<u32x2>(ob + vo) = w;
+                    // uniform base of the batch item (64-bit, scalar) + a 32-bit offset: uniform part + the lane's (C * L * 2 < 2^31: checked by the launcher)
+                    const unsigned uo = (unsigned)((m0 + wm0 + 32 * i + 8 * g) * L + q) * 2u;
+                    if (ok) *gptr<u32x2>(obase + (uo + vo)) = w;
                 }
+                __builtin_amdgcn_sched_barrier(0);          // (block by block: hoisting all 32 residual reads to the top spills accumulators)
             }
     };
 
+    V2W_STAMP(0);
     if constexpr (MODE == 0) {
         stage(a.in[0]);
+        V2W_STAMP(1);
         __syncthreads();
+        V2W_STAMP(2);
         for (int j = 0; j < nbr; ++j) {
             init_acc(j);
+            V2W_STAMP(3 + 3 * j);
             conv(rs_uni(a.wps[j]), rs_uni(a.K[j]), rs_uni(a.dil[j]));
+            V2W_STAMP(4 + 3 * j);
+#ifndef V2W_RS_ABL_NOEPI
             store_tile(rs_uni(a.out[j]), true, 0.f);
+#else
+            if (acc[0][0][0] == 12345.678f) store_tile(rs_uni(a.out[j]), true, 0.f);
+#endif
+            V2W_STAMP(5 + 3 * j);
         }
     } else {
         for (int j = 0; j < nbr; ++j) {
             if (j > 0) __syncthreads();                      // every wave is done with the previous branch's tile
+            V2W_STAMP(1 + 5 * j);
             stage(rs_uni(a.in[j]));
+            V2W_STAMP(2 + 5 * j);
             __syncthreads();
+            V2W_STAMP(3 + 5 * j);
             if (j == 0) init_acc(0);
             add_residual();
+            V2W_STAMP(4 + 5 * j);
             conv(rs_uni(a.wps[j]), rs_uni(a.K[j]), rs_uni(a.dil[j]));
+            V2W_STAMP(5 + 5 * j);
         }
+#ifndef V2W_RS_ABL_NOEPI
         store_tile(rs_uni(a.out[0]), false, a.out_div);
+#else
+        if (acc[0][0][0] == 12345.678f) store_tile(rs_uni(a.out[0]), false, a.out_div);
+#endif
     }
+    V2W_STAMP(20);
 }
 
 template <int MI, int NI, int WM, int WN>
@@ -402,6 +473,10 @@ int launch_res(const v2w_branch_convs_args* q, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef V2W_TIMELINE
+V2W_TL_SETTER(v2w_timeline_set_res)
+#endif
 
 #ifndef V2W_RS_C64_CFG
 #define V2W_RS_C64_CFG 0
