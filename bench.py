@@ -222,7 +222,7 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
     for tag, ts in per.items():
         names, fused = [], False
         staged = tag.startswith('stage:')       # whole residual section of a narrow stage in one kernel
-        for part in tag.replace('stage:', '').split('+'):   # 'resblocks.J.a&b' = convs a and b of block J fused
+        for part in tag.replace('stage:', '').split(':')[-1].split('+'):   # 'resblocks.J.a&b' = convs a and b of block J fused
             if '&' in part:
                 base, ab = part.rsplit('.', 1)
                 names += [f'{base}.{x}' for x in ab.split('&')]
@@ -230,12 +230,21 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             else:
                 names.append(part)
         ls = [layers[n] for n in names]
+        bconv = tag.startswith('bconv')           # v2w_branch_convs_bf16_fwd: the first / second convs of a wide stage's branches in one launch
+        if bconv:
+            tag_names = tag.split(':', 1)[1]
+            names = tag_names.split('+')
+            ls = [layers[n] for n in names]
         kname = kernel_of(ls[0], len(tag.split('+')))
+        if bconv:
+            kname = 'conv_bf16_res_kernel<%s, %d>' % ('2, 4, 2, 2' if ls[0]['cout'] % 128 == 0 else '1, 4, 2, 2', int(tag[5]))
         if fused:
             kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                     ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
             if staged and precision != 'f32':
-                kname = ('stage_bf16_kernel<%d' % ls[0]['cout']) if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
+                wide = {128: '<2, 2, 2, 4, 2>', 64: '<2, 2, 1, 4, 2>', 256: '<2, 2, 4, 2, 2>'}      # launch_wide configurations (v2w_stage_bf16_wide.hip)
+                kname = (('wide_stage_bf16_kernel' + wide[ls[0]['cout']]) if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
+                    if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         nbytes = sum(l['bytes'] for l in ls)
         if fused:                              # the intermediate is neither written nor re-read
             nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])

@@ -95,11 +95,77 @@ def child(C, variant):
         print(f'    kernel span {span} cycles')
 
 
+def child_stage(C, variant):
+    """The fused wide stage kernel (v2w_stage_bf16_wide.hip) at the configs[2] shape of stage C."""
+    os.environ['V2W_LIB'] = lib_of(variant)
+    import numpy as np
+    import torch
+    from wavthruvec_pytorch_amd import _hip, hipops
+    _hip.load()
+    raw = ctypes.CDLL(lib_of(variant))
+    stamps = hasattr(raw, 'v2w_timeline_set_wide')
+    if stamps:
+        raw.v2w_timeline_set_wide.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert raw.v2w_timeline_set_wide(None, 0) == 0
+    dev = torch.device('cuda:0')
+    B, L = 64, LEN[C]
+    ks = [3, 7, 11]
+    x = torch.randn(B, C, L, device=dev).bfloat16()
+    a = torch.rand(B, C, device=dev) + 0.5
+    s = torch.randn(B, C, device=dev) * 0.1
+    br = [dict(wps1=hipops.pack_split(torch.randn(k, C, C, device=dev) / (C * k) ** 0.5, bf16=True), b1=torch.zeros(C, device=dev),
+               wps2=hipops.pack_split(torch.randn(k, C, C, device=dev) / (C * k) ** 0.5, bf16=True), b2=torch.zeros(C, device=dev),
+               k=k, dil1=1, dil2=3) for k in ks]
+    out = torch.empty_like(x)
+    run = lambda: hipops.resblock2_stage_split(x, (a, s), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
+    assert run()
+    fl = 2 * 2.0 * C * C * sum(ks) * L * B
+    for _ in range(3):
+        run()
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    us = ts[len(ts) // 2]
+    print(f'[{variant or "base"}] stage C={C}: {us:7.1f} us ({fl / us / 1e6:6.1f} TF useful)', flush=True)
+    if not stamps:
+        return
+    W = {128: 256, 64: 512, 256: 128}[C]
+    nto = (W - 30) & ~3
+    nblk = B * ((L + nto - 1) // nto)
+    buf = torch.zeros((nblk * 4 * SLOTS,), device=dev, dtype=torch.int64)
+    assert raw.v2w_timeline_set_wide(buf.data_ptr(), nblk) == 0
+    run(); torch.cuda.synchronize()
+    assert raw.v2w_timeline_set_wide(None, 0) == 0
+    t = buf.cpu().numpy().reshape(nblk, 4, SLOTS).astype(np.int64)
+    t = t[t[:, 0, 0] != 0]
+    med = lambda v: int(np.median(v))
+    d = lambda i, j: med(t[:, :, i] - t[:, :, j])
+    nch = C // 32
+    mi, ni = 2, 2
+    print(f'  tile total {d(28, 0)} cycles over {t.shape[0]} tiles (waves 0-3 of 8 stamped); staging {d(1, 0)}  barrier {d(2, 1)}')
+    for j, k in enumerate(ks):
+        iss = k * nch * 2 * mi * ni * 32
+        print(f'    branch {j} (k={k}): init {d(3 + 6 * j, 2 if j == 0 else 8 + 6 * (j - 1))}  conv1 {d(4 + 6 * j, 3 + 6 * j)} (issue alone {iss})  barrier {d(5 + 6 * j, 4 + 6 * j)}  '
+              f't1 {d(6 + 6 * j, 5 + 6 * j)}  barrier {d(7 + 6 * j, 6 + 6 * j)}  conv2 {d(8 + 6 * j, 7 + 6 * j)}')
+    print(f'    barrier {d(27, 20)}  store {d(28, 27)}')
+    clk = (t[:, 0, 28] - t[:, 0, 0])
+    print(f'    clock: kernel {us:.1f} us; tiles per CU {t.shape[0] / 256:.2f}; sum of tile cycles per CU / kernel time = {np.sum(clk) / 256 / us / 1e3:.2f} GHz-equivalent')
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'build':
         build(sys.argv[2] if len(sys.argv) > 2 else '', sys.argv[3:])
     elif sys.argv[1] == 'child':
         child(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else '')
+    elif sys.argv[1] == 'child_stage':
+        child_stage(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else '')
+    elif sys.argv[1] == 'stage':
+        for rnd in range(2):
+            for v in (sys.argv[3:] or ['']):
+                subprocess.run([sys.executable, os.path.abspath(__file__), 'child_stage', sys.argv[2], v])
     else:
         C = int(sys.argv[1])
         variants = sys.argv[2:] or ['']

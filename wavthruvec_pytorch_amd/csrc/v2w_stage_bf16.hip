@@ -438,8 +438,11 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
 V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
 #endif
 
+int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16_wide.hip
+
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
+    if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
     if (a->C == 32) return launch_stage_bf16<32>(a, stream);
     if (a->C == 16) return launch_stage_bf16<16>(a, stream);
     return V2W_E_SHAPE;

@@ -1,0 +1,421 @@
+// Whole residual section of a WIDE ResBlock2 stage (C = 64 / 128 / 256) in ONE kernel on the bf16 matrix pipe, bf16 tensors in and out
+// (BASELINE configs[2]: bf16 compute / fp32 accumulate, bf16 activation storage); models.py:135-141 with ResBlock2.forward inlined:
+//   out = ( sum_j [ t1_j + conv_{k_j,d2_j}(lrelu(t1_j)) + b2_j ] ) / nk ,   t1_j = x + conv_{k_j,d1_j}(lrelu(x)) + b1_j ,   x = a * in + s
+//
+// As six separate convolutions these stages move 15 activation tensors per stage through HBM (x read three times, three t1 written and
+// read twice, two partial sums written and read) and each launch pays its own staging and epilogue; here x is read ONCE, the output
+// written ONCE, and t1_j never leaves the chip:
+//   * one workgroup of 8 waves per CU owns a window of W positions of all C channels.  LDS holds the activated x tile
+//     [C / 32 planes][W + 2 h1max rows][64 B] and the activated t1 tile [C / 32][W + 2 h2max][64 B] (both position-major bf16, the 16-byte
+//     slots of a row XOR-swizzled by (row >> 2) & 3: conflict-free ds_read_b128 operands at every tap offset - v2w_conv_bf16_res.hip);
+//   * per branch: conv1_j on the window (MFMA over every (plane, tap) of the resident x tile, no barrier inside) -> t1 = acc + x
+//     (the residual rebuilt from the tile itself, in the accumulator's layout) -> lrelu -> bf16 -> the t1 tile, 8-byte LDS stores straight
+//     from the accumulator layout (no transposition: rows ARE positions) -> barrier -> conv2_j over the t1 tile, accumulating onto ONE
+//     fp32 accumulator that runs over the branches and already holds sum_j (t1_j + b2_j) in fp32 (t1 is never rounded on that path);
+//   * valid outputs = window - h2max columns per side (conv2's halo); they leave through an fp32 LDS scratch (the dead t1 tile) as
+//     8-byte bf16 stores along positions;
+//   * weights: the fragments of v2w_pack_bf16 / v2w_split_pack_batch from L2 through a four-slot register ring, three k-steps ahead.
+#include <type_traits>
+#include "v2w_tile.h"
+
+namespace {
+
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define V2W_WS_MAXB 4
+#define V2W_WS_UNIT 2048     // byte pitch of the packed fragments of one (32-row block, 16-channel k-step, tap)
+#ifndef V2W_WS_RING
+#define V2W_WS_RING 2        // taps of weight fragments in flight per wave (2 or 4: measured the same, 1074 vs 1092 us at C = 128)
+#endif
+#ifndef V2W_WS_CFG
+#define V2W_WS_CFG 0
+#endif
+
+struct WideArgs {
+    const unsigned short* in; const float* in_a; const float* in_s;
+    const unsigned char* w1[V2W_WS_MAXB]; const float* bias1[V2W_WS_MAXB];
+    const unsigned char* w2[V2W_WS_MAXB]; const float* bias2[V2W_WS_MAXB];
+    int K[V2W_WS_MAXB], d1[V2W_WS_MAXB], d2[V2W_WS_MAXB];
+    unsigned short* out;
+    int nk, B, C, L;
+    int h1max, h2max, xoff, xrows, trows, nto, ntl, ntiles;
+    float slope, inv_slope, out_div;
+};
+
+__device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float ws_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float ws_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ int ws_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); return v; }
+
+// MI x NI blocks of 32 x 32 per wave, WM x WN waves: C = 32 MI WM channels, window W = 32 NI WN positions
+// OCC = waves per SIMD the register budget is cut for: 8-wave workgroups (one per CU) and 4-wave workgroups at two per CU: 2 (256 registers);
+// a 4-wave workgroup alone on its CU: 1 (the whole 512-register file)
+template <int MI, int NI, int WM, int WN, int OCC>
+__global__ void __launch_bounds__(64 * WM * WN, OCC)
+wide_stage_bf16_kernel(const WideArgs a) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int NTH = 64 * WM * WN, C = 32 * MI * WM, W = 32 * NI * WN, NCH = C / 32;
+    constexpr int XRMAX = W + 2 * 32 + 4;                                       // rows of the x tile at most (h1max <= 32)
+    constexpr int NPF = (NCH * 8 * (XRMAX / 4) + NTH - 1) / NTH;                // staging items (4 channels x 4 positions) per thread
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+
+    const int L = ws_uni(a.L), xrows = ws_uni(a.xrows), trows = ws_uni(a.trows), nk = ws_uni(a.nk);
+    const int h1max = ws_uni(a.h1max), h2max = ws_uni(a.h2max), nto = ws_uni(a.nto);
+    const int xpsz = xrows * 64, tpsz = trows * 64;                             // bytes per 32-channel plane
+    const unsigned xbase = 0, tbase = (unsigned)(NCH * xpsz);                   // LDS byte offsets of the two tiles
+    float* const btab = reinterpret_cast<float*>(smem_w + tbase + NCH * tpsz); // bias1[nk][C], then sum_j bias2_j [C], then a[C], s[C]
+    float* const b2tab = btab + V2W_WS_MAXB * C;
+    float* const atab = b2tab + C;
+    const float slope = a.slope, inv_slope = a.inv_slope;
+
+    const int tile = blockIdx.x;
+    const int b = tile / a.ntl;
+    const int n0 = (tile % a.ntl) * nto;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = ws_uni(tid >> 6);
+    const int lr = lane & 31, hk = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MI);
+    const int wn0 = (wave % WN) * (32 * NI);
+    const int pos0 = n0 - h2max - h1max - ws_uni(a.xoff);                       // position of x row 0 (multiple of 4)
+    const int xc0 = ws_uni(a.xoff) + h1max;                                     // x row of window column 0 (position n0 - h2max)
+    V2W_STAMP(0);
+
+    // ---- tables
+    for (int i = tid; i < nk * C; i += NTH) {
+        const int j = i / C, c = i - j * C;
+        btab[i] = a.bias1[j] ? a.bias1[j][c] : 0.f;
+    }
+    for (int c = tid; c < C; c += NTH) {
+        float v = 0.f;
+        for (int j = 0; j < nk; ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
+        b2tab[c] = v;
+        atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
+        atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
+    }
+
+    // ---- stage lrelu(a * in + s) as bf16, every channel of the window + halo in ONE burst of loads.  An item = 4 channels x 4 positions:
+    // four 8-byte loads (4 positions of one channel), four 8-byte LDS stores (the 4 channels of one position)
+    {
+        const int nq = xrows >> 2;
+        const int nitems = NCH * 8 * nq;
+        u32x2 pf[NPF][4];
+        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * C * L * 2;
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTH;
+            const int cq = idx & 7, rest = idx >> 3;
+            const int pq = rest % nq, ch = rest / nq;
+            const int pos = pos0 + pq * 4;
+            const bool ok = idx < nitems && pos >= 0 && pos < L;
+            unsigned vo = (unsigned)((32 * (idx < nitems ? ch : 0) + 4 * cq) * L + (ok ? pos : 0)) * 2u;
+            asm volatile("" : "+v"(vo));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[s][i] = *gptr<const u32x2>(inb + (size_t)i * L * 2 + vo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                    // the affine table is complete
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTH;
+            if (idx >= nitems) continue;
+            const int cq = idx & 7, rest = idx >> 3;
+            const int pq = rest % nq, ch = rest / nq;
+            const int pos = pos0 + pq * 4;
+            const bool ok = pos >= 0 && pos < L;           // L % 4 == 0 and pos % 4 == 0: a quad is inside or outside as a whole
+            const f32x4 av = *reinterpret_cast<const f32x4*>(atab + 32 * ch + 4 * cq);
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(atab + C + 32 * ch + 4 * cq);
+            const int row = pq * 4;
+            unsigned char* dst = smem_w + xbase + ch * xpsz + row * 64 + ((((cq >> 1) ^ (pq & 3)) << 4) | ((cq & 1) << 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xv = (e & 1) ? ws_hi(pf[s][i][e >> 1]) : ws_lo(pf[s][i][e >> 1]);
+                    v[i] = v2w_lrelu(fmaf(av[i], xv, sv[i]), slope);
+                }
+                u32x2 w = {ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
+                if (!ok) w = u32x2{0u, 0u};                 // the padding of the ACTIVATED signal is exactly 0
+                *reinterpret_cast<u32x2*>(dst + e * 64) = w;
+            }
+        }
+    }
+    V2W_STAMP(1);
+    __syncthreads();
+    V2W_STAMP(2);
+
+    acc_t acc1[MI][NI], oacc[MI][NI];
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
+    };
+    // this lane's 16 bytes of k-step 0 at (plane ch, row): slot hk, swizzled by the row; k-step 1 is the address ^ 32
+    auto baddr = [&](unsigned base, int psz, int ch, int row) {
+        return base + (unsigned)(ch * psz + row * 64 + ((hk ^ ((row >> 2) & 3)) << 4));
+    };
+
+    // ---- the MFMA loop of one conv over a resident tile (base, plane size psz): NCH * K taps walked in pairs (ring slots 0 / 1 even
+    // taps, 2 / 3 odd taps), B operands one set per k-step of a tap, refilled for the next tap.  r0 = tile row of (column lr of this
+    // wave's block 0, tap 0).
+    auto conv = [&](acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps, int K, int dil) {
+        const int nst = 2 * NCH * K;
+        const unsigned char* ap[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ap[i] = wps + (size_t)(wm0 / 32 + i) * nst * V2W_WS_UNIT;
+        // ring of V2W_WS_RING taps (two fragments per row block each): the fragments of tap g + RING are requested as tap g's k-steps
+        // retire, i.e. 2 RING - 1 k-steps ahead.  Measured: with 3 k-steps (768 cycles of issue) of lookahead every k-step waited -
+        // the fragment stream of a stage (every CU walks the same 1.4 MB at the same time) answers in ~1400 cycles, not the ~500 of
+        // an idle L2.
+        constexpr int RT = V2W_WS_RING;
+        u32x4 ar[2 * RT][MI];
+        auto load_frag = [&](u32x4 (&av)[MI], int ch, int s, int t) {     // k-step s of (plane ch, tap t); clamped past the end
+            unsigned l16 = lane16;
+            asm volatile("" : "+v"(l16));
+            const int chc = ch < NCH ? ch : NCH - 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                av[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_WS_UNIT + l16);
+        };
+        int qc = 0, qt = 0;                                  // the tap whose fragments are requested next
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            load_frag(ar[2 * r], qc, 0, qt);
+            load_frag(ar[2 * r + 1], qc, 1, qt);
+            if (++qt >= K) { qt = 0; ++qc; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int ch = 0, t = 0;                                   // the running tap
+        unsigned xt = baddr(base, psz, 0, r0);
+        u32x4 bb[2][NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bb[0][j] = *reinterpret_cast<const u32x4*>(smem_w + xt + j * 2048);
+            bb[1][j] = *reinterpret_cast<const u32x4*>(smem_w + (xt ^ 32u) + j * 2048);
+        }
+        auto kstep = [&](auto bs_c, const u32x4 (&av)[MI], unsigned nxt) {
+            constexpr int bs = decltype(bs_c)::value;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[bs][j]);
+#ifndef V2W_WS_ABL_NOB
+                bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_w + nxt + j * 2048);
+#else
+                asm volatile("" : "+v"(bb[bs][j]) : "v"(nxt));
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto tap = [&](auto par_c) {
+            constexpr int S0 = 2 * decltype(par_c)::value;
+            int nch_ = ch, nt_ = t + 1;                      // the next tap (past the end: this tap again - unused)
+            if (nt_ >= K) { nt_ = 0; ++nch_; }
+            if (nch_ >= NCH) { nch_ = ch; nt_ = t; }
+            const unsigned xn = baddr(base, psz, nch_, r0 + nt_ * dil);
+            kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
+#ifndef V2W_WS_ABL_NOA
+            load_frag(ar[S0], qc, 0, qt);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(std::integral_constant<int, 1>{}, ar[S0 + 1], xn ^ 32u);
+#ifndef V2W_WS_ABL_NOA
+            load_frag(ar[S0 + 1], qc, 1, qt);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (++qt >= K) { qt = 0; ++qc; }
+            ch = nch_; t = nt_; xt = xn;
+        };
+        const int TT = NCH * K;
+        int g = 0;
+        for (; g + RT <= TT; g += RT) {
+            tap(std::integral_constant<int, 0>{});
+            if constexpr (RT > 1) tap(std::integral_constant<int, 1>{});
+            if constexpr (RT > 2) tap(std::integral_constant<int, 2>{});
+            if constexpr (RT > 3) tap(std::integral_constant<int, 3>{});
+        }
+        if (g < TT) tap(std::integral_constant<int, 0>{});
+        if constexpr (RT > 2) { if (g + 1 < TT) tap(std::integral_constant<int, 1>{}); }
+        if constexpr (RT > 3) { if (g + 2 < TT) tap(std::integral_constant<int, 2>{}); }
+    };
+
+    // ---- the running output accumulator starts at sum_j b2_j
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2tab + wm0 + 32 * i + 8 * g + 4 * hk);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) oacc[i][j][4 * g + x] = bv[x];
+        }
+
+    for (int jb = 0; jb < nk; ++jb) {
+        const int K = ws_uni(a.K[jb]), d1 = ws_uni(a.d1[jb]), d2 = ws_uni(a.d2[jb]);
+        const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
+        // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(btab + jb * C + wm0 + 32 * i + 8 * g + 4 * hk);
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
+            }
+        V2W_STAMP(3 + 6 * jb);
+        conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
+        V2W_STAMP(4 + 6 * jb);
+        __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
+        V2W_STAMP(5 + 6 * jb);
+        // ---- t1 = acc + x (x rebuilt from the activated tile: registers 4g .. 4g+3 of block (i, j) <-> channels 8g + 4hk + {0..3} of plane
+        // wm0 / 32 + i at this lane's position = 8 contiguous bytes); the running output takes t1 in fp32, the tile lrelu(t1) as bf16
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int col = wn0 + lr;
+                asm volatile("" : "+v"(col));               // (recomputed per branch: hoisted out of the loop these addresses spill)
+                col += 32 * j;
+                const int pos = n0 - h2max + col;
+                const bool in_seq = pos >= 0 && pos < L;    // conv2 zero-pads t1 outside the sequence
+                const int xrow = xc0 + col, trow = h2max + col;
+                const unsigned xq = xbase + (unsigned)((wm0 / 32 + i) * xpsz + xrow * 64 + 8 * hk);
+                const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + trow * 64 + 8 * hk);
+                const int xsw = (xrow >> 2) & 3, tsw = (trow >> 2) & 3;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(smem_w + xq + ((g ^ xsw) << 4));
+                    const float xa[4] = {ws_lo(w[0]), ws_hi(w[0]), ws_lo(w[1]), ws_hi(w[1])};
+                    float t1v[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float xr = fminf(xa[x], xa[x] * inv_slope);          // lrelu undone (slope < 1)
+                        t1v[x] = in_seq ? acc1[i][j][4 * g + x] + xr : 0.f;
+                        oacc[i][j][4 * g + x] += t1v[x];
+                        t1v[x] = fmaxf(t1v[x], t1v[x] * slope);
+                    }
+                    *reinterpret_cast<u32x2*>(smem_w + tq + ((g ^ tsw) << 4)) = u32x2{ws_pack2(t1v[0], t1v[1]), ws_pack2(t1v[2], t1v[3])};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        V2W_STAMP(6 + 6 * jb);
+        __syncthreads();
+        V2W_STAMP(7 + 6 * jb);
+        // ---- conv2_j on the same window, onto the running accumulator
+        conv(oacc, tbase, tpsz, h2max - h2 + wn0 + lr, ws_uni(a.w2[jb]), K, d2);
+        V2W_STAMP(8 + 6 * jb);
+    }
+
+    // ---- store the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so
+    // that output position quads are 16-byte aligned, as 8-byte bf16 stores along positions (all waves: quads cross the waves' columns)
+    __syncthreads();
+    V2W_STAMP(27);
+    {
+        constexpr int SRS = W + 8;
+        float* const scr = reinterpret_cast<float*>(smem_w);
+        const int soff = (h2max + 3) & ~3;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int sc = wn0 + j * 32 + lr - h2max + soff;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) scr[(wm0 + 32 * i + F::row(e, hk)) * SRS + sc] = oacc[i][j][e];
+            }
+        __syncthreads();
+        const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
+        const int nq = nto >> 2;
+        const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * C * L * 2;
+        for (int idx = tid; idx < C * nq; idx += NTH) {
+            const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
+            const int pos = n0 + 4 * q;
+            if (pos >= L) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
+            if (a.out_div != 0.f) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], a.out_div, dinv);
+            }
+            *gptr<u32x2>(obase + (unsigned)(row * L + pos) * 2u) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
+        }
+    }
+    V2W_STAMP(28);
+}
+
+template <int MI, int NI, int WM, int WN, int OCC = 2>
+int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
+    constexpr int NTH = 64 * WM * WN, C = 32 * MI * WM, W = 32 * NI * WN;
+    WideArgs p{};
+    p.in = reinterpret_cast<const unsigned short*>(q->in); p.in_a = q->in_a; p.in_s = q->in_s;
+    p.out = reinterpret_cast<unsigned short*>(q->out);
+    p.nk = q->nk; p.B = q->B; p.C = q->C; p.L = q->L; p.slope = q->slope; p.inv_slope = 1.f / q->slope; p.out_div = q->out_div;
+    for (int j = 0; j < q->nk; ++j) {
+        p.w1[j] = static_cast<const unsigned char*>(q->wps1[j]); p.bias1[j] = q->bias1[j];
+        p.w2[j] = static_cast<const unsigned char*>(q->wps2[j]); p.bias2[j] = q->bias2[j];
+        p.K[j] = q->k[j]; p.d1[j] = q->dil1[j]; p.d2[j] = q->dil2[j];
+        const int h1 = q->dil1[j] * (q->k[j] - 1) / 2, h2 = q->dil2[j] * (q->k[j] - 1) / 2;
+        if (h1 > p.h1max) p.h1max = h1;
+        if (h2 > p.h2max) p.h2max = h2;
+    }
+    if (p.h1max > 32 || p.h2max > 32) return V2W_E_SHAPE;
+    p.nto = (W - 2 * p.h2max) & ~3;
+    if (p.nto < W / 2) return V2W_E_SHAPE;
+    const int hsum = p.h1max + p.h2max;
+    p.xoff = ((hsum + 3) & ~3) - hsum;
+    p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
+    p.trows = (W + 2 * p.h2max + 3) & ~3;
+    p.ntl = (q->L + p.nto - 1) / p.nto;
+    p.ntiles = q->B * p.ntl;
+    const size_t tiles = (size_t)(C / 32) * (p.xrows + p.trows) * 64;
+    const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float);
+    if (lds * ((OCC * 4) / (WM * WN)) > 160 * 1024) return V2W_E_SHAPE;       // (two workgroups per CU where the configuration counts on it)
+    if (tiles < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;     // the store scratch [C][W + 8] overlays the two tiles
+    if (!(q->slope > 0.f && q->slope <= 1.f)) return V2W_E_SHAPE;            // lrelu as max(v, slope v), undone as min(a, a / slope)
+    auto kern = wide_stage_bf16_kernel<MI, NI, WM, WN, OCC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
+    return v2w_launch_status();
+}
+
+}  // namespace
+
+#ifdef V2W_TIMELINE
+V2W_TL_SETTER(v2w_timeline_set_wide)
+#endif
+
+// Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for C >= 64 on bf16 tensors.  V2W_E_SHAPE: the caller issues the convs one by one.
+int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream) {
+    if (a->io_bf16 != 3 || a->nk > V2W_WS_MAXB) return V2W_E_SHAPE;
+    auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+    if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out)) return V2W_E_SHAPE;
+    if ((long long)a->C * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;           // 32-bit offsets inside one batch item
+    // Measured (one MI355X, configs[2] shapes, us per stage): 8 waves of 64 x 64 outputs 1074 / 1225 / 1133 (C = 128 / 64 / 256) against 4 waves of
+    // 64 x 128 with the whole register file 1227 / 1467 / 1199: the single wave per SIMD runs its bare MFMA loop at 89 % of the issue rate
+    // but nothing covers its epilogues.  C = 64 fits twice per CU as 4-wave workgroups of 256 positions, which run out of phase.
+#if V2W_WS_CFG == 1
+    if (a->C == 128) return launch_wide<2, 4, 2, 2, 1>(a, stream);
+    if (a->C == 64) return launch_wide<2, 4, 1, 4, 1>(a, stream);
+    if (a->C == 256) return launch_wide<2, 4, 4, 1, 1>(a, stream);
+#else
+    if (a->C == 128) return launch_wide<2, 2, 2, 4>(a, stream);                   // 128 channels x 256 positions, 8 waves
+#if V2W_WS_CFG == 2
+    if (a->C == 64) return launch_wide<2, 2, 1, 8>(a, stream);                    // 64 channels x 512 positions, 8 waves
+#else
+    if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);                    // 64 channels x 256 positions, 4 waves, two workgroups per CU
+#endif
+    if (a->C == 256) return launch_wide<2, 2, 4, 2>(a, stream);                   // 256 channels x 128 positions, 8 waves
+#endif
+    return V2W_E_SHAPE;
+}

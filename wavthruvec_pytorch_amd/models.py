@@ -206,6 +206,7 @@ class Generator(nn.Module):
         self.split_min_channels = 64
         self.bf16_storage = True              # precision == 'bf16': keep activations in bf16 between layers (no-grad forwards)
         self.fuse_wide = True                 # bf16 storage: the residual convs of the wide stages (C >= 64) as one launch per conv position
+        self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
@@ -627,6 +628,15 @@ class Generator(nn.Module):
                                                    dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
                                               for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
                                              bf16=self.precision == 'bf16', io_bf16=3 if st else 0)
+                        if not ok and st and self.fuse_wide_stage and C >= 64 and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
+                            # wide stage on bf16 tensors: the WHOLE residual section in one kernel (v2w_stage_bf16_wide.hip): x read once,
+                            # t1_j on chip, one fp32 accumulator over the branches
+                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
+                                             [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                   wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
+                                             bf16=True, io_bf16=3)
                         if st and not ok and C in (16, 32):
                             raise RuntimeError('bf16 storage: the fused narrow-stage kernel did not take this shape '
                                                '(set generator.bf16_storage = False)')
