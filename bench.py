@@ -313,6 +313,11 @@ class stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:                                   # the banner sits in libc's stdout buffer (a file or pipe is block-buffered): out with it
+            import ctypes                      # while fd 1 still is stderr
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self.keep, 1)
         os.close(self.keep)
 

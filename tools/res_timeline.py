@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SLOTS = 32
-LEN = {256: 2560, 128: 10240, 64: 40960}
+LEN = {256: 2560, 128: 10240, 64: 40960, 32: 81920, 16: 163840}
 
 
 def lib_of(variant):
@@ -132,7 +132,7 @@ def child_stage(C, variant):
     print(f'[{variant or "base"}] stage C={C}: {us:7.1f} us ({fl / us / 1e6:6.1f} TF useful)', flush=True)
     if not stamps:
         return
-    W = {128: 256, 64: 512, 256: 128}[C]
+    W = {128: 256, 64: 256, 256: 128, 32: 256}[C]
     nto = (W - 30) & ~3
     nblk = B * ((L + nto - 1) // nto)
     buf = torch.zeros((nblk * 4 * SLOTS,), device=dev, dtype=torch.int64)
@@ -141,10 +141,11 @@ def child_stage(C, variant):
     assert raw.v2w_timeline_set_wide(None, 0) == 0
     t = buf.cpu().numpy().reshape(nblk, 4, SLOTS).astype(np.int64)
     t = t[t[:, 0, 0] != 0]
-    med = lambda v: int(np.median(v))
+    med = lambda v: f'{int(np.median(v))}/{int(np.mean(v))}'
     d = lambda i, j: med(t[:, :, i] - t[:, :, j])
     nch = C // 32
     mi, ni = 2, 2
+    print('  (median/mean cycles)')
     print(f'  tile total {d(28, 0)} cycles over {t.shape[0]} tiles (waves 0-3 of 8 stamped); staging {d(1, 0)}  barrier {d(2, 1)}')
     for j, k in enumerate(ks):
         iss = k * nch * 2 * mi * ni * 32
