@@ -320,6 +320,123 @@ def test_convt1d_bf16_operands(dev, B, cin, cout, L, k, u):
     assert (sums[:, 1] - (o * o).sum((0, 2))).abs().max().item() <= 1e-4 * (o * o).sum((0, 2)).max().item()
 
 
+@pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 256, 128, 264, 8, 4), (3, 128, 64, 1000, 8, 4), (2, 64, 32, 2052, 4, 2),
+                                              (2, 32, 16, 4100, 4, 2), (1, 64, 32, 36, 4, 2), (2, 128, 64, 72, 16, 8),
+                                              (2, 512, 256, 52, 11, 5), (2, 64, 32, 37, 4, 2)])
+def test_convt1d_bf16_activation_storage(dev, B, cin, cout, L, k, u):
+    """io_bf16 = 3: the transposed conv on bf16 TENSORS (models.py:128-129 under BASELINE configs[2] with bf16 activation storage).  Strides
+    2 / 4 / 8 at L % 4 == 0 run on the resident-tile kernel (v2w_convt_bf16_res.hip: stores straight from the accumulators), stride 5 and
+    ragged lengths on the chunked kernel: both against an fp64 ConvTranspose1d of the same bf16 operands to the rounding of the bf16
+    store, and the fused BatchNorm partial sums (taken from the fp32 values before rounding) against the reference's sums.  The rows of
+    `stats_part` are asked for with the same tensors and io_bf16 (the tile width follows the kernel)."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(23)
+    x = torch.from_numpy(r.standard_normal((B, cin, L), dtype=np.float32)).bfloat16()
+    w = (r.standard_normal((cin, cout, k)) / np.sqrt(cin * k / u)).astype(np.float32)
+    bias = r.standard_normal(cout).astype(np.float32)
+    xa = F.leaky_relu(x.float(), 0.1).bfloat16().double()
+    want = F.conv_transpose1d(xa, torch.from_numpy(w).bfloat16().double(), torch.from_numpy(bias).double(), stride=u, padding=(k - u) // 2)
+    wps = hipops.pack_bf16_convt(_t(np.ascontiguousarray(w.transpose(2, 0, 1)), dev), u)
+    assert wps is not None
+    xd = x.to(dev)
+    out = torch.full((B, cout, L * u), float('nan'), device=dev, dtype=torch.bfloat16)
+    nt = hipops.convt_bf16_stats_tiles(xd, out, k, u, io_bf16=3)
+    assert nt > 0
+    part = torch.full((nt * cout * 2,), float('nan'), device=dev)
+    hipops.convt1d_bf16(xd, wps, _t(bias, dev), out, k=k, u=u, slope=0.1, stats_part=part, io_bf16=3)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(part).all()
+    err = (out.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 1e-6).all(), f'max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    sums = part.view(nt, cout, 2).double().sum(0).cpu()
+    assert (sums[:, 0] - want.sum((0, 2))).abs().max().item() <= 1e-3 * max(1.0, want.sum((0, 2)).abs().max().item())
+    assert (sums[:, 1] - (want * want).sum((0, 2))).abs().max().item() <= 1e-4 * (want * want).sum((0, 2)).max().item()
+    # without the statistics (eval mode) the same values
+    out2 = torch.empty_like(out)
+    hipops.convt1d_bf16(xd, wps, _t(bias, dev), out2, k=k, u=u, slope=0.1, io_bf16=3)
+    assert torch.equal(out2, out)
+
+
+def _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, slope, rebuilt_residual):
+    """ResBlock2 section of a stage on bf16-rounded operands in fp64: out = mean_j [t1_j + conv2_j(lrelu(t1_j)) + b2_j],
+    t1_j = x + conv1_j(lrelu(x)) + b1_j, x = a * xr + s.  rebuilt_residual: x on the residual path is the ACTIVATED bf16 operand with the
+    leaky_relu undone (what the wide kernels do), else the fp32 affine result."""
+    xa = (a[:, :, None] * x.float() + s[:, :, None])
+    xact = F.leaky_relu(xa, slope).bfloat16().double()
+    xres = torch.where(xact > 0, xact, xact / slope) if rebuilt_residual else xa.double()
+    tot, t1s = 0, []
+    for j, k in enumerate(ks):
+        t1 = xres + F.conv1d(xact, w1[j].bfloat16().double(), b1[j].double(), dilation=d1[j], padding=d1[j] * (k - 1) // 2)
+        tact = F.leaky_relu(t1.float(), slope).bfloat16().double()
+        tot = tot + t1 + F.conv1d(tact, w2[j].bfloat16().double(), b2[j].double(), dilation=d2[j], padding=d2[j] * (k - 1) // 2)
+        t1s.append(t1)
+    return tot / len(ks), t1s
+
+
+@pytest.mark.parametrize('B,C,L', [(2, 128, 512), (3, 128, 1004), (1, 128, 20), (2, 64, 1024), (3, 64, 2000), (2, 256, 256), (3, 256, 500)])
+def test_resblock2_wide_stage_bf16_storage(dev, B, C, L):
+    """The whole residual section of a WIDE stage (C = 64 / 128 / 256) on bf16 tensors in one kernel (v2w_stage_bf16_wide.hip through
+    v2w_resblock2_stage_split_fwd; models.py:135-141 with ResBlock2.forward inlined): windows that straddle the sequence ends, ragged
+    tile counts, the generator's kernel sizes and dilations - against fp64 math on the same bf16 operands, to the rounding of the bf16
+    store (t1 itself stays fp32 inside the kernel)."""
+    from wavthruvec_pytorch_amd import hipops
+    g = torch.Generator().manual_seed(100 + C + L)
+    ks, d1, d2 = [3, 7, 11], [1, 1, 1], [3, 3, 3]
+    x = torch.randn(B, C, L, generator=g).bfloat16()
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    want, _ = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, True)
+    br = [dict(wps1=hipops.pack_split(w1[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b1=b1[j].to(dev),
+               wps2=hipops.pack_split(w2[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b2=b2[j].to(dev),
+               k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(3)]
+    out = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    ok = hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
+    assert ok, 'the wide stage kernel declined a shape it is built for'
+    assert torch.isfinite(out.float()).all()
+    err = (out.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 2e-2).all(), f'max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    assert err.mean().item() <= 4e-3
+
+
+@pytest.mark.parametrize('B,C,L', [(2, 64, 256), (3, 64, 1000), (2, 128, 512), (3, 128, 1004), (1, 128, 20)])
+def test_branch_convs_bf16(dev, B, C, L):
+    """v2w_branch_convs_bf16_fwd: the first convs of all branches of a wide stage in one launch (mode 0: x staged once, three t1
+    tensors), then the second convs on one accumulator (mode 1: one output) - the two-launch form of a wide stage, against fp64 math
+    on the same bf16 operands (the residuals rebuilt from the activated operand, as the kernel does)."""
+    from wavthruvec_pytorch_amd import hipops
+    g = torch.Generator().manual_seed(7 + C + L)
+    ks, d1, d2 = [3, 7, 11], [1, 1, 1], [3, 3, 3]
+    x = torch.randn(B, C, L, generator=g).bfloat16()
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    _, t1_want = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, True)
+    wp1 = [hipops.pack_split(w.permute(2, 1, 0).contiguous().to(dev), bf16=True)[0] for w in w1]
+    wp2 = [hipops.pack_split(w.permute(2, 1, 0).contiguous().to(dev), bf16=True)[0] for w in w2]
+    t1 = [torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16) for _ in ks]
+    assert hipops.branch_convs_bf16(0, [x.to(dev)], (a.to(dev), s.to(dev)), wp1, [b.to(dev) for b in b1], t1, ks, d1, slope=0.1)
+    for got, want in zip(t1, t1_want):
+        err = (got.cpu().double() - want).abs()
+        assert (err <= 2.0 ** -8 * want.abs() + 1e-2).all(), f'mode 0: max err {err.max().item()}'
+    # mode 1 on the kernel's own (bf16) t1 tensors
+    tot = 0
+    for j, k in enumerate(ks):
+        tact = F.leaky_relu(t1[j].cpu().float(), 0.1).bfloat16().double()
+        tres = torch.where(tact > 0, tact, tact / 0.1)
+        tot = tot + tres + F.conv1d(tact, w2[j].bfloat16().double(), b2[j].double(), dilation=d2[j], padding=d2[j] * (k - 1) // 2)
+    want = tot / 3.0
+    out = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    assert hipops.branch_convs_bf16(1, t1, None, wp2, [b.to(dev) for b in b2], [out], ks, d2, slope=0.1, out_div=3.0)
+    err = (out.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 1e-2).all(), f'mode 1: max err {err.max().item()}'
+
+
 @pytest.mark.parametrize('C', [32, 16])
 @pytest.mark.parametrize('B,L,bf16', [(2, 1000, False), (3, 4099, False), (1, 300, False), (2, 1000, True)])
 def test_resblock2_stage_split(dev, B, L, bf16, C):

@@ -859,6 +859,10 @@ pack_bf16_convt_kernel(const float* __restrict__ wf, b8* __restrict__ wps, int K
     }
 }
 
+}  // namespace
+int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipStream_t stream, int* ntiles_out, int32_t* cfg);   // v2w_convt_bf16_res.hip
+namespace {
+
 struct ConvtGeom { int UP, hl, hr, KV; };
 static ConvtGeom convt_geom(int k, int u) {
     ConvtGeom g{1, 0, 0, 0};
@@ -922,6 +926,10 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     p.in = a->in; p.wps = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out * g.UP; p.L = a->L; p.K = g.KV; p.dil = 1;
     p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP; p.io_bf16 = a->io_bf16;
+    if (a->io_bf16 == 3 && g.UP == a->u) {        // bf16 tensors, no padding phases: the resident-tile kernel (v2w_convt_bf16_res.hip)
+        const int rc = v2w_convt1d_bf16_res(a, g.UP, g.hl, g.KV, stream, ntiles_out, cfg);
+        if (rc != V2W_E_SHAPE) return rc;
+    }
     const int rows = p.Cout;
     // the stats tiling (rows of stats_part) depends on the tile width only: every configuration here is 256 or 512 positions wide, the
     // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin

@@ -1,0 +1,367 @@
+// leaky_relu -> ConvTranspose1d(k, stride U, padding (k - U) / 2) -> + bias (+ the BatchNorm partial sums of its output) on bf16 tensors with
+// the input tile RESIDENT in LDS (models.py:128-129; BASELINE configs[2]: bf16 compute / fp32 accumulate, bf16 activation storage).
+//
+// The transposed conv is the 3-tap Conv1d over UP * C_out virtual rows of v2w_conv_bf16.hip (row = co * UP + phase, the polyphase taps in the
+// fragments of v2w_pack_bf16_convt).  That kernel walks C_in in 32-channel chunks with a barrier each - and with 3 taps a chunk holds
+// ~1.5 k cycles of MFMA issue against one exposed memory latency (~4 us): 259 us for a layer whose bytes take 40 us.  Here, as in
+// v2w_conv_bf16_res.hip:
+//   * every input channel of the tile is staged in ONE burst (64-byte rows, slots XOR-swizzled: conflict-free operand reads), one barrier,
+//     then the MFMA loop runs over all (plane, tap) without another;
+//   * U == UP (2, 4, 8): the phases of an output channel are ADJACENT accumulator registers of one lane - a lane holds U consecutive
+//     output positions of a channel (or 4 of the 8), so the output leaves straight from the accumulators as 4- / 8-byte bf16 stores,
+//     consecutive lanes = consecutive addresses: no LDS scratch, no transposition;
+//   * the BatchNorm partial sums (sum, sum of squares of the fp32 values, before rounding) are reduced across the lanes of a column block
+//     with DPP adds in a fixed order, across the waves of a tile through LDS in a fixed order: one slot per (tile, channel) as before.
+#include <type_traits>
+#include "v2w_tile.h"
+
+namespace {
+
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define V2W_CT_UNIT 2048
+
+struct CtArgs {
+    const unsigned short* in; const unsigned char* wps; const float* bias; unsigned short* out; float* stats_part;
+    int B, Cin, CoutR, L;      // CoutR: real output channels; the kernel's rows are CoutR * UP
+    int KV, hl;                // virtual taps and the left halo (input positions)
+    int hla, xrows, ntl, ntiles;
+    float slope;
+};
+
+__device__ __forceinline__ unsigned int ct_pack2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float ct_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float ct_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ int ct_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CTRL> __device__ __forceinline__ float ct_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row (fixed order): quad xor 1, quad xor 2, half mirror, mirror
+__device__ __forceinline__ float ct_row_sum(float v) {
+    v += ct_dpp<0xB1>(v);
+    v += ct_dpp<0x4E>(v);
+    v += ct_dpp<0x141>(v);
+    v += ct_dpp<0x140>(v);
+    return v;
+}
+
+template <int MI, int NI, int WM, int WN, int UP>
+__global__ void __launch_bounds__(64 * WM * WN, MI * NI >= 8 ? 2 : 3)
+convt_bf16_res_kernel(const CtArgs a) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
+    constexpr int NPF = (8 * ((NT + 16) / 4) + NTH - 1) / NTH;                 // staging items of one 32-channel plane per thread
+    static_assert(UP == 2 || UP == 4 || UP == 8, "phases per channel");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+
+    const int Cin = ct_uni(a.Cin), L = ct_uni(a.L), xrows = ct_uni(a.xrows), hla = ct_uni(a.hla), KV = ct_uni(a.KV);
+    const int CoutR = ct_uni(a.CoutR);
+    const int nch = Cin >> 5, psz = xrows * 64;
+    float* const btab = reinterpret_cast<float*>(smem_c + nch * psz);         // bias of this M-tile's channels [MT / UP]
+    float* const red = btab + MT / UP;                                          // [WN][MT / UP][2] partial sums of the waves
+    const float slope = a.slope;
+
+    const int mtiles = (CoutR * UP) / MT;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * mtiles), rem = id % (8 * mtiles);
+    const int mt = rem >> 3;
+    const int tile = grp * 8 + (rem & 7);
+    if (tile >= a.ntiles) return;
+    const int b = tile / a.ntl;
+    const int n0 = (tile % a.ntl) * NT;
+    const int m0 = mt * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = ct_uni(tid >> 6);
+    const int lr = lane & 31, hk = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MI);
+    const int wn0 = (wave % WN) * (32 * NI);
+    const int pos0 = n0 - hla;
+
+    for (int c = tid; c < MT / UP; c += NTH) btab[c] = a.bias ? a.bias[m0 / UP + c] : 0.f;
+
+    // ---- stage lrelu(in) as bf16: every plane of the tile, two planes of loads in flight (an item = 4 channels x 4 positions)
+    {
+        const int nq = xrows >> 2;
+        unsigned poff[NPF];
+        bool in_img[NPF], in_seq[NPF];
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTH;
+            const int cq = idx & 7, pq = idx >> 3;
+            in_img[s] = pq < nq;
+            const int pos = pos0 + pq * 4;
+            in_seq[s] = in_img[s] && pos >= 0 && pos < L;
+            poff[s] = (unsigned)(4 * cq * L + (in_seq[s] ? pos : 0)) * 2u;
+            asm volatile("" : "+v"(poff[s]));
+        }
+        auto prefetch = [&](int ch, u32x2 (&pf)[NPF][4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* base = reinterpret_cast<const unsigned char*>(a.in) + (size_t)(b * Cin + 32 * ch + i) * L * 2;
+#pragma unroll
+                for (int s = 0; s < NPF; ++s) pf[s][i] = *gptr<const u32x2>(base + poff[s]);
+            }
+        };
+        auto commit = [&](int ch, const u32x2 (&pf)[NPF][4]) {
+            unsigned char* const plane = smem_c + ch * psz;
+#pragma unroll
+            for (int s = 0; s < NPF; ++s) {
+                if (!in_img[s]) continue;
+                const int idx = tid + s * NTH;
+                const int cq = idx & 7, pq = idx >> 3;
+                unsigned char* dst = plane + pq * 256 + ((((cq >> 1) ^ (pq & 3)) << 4) | ((cq & 1) << 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xv = (e & 1) ? ct_hi(pf[s][i][e >> 1]) : ct_lo(pf[s][i][e >> 1]);
+                        v[i] = fmaxf(xv, xv * slope);
+                    }
+                    u32x2 w = {ct_pack2(v[0], v[1]), ct_pack2(v[2], v[3])};
+                    if (!in_seq[s]) w = u32x2{0u, 0u};
+                    *reinterpret_cast<u32x2*>(dst + e * 64) = w;
+                }
+            }
+        };
+        u32x2 pf0[NPF][4], pf1[NPF][4];
+        prefetch(0, pf0);
+        if (nch > 1) prefetch(1, pf1);
+        __builtin_amdgcn_sched_barrier(0);
+        int ch = 0;
+        for (; ch + 2 < nch; ch += 2) {
+            commit(ch, pf0);
+            prefetch(ch + 2, pf0);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(ch + 1, pf1);
+            if (ch + 3 < nch) prefetch(ch + 3, pf1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        commit(ch, pf0);
+        if (ch + 1 < nch) commit(ch + 1, pf1);
+    }
+    __syncthreads();
+
+    // ---- the MFMA loop over the resident tile: nch * KV taps in pairs (ring slots 0 / 1 even taps, 2 / 3 odd taps)
+    acc_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    {
+        const unsigned lane16 = (unsigned)lane * 16u;
+        auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
+        };
+        auto baddr = [&](int ch, int row) { return (unsigned)(ch * psz + row * 64 + ((hk ^ ((row >> 2) & 3)) << 4)); };
+        const int K = KV;
+        const int nst = 2 * nch * K;
+        const unsigned char* ap[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ap[i] = a.wps + (size_t)((m0 + wm0) / 32 + i) * nst * V2W_CT_UNIT;
+        u32x4 ar[4][MI];
+        auto load_frag = [&](u32x4 (&av)[MI], int ch, int s, int t) {
+            unsigned l16 = lane16;
+            asm volatile("" : "+v"(l16));
+            const int chc = ch < nch ? ch : nch - 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                av[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_CT_UNIT + l16);
+        };
+        load_frag(ar[0], 0, 0, 0);
+        load_frag(ar[1], 0, 1, 0);
+        {
+            const int c1 = K > 1 ? 0 : 1, t1 = K > 1 ? 1 : 0;
+            load_frag(ar[2], c1, 0, t1);
+            load_frag(ar[3], c1, 1, t1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int ch = 0, t = 0, qc = 0, qt = 2;
+        while (qt >= K) { qt -= K; ++qc; }
+        const int r0 = hla - ct_uni(a.hl) + wn0 + lr;
+        unsigned xt = baddr(0, r0);
+        u32x4 bb[2][NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            bb[0][j] = *reinterpret_cast<const u32x4*>(smem_c + xt + j * 2048);
+            bb[1][j] = *reinterpret_cast<const u32x4*>(smem_c + (xt ^ 32u) + j * 2048);
+        }
+        auto kstep = [&](auto bs_c, const u32x4 (&av)[MI], unsigned nxt) {
+            constexpr int bs = decltype(bs_c)::value;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[bs][j]);
+                bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_c + nxt + j * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto tap = [&](auto par_c) {
+            constexpr int S0 = 2 * decltype(par_c)::value;
+            int nch_ = ch, nt_ = t + 1;
+            if (nt_ >= K) { nt_ = 0; ++nch_; }
+            if (nch_ >= nch) { nch_ = ch; nt_ = t; }
+            const unsigned xn = baddr(nch_, r0 + nt_);
+            kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
+            load_frag(ar[S0], qc, 0, qt);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(std::integral_constant<int, 1>{}, ar[S0 + 1], xn ^ 32u);
+            load_frag(ar[S0 + 1], qc, 1, qt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++qt >= K) { qt = 0; ++qc; }
+            ch = nch_; t = nt_; xt = xn;
+        };
+        const int TT = nch * K;
+        int g = 0;
+        for (; g + 1 < TT; g += 2) { tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); }
+        if (g < TT) tap(std::integral_constant<int, 0>{});
+    }
+
+    // ---- epilogue: + bias, partial sums, bf16 stores straight from the accumulators.  Block (i, j), register quad g, lane (lr, hk):
+    // virtual rows 32 i + 8 g + 4 hk + {0..3} at input position q = n0 + wn0 + 32 j + lr, i.e.
+    //   UP = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};   UP = 8: channel 4 i + g, outputs 8 q + 4 hk + {0..3};
+    //   UP = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1} each
+    constexpr int CPB = 32 / UP;                                                // channels per 32-row block
+    const int Lout = L * UP;
+    const bool stats = a.stats_part != nullptr;
+    unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * CoutR * Lout * 2;
+    const int cw0 = (m0 + wm0) / UP;                                            // first channel of this wave (inside the tensor)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            constexpr int NC = UP == 2 ? 2 : 1;                                 // channels of a register quad
+            const int cl = UP == 4 ? 2 * g + hk : (UP == 8 ? g : 4 * g + 2 * hk);      // channel inside block i (+ 1 for the second of UP = 2)
+            float bias[NC], s1[NC], s2[NC];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) { bias[n] = btab[(wm0 / UP) + CPB * i + cl + n]; s1[n] = s2[n] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int q = wn0 + lr;
+                asm volatile("" : "+v"(q));
+                q += n0 + 32 * j;
+                const bool ok = q < L;
+                float v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    v[x] = acc[i][j][4 * g + x] + bias[UP == 2 ? (x >> 1) : 0];
+                    if (!ok) v[x] = 0.f;
+                    s1[UP == 2 ? (x >> 1) : 0] += v[x];
+                    s2[UP == 2 ? (x >> 1) : 0] = fmaf(v[x], v[x], s2[UP == 2 ? (x >> 1) : 0]);
+                }
+                if (ok) {
+                    const int c = cw0 + CPB * i + cl;
+                    if constexpr (UP == 2) {
+                        *gptr<unsigned>(obase + (unsigned)(c * Lout + 2 * q) * 2u) = ct_pack2(v[0], v[1]);
+                        *gptr<unsigned>(obase + (unsigned)((c + 1) * Lout + 2 * q) * 2u) = ct_pack2(v[2], v[3]);
+                    } else {
+                        const int o = UP == 4 ? 4 * q : 8 * q + 4 * hk;
+                        *gptr<u32x2>(obase + (unsigned)(c * Lout + o) * 2u) = u32x2{ct_pack2(v[0], v[1]), ct_pack2(v[2], v[3])};
+                    }
+                }
+            }
+            if (stats) {
+                // the 32 lanes that share hk hold one channel's columns (UP = 8: both halves hold the same channel): DPP row sums, then the
+                // rows of a half (and the halves) in a fixed order
+#pragma unroll
+                for (int n = 0; n < NC; ++n) {
+                    const float r1 = ct_row_sum(s1[n]), r2 = ct_row_sum(s2[n]);
+                    const float a1 = __builtin_amdgcn_readlane(r1, 0) + __builtin_amdgcn_readlane(r1, 16);
+                    const float b1 = __builtin_amdgcn_readlane(r1, 32) + __builtin_amdgcn_readlane(r1, 48);
+                    const float a2 = __builtin_amdgcn_readlane(r2, 0) + __builtin_amdgcn_readlane(r2, 16);
+                    const float b2 = __builtin_amdgcn_readlane(r2, 32) + __builtin_amdgcn_readlane(r2, 48);
+                    float* rd = red + ((wave % WN) * (MT / UP) + (wm0 / UP) + CPB * i) * 2;
+                    if constexpr (UP == 8) {
+                        if (lane == 0) { rd[2 * g] = a1 + b1; rd[2 * g + 1] = a2 + b2; }
+                    } else if constexpr (UP == 4) {
+                        if (lane == 0) { rd[2 * (2 * g)] = a1; rd[2 * (2 * g) + 1] = a2; rd[2 * (2 * g + 1)] = b1; rd[2 * (2 * g + 1) + 1] = b2; }
+                    } else {
+                        if (lane == 0) { rd[2 * (4 * g + n)] = a1; rd[2 * (4 * g + n) + 1] = a2; rd[2 * (4 * g + 2 + n)] = b1; rd[2 * (4 * g + 2 + n) + 1] = b2; }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    if (stats) {
+        __syncthreads();
+        for (int c = tid; c < MT / UP; c += NTH) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { t1 += red[(w * (MT / UP) + c) * 2]; t2 += red[(w * (MT / UP) + c) * 2 + 1]; }
+            gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
+            gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
+        }
+    }
+}
+
+template <int MI, int NI, int WM, int WN, int UP>
+int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
+    constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
+    if ((p.CoutR * UP) % MT != 0 || p.Cin % 32 != 0) return V2W_E_SHAPE;
+    const int nch = p.Cin / 32;
+    if (nch > 1 && (nch & 1)) return V2W_E_SHAPE;                    // planes are staged in pairs
+    p.hla = (p.hl + 3) & ~3;
+    const int hr = p.KV - 1 - p.hl;
+    if (p.hla > 8 || hr > 8) return V2W_E_SHAPE;
+    p.ntl = (p.L + NT - 1) / NT;
+    p.ntiles = p.B * p.ntl;
+    p.xrows = (p.hla + NT + hr + 3) & ~3;
+    const size_t lds = (size_t)nch * p.xrows * 64 + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
+    constexpr int WGS = MI * NI >= 8 ? 2 : 3;                        // workgroups per CU the register budget allows (4-wave workgroups)
+    if (lds * (WGS > 2 ? 2 : WGS) > 160 * 1024) return V2W_E_SHAPE;
+    if (cfg) { const int32_t c[10] = {MI, NI, WM, WN, UP, 102 /* = this kernel */, 1, 1, 32, 1}; for (int i = 0; i < 10; ++i) cfg[i] = c[i]; }
+    if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
+    const int grid = ((p.ntiles + 7) / 8) * 8 * ((p.CoutR * UP) / MT);
+    auto kern = convt_bf16_res_kernel<MI, NI, WM, WN, UP>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, p);
+    return v2w_launch_status();
+}
+
+}  // namespace
+
+// Called by the dispatcher of v2w_conv_bf16.hip for bf16 tensors (io_bf16 == 3), aligned, L % 4 == 0, U == UP in {2, 4, 8}.
+// hl / KV: the virtual conv's geometry (convt_geom).  V2W_E_SHAPE: the chunked kernel runs instead.
+int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
+    if (a->io_bf16 != 3 || a->u != UP || a->L % 4 != 0) return V2W_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(a->in) & 15) || (reinterpret_cast<uintptr_t>(a->out) & 15)) return V2W_E_SHAPE;    // (queries carry the pointers too)
+    if ((long long)a->C_out * a->L * UP * 2 >= (1ll << 31) || (long long)a->C_in * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;
+    if (!(a->slope > 0.f && a->slope <= 1.f)) return V2W_E_SHAPE;
+    CtArgs p{};
+    p.in = reinterpret_cast<const unsigned short*>(a->in); p.wps = reinterpret_cast<const unsigned char*>(a->wp); p.bias = a->bias;
+    p.out = reinterpret_cast<unsigned short*>(a->out); p.stats_part = a->stats_part;
+    p.B = a->B; p.Cin = a->C_in; p.CoutR = a->C_out; p.L = a->L; p.KV = KV; p.hl = hl; p.slope = a->slope;
+    const int rows = a->C_out * UP;
+    if (UP == 4) {
+        if (rows % 256 == 0) return launch_ct<4, 2, 2, 2, 4>(p, stream, ntiles_out, cfg);       // 256 rows x 128 positions
+        if (rows % 128 == 0) return launch_ct<2, 4, 2, 2, 4>(p, stream, ntiles_out, cfg);       // 128 rows x 256 positions
+        if (rows % 64 == 0) return launch_ct<2, 4, 1, 4, 4>(p, stream, ntiles_out, cfg);        // 64 rows x 512 positions
+        return V2W_E_SHAPE;
+    }
+    if (UP == 2) {
+        if (rows % 64 == 0) return launch_ct<2, 4, 1, 4, 2>(p, stream, ntiles_out, cfg);        // 64 rows x 512 positions
+        if (rows % 32 == 0) return launch_ct<1, 4, 1, 4, 2>(p, stream, ntiles_out, cfg);        // 32 rows x 512 positions
+        return V2W_E_SHAPE;
+    }
+    if (UP == 8) {
+        if (rows % 256 == 0) return launch_ct<4, 2, 2, 2, 8>(p, stream, ntiles_out, cfg);
+        if (rows % 128 == 0) return launch_ct<2, 4, 2, 2, 8>(p, stream, ntiles_out, cfg);
+        return V2W_E_SHAPE;
+    }
+    return V2W_E_SHAPE;
+}

@@ -242,9 +242,10 @@ def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16=0):
     return a
 
 
-def convt_bf16_stats_tiles(x, out, k, u):
-    """Rows of `stats_part` the bf16 transposed conv fills (0: shape not served)."""
-    n = _hip.load().v2w_convt1d_bf16_tiles(C.byref(_convt_bf16_args(x, None, None, out, k, u, 1.0, None)))
+def convt_bf16_stats_tiles(x, out, k, u, io_bf16=0):
+    """Rows of `stats_part` the bf16 transposed conv fills for exactly this call (tensors, io_bf16: the kernel and with it the tile
+    width follow them); 0: shape not served."""
+    n = _hip.load().v2w_convt1d_bf16_tiles(C.byref(_convt_bf16_args(x, None, None, out, k, u, 1.0, None, io_bf16)))
     return n if n > 0 else 0
 
 
@@ -345,6 +346,8 @@ def conv_bf16_config(B, nprob, c_in, c_out, L, k, dil=1, u=1, io_bf16=3):
     if rc != 0:
         return None
     v = list(cfg)
+    if v[5] == 102:         # the resident-tile transposed conv (v2w_convt_bf16_res.hip)
+        return 'convt_bf16_res_kernel<' + ', '.join(str(x) for x in v[:5]) + '>'
     tf = lambda b: 'true' if b else 'false'
     return 'conv_bf16_kernel<' + ', '.join(str(x) for x in v[:6]) + f', {tf(v[6])}, {tf(v[7])}, {v[8]}, {tf(v[9])}>'
 

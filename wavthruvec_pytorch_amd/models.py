@@ -552,7 +552,7 @@ class Generator(nn.Module):
                     stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
                     # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
                     if f'ups.{i}' in wps:
-                        nt_stats = hipops.convt_bf16_stats_tiles(cur, xr, up.kernel_size, up.stride)
+                        nt_stats = hipops.convt_bf16_stats_tiles(cur, xr, up.kernel_size, up.stride, io_bf16=3 if st else 0)
                     elif algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
                         nt_stats = hipops.convt_stats_tiles(B, up.in_channels, C, L, up.kernel_size, up.stride)
                     if nt_stats:
