@@ -43,6 +43,9 @@ __device__ __forceinline__ int ct_uni(int v) { return __builtin_amdgcn_readfirst
 template <int CTRL> __device__ __forceinline__ float ct_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float ct_readlane(float v, int l) {           // (the builtin is typed int: a float argument would be CONVERTED)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 // sum over the 16 lanes of a DPP row, in every lane of the row (fixed order): quad xor 1, quad xor 2, half mirror, mirror
 __device__ __forceinline__ float ct_row_sum(float v) {
     v += ct_dpp<0xB1>(v);
@@ -278,10 +281,10 @@ convt_bf16_res_kernel(const CtArgs a) {
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     const float r1 = ct_row_sum(s1[n]), r2 = ct_row_sum(s2[n]);
-                    const float a1 = __builtin_amdgcn_readlane(r1, 0) + __builtin_amdgcn_readlane(r1, 16);
-                    const float b1 = __builtin_amdgcn_readlane(r1, 32) + __builtin_amdgcn_readlane(r1, 48);
-                    const float a2 = __builtin_amdgcn_readlane(r2, 0) + __builtin_amdgcn_readlane(r2, 16);
-                    const float b2 = __builtin_amdgcn_readlane(r2, 32) + __builtin_amdgcn_readlane(r2, 48);
+                    const float a1 = ct_readlane(r1, 0) + ct_readlane(r1, 16);
+                    const float b1 = ct_readlane(r1, 32) + ct_readlane(r1, 48);
+                    const float a2 = ct_readlane(r2, 0) + ct_readlane(r2, 16);
+                    const float b2 = ct_readlane(r2, 32) + ct_readlane(r2, 48);
                     float* rd = red + ((wave % WN) * (MT / UP) + (wm0 / UP) + CPB * i) * 2;
                     if constexpr (UP == 8) {
                         if (lane == 0) { rd[2 * g] = a1 + b1; rd[2 * g + 1] = a2 + b2; }

@@ -443,9 +443,7 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
-#ifdef V2W_WS_NARROW32
     if (a->C == 32 && a->io_bf16 == 3) { const int rc = v2w_resblock2_stage_bf16_wide(a, stream); if (rc != V2W_E_SHAPE) return rc; }
-#endif
     if (a->C == 32) return launch_stage_bf16<32>(a, stream);
     if (a->C == 16) return launch_stage_bf16<16>(a, stream);
     return V2W_E_SHAPE;

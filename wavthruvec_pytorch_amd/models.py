@@ -309,7 +309,7 @@ class Generator(nn.Module):
         counters; a `.data` mutation (`p.data.copy_(ema)`, `m.weight.data.normal_()`) changes neither - call this after one."""
         self._fold_key.clear()
 
-    def _fold_weights(self, device, need_wf=False):
+    def _fold_weights(self, device, need_wf=False, bf16_only=False):
         """K0: weight-norm fold of every conv.  Layers with an MFMA tile configuration are folded AND packed into their
         fragment stream `wp` by one batched call (two launches for the whole generator); the others (conv_post, odd
         shapes, or everything under ALGO_DIRECT) are folded one by one into `wf` [k][C_in][C_out].  Skipped while the
@@ -319,12 +319,15 @@ class Generator(nn.Module):
         for name, m in layers:
             ps = (m.weight_v, m.weight_g) if m.weight_normed else (m.weight,)
             vers.append(tuple((p.data_ptr(), p._version) for p in ps))
-        state = (tuple(vers), self.algo, str(device), need_wf)
+        state = (tuple(vers), self.algo, str(device), need_wf, bf16_only)
         force = (self.training and self.always_refold) or need_wf
         if not force and self._fold_key.get('state') == state:
             return self._fold_key['wf'], self._fold_key['wp']
         wf, wp, batch = {}, {}, []
         for name, m in layers:
+            if bf16_only and name != 'conv_post':      # bf16 activation storage: every other layer runs on its bf16 fragments (_split_weights):
+                wf[name], wp[name] = None, None        # no fp32 fold / fragment stream is read, none is built
+                continue
             v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
             u = m.stride if m.transposed else 1
             mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
@@ -502,7 +505,7 @@ class Generator(nn.Module):
         st = adt == torch.bfloat16
 
         with torch.no_grad():
-            wf, wp = self._fold_weights(dev, need_wf=save is not None)
+            wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
             wps = self._split_weights(dev, all_ups=st)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
 
             def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
