@@ -242,7 +242,8 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                     ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
             if staged and precision != 'f32':
-                wide = {128: '<2, 2, 2, 4, 2>', 64: '<2, 2, 1, 4, 2>', 256: '<2, 2, 4, 2, 2>'}      # launch_wide configurations (v2w_stage_bf16_wide.hip)
+                wide = {128: '<2, 2, 2, 4, 2, 32>', 64: '<2, 2, 1, 4, 2, 32>', 256: '<2, 2, 4, 2, 2, 32>', 32: '<1, 4, 1, 2, 2, 32>',
+                        16: '<1, 4, 1, 2, 2, 16>'}        # launch_wide configurations (v2w_stage_bf16_wide.hip)
                 kname = (('wide_stage_bf16_kernel' + wide[ls[0]['cout']]) if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         nbytes = sum(l['bytes'] for l in ls)
@@ -251,6 +252,8 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
         if staged:                             # x read once, no per-branch outputs / running-sum traffic
             act = B * ls[0]['cout'] * ls[0]['L'] * act_bytes
             nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
+            if names[-1] == 'conv_post':          # the fused tail: the stage's output is not written, the fp32 audio is
+                nbytes += B * ls[0]['L'] * 4 - act
         launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
                              t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
     groups = {}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 25
+#define V2W_ABI_VERSION 26
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -203,7 +203,8 @@ typedef struct {
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
 
-/* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16: wps / sc from v2w_pack_split or
+/* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16 - and, with bf16 != 0 on bf16 tensors
+ * (io_bf16 == 3), for the wide stages C == 64 / 128 / 256 as well (csrc/v2w_stage_bf16_wide.hip: x and t1_j resident in LDS, one kernel): wps / sc from v2w_pack_split or
  * v2w_pack_bf16 (or the batch) of the (k, C, C) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise.
  * The 2*nk fragment streams must lie BACK TO BACK in execution order (wps1[0], wps2[0], wps1[1], ...; (C/16)*k units of 2 KiB each,
  * pack them into slices of one buffer): the kernel prefetches along one pointer; V2W_E_ARG if they do not. */
@@ -217,6 +218,12 @@ typedef struct {
     float slope, out_div;
     int32_t bf16;
     int32_t io_bf16;   /* bf16 != 0 only: bit 0 `in` is bf16, bit 1 `out` is bf16 (see v2w_conv1d_args) */
+    /* optional fused tail of the generator (bf16 != 0, io_bf16 == 3, C == 16 only; models.py:143-145): when post_out != NULL the kernel does
+     * not write `out` (it may be NULL) but  post_out (B, 1, L) fp32 = tanh(conv_post(leaky_relu(stage output, post_slope)))  with
+     * post_w = the folded conv_post weight [post_k][C][1] (v2w_wn_fold_conv), post_b its bias (1 value or NULL), post_k odd <= 9 */
+    const float* post_w; const float* post_b; float* post_out;
+    int32_t post_k;
+    float post_slope;
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 

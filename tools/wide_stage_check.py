@@ -97,6 +97,7 @@ sd = synthetic.make_state_dict(h, seed=0)
 def gen(prec, fuse_wide=True):
     g = Generator(h); g.load_state_dict(sd); g = g.to(dev).train(); g.precision = prec
     g.fuse_wide = fuse_wide in (True, 'convs'); g.fuse_wide_stage = fuse_wide is True
+    g.fuse_post = os.environ.get('V2W_NOPOST') is None
     return g
 
 

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -68,7 +68,8 @@ class StageSplitArgs(C.Structure):
                 ('wps1', _P4), ('sc1', _P4), ('bias1', _P4), ('wps2', _P4), ('sc2', _P4), ('bias2', _P4),
                 ('k', _I4), ('dil1', _I4), ('dil2', _I4), ('out', _fp),
                 ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
-                ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32)]
+                ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32),
+                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float)]
 
 
 class BranchConvsArgs(C.Structure):

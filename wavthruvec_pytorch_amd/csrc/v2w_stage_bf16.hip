@@ -443,7 +443,13 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
-    if (a->C == 32 && a->io_bf16 == 3) { const int rc = v2w_resblock2_stage_bf16_wide(a, stream); if (rc != V2W_E_SHAPE) return rc; }
+    // C = 32: the resident-tile family (two-wave workgroups, 729 us against 838 at configs[2]).  C = 16: only for the fused tail - as a plain
+    // stage its one-k-step-per-tap form of that kernel measured 912 us against the 791 us of stage_bf16_kernel<16> below
+    if ((a->C == 32 || (a->C == 16 && a->post_out)) && a->io_bf16 == 3) {
+        const int rc = v2w_resblock2_stage_bf16_wide(a, stream);
+        if (rc != V2W_E_SHAPE) return rc;
+    }
+    if (a->post_out) return V2W_E_SHAPE;
     if (a->C == 32) return launch_stage_bf16<32>(a, stream);
     if (a->C == 16) return launch_stage_bf16<16>(a, stream);
     return V2W_E_SHAPE;

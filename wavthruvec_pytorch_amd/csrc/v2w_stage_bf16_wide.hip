@@ -42,6 +42,11 @@ struct WideArgs {
     int nk, B, C, L;
     int h1max, h2max, xoff, xrows, trows, nto, ntl, ntiles;
     float slope, inv_slope, out_div;
+    // fused tail (C = 16 only): leaky_relu(post_slope) -> conv_post (post_k taps, C -> 1) -> tanh (models.py:143-145) of the stage's output;
+    // `out` is not written.  hout = (post_k - 1) / 2 columns of the valid window per side feed the taps only (0 without the tail).
+    const float* post_w; const float* post_b; float* post_out;
+    int post_k, hout;
+    float post_slope;
 };
 
 __device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
@@ -57,29 +62,41 @@ template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); ret
 // MI x NI blocks of 32 x 32 per wave, WM x WN waves: C = 32 MI WM channels, window W = 32 NI WN positions
 // OCC = waves per SIMD the register budget is cut for: 8-wave workgroups (one per CU) and 4-wave workgroups at two per CU: 2 (256 registers);
 // a 4-wave workgroup alone on its CU: 1 (the whole 512-register file)
-template <int MI, int NI, int WM, int WN, int OCC>
+// CH = channels of a plane that exist: 32, or 16 for the C = 16 stage (ONE plane of 32-byte rows, one k-step per tap, the MFMA's rows 16-31
+// are the zero rows of the packed fragments: half of every MFMA is padding, on a stage that the vector ALU and the memory bound anyway)
+template <int MI, int NI, int WM, int WN, int OCC, int CH>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 wide_stage_bf16_kernel(const WideArgs a) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
-    constexpr int NTH = 64 * WM * WN, C = 32 * MI * WM, W = 32 * NI * WN, NCH = C / 32;
+    static_assert(CH == 32 || (CH == 16 && MI == 1 && WM == 1), "16 channels: one row block");
+    constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32;
+    constexpr int RB = 2 * CH;                                                  // bytes of a tile row (one position of one plane)
+    constexpr int KS = CH / 16;                                                 // k-steps per (plane, tap)
+    constexpr int NG = CH / 8;                                                  // accumulator register quads that hold real channels
+    constexpr int NQC = CH / 4;                                                 // channel quads of a plane
+    constexpr int CB = 32 * RB;                                                 // bytes between the column blocks of a wave
     constexpr int XRMAX = W + 2 * 32 + 4;                                       // rows of the x tile at most (h1max <= 32)
-    constexpr int NPF = (NCH * 8 * (XRMAX / 4) + NTH - 1) / NTH;                // staging items (4 channels x 4 positions) per thread
+    constexpr int NPF = (NCH * NQC * (XRMAX / 4) + NTH - 1) / NTH;              // staging items (4 channels x 4 positions) per thread
+    // 16-byte slot swizzle of a row: 64-byte rows (4 slots) by (row >> 2) & 3, 32-byte rows (2 slots) by (row >> 3) & 1 - the 16 lanes of a
+    // ds_read_b128 group then fall on 16 different slots of the 256-byte bank row at every tap offset
+    auto swz = [](int row) { return CH == 32 ? ((row >> 2) & 3) : ((row >> 3) & 1); };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
 
     const int L = ws_uni(a.L), xrows = ws_uni(a.xrows), trows = ws_uni(a.trows), nk = ws_uni(a.nk);
     const int h1max = ws_uni(a.h1max), h2max = ws_uni(a.h2max), nto = ws_uni(a.nto);
-    const int xpsz = xrows * 64, tpsz = trows * 64;                             // bytes per 32-channel plane
+    const int xpsz = xrows * RB, tpsz = trows * RB;                             // bytes per plane
     const unsigned xbase = 0, tbase = (unsigned)(NCH * xpsz);                   // LDS byte offsets of the two tiles
     float* const btab = reinterpret_cast<float*>(smem_w + tbase + NCH * tpsz); // bias1[nk][C], then sum_j bias2_j [C], then a[C], s[C]
     float* const b2tab = btab + V2W_WS_MAXB * C;
     float* const atab = b2tab + C;
     const float slope = a.slope, inv_slope = a.inv_slope;
 
+    const int hout = ws_uni(a.hout);
     const int tile = blockIdx.x;
     const int b = tile / a.ntl;
-    const int n0 = (tile % a.ntl) * nto;
+    const int n0 = (tile % a.ntl) * (nto - 2 * hout) - hout;                    // position of the first valid output column of the window
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = ws_uni(tid >> 6);
     const int lr = lane & 31, hk = lane >> 5;
@@ -106,13 +123,13 @@ wide_stage_bf16_kernel(const WideArgs a) {
     // four 8-byte loads (4 positions of one channel), four 8-byte LDS stores (the 4 channels of one position)
     {
         const int nq = xrows >> 2;
-        const int nitems = NCH * 8 * nq;
+        const int nitems = NCH * NQC * nq;
         u32x2 pf[NPF][4];
         const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * C * L * 2;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTH;
-            const int cq = idx & 7, rest = idx >> 3;
+            const int cq = idx % NQC, rest = idx / NQC;
             const int pq = rest % nq, ch = rest / nq;
             const int pos = pos0 + pq * 4;
             const bool ok = idx < nitems && pos >= 0 && pos < L;
@@ -127,14 +144,14 @@ wide_stage_bf16_kernel(const WideArgs a) {
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTH;
             if (idx >= nitems) continue;
-            const int cq = idx & 7, rest = idx >> 3;
+            const int cq = idx % NQC, rest = idx / NQC;
             const int pq = rest % nq, ch = rest / nq;
             const int pos = pos0 + pq * 4;
             const bool ok = pos >= 0 && pos < L;           // L % 4 == 0 and pos % 4 == 0: a quad is inside or outside as a whole
             const f32x4 av = *reinterpret_cast<const f32x4*>(atab + 32 * ch + 4 * cq);
             const f32x4 sv = *reinterpret_cast<const f32x4*>(atab + C + 32 * ch + 4 * cq);
             const int row = pq * 4;
-            unsigned char* dst = smem_w + xbase + ch * xpsz + row * 64 + ((((cq >> 1) ^ (pq & 3)) << 4) | ((cq & 1) << 3));
+            unsigned char* dst = smem_w + xbase + ch * xpsz + row * RB + ((((cq >> 1) ^ swz(row)) << 4) | ((cq & 1) << 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v[4];
@@ -145,7 +162,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
                 u32x2 w = {ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
                 if (!ok) w = u32x2{0u, 0u};                 // the padding of the ACTIVATED signal is exactly 0
-                *reinterpret_cast<u32x2*>(dst + e * 64) = w;
+                *reinterpret_cast<u32x2*>(dst + e * RB) = w;
             }
         }
     }
@@ -158,48 +175,57 @@ wide_stage_bf16_kernel(const WideArgs a) {
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
     };
-    // this lane's 16 bytes of k-step 0 at (plane ch, row): slot hk, swizzled by the row; k-step 1 is the address ^ 32
+    // this lane's 16 bytes of k-step 0 at (plane ch, row): slot hk, swizzled by the row; with 64-byte rows k-step 1 is the address ^ 32
     auto baddr = [&](unsigned base, int psz, int ch, int row) {
-        return base + (unsigned)(ch * psz + row * 64 + ((hk ^ ((row >> 2) & 3)) << 4));
+        return base + (unsigned)(ch * psz + row * RB + ((hk ^ swz(row)) << 4));
     };
 
-    // ---- the MFMA loop of one conv over a resident tile (base, plane size psz): NCH * K taps walked in pairs (ring slots 0 / 1 even
-    // taps, 2 / 3 odd taps), B operands one set per k-step of a tap, refilled for the next tap.  r0 = tile row of (column lr of this
-    // wave's block 0, tap 0).
+    // ---- the MFMA loop of one conv over a resident tile (base, plane size psz): the NCH * K taps, a ring of V2W_WS_RING taps of weight
+    // fragments (KS per row block and tap) refilled as their k-steps retire.  B operands: two sets, k-step q uses set q & 1 and refills it
+    // with k-step q + 2 (64-byte rows: the same k-step of the next tap; 32-byte rows: the tap after the next).  r0 = tile row of (column lr
+    // of this wave's block 0, tap 0).
     auto conv = [&](acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps, int K, int dil) {
-        const int nst = 2 * NCH * K;
+        const int nst = KS * NCH * K;
         const unsigned char* ap[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) ap[i] = wps + (size_t)(wm0 / 32 + i) * nst * V2W_WS_UNIT;
-        // ring of V2W_WS_RING taps (two fragments per row block each): the fragments of tap g + RING are requested as tap g's k-steps
-        // retire, i.e. 2 RING - 1 k-steps ahead.  Measured: with 3 k-steps (768 cycles of issue) of lookahead every k-step waited -
-        // the fragment stream of a stage (every CU walks the same 1.4 MB at the same time) answers in ~1400 cycles, not the ~500 of
-        // an idle L2.
+        // (Measured at C = 128: 3 or 7 k-steps of lookahead time the same - the loop is not bound by the fragments' latency.)
         constexpr int RT = V2W_WS_RING;
-        u32x4 ar[2 * RT][MI];
+        u32x4 ar[KS * RT][MI];
         auto load_frag = [&](u32x4 (&av)[MI], int ch, int s, int t) {     // k-step s of (plane ch, tap t); clamped past the end
             unsigned l16 = lane16;
             asm volatile("" : "+v"(l16));
             const int chc = ch < NCH ? ch : NCH - 1;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                av[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_WS_UNIT + l16);
+                av[i] = *gptr<const u32x4>(ap[i] + (size_t)((KS * chc + s) * K + t) * V2W_WS_UNIT + l16);
         };
         int qc = 0, qt = 0;                                  // the tap whose fragments are requested next
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            load_frag(ar[2 * r], qc, 0, qt);
-            load_frag(ar[2 * r + 1], qc, 1, qt);
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) load_frag(ar[KS * r + s2], qc, s2, qt);
             if (++qt >= K) { qt = 0; ++qc; }
         }
         __builtin_amdgcn_sched_barrier(0);
-        int ch = 0, t = 0;                                   // the running tap
-        unsigned xt = baddr(base, psz, 0, r0);
+        // (lc, lt): the tap whose B operands are read next - one tap ahead of the running one (two with one k-step per tap)
+        int lc = 0, lt = 0;
+        auto advance = [&]() {
+            int nc = lc, nt = lt + 1;
+            if (nt >= K) { nt = 0; ++nc; }
+            if (nc < NCH) { lc = nc; lt = nt; }              // (past the end: the last tap again - read, never used)
+        };
         u32x4 bb[2][NI];
+        {
+            const unsigned x0 = baddr(base, psz, 0, r0);
+            advance();
+            const unsigned x1 = KS == 2 ? (x0 ^ 32u) : baddr(base, psz, lc, r0 + lt * dil);
+            if constexpr (KS == 1) advance();
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bb[0][j] = *reinterpret_cast<const u32x4*>(smem_w + xt + j * 2048);
-            bb[1][j] = *reinterpret_cast<const u32x4*>(smem_w + (xt ^ 32u) + j * 2048);
+            for (int j = 0; j < NI; ++j) {
+                bb[0][j] = *reinterpret_cast<const u32x4*>(smem_w + x0 + j * CB);
+                bb[1][j] = *reinterpret_cast<const u32x4*>(smem_w + x1 + j * CB);
+            }
         }
         auto kstep = [&](auto bs_c, const u32x4 (&av)[MI], unsigned nxt) {
             constexpr int bs = decltype(bs_c)::value;
@@ -208,7 +234,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[bs][j]);
 #ifndef V2W_WS_ABL_NOB
-                bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_w + nxt + j * 2048);
+                bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_w + nxt + j * CB);
 #else
                 asm volatile("" : "+v"(bb[bs][j]) : "v"(nxt));
 #endif
@@ -216,23 +242,27 @@ wide_stage_bf16_kernel(const WideArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto tap = [&](auto par_c) {
-            constexpr int S0 = 2 * decltype(par_c)::value;
-            int nch_ = ch, nt_ = t + 1;                      // the next tap (past the end: this tap again - unused)
-            if (nt_ >= K) { nt_ = 0; ++nch_; }
-            if (nch_ >= NCH) { nch_ = ch; nt_ = t; }
-            const unsigned xn = baddr(base, psz, nch_, r0 + nt_ * dil);
-            kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
+            constexpr int P = decltype(par_c)::value, S0 = KS * P;
+            const unsigned xn = baddr(base, psz, lc, r0 + lt * dil);
+            advance();
+            if constexpr (KS == 2) {
+                kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
 #ifndef V2W_WS_ABL_NOA
-            load_frag(ar[S0], qc, 0, qt);
+                load_frag(ar[S0], qc, 0, qt);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(std::integral_constant<int, 1>{}, ar[S0 + 1], xn ^ 32u);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(std::integral_constant<int, 1>{}, ar[S0 + 1], xn ^ 32u);
 #ifndef V2W_WS_ABL_NOA
-            load_frag(ar[S0 + 1], qc, 1, qt);
+                load_frag(ar[S0 + 1], qc, 1, qt);
 #endif
+            } else {
+                kstep(std::integral_constant<int, P & 1>{}, ar[S0], xn);
+#ifndef V2W_WS_ABL_NOA
+                load_frag(ar[S0], qc, 0, qt);
+#endif
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (++qt >= K) { qt = 0; ++qc; }
-            ch = nch_; t = nt_; xt = xn;
         };
         const int TT = NCH * K;
         int g = 0;
@@ -252,7 +282,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2tab + wm0 + 32 * i + 8 * g + 4 * hk);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};                  // (registers of the padding rows stay 0)
+            if (g < NG) bv = *reinterpret_cast<const f32x4*>(b2tab + wm0 + 32 * i + 8 * g + 4 * hk);
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -267,7 +298,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(btab + jb * C + wm0 + 32 * i + 8 * g + 4 * hk);
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (g < NG) bv = *reinterpret_cast<const f32x4*>(btab + jb * C + wm0 + 32 * i + 8 * g + 4 * hk);
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -290,11 +322,11 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 const int pos = n0 - h2max + col;
                 const bool in_seq = pos >= 0 && pos < L;    // conv2 zero-pads t1 outside the sequence
                 const int xrow = xc0 + col, trow = h2max + col;
-                const unsigned xq = xbase + (unsigned)((wm0 / 32 + i) * xpsz + xrow * 64 + 8 * hk);
-                const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + trow * 64 + 8 * hk);
-                const int xsw = (xrow >> 2) & 3, tsw = (trow >> 2) & 3;
+                const unsigned xq = xbase + (unsigned)((wm0 / 32 + i) * xpsz + xrow * RB + 8 * hk);
+                const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + trow * RB + 8 * hk);
+                const int xsw = swz(xrow), tsw = swz(trow);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < NG; ++g) {
                     const u32x2 w = *reinterpret_cast<const u32x2*>(smem_w + xq + ((g ^ xsw) << 4));
                     const float xa[4] = {ws_lo(w[0]), ws_hi(w[0]), ws_lo(w[1]), ws_hi(w[1])};
                     float t1v[4];
@@ -317,45 +349,92 @@ wide_stage_bf16_kernel(const WideArgs a) {
         V2W_STAMP(8 + 6 * jb);
     }
 
-    // ---- store the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so
-    // that output position quads are 16-byte aligned, as 8-byte bf16 stores along positions (all waves: quads cross the waves' columns)
+    // ---- the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so that
+    // output position quads are 16-byte aligned (all waves: quads cross the waves' columns), then either the stage's output - 8-byte bf16
+    // stores along positions - or, fused, the generator's tail on it
     __syncthreads();
     V2W_STAMP(27);
     {
         constexpr int SRS = W + 8;
         float* const scr = reinterpret_cast<float*>(smem_w);
         const int soff = (h2max + 3) & ~3;
+        const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
+        const bool tail = a.post_out != nullptr;
+        const float pslope = a.post_slope;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int sc = wn0 + j * 32 + lr - h2max + soff;
+                const int col = wn0 + j * 32 + lr;
+                const int sc = col - h2max + soff;
+                const int pos = n0 - h2max + col;
+                const bool in_seq = pos >= 0 && pos < L;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) scr[(wm0 + 32 * i + F::row(e, hk)) * SRS + sc] = oacc[i][j][e];
+                for (int e = 0; e < 4 * NG; ++e) {
+                    float v = oacc[i][j][e];
+                    if (tail) {                              // conv_post reads leaky_relu(x / nk), zero-padded outside the sequence
+                        if (a.out_div != 0.f) v = v2w_div_by(v, a.out_div, dinv);
+                        v = in_seq ? v2w_lrelu(v, pslope) : 0.f;
+                    }
+                    scr[(wm0 + 32 * i + F::row(e, hk)) * SRS + sc] = v;
+                }
             }
         __syncthreads();
-        const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
-        const int nq = nto >> 2;
-        const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
-        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * C * L * 2;
-        for (int idx = tid; idx < C * nq; idx += NTH) {
-            const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
-            const int pos = n0 + 4 * q;
-            if (pos >= L) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
-            if (a.out_div != 0.f) {
+        if (!tail) {
+            const int nq = nto >> 2;
+            const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
+            unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * C * L * 2;
+            for (int idx = tid; idx < C * nq; idx += NTH) {
+                const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
+                const int pos = n0 + 4 * q;
+                if (pos >= L) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
+                if (a.out_div != 0.f) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], a.out_div, dinv);
+                    for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], a.out_div, dinv);
+                }
+                *gptr<u32x2>(obase + (unsigned)(row * L + pos) * 2u) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
             }
-            *gptr<u32x2>(obase + (unsigned)(row * L + pos) * 2u) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
+        } else {
+            // y[p] = tanh(b + sum_{t, c} w[t][c] * z[c][p + t - hout]) for the nto - 2 hout positions p = n0 + hout + m: scratch column of
+            // z[c][p + t - hout] is soff + m + t.  A thread takes 4 consecutive outputs: per channel 3 aligned float4s of the scratch row.
+            const int nty = nto - 2 * hout;
+            const int PK = a.post_k;
+            const float pb = a.post_b ? a.post_b[0] : 0.f;
+            for (int qd = tid; qd * 4 < nty; qd += NTH) {
+                const int m = 4 * qd;
+                const int p0 = n0 + hout + m;
+                if (p0 >= L) continue;
+                f32x4 y = {pb, pb, pb, pb};
+                for (int c = 0; c < C; ++c) {
+                    const float* zr = scr + c * SRS + soff + m;
+                    float z[12];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 4 * u);
+                        z[4 * u] = zz[0]; z[4 * u + 1] = zz[1]; z[4 * u + 2] = zz[2]; z[4 * u + 3] = zz[3];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        if (t < PK) {
+                            const float wv = a.post_w[t * C + c];
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) y[x] = fmaf(wv, z[t + x], y[x]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) y[x] = tanhf(y[x]);
+                *gptr<f32x4>(a.post_out + (size_t)b * L + p0) = y;
+            }
         }
     }
     V2W_STAMP(28);
 }
 
-template <int MI, int NI, int WM, int WN, int OCC = 2>
+template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32>
 int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
-    constexpr int NTH = 64 * WM * WN, C = 32 * MI * WM, W = 32 * NI * WN;
+    constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32, RB = 2 * CH;
     WideArgs p{};
     p.in = reinterpret_cast<const unsigned short*>(q->in); p.in_a = q->in_a; p.in_s = q->in_s;
     p.out = reinterpret_cast<unsigned short*>(q->out);
@@ -369,20 +448,27 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
         if (h2 > p.h2max) p.h2max = h2;
     }
     if (p.h1max > 32 || p.h2max > 32) return V2W_E_SHAPE;
+    if (q->post_out) {                         // the fused tail: C = 16 (one plane), an odd tap count <= 9, fp32 (B, 1, L) output
+        if (CH != 16 || !q->post_w || q->post_k < 1 || q->post_k > 9 || !(q->post_k & 1)) return V2W_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(q->post_out) & 15) return V2W_E_SHAPE;
+        p.post_w = q->post_w; p.post_b = q->post_b; p.post_out = q->post_out; p.post_k = q->post_k; p.post_slope = q->post_slope;
+        p.hout = (q->post_k - 1) / 2;
+    } else if (!q->out) return V2W_E_ARG;
     p.nto = (W - 2 * p.h2max) & ~3;
-    if (p.nto < W / 2) return V2W_E_SHAPE;
-    const int hsum = p.h1max + p.h2max;
+    if (p.hout) p.nto = ((W - 2 * p.h2max - 2 * p.hout) & ~3) + 2 * p.hout;     // the tile advances by nto - 2 hout: a multiple of 4
+    if (p.nto - 2 * p.hout < W / 2) return V2W_E_SHAPE;
+    const int hsum = p.h1max + p.h2max + p.hout;
     p.xoff = ((hsum + 3) & ~3) - hsum;
     p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
     p.trows = (W + 2 * p.h2max + 3) & ~3;
-    p.ntl = (q->L + p.nto - 1) / p.nto;
+    p.ntl = (q->L + (p.nto - 2 * p.hout) - 1) / (p.nto - 2 * p.hout);
     p.ntiles = q->B * p.ntl;
-    const size_t tiles = (size_t)(C / 32) * (p.xrows + p.trows) * 64;
+    const size_t tiles = (size_t)NCH * (p.xrows + p.trows) * RB;
     const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float);
-    if (lds * ((OCC * 4) / (WM * WN)) > 160 * 1024) return V2W_E_SHAPE;       // (two workgroups per CU where the configuration counts on it)
+    if (lds * ((OCC * 4) / (WM * WN)) > 160 * 1024) return V2W_E_SHAPE;       // (as many workgroups per CU as the configuration counts on)
     if (tiles < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;     // the store scratch [C][W + 8] overlays the two tiles
     if (!(q->slope > 0.f && q->slope <= 1.f)) return V2W_E_SHAPE;            // lrelu as max(v, slope v), undone as min(a, a / slope)
-    auto kern = wide_stage_bf16_kernel<MI, NI, WM, WN, OCC>;
+    auto kern = wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
@@ -398,6 +484,7 @@ V2W_TL_SETTER(v2w_timeline_set_wide)
 // Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for C >= 64 on bf16 tensors.  V2W_E_SHAPE: the caller issues the convs one by one.
 int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream) {
     if (a->io_bf16 != 3 || a->nk > V2W_WS_MAXB) return V2W_E_SHAPE;
+    if (a->post_out && a->C != 16) return V2W_E_SHAPE;
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
     if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out)) return V2W_E_SHAPE;
     if ((long long)a->C * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;           // 32-bit offsets inside one batch item
@@ -420,5 +507,6 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
     // 32 channels x 256 positions, TWO waves of 32 x 128 outputs, four workgroups per CU (the workgroups run out of phase: 870 us against the
     // 940 us of stage_bf16_kernel<32>, whose four waves share every barrier)
     if (a->C == 32) return launch_wide<1, 4, 1, 2>(a, stream);
+    if (a->C == 16) return launch_wide<1, 4, 1, 2, 2, 16>(a, stream);            // 16 channels x 256 positions, two waves (+ the fused tail)
     return V2W_E_SHAPE;
 }

@@ -385,7 +385,8 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16.hip
 
 extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream) {
-    if (!a || !a->in || !a->out || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+    if (!a || !a->in || (!a->out && !a->post_out) || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+    if (a->post_out && !(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;                 // the fused tail exists on the bf16-tensor path only
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
     for (int j = 0; j < a->nk; ++j) {

@@ -466,7 +466,7 @@ def resblock_pair_multi(problems):
     return True
 
 
-def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0):
+def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None):
     """Split-operand (f16x3 / bf16) form of resblock2_stage for C == 32.  `branches`: list of dicts(wps1, b1, wps2, b2, k, dil1, dil2)
     with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken."""
     B, Cc, L = x.shape
@@ -477,10 +477,13 @@ def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=F
         a.wps1[j], a.sc1[j], a.bias1[j] = q['wps1'][0].data_ptr(), q['wps1'][1].data_ptr(), _hip.ptr(q['b1'])
         a.wps2[j], a.sc2[j], a.bias2[j] = q['wps2'][0].data_ptr(), q['wps2'][1].data_ptr(), _hip.ptr(q['b2'])
         a.k[j], a.dil1[j], a.dil2[j] = q['k'], q['dil1'], q['dil2']
-    a.out = out.data_ptr()
+    a.out = _hip.ptr(out)
     a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
     a.slope, a.out_div, a.bf16 = slope, out_div, int(bf16)
     a.io_bf16 = io_bf16
+    if post is not None:      # (wf [k][C][1], bias | None, y (B, 1, L) fp32, k, slope): the generator's tail fused behind the C = 16 stage
+        a.post_w, a.post_b, a.post_out = post[0].data_ptr(), _hip.ptr(post[1]), post[2].data_ptr()
+        a.post_k, a.post_slope = post[3], post[4]
     rc = _hip.load().v2w_resblock2_stage_split_fwd(C.byref(a), _stream(x))
     if rc == -2:
         return False

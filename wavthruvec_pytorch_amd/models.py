@@ -207,6 +207,8 @@ class Generator(nn.Module):
         self.bf16_storage = True              # precision == 'bf16': keep activations in bf16 between layers (no-grad forwards)
         self.fuse_wide = True                 # bf16 storage: the residual convs of the wide stages (C >= 64) as one launch per conv position
         self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
+        self.fuse_post = False                # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage
+                                              # (opt-in: measured 1162 us against 791 + 190 us for the two kernels at configs[2])
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
@@ -536,6 +538,7 @@ class Generator(nn.Module):
                     gbs, z_ws, sigma_ws, training)
             cond_joined = False
 
+            y = None
             # ---- K1: conv_pre (no activation in front of it)
             cur = self._buf('act.pre', (B, c0, T), dtype=adt, device=dev)
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
@@ -625,12 +628,22 @@ class Generator(nn.Module):
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
                         if C in (16, 32) and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
-                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
-                                             [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
-                                                   wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
-                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
-                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
-                                             bf16=self.precision == 'bf16', io_bf16=3 if st else 0)
+                            branches = [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                             wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                             dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation) for nm, rb in zip(names, rbs)]
+                            if st and self.fuse_post and i == ns - 1 and C == 16 and self.conv_post.kernel_size <= 9:
+                                # the last stage with the generator's tail behind it in ONE kernel (models.py:143-145): the stage's output never
+                                # leaves the chip, y is written instead
+                                y = torch.empty((B, 1, Lo), device=dev, dtype=torch.float32)
+                                ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names) + '+conv_post', hipops.resblock2_stage_split,
+                                                 xr, aff, branches, None, slope=LRELU_SLOPE, out_div=float(nk), bf16=True, io_bf16=3,
+                                                 post=(wf['conv_post'], self.conv_post.bias.detach(), y, self.conv_post.kernel_size, 0.01))
+                                if not ok:
+                                    y = None
+                            if not ok:
+                                ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
+                                                 branches, xs, slope=LRELU_SLOPE, out_div=float(nk),
+                                                 bf16=self.precision == 'bf16', io_bf16=3 if st else 0)
                         if not ok and st and self.fuse_wide_stage and C >= 64 and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
                             # wide stage on bf16 tensors: the WHOLE residual section in one kernel (v2w_stage_bf16_wide.hip): x read once,
                             # t1_j on chip, one fp32 accumulator over the branches
@@ -745,10 +758,11 @@ class Generator(nn.Module):
                 L = Lo
             if not cond_joined:
                 main.wait_stream(side)
-            # ---- K8: leaky_relu(0.01) -> conv_post -> tanh
-            y = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
-            self._timed('conv_post', hipops.conv_post_tanh, cur, wf['conv_post'], self.conv_post.bias.detach(), y, k=7,
-                        slope=0.01)
+            # ---- K8: leaky_relu(0.01) -> conv_post -> tanh (unless the last stage's kernel has already done it)
+            if y is None:
+                y = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
+                self._timed('conv_post', hipops.conv_post_tanh, cur, wf['conv_post'], self.conv_post.bias.detach(), y, k=7,
+                            slope=0.01)
 
         if save is not None:
             # the spectral-norm vectors AS THIS FORWARD LEFT THEM: the backward of sigma = u^T W v must not see a later forward's
