@@ -242,8 +242,12 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                     ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
             if staged and precision != 'f32':
-                wide = {128: '<2, 2, 2, 4, 2, 32>', 64: '<2, 2, 1, 4, 2, 32>', 256: '<2, 2, 4, 2, 2, 32>', 32: '<1, 4, 1, 2, 2, 32>',
-                        16: '<1, 4, 1, 2, 2, 16>'}        # launch_wide configurations (v2w_stage_bf16_wide.hip)
+                # launch_wide configurations (v2w_stage_bf16_wide.hip; the trailing 'false, true': fragments through registers, the generator's
+                # own (k, dilation) set at compile time); C = 16 runs there only with the fused tail (fuse_post)
+                wide = {128: '<1, 4, 4, 2, 2, 32, false, true>', 64: '<2, 2, 1, 4, 2, 32, false, true>', 256: '<1, 4, 8, 1, 2, 32, false, true>',
+                        32: '<1, 4, 1, 2, 2, 32, false, true>'}
+                if names[-1] == 'conv_post':
+                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false>'
                 kname = (('wide_stage_bf16_kernel' + wide[ls[0]['cout']]) if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         nbytes = sum(l['bytes'] for l in ls)

@@ -32,6 +32,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef V2W_WS_CFG
 #define V2W_WS_CFG 0
 #endif
+#ifndef V2W_WS_PERSIST
+#define V2W_WS_PERSIST 0     // 1: one residency of workgroups, each walks its tiles with the next tile's x loads in flight under its stores.  Measured
+#endif                       // SLOWER (C = 128 / 64 / 256: 1028-1058 / 1208-1220 / 1103-1133 us against 1003-1022 / 1152-1155 / 1072-1113): the hardware's
+                             // own dispatch of one workgroup per tile keeps the workgroups of a CU out of phase, which is what hides the epilogues
+#ifndef V2W_WS_PRIO
+#define V2W_WS_PRIO 0
+#endif
 
 struct WideArgs {
     const unsigned short* in; const float* in_a; const float* in_s;
@@ -64,7 +71,14 @@ template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); ret
 // a 4-wave workgroup alone on its CU: 1 (the whole 512-register file)
 // CH = channels of a plane that exist: 32, or 16 for the C = 16 stage (ONE plane of 32-byte rows, one k-step per tap, the MFMA's rows 16-31
 // are the zero rows of the packed fragments: half of every MFMA is padding, on a stage that the vector ALU and the memory bound anyway)
-template <int MI, int NI, int WM, int WN, int OCC, int CH>
+// WLDS: the weight fragments reach the waves through an LDS ring filled by LDS-DMA (global_load_lds_dwordx4), each fragment fetched ONCE per
+// workgroup and tap instead of once per wave that needs it.  Measured why: with the fragments loaded straight into registers the 8 waves of a
+// C = 128 tile ask the CU's vector memory pipe for 2 KB per 4 MFMAs each - 128 B / clk at full matrix rate against the 64 B / clk it delivers;
+// the conv phases ran at 57 % of the MFMA issue rate (71 % with the loads compiled out).
+// STD: the kernel is compiled for the generator's own residual blocks - three branches of 3 / 7 / 11 taps, dilation 1 in the first convs and 3 in
+// the second (hparams.py:42-43 with ResBlock2) - with every tap count and dilation a compile-time constant (conv_ct below); the launcher
+// checks the arguments against it.  !STD: any branch count / kernel size / dilation at run time.
+template <int MI, int NI, int WM, int WN, int OCC, int CH, bool WLDS, bool STD>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 wide_stage_bf16_kernel(const WideArgs a) {
     typedef Frag<32> F;
@@ -91,55 +105,49 @@ wide_stage_bf16_kernel(const WideArgs a) {
     float* const btab = reinterpret_cast<float*>(smem_w + tbase + NCH * tpsz); // bias1[nk][C], then sum_j bias2_j [C], then a[C], s[C]
     float* const b2tab = btab + V2W_WS_MAXB * C;
     float* const atab = b2tab + C;
+    const unsigned wring = tbase + (unsigned)(NCH * tpsz) + (unsigned)((V2W_WS_MAXB + 3) * C * sizeof(float));     // WLDS: the fragment ring
     const float slope = a.slope, inv_slope = a.inv_slope;
 
     const int hout = ws_uni(a.hout);
-    const int tile = blockIdx.x;
-    const int b = tile / a.ntl;
-    const int n0 = (tile % a.ntl) * (nto - 2 * hout) - hout;                    // position of the first valid output column of the window
+    // one tile per workgroup (V2W_WS_PERSIST: a workgroup walks tiles blockIdx.x, + gridDim.x, ... with the x loads of its next tile in flight)
+    int b = 0, n0 = 0, pos0 = 0;                                                // batch item, position of the first valid output column, position of x row 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = ws_uni(tid >> 6);
-    const int lr = lane & 31, hk = lane >> 5;
+    int lr = lane & 31, hk = lane >> 5;                        // (not const: made opaque again at every tile, see the tile loop)
     const int wm0 = (wave / WN) * (32 * MI);
     const int wn0 = (wave % WN) * (32 * NI);
-    const int pos0 = n0 - h2max - h1max - ws_uni(a.xoff);                       // position of x row 0 (multiple of 4)
     const int xc0 = ws_uni(a.xoff) + h1max;                                     // x row of window column 0 (position n0 - h2max)
+    auto tile_origin = [&](int tile, int& tb, int& tn0, int& tpos0) {
+        tb = tile / a.ntl;
+        tn0 = (tile % a.ntl) * (nto - 2 * hout) - hout;
+        tpos0 = tn0 - h2max - h1max - ws_uni(a.xoff);                           // (a multiple of 4)
+    };
     V2W_STAMP(0);
 
-    // ---- tables
-    for (int i = tid; i < nk * C; i += NTH) {
-        const int j = i / C, c = i - j * C;
-        btab[i] = a.bias1[j] ? a.bias1[j][c] : 0.f;
-    }
-    for (int c = tid; c < C; c += NTH) {
-        float v = 0.f;
-        for (int j = 0; j < nk; ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
-        b2tab[c] = v;
-        atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
-        atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
-    }
-
     // ---- stage lrelu(a * in + s) as bf16, every channel of the window + halo in ONE burst of loads.  An item = 4 channels x 4 positions:
-    // four 8-byte loads (4 positions of one channel), four 8-byte LDS stores (the 4 channels of one position)
-    {
-        const int nq = xrows >> 2;
-        const int nitems = NCH * NQC * nq;
-        u32x2 pf[NPF][4];
-        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * C * L * 2;
+    // four 8-byte loads (4 positions of one channel), four 8-byte LDS stores (the 4 channels of one position).  Loads (issue_x) and the
+    // LDS writes (commit_x) are apart: the next tile's loads fly while the current tile is stored.
+    const int nq = xrows >> 2;
+    const int nitems = NCH * NQC * nq;
+    u32x2 pf[NPF][4];
+    auto issue_x = [&](int tile) {
+        int tb, tn0, tpos0;
+        tile_origin(tile, tb, tn0, tpos0);
+        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)tb * C * L * 2;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTH;
             const int cq = idx % NQC, rest = idx / NQC;
             const int pq = rest % nq, ch = rest / nq;
-            const int pos = pos0 + pq * 4;
+            const int pos = tpos0 + pq * 4;
             const bool ok = idx < nitems && pos >= 0 && pos < L;
             unsigned vo = (unsigned)((32 * (idx < nitems ? ch : 0) + 4 * cq) * L + (ok ? pos : 0)) * 2u;
             asm volatile("" : "+v"(vo));
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[s][i] = *gptr<const u32x2>(inb + (size_t)i * L * 2 + vo);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                    // the affine table is complete
+    };
+    auto commit_x = [&]() {                                  // (b, pos0: the tile the loads were issued for; the affine table of b is complete)
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTH;
@@ -165,13 +173,14 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 *reinterpret_cast<u32x2*>(dst + e * RB) = w;
             }
         }
-    }
-    V2W_STAMP(1);
-    __syncthreads();
-    V2W_STAMP(2);
+    };
 
+    const bool young = wave >= (WM * WN) / 2;                 // (uniform) the second-dispatched half of the workgroup's waves
+#if V2W_WS_PRIO == 1
+    if (young) __builtin_amdgcn_s_setprio(1);
+#endif
     acc_t acc1[MI][NI], oacc[MI][NI];
-    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned lane16 = (unsigned)lane * 16u;
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
     };
@@ -186,6 +195,98 @@ wide_stage_bf16_kernel(const WideArgs a) {
     // of this wave's block 0, tap 0).
     auto conv = [&](acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps, int K, int dil) {
         const int nst = KS * NCH * K;
+        // The t1 tile has no halo rows of its own: a tap that reaches past it reads whatever lies h2max rows before / after the plane (the
+        // neighbouring plane, the x tile, the tables, the slack the launcher allocates behind them).  An output column depends on the operand
+        // rows of that column alone, so the garbage (NaN patterns included) stays in window columns that are never stored.
+        auto rowaddr = [&](int ch, int row) { return baddr(base, psz, ch, row); };
+        if constexpr (WLDS) {
+            // ---- fragments through the LDS ring.  A tap = FT = (C / 32) * KS fragments of 1 KiB, fragment f = (row block f / KS, k-step f % KS);
+            // wave w copies fragments w * FPW .. of every tap (one global_load_lds_dwordx4 each: 64 lanes x 16 bytes, the LDS address
+            // in M0).  Three slots: at the top of tap g every wave has waited for its part of tap g + 1 (counted vmcnt: the copies
+            // retire in order), the barrier makes the whole tap visible and frees the slot of tap g (its fragments sit in registers since
+            // tap g - 1) for the copy of tap g + 3; tap g + 1's fragments are read into the other register set under tap g's MFMAs.
+            static_assert(KS == 2, "ring of 64-byte-row tiles");
+            constexpr int NW = WM * WN, FT = (C / 32) * KS, FPW = (FT + NW - 1) / NW, SLOT = FT * 1024;
+            static_assert(FT % NW == 0 || FT < NW, "whole fragments per wave");
+            const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_w) + wring;
+            const unsigned lane16w = lane16;
+            auto dma = [&](int slot, int ch, int t) {            // this wave's fragments of (plane ch, tap t) -> ring slot (uniform arguments)
+                const int chc = ch < NCH ? ch : NCH - 1;
+#pragma unroll
+                for (int u = 0; u < FPW; ++u) {
+                    const int f = wave * FPW + u;
+                    if (FT < NW && f >= FT) break;               // (more waves than fragments: the first FT waves copy)
+                    const int rb = f / KS, sq = f % KS;
+                    const unsigned char* src = wps + ((size_t)rb * nst + (size_t)(KS * chc + sq) * K + t) * V2W_WS_UNIT + lane16w;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(slot * SLOT + f * 1024));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
+            };
+            constexpr int MYF = FT < NW ? 1 : FPW;               // copies a wave has in flight per tap (waves beyond FT: none - they only wait less)
+            int qc = 0, qt = 0;
+            auto next_q = [&]() { if (++qt >= K) { qt = 0; ++qc; } };
+            __syncthreads();                                     // every wave is done with the ring (the previous conv's last taps)
+            dma(0, qc, qt); next_q();
+            dma(1, qc, qt); next_q();
+            dma(2, qc, qt); next_q();
+            u32x4 areg[2][KS][MI];
+            auto read_a = [&](u32x4 (&av)[KS][MI], int slot) {
+#pragma unroll
+                for (int sq = 0; sq < KS; ++sq)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        av[sq][i] = *reinterpret_cast<const u32x4*>(smem_w + wring + slot * SLOT + ((wm0 / 32 + i) * KS + sq) * 1024 + lane16);
+            };
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * MYF) : "memory");
+            __builtin_amdgcn_s_barrier();
+            read_a(areg[0], 0);
+            int lc = 0, lt = 0;
+            auto advance = [&]() {
+                int nc = lc, nt = lt + 1;
+                if (nt >= K) { nt = 0; ++nc; }
+                if (nc < NCH) { lc = nc; lt = nt; }
+            };
+            u32x4 bb[2][NI];
+            {
+                const unsigned x0 = rowaddr(0, r0);
+                advance();
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bb[0][j] = *reinterpret_cast<const u32x4*>(smem_w + x0 + j * CB);
+                    bb[1][j] = *reinterpret_cast<const u32x4*>(smem_w + (x0 ^ 32u) + j * CB);
+                }
+            }
+            int slot_n = 1, slot_q = 0;                          // slot of tap g + 1 (read next), slot the next copy goes to (= tap g's)
+            auto tapw = [&](auto par_c) {
+                constexpr int P = decltype(par_c)::value;
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(MYF) : "memory");      // tap g + 1 has landed; my reads of tap g are back
+                __builtin_amdgcn_s_barrier();
+                dma(slot_q, qc, qt); next_q();
+                read_a(areg[P ^ 1], slot_n);
+                slot_q = slot_q == 2 ? 0 : slot_q + 1;
+                slot_n = slot_n == 2 ? 0 : slot_n + 1;
+                const unsigned xn = rowaddr(lc, r0 + lt * dil);
+                advance();
+#pragma unroll
+                for (int sq = 0; sq < KS; ++sq) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], areg[P][sq][i], bb[sq][j]);
+                        bb[sq][j] = *reinterpret_cast<const u32x4*>(smem_w + (sq ? (xn ^ 32u) : xn) + j * CB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            const int TT = NCH * K;
+            int g = 0;
+            for (; g + 2 <= TT; g += 2) { tapw(std::integral_constant<int, 0>{}); tapw(std::integral_constant<int, 1>{}); }
+            if (g < TT) tapw(std::integral_constant<int, 0>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the copies past the last tap (clamped re-reads) have landed before the ring is reused
+            return;
+        }
         const unsigned char* ap[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) ap[i] = wps + (size_t)(wm0 / 32 + i) * nst * V2W_WS_UNIT;
@@ -217,9 +318,9 @@ wide_stage_bf16_kernel(const WideArgs a) {
         };
         u32x4 bb[2][NI];
         {
-            const unsigned x0 = baddr(base, psz, 0, r0);
+            const unsigned x0 = rowaddr(0, r0);
             advance();
-            const unsigned x1 = KS == 2 ? (x0 ^ 32u) : baddr(base, psz, lc, r0 + lt * dil);
+            const unsigned x1 = KS == 2 ? (x0 ^ 32u) : rowaddr(lc, r0 + lt * dil);
             if constexpr (KS == 1) advance();
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -243,7 +344,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
         };
         auto tap = [&](auto par_c) {
             constexpr int P = decltype(par_c)::value, S0 = KS * P;
-            const unsigned xn = baddr(base, psz, lc, r0 + lt * dil);
+            const unsigned xn = rowaddr(lc, r0 + lt * dil);
             advance();
             if constexpr (KS == 2) {
                 kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
@@ -277,21 +378,99 @@ wide_stage_bf16_kernel(const WideArgs a) {
         if constexpr (RT > 3) { if (g + 2 < TT) tap(std::integral_constant<int, 2>{}); }
     };
 
-    // ---- the running output accumulator starts at sum_j b2_j
+    // ---- the same loop with the tap count and dilation as COMPILE-TIME constants (the generator's residual blocks: 3 / 7 / 11 taps, dilation
+    // 1 and 3).  Measured on the runtime form: a tap of 8 MFMAs (256 cycles of issue) costs 870 cycles with two waves per SIMD and 725 with
+    // every load compiled out - the scalar bookkeeping of a tap (which plane, which tap, wrap-arounds, fragment index multiplies: ~40
+    // dependent SALU instructions) stands between the MFMAs of a wave, and two waves that run the same code hit those stretches together.
+    // Unrolled over the taps of a plane, every offset is an immediate or one add.
+    auto conv_ct = [&](auto k_c, auto d_c, acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps) {
+        constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value;
+        static_assert(KS == 2 && K >= 2, "64-byte rows");
+        const unsigned char* ap[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) ap[i] = wps + (size_t)(wm0 / 32 + i) * (KS * NCH * K) * V2W_WS_UNIT;
+        u32x4 ar[4][MI];                                      // fragments of two taps: slots 2 (g & 1) + s for global tap g
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));
+        auto frag = [&](u32x4 (&av)[MI], int foff) {          // foff: (uniform) byte offset of the fragment inside a row block's stream
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};                  // (registers of the padding rows stay 0)
-            if (g < NG) bv = *reinterpret_cast<const f32x4*>(b2tab + wm0 + 32 * i + 8 * g + 4 * hk);
+            for (int i = 0; i < MI; ++i) av[i] = *gptr<const u32x4>(ap[i] + foff + l16);
+        };
+        auto addr = [&](unsigned pbase, int row) { return pbase + (unsigned)(row * RB + ((hk ^ swz(row)) << 4)); };
+        // fragment (plane ch, k-step s, tap t) of a row block sits at ((2 ch + s) K + t) units
+        frag(ar[0], 0);
+        frag(ar[1], K * V2W_WS_UNIT);
+        frag(ar[2], 1 * V2W_WS_UNIT);
+        frag(ar[3], (K + 1) * V2W_WS_UNIT);
+        u32x4 bb[2][NI];
+        {
+            const unsigned x0 = addr(base, r0);
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) oacc[i][j][4 * g + x] = bv[x];
+            for (int j = 0; j < NI; ++j) {
+                bb[0][j] = *reinterpret_cast<const u32x4*>(smem_w + x0 + j * CB);
+                bb[1][j] = *reinterpret_cast<const u32x4*>(smem_w + (x0 ^ 32u) + j * CB);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        auto plane = [&](auto par_c, int ch) {
+            constexpr int PAR = decltype(par_c)::value;       // parity of the plane's first tap in the global tap order (K is odd)
+            const unsigned pbase = base + (unsigned)(ch * psz);
+            const bool lastp = ch + 1 >= NCH;
+            const int fbase = 2 * ch * K * V2W_WS_UNIT;       // (uniform) the plane's k-step 0, tap 0
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+#if V2W_WS_PRIO == 2
+                // the two waves of a SIMD take turns at the higher priority, tap by tap (the older wave wins every arbitration otherwise and the
+                // younger one runs its loop after it: the workgroup then waits for the younger half at every barrier)
+                if (young == (((PAR + t) & 1) != 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+                const int sl = 2 * ((PAR + t) & 1);
+                // B operands of the next tap: this plane one dilation step on, or tap 0 of the next plane (past the end: this tap again)
+                const bool wrapn = t + 1 >= K;
+                const unsigned xn = wrapn ? (lastp ? addr(pbase, r0 + t * DIL) : addr(pbase + (unsigned)psz, r0)) : addr(pbase, r0 + (t + 1) * DIL);
+                // fragments two taps on: this plane, or the next one (its blocks lie 2 K units further; past the end: this plane's again)
+                const int t2 = (t + 2) % K;
+                const int f2 = fbase + ((t + 2 >= K && !lastp) ? 2 * K * V2W_WS_UNIT : 0) + t2 * V2W_WS_UNIT;
+#pragma unroll
+                for (int sq = 0; sq < 2; ++sq) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], ar[sl + sq][i], bb[sq][j]);
+                        bb[sq][j] = *reinterpret_cast<const u32x4*>(smem_w + (sq ? (xn ^ 32u) : xn) + j * CB);
+                    }
+                    frag(ar[sl + sq], f2 + sq * K * V2W_WS_UNIT);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if constexpr (NCH == 1) {
+            plane(std::integral_constant<int, 0>{}, 0);
+        } else {
+            for (int ch = 0; ch < NCH; ch += 2) {
+                plane(std::integral_constant<int, 0>{}, ch);
+                plane(std::integral_constant<int, 1>{}, ch + 1);
+            }
+        }
+    };
+    // ---- the running output accumulator starts at sum_j b2_j
+    auto init_oacc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};              // (registers of the padding rows stay 0)
+                if (g < NG) bv = *reinterpret_cast<const f32x4*>(b2tab + wm0 + 32 * i + 8 * g + 4 * hk);
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) oacc[i][j][4 * g + x] = bv[x];
+            }
+    };
 
-    for (int jb = 0; jb < nk; ++jb) {
-        const int K = ws_uni(a.K[jb]), d1 = ws_uni(a.d1[jb]), d2 = ws_uni(a.d2[jb]);
+    auto branch = [&](int jb, auto k_c) {
+        constexpr int KC = decltype(k_c)::value;             // > 0: the tap count at compile time (dilations 1 and 3), 0: run-time arguments
+        const int K = KC ? KC : ws_uni(a.K[jb]), d1 = KC ? 1 : ws_uni(a.d1[jb]), d2 = KC ? 3 : ws_uni(a.d2[jb]);
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col
 #pragma unroll
@@ -306,7 +485,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
                     for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
             }
         V2W_STAMP(3 + 6 * jb);
-        conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
+        else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
         V2W_STAMP(4 + 6 * jb);
         __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
         V2W_STAMP(5 + 6 * jb);
@@ -321,7 +501,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 col += 32 * j;
                 const int pos = n0 - h2max + col;
                 const bool in_seq = pos >= 0 && pos < L;    // conv2 zero-pads t1 outside the sequence
-                const int xrow = xc0 + col, trow = h2max + col;
+                const int xrow = xc0 + col, trow = col;
                 const unsigned xq = xbase + (unsigned)((wm0 / 32 + i) * xpsz + xrow * RB + 8 * hk);
                 const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + trow * RB + 8 * hk);
                 const int xsw = swz(xrow), tsw = swz(trow);
@@ -345,8 +525,45 @@ wide_stage_bf16_kernel(const WideArgs a) {
         __syncthreads();
         V2W_STAMP(7 + 6 * jb);
         // ---- conv2_j on the same window, onto the running accumulator
-        conv(oacc, tbase, tpsz, h2max - h2 + wn0 + lr, ws_uni(a.w2[jb]), K, d2);
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
+        else conv(oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), K, d2);
         V2W_STAMP(8 + 6 * jb);
+    };
+    issue_x(blockIdx.x);
+#if V2W_WS_PERSIST
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+#else
+    {
+    const int tile = blockIdx.x;
+#endif
+    tile_origin(tile, b, n0, pos0);
+    // every per-lane address term of the unrolled convs derives from these three: opaque per tile, or hipcc hoists ~100 registers of
+    // loop-invariant offsets out of the tile loop and spills the accumulators
+    asm volatile("" : "+v"(lr), "+v"(hk), "+v"(lane16));
+    __syncthreads();              // the previous tile's stores have read the scratch (which overlays the tiles and tables)
+    for (int i = tid; i < nk * C; i += NTH) {
+        const int j = i / C, c = i - j * C;
+        btab[i] = a.bias1[j] ? a.bias1[j][c] : 0.f;
+    }
+    for (int c = tid; c < C; c += NTH) {
+        float v = 0.f;
+        for (int j = 0; j < nk; ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
+        b2tab[c] = v;
+        atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
+        atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
+    }
+    __syncthreads();
+    commit_x();
+    V2W_STAMP(1);
+    __syncthreads();
+    V2W_STAMP(2);
+    init_oacc();
+    if constexpr (STD) {
+        branch(0, std::integral_constant<int, 3>{});
+        branch(1, std::integral_constant<int, 7>{});
+        branch(2, std::integral_constant<int, 11>{});
+    } else {
+        for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{});
     }
 
     // ---- the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so that
@@ -380,6 +597,11 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
             }
         __syncthreads();
+        // the next tile's x: in flight under this tile's stores.  Unconditional (past the end: the last tile again, never committed) - under
+        // a condition the old values stay live through the whole iteration as the other input of the join: 48 registers, 100 spills
+#if V2W_WS_PERSIST
+        issue_x(min(tile + (int)gridDim.x, a.ntiles - 1));
+#endif
         if (!tail) {
             const int nq = nto >> 2;
             const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
@@ -430,9 +652,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
         }
     }
     V2W_STAMP(28);
+    }
 }
 
-template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32>
+template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32, bool WLDS = false>
 int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
     constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32, RB = 2 * CH;
     WideArgs p{};
@@ -460,18 +683,33 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
     const int hsum = p.h1max + p.h2max + p.hout;
     p.xoff = ((hsum + 3) & ~3) - hsum;
     p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
-    p.trows = (W + 2 * p.h2max + 3) & ~3;
+    p.trows = W;                                      // (no halo rows: conv2's taps read up to h2max rows around the plane, see conv)
     p.ntl = (q->L + (p.nto - 2 * p.hout) - 1) / (p.nto - 2 * p.hout);
     p.ntiles = q->B * p.ntl;
     const size_t tiles = (size_t)NCH * (p.xrows + p.trows) * RB;
-    const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float);
+    // (+ 32 rows of slack: conv2's taps past the last plane of the t1 tile stay inside the allocation)
+    const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float) + (WLDS ? (size_t)3 * (C / 32) * (CH / 16) * 1024 : 0) + 32 * RB;
     if (lds * ((OCC * 4) / (WM * WN)) > 160 * 1024) return V2W_E_SHAPE;       // (as many workgroups per CU as the configuration counts on)
-    if (tiles < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;     // the store scratch [C][W + 8] overlays the two tiles
+    if (lds < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;       // the store scratch [C][W + 8] overlays the tiles (and the dead tables / ring)
     if (!(q->slope > 0.f && q->slope <= 1.f)) return V2W_E_SHAPE;            // lrelu as max(v, slope v), undone as min(a, a / slope)
-    auto kern = wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH>;
+    bool std_cfg = CH == 32 && !WLDS && q->nk == 3;          // the generator's own blocks: the compile-time form
+    for (int j = 0; j < 3 && std_cfg; ++j) std_cfg = q->k[j] == 3 + 4 * j && q->dil1[j] == 1 && q->dil2[j] == 3;
+#ifdef V2W_WS_NOCT
+    std_cfg = false;
+#endif
+    auto kern = (std_cfg && CH == 32 && !WLDS) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, (CH == 32 && !WLDS)>
+                                               : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
+    // V2W_WS_PERSIST: one residency of the chip (workgroups per CU as the configuration counts on), each workgroup walks its tiles
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu = n;
+    }
+    const int slots = V2W_WS_PERSIST ? ncu * ((OCC * 4) / (WM * WN)) : p.ntiles;
+    hipLaunchKernelGGL(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 
@@ -495,14 +733,17 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
     if (a->C == 128) return launch_wide<2, 4, 2, 2, 1>(a, stream);
     if (a->C == 64) return launch_wide<2, 4, 1, 4, 1>(a, stream);
     if (a->C == 256) return launch_wide<2, 4, 4, 1, 1>(a, stream);
+#elif V2W_WS_CFG == 2
+    // 64 x 64 outputs per wave: a weight fragment (global -> register: the CU's vector memory pipe moves 64 B / clk) feeds TWO MFMAs
+    if (a->C == 128) return launch_wide<2, 2, 2, 4>(a, stream);
+    if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);
+    if (a->C == 256) return launch_wide<2, 2, 4, 2>(a, stream);
 #else
-    if (a->C == 128) return launch_wide<2, 2, 2, 4>(a, stream);                   // 128 channels x 256 positions, 8 waves
-#if V2W_WS_CFG == 2
-    if (a->C == 64) return launch_wide<2, 2, 1, 8>(a, stream);                    // 64 channels x 512 positions, 8 waves
-#else
-    if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);                    // 64 channels x 256 positions, 4 waves, two workgroups per CU
-#endif
-    if (a->C == 256) return launch_wide<2, 2, 4, 2>(a, stream);                   // 256 channels x 128 positions, 8 waves
+    // 32 x 128 outputs per wave: a weight fragment feeds FOUR MFMAs (half the vector-memory traffic of the 64 x 64 form, the operand reads
+    // from LDS double: 128 B / clk of its 256)
+    if (a->C == 128) return launch_wide<1, 4, 4, 2>(a, stream);                   // 128 channels x 256 positions, 8 waves
+    if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);                    // 64 channels x 256 positions, 4 waves of 64 x 64, two workgroups per CU (1135-1145 us; <1, 4, 2, 2>: 1160-1173)
+    if (a->C == 256) return launch_wide<1, 4, 8, 1>(a, stream);                   // 256 channels x 128 positions, 8 waves
 #endif
     // 32 channels x 256 positions, TWO waves of 32 x 128 outputs, four workgroups per CU (the workgroups run out of phase: 870 us against the
     // 940 us of stage_bf16_kernel<32>, whose four waves share every barrier)
