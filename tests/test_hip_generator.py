@@ -40,8 +40,8 @@ def test_generator_matches_reference_golden(dev, name, algo):
     """algo 'f16x3': the split-f16 precision mode (wide Conv1d layers on the f16 matrix pipe) is held to the SAME 1e-4 bar
     against the same reference goldens as the exact-fp32 path."""
     from wavthruvec_pytorch_amd import hipops
-    if algo == 'direct' and name not in ('rb2_train_b2_t8', 'rb1_train_b2_t8', 'rb2_1024_x640_train_b2_t8'):
-        pytest.skip('direct (scalar) kernels are cross-checked on three representative cases')
+    if algo == 'direct' and name not in ('rb2_train_b2_t8', 'rb1_train_b2_t8', 'rb2_1024_x640_train_b2_t8', 'rb2_6stage_x640_train_b2_t8'):
+        pytest.skip('direct (scalar) kernels are cross-checked on four representative cases')
     z, meta = load_golden(name)
     h, sd, inp, inp2 = case_setup(meta)
     mode = meta['mode']
@@ -207,6 +207,8 @@ def test_generator_cfg3_bf16_full_size(dev):
     (1, 4, 64, 768, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]),
     ('1', 2, 40, 768, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]),
     (1, 2, 33, 1024, [8, 5, 4, 2, 2], [16, 11, 8, 4, 4]),
+    (1, 3, 19, 768, [5, 4, 4, 2, 2, 2], [11, 8, 8, 4, 4, 4]),          # six stages, x640: the last residual stage has 8 channels
+    ('1', 2, 11, 768, [5, 4, 4, 2, 2, 2], [11, 8, 8, 4, 4, 4]),
 ])
 @pytest.mark.parametrize('training', [True, False])
 def test_generator_matches_oracle_medium(dev, resblock, B, T, nf, rates, ks, training):
@@ -521,6 +523,44 @@ def test_generator_backward_wide_halo_resblock2(dev):
         floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6
         err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
         if err > 4e-3:
+            bad[n] = err
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_generator_six_stages_backward_and_bf16(dev, precision):
+    """upsample_rates (5, 4, 4, 2, 2, 2): the sixth stage runs ResBlock2 on 512 / 2^6 = 8 channels, below every fused-stage and MFMA tile
+    shape.  f32: forward and every parameter gradient against the oracle's autograd.  bf16: the forward stays as close to the fp32
+    oracle as bf16 operands allow (the bar of test_generator_bf16_operand_mode) whichever kernels the 8-channel layers fall to."""
+    h = synthetic.make_hparams(num_wv_feat=768, upsample_rates=[5, 4, 4, 2, 2, 2], upsample_kernel_sizes=[11, 8, 8, 4, 4, 4])
+    sd = synthetic.make_state_dict(h, seed=0)
+    B, T = 2, 9
+    inp = synthetic.make_inputs(h, B, T, seed=21)
+    dy = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 1, T * 640)).astype(np.float32))
+    # fp64 oracle.  Through six stages the fp32 oracle's OWN gradients of the parameters ahead of the first BatchNorm (fcs.0, cbns.0,
+    # ups.0, conv_pre) sit 0.5 - 1.1 % off its fp64 form on these inputs (every later parameter: 2e-6), and so do the HIP path's:
+    # those are held to 2e-2, everything else to the 4e-3 of the five-stage tests
+    y_ref, g_ref, _ = O.generator_gradients(sd, h, *[t.double() for t in inp], dy, training=True, dtype=torch.float64)
+    y_ref = y_ref.float()
+    g = build_generator(h, sd, dev, training=True)
+    if precision == 'bf16':
+        g.precision = 'bf16'
+        with torch.no_grad():
+            y = g(*to_dev(inp, dev))
+        assert y.shape == (B, 1, T * 640) and torch.isfinite(y).all()
+        d = (y.cpu() - y_ref).abs().max().item()
+        assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
+        return
+    y = g(*to_dev(inp, dev))
+    assert (y.detach().cpu() - y_ref).abs().max().item() <= TOL
+    (y * dy.to(dev)).sum().backward()
+    bad = {}
+    for n, p in g.named_parameters():
+        assert p.grad is not None, n
+        ref = g_ref[n]
+        floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6
+        err = (p.grad.cpu().double() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
+        if err > (2e-2 if n.startswith(('fcs.0.', 'cbns.0.', 'ups.0.', 'conv_pre.')) else 4e-3):
             bad[n] = err
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
 

@@ -915,7 +915,9 @@ def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
 @pytest.mark.parametrize('B,cin,cout,L,k,dil,u', [(2, 256, 256, 300, 11, 3, 1), (2, 64, 64, 1000, 7, 1, 1), (3, 32, 32, 777, 3, 5, 1),
                                                    (2, 16, 16, 3000, 11, 1, 1), (2, 768, 512, 50, 7, 1, 1),
                                                    (2, 512, 256, 50, 11, 1, 5), (2, 128, 64, 333, 8, 1, 4), (2, 64, 32, 500, 4, 1, 2),
-                                                   (2, 32, 16, 1000, 4, 1, 2), (1, 512, 256, 17, 16, 1, 8)])
+                                                   (2, 32, 16, 1000, 4, 1, 2), (1, 512, 256, 17, 16, 1, 8),
+                                                   # the 8-channel stage of a six-stage (x640) generator: 16-row tiles with the missing rows staged as 0
+                                                   (2, 8, 8, 1999, 11, 3, 1), (2, 8, 8, 640, 3, 1, 1), (2, 16, 8, 700, 4, 1, 2)])
 def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
     """dW of the fused [affine] -> lrelu -> Conv1d / ConvTranspose1d against torch autograd (weights in [k][C_in][C_out] layout)."""
     from wavthruvec_pytorch_amd import hipops

@@ -46,6 +46,10 @@ CASES = [
     dict(name='rb2_1024_x640_train_b2_t8',
          hp=dict(num_wv_feat=1024, upsample_rates=[8, 5, 4, 2, 2], upsample_kernel_sizes=[16, 11, 8, 4, 4]),
          B=2, T=8, mode='train'),
+    # six upsampling stages (x640 from 512 initial channels): the last ResBlock stage has 8 channels
+    dict(name='rb2_6stage_x640_train_b2_t8',
+         hp=dict(num_wv_feat=768, upsample_rates=[5, 4, 4, 2, 2, 2], upsample_kernel_sizes=[11, 8, 8, 4, 4, 4]),
+         B=2, T=8, mode='train'),
     dict(name='rb2_train2step_b2_t8', hp=dict(num_wv_feat=768), B=2, T=8, mode='train2'),
     dict(name='rb2_rmwn_train_b2_t8', hp=dict(num_wv_feat=768), B=2, T=8, mode='train_rmwn'),
 ]

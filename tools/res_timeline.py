@@ -132,7 +132,7 @@ def child_stage(C, variant):
     print(f'[{variant or "base"}] stage C={C}: {us:7.1f} us ({fl / us / 1e6:6.1f} TF useful)', flush=True)
     if not stamps:
         return
-    W = {128: 256, 64: 256, 256: 128, 32: 256}[C]
+    W = {128: 256, 64: 256, 256: 128, 32: 256, 16: 256}[C]
     nto = (W - 30) & ~3
     nblk = B * ((L + nto - 1) // nto)
     buf = torch.zeros((nblk * 4 * SLOTS,), device=dev, dtype=torch.int64)
@@ -142,8 +142,10 @@ def child_stage(C, variant):
     t = buf.cpu().numpy().reshape(nblk, 4, SLOTS).astype(np.int64)
     t = t[t[:, 0, 0] != 0]
     med = lambda v: f'{int(np.median(v))}/{int(np.mean(v))}'
-    d = lambda i, j: med(t[:, :, i] - t[:, :, j])
-    nch = C // 32
+    tw = t.reshape(-1, SLOTS)
+    tw = tw[tw[:, 0] != 0]                                  # (workgroups of two waves leave the slots of waves 2-3 empty)
+    d = lambda i, j: med(tw[:, i] - tw[:, j])
+    nch = max(1, C // 32)
     mi, ni = 2, 2
     print('  (median/mean cycles)')
     print(f'  tile total {d(28, 0)} cycles over {t.shape[0]} tiles (waves 0-3 of 8 stamped); staging {d(1, 0)}  barrier {d(2, 1)}')

@@ -52,7 +52,7 @@ wgrad_kernel(const WgradArgs p) {
     float* const DYs = smem;                 // [CO_T][ptw]
     float* const Xas = smem + CO_T * p.ptw;  // [CI_T][xtw]
 
-    const int cot = p.Cout / CO_T;
+    const int cot = (p.Cout + CO_T - 1) / CO_T;          // (channel counts below a multiple of the tile: the missing rows stage as 0)
     const int co0 = (blockIdx.x % cot) * CO_T, ci0 = (blockIdx.x / cot) * CI_T;
     const int s = blockIdx.y;
     const int cob = blockIdx.z * p.Cout + co0, cib = blockIdx.z * p.Cin + ci0;     // channel bases inside the x / dy tensors
@@ -61,6 +61,7 @@ wgrad_kernel(const WgradArgs p) {
     const int lr = lane & (MF - 1), hk = lane / MF;
     const int w_p = wave % p.wp, w_ci = (wave / p.wp) % p.wci, w_co = wave / (p.wp * p.wci);
     const int Lq = p.Lq, Ldy = p.Lq * p.u;
+    const int co_n = min(CO_T, p.Cout - co0), ci_n = min(CI_T, p.Cin - ci0);       // real rows of this tile
 
     acc_t acc[V2W_WG_TG];
 #pragma unroll
@@ -84,7 +85,7 @@ wgrad_kernel(const WgradArgs p) {
                 const int row = idx >> 5, col = (idx & 31) * 4;           // PT / 4 == 32 float4 per row
                 const int q = q0 + col;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q < Lq) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + cob + row) * Ldy + q);
+                if (q < Lq && row < co_n) v = *reinterpret_cast<const f32x4*>(p.dy + ((size_t)b * p.CoutT + cob + row) * Ldy + q);
                 float* d = DYs + row * p.ptw + col;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
@@ -95,7 +96,7 @@ wgrad_kernel(const WgradArgs p) {
                 const int q = qa + col;
                 const int ch = b * p.CinT + cib + row;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q >= 0 && q < Lq) {
+                if (q >= 0 && q < Lq && row < ci_n) {
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.x + (size_t)ch * Lq + q);
                     const float av = p.x_a ? p.x_a[ch] : 1.f, sv = p.x_a ? p.x_s[ch] : 0.f;
 #pragma unroll
@@ -108,14 +109,14 @@ wgrad_kernel(const WgradArgs p) {
             for (int idx = tid; idx < CO_T * PT; idx += 256) {
                 const int row = idx / PT, col = idx - row * PT;
                 const int q = q0 + col;
-                DYs[row * p.ptw + col] = q < Lq ? p.dy[((size_t)b * p.CoutT + cob + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
+                DYs[row * p.ptw + col] = (q < Lq && row < co_n) ? p.dy[((size_t)b * p.CoutT + cob + row) * Ldy + (size_t)p.u * q + p.r] : 0.f;
             }
             for (int idx = tid; idx < CI_T * xcols; idx += 256) {
                 const int row = idx / xcols, col = idx - row * xcols;
                 const int q = q0 - p.hla + col;
                 const int ch = b * p.CinT + cib + row;
                 float v = 0.f;
-                if (q >= 0 && q < Lq) {
+                if (q >= 0 && q < Lq && row < ci_n) {
                     const float av = p.x_a ? p.x_a[ch] : 1.f, sv = p.x_a ? p.x_s[ch] : 0.f;
                     v = v2w_lrelu(fmaf(av, p.x[(size_t)ch * Lq + q], sv), p.slope);
                 }
@@ -144,7 +145,7 @@ wgrad_kernel(const WgradArgs p) {
         for (int e = 0; e < F::NREG; ++e) {
             const int ci = ci0 + w_ci * MF + F::row(e, hk);
             const int co = co0 + w_co * MF + lr;
-            dst[((size_t)p.tap[t] * p.Cin + ci) * p.Cout + co] = acc[t][e];
+            if (ci < p.Cin && co < p.Cout) dst[((size_t)p.tap[t] * p.Cin + ci) * p.Cout + co] = acc[t][e];
         }
     }
 }
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* slab, float* dwf, size_t n, int nslab) {
     __shared__ f32x4 part[4][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const size_t i = ((size_t)blockIdx.x * 64 + o) * 4;             // n % 4 == 0: weights are k * C_in * C_out, C % 16 == 0
+    const size_t i = ((size_t)blockIdx.x * 64 + o) * 4;             // n % 4 == 0 (checked by the plan): weights are k * C_in * C_out
     slab += (size_t)blockIdx.y * nslab * n; dwf += (size_t)blockIdx.y * n;   // grid.y = group
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
@@ -374,17 +375,22 @@ wgrad_reduce_kernel(const float* slab, float* dwf, size_t n, int nslab) {
 // 2 x 2 x 1 when both channel counts allow two MFMA row blocks, else 1 x 1 x 4 - the shapes the pipelined kernel is instantiated
 // for (a mixed 2 x 1 would take the scalar kernel).  Transposed convs keep the arrangement their instantiations were tuned with.
 static int v2w_wgrad_plan(int B, int c_in, int c_out, int Lq, int u, int* mf_o, int* wco_o, int* wci_o, int ngroups = 1) {
-    const int mf = (c_out % 32 == 0 && c_in % 32 == 0) ? 32 : ((c_out % 16 == 0 && c_in % 16 == 0) ? 16 : 0);
-    if (!mf) return 0;
+    int mf = (c_out % 32 == 0 && c_in % 32 == 0) ? 32 : ((c_out % 16 == 0 && c_in % 16 == 0) ? 16 : 0);
+    const bool padded = !mf;                   // any other channel counts (the 8-channel stage of a x640 generator): 16-row tiles, the missing rows staged
+    if (padded) {                              // as 0 by the generic kernel; the slab reduce sums float4s of the k * c_in * c_out weights
+        if (ngroups != 1 || (c_in * c_out) % 4 != 0) return 0;
+        mf = 16;
+    }
     int wco = 1, wci = 1;
-    if (u == 1) {
+    if (padded) {
+    } else if (u == 1) {
         if (c_out % (2 * mf) == 0 && c_in % (2 * mf) == 0) wco = wci = 2;
     } else {
         if (c_out % (2 * mf) == 0) wco = 2;
         if (c_in % (2 * mf) == 0 && wco * 2 <= 4) wci = 2;
     }
     const int wp = 4 / (wco * wci);
-    const int tiles = (c_out / (wco * mf)) * (c_in / (wci * mf));
+    const int tiles = ((c_out + wco * mf - 1) / (wco * mf)) * ((c_in + wci * mf - 1) / (wci * mf));
     const int items = B * ((Lq + 127) / 128);
     int S = (2 * 256 + tiles * ngroups - 1) / (tiles * ngroups);       // ~2 workgroups per CU in flight (all groups of one launch together)
     if (S > items) S = items;
@@ -449,7 +455,8 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
     p.wp = 4 / (p.wco * p.wci);
     p.S = nslab / p.wp;
     p.nslab = nslab;
-    const int tiles = (c_out / (p.wco * mf)) * (c_in / (p.wci * mf));
+    const int tiles = ((c_out + p.wco * mf - 1) / (p.wco * mf)) * ((c_in + p.wci * mf - 1) / (p.wci * mf));
+    const bool padded = c_out % 16 != 0 || c_in % 16 != 0;        // (generic kernel only: the pipelined ones stage whole tiles)
     const int pad = u > 1 ? (k - u) / 2 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (Lq % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
@@ -492,7 +499,7 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
 
     // 1) pipelined kernel: groups of taps across phases, one staged dy tile holds all u phases
     const int ptq = v2w_wg_ptq(u);
-    bool piped = aligned && ptq > 0;
+    bool piped = aligned && ptq > 0 && !padded;
     if (piped) {
         p.vec4 = 1;
         p.nchunk = (Lq + ptq - 1) / ptq;
