@@ -205,6 +205,8 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
 
     def kernel_of(l, nprob=1):
         if l['name'] == 'conv_post':
+            if bf16_run and act_bytes == 2 and l['cin'] in (8, 16) and l['k'] <= 9 and l['L'] % 4 == 0:
+                return 'conv_post_tanh_mfma_kernel<%d>' % l['cin']            # v2w_conv_post_bf16.hip
             return 'conv_post_tanh_vec4_kernel'
         direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
         if algo == 'direct':

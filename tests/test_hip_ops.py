@@ -725,6 +725,26 @@ def test_conv_post_tanh(dev, B, C, L, k):
     assert (out.cpu() - want).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize('B,C,L,k', [(2, 16, 8000, 7), (3, 16, 8, 7), (2, 16, 1024, 7), (1, 16, 12296, 9), (2, 8, 5000, 3), (1, 16, 1032, 1),
+                                     (2, 16, 4100, 5), (3, 16, 4, 7), (2, 16, 1025, 7), (1, 16, 640, 11), (2, 32, 512, 7)])
+def test_conv_post_tanh_bf16_input(dev, B, C, L, k):
+    """The tail on bf16 activations (v2w_conv_post_tanh_bf16in).  C = 16 / 8, k <= 9, L % 8 == 0: the Toeplitz-MFMA kernel
+    (v2w_conv_post_bf16.hip: weights as hi + lo bf16, relu on packed bf16, v_exp / v_rcp tanh) - rows shorter than a tile, rows ending
+    inside a wave's tiles, several jobs per row; the other shapes: the vector-ALU kernels.  Reference: fp64 on the same bf16 values."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(8)
+    x = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32) * 2).bfloat16()
+    w = (r.standard_normal((1, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    bias = r.standard_normal(1).astype(np.float32) * 0.3
+    want = torch.tanh(F.conv1d(F.leaky_relu(x.double(), 0.01), torch.from_numpy(w).double(), torch.from_numpy(bias).double(), padding=(k - 1) // 2))
+    out = torch.full((B, 1, L), float('nan'), device=dev)
+    hipops.conv_post_tanh(x.to(dev), _t(_relayout(torch.from_numpy(w)).numpy(), dev), _t(bias, dev), out, k=k, slope=0.01)
+    err = (out.cpu().double() - want).abs().max().item()
+    # the dominant (1 - slope) relu term carries 16 weight mantissa bits, the slope-scaled 1 % term 8: 2^-9 of 0.01 * sum |w x| (~3) here;
+    # the rounding of the bf16 activations themselves is 50 times that
+    assert err <= 2e-4, err
+
+
 def test_conditional_batchnorm_module(dev):
     """`ConditionalBatchNorm1d(num_features).forward(inputs, noise)` standalone (reference modules.py:32-40 smoke shape)."""
     from wavthruvec_pytorch_amd import ConditionalBatchNorm1d

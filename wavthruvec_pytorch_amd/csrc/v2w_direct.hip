@@ -235,7 +235,14 @@ extern "C" int v2w_conv_post_tanh(const float* in, const float* wf, const float*
     return conv_post_tanh_impl<InF32>(in, wf, bias, out, B, C_in, L, k, slope, stream);
 }
 
+int v2w_conv_post_tanh_bf16_mfma(const unsigned short* in, const float* wf, const float* bias, float* out,
+                                 int B, int C_in, int L, int k, float slope, hipStream_t stream);      // v2w_conv_post_bf16.hip
+
 extern "C" int v2w_conv_post_tanh_bf16in(const void* x_bf16, const float* wf, const float* bias, float* out,
                                          int B, int C_in, int L, int k, float slope, void* stream) {
+    if (x_bf16 && wf && out && B > 0) {          // 16 / 8 channels, aligned rows: the taps as a Toeplitz product on the matrix pipe
+        const int rc = v2w_conv_post_tanh_bf16_mfma(static_cast<const unsigned short*>(x_bf16), wf, bias, out, B, C_in, L, k, slope, (hipStream_t)stream);
+        if (rc != V2W_E_SHAPE) return rc;
+    }
     return conv_post_tanh_impl<InBf16>(static_cast<const unsigned short*>(x_bf16), wf, bias, out, B, C_in, L, k, slope, stream);
 }

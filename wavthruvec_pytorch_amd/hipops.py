@@ -342,6 +342,7 @@ def conv_bf16_config(B, nprob, c_in, c_out, L, k, dil=1, u=1, io_bf16=3):
     else:
         a = _hip.ConvT1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, c_in, c_out, L, k, u
         a.io_bf16 = io_bf16
+        a.slope = 0.1              # (the generator's upsamplers; the resident-tile kernel rebuilds nothing from it but checks 0 < slope <= 1)
         rc = _hip.load().v2w_convt1d_bf16_config(C.byref(a), cfg)
     if rc != 0:
         return None
