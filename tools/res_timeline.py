@@ -103,10 +103,12 @@ def child_stage(C, variant):
     from wavthruvec_pytorch_amd import _hip, hipops
     _hip.load()
     raw = ctypes.CDLL(lib_of(variant))
-    stamps = hasattr(raw, 'v2w_timeline_set_wide')
+    n16 = C == 16 and hasattr(raw, 'v2w_timeline_set_n16') and not os.environ.get('V2W_TL_WIDE16')
+    setter = getattr(raw, 'v2w_timeline_set_n16' if n16 else 'v2w_timeline_set_wide', None)
+    stamps = setter is not None
     if stamps:
-        raw.v2w_timeline_set_wide.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        assert raw.v2w_timeline_set_wide(None, 0) == 0
+        setter.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert setter(None, 0) == 0
     dev = torch.device('cuda:0')
     B, L = 64, LEN[C]
     ks = [3, 7, 11]
@@ -136,15 +138,22 @@ def child_stage(C, variant):
     nto = (W - 30) & ~3
     nblk = B * ((L + nto - 1) // nto)
     buf = torch.zeros((nblk * 4 * SLOTS,), device=dev, dtype=torch.int64)
-    assert raw.v2w_timeline_set_wide(buf.data_ptr(), nblk) == 0
+    assert setter(buf.data_ptr(), nblk) == 0
     run(); torch.cuda.synchronize()
-    assert raw.v2w_timeline_set_wide(None, 0) == 0
+    assert setter(None, 0) == 0
     t = buf.cpu().numpy().reshape(nblk, 4, SLOTS).astype(np.int64)
     t = t[t[:, 0, 0] != 0]
     med = lambda v: f'{int(np.median(v))}/{int(np.mean(v))}'
     tw = t.reshape(-1, SLOTS)
     tw = tw[tw[:, 0] != 0]                                  # (workgroups of two waves leave the slots of waves 2-3 empty)
     d = lambda i, j: med(tw[:, i] - tw[:, j])
+    if n16:     # persistent workgroups: the stamps of each workgroup's LAST tile
+        print(f'  (median/mean cycles, last tile of {t.shape[0]} workgroups)  tile total {d(20, 0)}; staging {d(1, 0)}  barrier {d(2, 1)}')
+        for j, k in enumerate(ks):
+            print(f'    branch {j} (k={k}): conv1 {d(3 + 5 * j, 2 if j == 0 else 7 + 5 * (j - 1))} (issue alone {((k + 1) // 2) * 8 * 16})  barrier {d(4 + 5 * j, 3 + 5 * j)}  '
+                  f't1 {d(5 + 5 * j, 4 + 5 * j)}  barrier {d(6 + 5 * j, 5 + 5 * j)}  conv2 {d(7 + 5 * j, 6 + 5 * j)}')
+        print(f'    barrier {d(18, 17)}  scratch {d(19, 18)}  store {d(20, 19)}')
+        return
     nch = max(1, C // 32)
     mi, ni = 2, 2
     print('  (median/mean cycles)')
