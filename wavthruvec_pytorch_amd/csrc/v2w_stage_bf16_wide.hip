@@ -36,6 +36,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define V2W_WS_PERSIST 0     // 1: one residency of workgroups, each walks its tiles with the next tile's x loads in flight under its stores.  Measured
 #endif                       // SLOWER (C = 128 / 64 / 256: 1028-1058 / 1208-1220 / 1103-1133 us against 1003-1022 / 1152-1155 / 1072-1113): the hardware's
                              // own dispatch of one workgroup per tile keeps the workgroups of a CU out of phase, which is what hides the epilogues
+#ifndef V2W_WS_PRE
+#define V2W_WS_PRE 0         // 1: the first fragments of a conv's weight ring are requested BEFORE the barrier / epilogue that precedes the conv.
+#endif                       // Measured the same within noise (C = 128 / 64 / 256 / 32: 1062-1077 / 1228-1236 / 1122-1124 / 833-839 us against 1052-1078 /
+                             // 1221-1241 / 1111-1114 / 820-826): a wave's cold start is covered by the other wave of its SIMD
 #ifndef V2W_WS_PRIO
 #define V2W_WS_PRIO 0
 #endif
@@ -383,8 +387,27 @@ wide_stage_bf16_kernel(const WideArgs a) {
     // every load compiled out - the scalar bookkeeping of a tap (which plane, which tap, wrap-arounds, fragment index multiplies: ~40
     // dependent SALU instructions) stands between the MFMAs of a wave, and two waves that run the same code hit those stretches together.
     // Unrolled over the taps of a plane, every offset is an immediate or one add.
-    auto conv_ct = [&](auto k_c, auto d_c, acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps) {
+    // A conv's loop starts cold: its first four fragments (taps 0 and 1) come from L2, ~1.5 k cycles in which the wave issues nothing
+    // (measured per conv: loop time - MFMA issue time, the same for 3, 7 and 11 taps).  conv_pre requests them into `arp` ahead of time -
+    // before the barrier and epilogue in front of conv2_j, before the staging barrier in front of a tile's first conv - and conv_ct
+    // (PRE) starts from those registers.
+    u32x4 arp[4][MI];
+    auto conv_pre = [&](auto k_c, const unsigned char* wps) {
+        constexpr int K = decltype(k_c)::value;
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned char* ap = wps + (size_t)(wm0 / 32 + i) * (KS * NCH * K) * V2W_WS_UNIT + l16;
+            arp[0][i] = *gptr<const u32x4>(ap);
+            arp[1][i] = *gptr<const u32x4>(ap + K * V2W_WS_UNIT);
+            arp[2][i] = *gptr<const u32x4>(ap + 1 * V2W_WS_UNIT);
+            arp[3][i] = *gptr<const u32x4>(ap + (K + 1) * V2W_WS_UNIT);
+        }
+    };
+    auto conv_ct = [&](auto k_c, auto d_c, auto pre_c, acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps) {
         constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value;
+        constexpr bool PRE = decltype(pre_c)::value;
         static_assert(KS == 2 && K >= 2, "64-byte rows");
         const unsigned char* ap[MI];
 #pragma unroll
@@ -398,10 +421,17 @@ wide_stage_bf16_kernel(const WideArgs a) {
         };
         auto addr = [&](unsigned pbase, int row) { return pbase + (unsigned)(row * RB + ((hk ^ swz(row)) << 4)); };
         // fragment (plane ch, k-step s, tap t) of a row block sits at ((2 ch + s) K + t) units
-        frag(ar[0], 0);
-        frag(ar[1], K * V2W_WS_UNIT);
-        frag(ar[2], 1 * V2W_WS_UNIT);
-        frag(ar[3], (K + 1) * V2W_WS_UNIT);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) ar[q][i] = arp[q][i];
+        } else {
+            frag(ar[0], 0);
+            frag(ar[1], K * V2W_WS_UNIT);
+            frag(ar[2], 1 * V2W_WS_UNIT);
+            frag(ar[3], (K + 1) * V2W_WS_UNIT);
+        }
         u32x4 bb[2][NI];
         {
             const unsigned x0 = addr(base, r0);
@@ -468,8 +498,9 @@ wide_stage_bf16_kernel(const WideArgs a) {
             }
     };
 
-    auto branch = [&](int jb, auto k_c) {
+    auto branch = [&](int jb, auto k_c, auto pre1_c) {
         constexpr int KC = decltype(k_c)::value;             // > 0: the tap count at compile time (dilations 1 and 3), 0: run-time arguments
+        constexpr bool PRE1 = decltype(pre1_c)::value && V2W_WS_PRE, PRE2 = KC > 0 && V2W_WS_PRE;      // conv1 / conv2 start from `arp`
         const int K = KC ? KC : ws_uni(a.K[jb]), d1 = KC ? 1 : ws_uni(a.d1[jb]), d2 = KC ? 3 : ws_uni(a.d2[jb]);
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col
@@ -485,9 +516,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
                     for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
             }
         V2W_STAMP(3 + 6 * jb);
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, PRE1>{}, acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
         else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
         V2W_STAMP(4 + 6 * jb);
+        if constexpr (PRE2) conv_pre(k_c, ws_uni(a.w2[jb]));          // conv2_j's first fragments: in flight under the barrier and the epilogue
         __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
         V2W_STAMP(5 + 6 * jb);
         // ---- t1 = acc + x (x rebuilt from the activated tile: registers 4g .. 4g+3 of block (i, j) <-> channels 8g + 4hk + {0..3} of plane
@@ -525,7 +557,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
         __syncthreads();
         V2W_STAMP(7 + 6 * jb);
         // ---- conv2_j on the same window, onto the running accumulator
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, std::integral_constant<bool, PRE2>{}, oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
         else conv(oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), K, d2);
         V2W_STAMP(8 + 6 * jb);
     };
@@ -537,6 +569,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
     const int tile = blockIdx.x;
 #endif
     tile_origin(tile, b, n0, pos0);
+    if constexpr (STD && V2W_WS_PRE) conv_pre(std::integral_constant<int, 3>{}, ws_uni(a.w1[0]));      // the tile's first conv: under the staging
     // every per-lane address term of the unrolled convs derives from these three: opaque per tile, or hipcc hoists ~100 registers of
     // loop-invariant offsets out of the tile loop and spills the accumulators
     asm volatile("" : "+v"(lr), "+v"(hk), "+v"(lane16));
@@ -559,11 +592,11 @@ wide_stage_bf16_kernel(const WideArgs a) {
     V2W_STAMP(2);
     init_oacc();
     if constexpr (STD) {
-        branch(0, std::integral_constant<int, 3>{});
-        branch(1, std::integral_constant<int, 7>{});
-        branch(2, std::integral_constant<int, 11>{});
+        branch(0, std::integral_constant<int, 3>{}, std::true_type{});
+        branch(1, std::integral_constant<int, 7>{}, std::false_type{});
+        branch(2, std::integral_constant<int, 11>{}, std::false_type{});
     } else {
-        for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{});
+        for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{}, std::false_type{});
     }
 
     // ---- the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so that
