@@ -34,7 +34,17 @@ python3 tools/pmc_sq.py $O/sq_a $O/sq_b > $O/sq_counters.json 2> $O/sq.err
 python3 tools/pmc_traffic.py $O/c3_fetch $O/c3_write > $O/cfg3_bf16_hbm_traffic.json 2> $O/c3pmc.err
 python3 tools/pmc_sq.py $O/c3_sq_a $O/c3_sq_b > $O/cfg3_bf16_sq_counters.json 2> $O/c3sq.err
 cp $O/hbm_traffic.json profiles/${TAG}_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
+cp $O/cfg3_bf16_hbm_traffic.json profiles/${TAG}_cfg3_bf16_hbm_traffic.json
 timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
+# the RCCL branch on a one-rank communicator: the per-step cost of the five statistics all-reduces (bench.py `stat_sync`)
+python3 - "$O" > $O/sync_overhead.txt <<'PYEOF'
+import json, sys
+d = json.load(open(sys.argv[1] + '/bench.json'))
+s = d.get('stat_sync') or {}
+print('bench.py stat_sync block (one-rank RCCL group on one MI355X, BASELINE configs[1] forward, fp32):')
+for k, v in s.items():
+    print(f'  {k}: {v}')
+PYEOF
 python3 tools/config_bench.py > $O/all_configs.txt 2>&1
 tail -c 600 $O/bench.json; grep ms/step $O/ks_train.log
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete

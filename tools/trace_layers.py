@@ -25,7 +25,7 @@ def main(path, B=32, T=256, which=-2, act_bytes=4):
         js = sorted(range(nk), key=lambda j: -h.resblock_kernel_sizes[j])
         groups.append([f'ups.{i}'])
         C = h.upsample_initial_channel // 2 ** (i + 1)
-        if C in (16, 32):   # Generator.fuse_stage default: the whole residual section of the stage is ONE launch
+        if C in (16, 32) or act_bytes == 2:   # Generator.fuse_stage default (and every stage on bf16 tensors): the whole residual section is ONE launch
             groups.append([f'resblocks.{i * nk + j}.{c}' for j in range(nk) for c in (0, 1)])
         else:
             groups.append([f'resblocks.{i * nk + j}.0' for j in js])
@@ -40,7 +40,7 @@ def main(path, B=32, T=256, which=-2, act_bytes=4):
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += d
         if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n or 'resblock2_stage' in n or 'conv_bf16' in n or 'stage_bf16' in n\
-                or 'conv_split' in n or 'stage_split' in n:
+                or 'conv_split' in n or 'stage_split' in n or 'convt_bf16' in n or 'n16_stage' in n:
             grp = groups[li]; li += 1
             l = dict(name='+'.join(g.replace('resblocks.', 'rb') for g in grp), flops=sum(by_name[g]['flops'] for g in grp),
                      bytes=sum(by_name[g]['bytes'] for g in grp))
