@@ -13,6 +13,7 @@ import math
 import warnings
 from typing import Dict, List, Optional
 
+import contextlib
 import torch
 import torch.nn as nn
 
@@ -360,9 +361,11 @@ class Generator(nn.Module):
         self._fold_key.update(state=state, wf=wf, wp=wp, gen=self._fold_key.get('gen', 0) + 1)
         return wf, wp
 
-    def _split_weights(self, device, all_ups=False):
+    def _split_weights(self, device, all_ups=False, ups_stream=None):
         """precision == 'f16x3': (hi, lo) half-precision fragments + scale record of every Conv1d layer the split kernel
-        serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward)."""
+        serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward).
+        `ups_stream`: the upsamplers' fold + pack launches (ten latency-bound kernels, ~55 us at five stages) go to that stream - the
+        caller joins it before the first upsampler; they then run beside the Conv1d batch and conv_pre."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
         if self.precision not in ('f16x3', 'bf16'):
@@ -408,17 +411,19 @@ class Generator(nn.Module):
                 self._fold_key['split_plan'] = plan
             plan.run()
         if self.precision == 'bf16':      # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd)
-            for i, m in enumerate(self.ups):
-                if m.out_channels < 64 and not all_ups:   # the narrow upsamplers are memory-side: with fp32 tensors the f32 kernel's epilogue
-                    continue                              # moves their bytes faster; with bf16 storage every upsampler runs here
-                v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
-                wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
-                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
-                hipops.fold_convt_weight(v, g, wfb, scratch)
-                w = hipops.pack_bf16_convt(wfb, m.stride, out=self._ws.get(f'wpsbf.ups.{i}'))
-                if w is not None:
-                    self._ws[f'wpsbf.ups.{i}'] = w
-                    out[f'ups.{i}'] = w
+            with (torch.cuda.stream(ups_stream) if ups_stream is not None else contextlib.nullcontext()):
+                for i, m in enumerate(self.ups):
+                    if m.out_channels < 64 and not all_ups:   # the narrow upsamplers are memory-side: with fp32 tensors the f32 kernel's epilogue
+                        continue                              # moves their bytes faster; with bf16 storage every upsampler runs here
+                    v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+                    wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                    # (its own scratch: `wf_scratch` is in use by the folds of the main stream)
+                    scratch = self._buf('wf_scratch_ups', (max(2048, m.out_channels, m.in_channels),), device=device)
+                    hipops.fold_convt_weight(v, g, wfb, scratch)
+                    w = hipops.pack_bf16_convt(wfb, m.stride, out=self._ws.get(f'wpsbf.ups.{i}'))
+                    if w is not None:
+                        self._ws[f'wpsbf.ups.{i}'] = w
+                        out[f'ups.{i}'] = w
         self._fold_key['wps'] = (gen, out)
         return out
 
@@ -507,8 +512,11 @@ class Generator(nn.Module):
         st = adt == torch.bfloat16
 
         with torch.no_grad():
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            side.wait_stream(main)
             wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
-            wps = self._split_weights(dev, all_ups=st)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
+            wps = self._split_weights(dev, all_ups=st, ups_stream=side)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
 
             def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
                 if nm in wps and nm in self._split_wide:
@@ -524,11 +532,8 @@ class Generator(nn.Module):
             gbs = [self._buf(f'gb.{i}', (B, 2 * self.cbns[i].num_features), device=dev) for i in range(ns)]
             z_ws = self._buf('z_ws', (ns * B * _Z_CHANNEL,), device=dev)
             sigma_ws = self._buf('sigma_ws', (ns,), device=dev)
-            # (depends on spk / noise and the conditioning weights only: three latency-bound launches, ~70 us, that run on a side
-            # stream beside the weight fold, conv_pre and the first upsampler; joined before the first bn_finalize reads gb)
-            main = torch.cuda.current_stream(dev)
-            side = self._side_stream(dev)
-            side.wait_stream(main)
+            # (depends on spk / noise and the conditioning weights only: three latency-bound launches, ~140 us, that run on the side
+            # stream - behind the upsamplers' weight folds - beside the Conv1d weight batch and conv_pre; joined before the first upsampler)
             with torch.cuda.stream(side):
                 hipops.cond_gamma_beta(
                     spk, nz,
@@ -550,6 +555,9 @@ class Generator(nn.Module):
                 Lo = L * up.stride
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
                 xr = self._buf(f'act.up{i}', (B, C, Lo), dtype=adt, device=dev)
+                if not cond_joined:       # the side stream: this upsampler's packed weights (bf16 mode) and, for its BatchNorm, gamma / beta
+                    main.wait_stream(side)
+                    cond_joined = True
                 cbn = self.cbns[i]
                 bn = cbn.batch_nrom
                 stats = part = None
@@ -582,9 +590,6 @@ class Generator(nn.Module):
                         self._timed(f'stat_sync.{i}', self.stat_sync, stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
                 s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
-                if not cond_joined:
-                    main.wait_stream(side)
-                    cond_joined = True
                 hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                    training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
