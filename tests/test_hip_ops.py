@@ -211,12 +211,14 @@ def test_conv1d_bf16_activation_storage(dev, B, C, L, k, dil, streams):
 
 
 @pytest.mark.parametrize('C', [32, 16])
-@pytest.mark.parametrize('L', [2051, 2052])
+@pytest.mark.parametrize('L', [2051, 2052, 4, 484, 7684])
 def test_resblock2_stage_bf16_storage(dev, C, L):
     """The fused C = 32 / 16 stage with bf16 tensors on both sides (io_bf16 = 3) against the fp32-tensor kernel (stage_bf16_kernel, io_bf16 = 0)
     on fp32 copies of the same values.  A ragged length (L % 4 != 0) runs stage_bf16_kernel's own bf16-tensor form: the same fp32 arithmetic,
-    equal up to the rounding of the bf16 store.  L % 4 == 0 runs on the resident-tile kernel (v2w_stage_bf16_wide.hip), whose residual is
-    rebuilt from the activated bf16 operand and whose t1 stays fp32 on the output path: equal to bf16 rounding."""
+    equal up to the rounding of the bf16 store.  L % 4 == 0 runs on the resident-tile kernels (C = 32: v2w_stage_bf16_wide.hip, residual
+    rebuilt from the activated bf16 operand; C = 16: v2w_stage_bf16_n16.hip, weights in registers, persistent workgroups, residual from a
+    bf16 copy of x) whose t1 stays fp32 on the output path: equal to bf16 rounding.  Lengths: a row shorter than a tile (4), one valid
+    window + 4 (484: the second tile holds one position quad), several tiles per row with the sequence end inside a tile."""
     from wavthruvec_pytorch_amd import hipops
     r = _rng(33)
     B = 3
