@@ -412,6 +412,37 @@ def test_resblock2_wide_stage_bf16_storage(dev, B, C, L):
     assert err.mean().item() <= 4e-3
 
 
+@pytest.mark.parametrize('ks,d1,d2', [([3, 5], [1, 2], [2, 1]), ([3, 7, 11], [1, 1, 1], [3, 3, 5]), ([9], [3], [1]), ([5, 5, 3, 7], [1, 2, 3, 1], [1, 1, 2, 4])])
+@pytest.mark.parametrize('B,C,L', [(2, 128, 516), (2, 64, 1024), (1, 256, 260), (3, 32, 2000)])
+def test_resblock2_wide_stage_other_block_sets(dev, B, C, L, ks, d1, d2):
+    """The same kernel family on block sets OTHER than the generator's default (3, 7, 11) x (1, 3): one to four branches, other tap counts
+    and dilations on either conv - the run-time-argument form of the tap loops (the default set runs a compile-time specialisation)."""
+    from wavthruvec_pytorch_amd import hipops
+    g = torch.Generator().manual_seed(7 + C + L + len(ks))
+    nk = len(ks)
+    x = torch.randn(B, C, L, generator=g).bfloat16()
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    want, _ = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, True)
+    # the 2 nk fragment streams back to back in execution order (include/vec2wav_hip.h: v2w_stage_split_args)
+    packed = [hipops.pack_split(w.permute(2, 1, 0).contiguous().to(dev), bf16=True) for j in range(nk) for w in (w1[j], w2[j])]
+    arena = torch.cat([p[0] for p in packed])
+    offs = np.cumsum([0] + [p[0].numel() for p in packed])
+    views = [(arena[offs[i]:offs[i + 1]], packed[i][1]) for i in range(2 * nk)]
+    br = [dict(wps1=views[2 * j], b1=b1[j].to(dev), wps2=views[2 * j + 1], b2=b2[j].to(dev), k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(nk)]
+    out = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    ok = hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, out, slope=0.1, out_div=float(nk), bf16=True, io_bf16=3)
+    assert ok, 'the wide stage kernel declined a shape it is built for'
+    assert torch.isfinite(out.float()).all()
+    err = (out.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 2e-2).all(), f'max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    assert err.mean().item() <= 4e-3
+
+
 @pytest.mark.parametrize('B,L', [(2, 1000), (3, 4100), (1, 24), (2, 216), (2, 220), (2, 224)])
 def test_resblock2_stage16_with_the_fused_tail(dev, B, L):
     """The last (C = 16) stage with leaky_relu(0.01) -> conv_post -> tanh (models.py:143-145) inside the same kernel: the stage's output is
