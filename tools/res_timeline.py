@@ -104,7 +104,8 @@ def child_stage(C, variant):
     _hip.load()
     raw = ctypes.CDLL(lib_of(variant))
     n16 = C == 16 and hasattr(raw, 'v2w_timeline_set_n16') and not os.environ.get('V2W_TL_WIDE16')
-    setter = getattr(raw, 'v2w_timeline_set_n16' if n16 else 'v2w_timeline_set_wide', None)
+    n32 = C == 32 and hasattr(raw, 'v2w_timeline_set_n32') and not os.environ.get('V2W_TL_WIDE32')
+    setter = getattr(raw, 'v2w_timeline_set_n16' if n16 else ('v2w_timeline_set_n32' if n32 else 'v2w_timeline_set_wide'), None)
     stamps = setter is not None
     if stamps:
         setter.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -147,6 +148,13 @@ def child_stage(C, variant):
     tw = t.reshape(-1, SLOTS)
     tw = tw[tw[:, 0] != 0]                                  # (workgroups of two waves leave the slots of waves 2-3 empty)
     d = lambda i, j: med(tw[:, i] - tw[:, j])
+    if n32:     # conv1 waves of the role-specialised kernel, the last full iteration of each workgroup is overwritten by the drain iteration: read with care
+        print(f'  (median/mean cycles, conv1 waves, last iteration of {t.shape[0]} workgroups)  iteration {d(13, 0)}')
+        print(f'    slot 0: sum -> SF + commit {d(1, 0)}  wait {d(2, 1)}')
+        print(f'    slot 1: conv1_0 {d(3, 2)}  epilogue {d(4, 3)}  wait {d(5, 4)}')
+        print(f'    slot 2: conv1_1 {d(6, 5)}  epilogue {d(7, 6)}  wait {d(8, 7)}')
+        print(f'    slot 3: conv1_2 {d(9, 8)}  issue + epilogue {d(10, 9)}  wait {d(13, 10)}')
+        return
     if n16:     # persistent workgroups: the stamps of each workgroup's LAST tile
         print(f'  (median/mean cycles, last tile of {t.shape[0]} workgroups)  tile total {d(20, 0)}; staging {d(1, 0)}  barrier {d(2, 1)}')
         for j, k in enumerate(ks):

@@ -16,6 +16,7 @@
 //     residual read and the t1 write of the epilogue are single 8-byte LDS accesses.
 // One operand read per MFMA is exactly the LDS's 256 B / clk / CU: the conv loops are LDS-bound (~0.13 ms at configs[2]), not weight-bound.
 #include <type_traits>
+#include <utility>
 #include "v2w_tile.h"
 
 namespace {
@@ -40,6 +41,12 @@ __device__ __forceinline__ unsigned int n16_pack2(float lo, float hi) {
 }
 __device__ __forceinline__ float n16_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float n16_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+template <int... I, class F> __device__ __forceinline__ void n16_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+// Workgroup barrier for LDS hand-overs only: __syncthreads() also fences global memory - a wave that has just issued its tile's output
+// stores would wait vmcnt(0) (the stores' acknowledgement, thousands of cycles under load) before it may even arrive at the barrier.
+__device__ __forceinline__ void n16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int N16_H1 = 5, N16_H2 = 15;           // halos of the widest branch: 11 taps at dilation 1 / 3
 constexpr int N16_NB = 8;                        // 16-column blocks per wave (128 columns)
@@ -99,21 +106,39 @@ n16_stage_kernel(const N16Args a) {
     };
     const int col0 = 128 * wave + j;                                            // this lane's column in block 0 of its wave
     // one conv over a resident tile: K taps at dilation DIL, pairs P0 .. of weight set S; r0 = tile row of (column col0, tap 0)
+    // The loop is ONE sequence of (pair, block) steps with a ring of RING operands in flight, written in inline assembly: left to itself hipcc
+    // (at the register limit) issued one ds_read_b128, waited lgkmcnt(0), issued its MFMA - an LDS round trip per 16-cycle MFMA - and it
+    // sinks plain C++ loads back to their uses.  `asm volatile` statements keep their order; the s_waitcnt names the operand it guards so
+    // that the MFMA cannot move above it.  LDS reads return in order: before step n at most min(RING - 1, N - 1 - n) younger reads may be
+    // outstanding.  (No scalar loads inside: sched_barrier on both sides.)
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_n);
     auto conv = [&](auto k_c, auto d_c, auto s_c, auto p_c, f32x4 (&acc)[NB], unsigned base, int r0) {
         constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value, S = decltype(s_c)::value, P0 = decltype(p_c)::value;
-        unsigned ab = base + (unsigned)(r0 * RB + (kg & 1) * 16);
+        constexpr int NP = (K + 1) / 2, N = NP * NB, RING = 8;
+        unsigned ab = lds0 + base + (unsigned)(r0 * RB + (kg & 1) * 16);
         asm volatile("" : "+v"(ab));
         const unsigned ab2 = ab + (unsigned)((kg >> 1) * DIL * RB);             // lanes of the pair's second tap: one dilation step on
-#pragma unroll
-        for (int p = 0; 2 * p < K; ++p) {
-            // (the zero tap past the end reads the last real tap's rows: finite values under zero weights)
-            const bool last_odd = 2 * p + 1 >= K;
-#pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-                const u32x4 bv = *reinterpret_cast<const u32x4*>(smem_n + (last_odd ? ab : ab2) + (2 * p * DIL + 16 * cb) * RB);
-                acc[cb] = mfma(acc[cb], wa[S][P0 + p], bv);
+        u32x4 ring[RING];
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the zero tap past the end reads the last real tap's rows: finite values under zero weights)
+        n16_for(std::make_integer_sequence<int, RING>{}, [&ring, &ab, &ab2](auto n_c) {
+            constexpr int n = decltype(n_c)::value, p = n / NB, cb = n % NB;
+            if constexpr (2 * p + 1 >= K) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n]) : "v"(ab), "n"((2 * p * DIL + 16 * cb) * RB));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n]) : "v"(ab2), "n"((2 * p * DIL + 16 * cb) * RB));
+        });
+        n16_for(std::make_integer_sequence<int, N>{}, [&ring, &ab, &ab2, &acc, &wa, &mfma](auto n_c) {
+            constexpr int n = decltype(n_c)::value;
+            constexpr int left = (N - 1 - n) < (RING - 1) ? (N - 1 - n) : (RING - 1);
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[n % RING]) : "n"(left));
+            acc[n % NB] = mfma(acc[n % NB], wa[S][P0 + n / NB], ring[n % RING]);
+            if constexpr (n + RING < N) {
+                constexpr int m = n + RING, p = m / NB, cb = m % NB;
+                if constexpr (2 * p + 1 >= K) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(ab), "n"((2 * p * DIL + 16 * cb) * RB));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(ab2), "n"((2 * p * DIL + 16 * cb) * RB));
             }
-        }
+        });
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- staging, in two halves: issue = the global loads of a tile's x (an item = 4 channels x 4 positions: four 8-byte loads) and of its
@@ -173,11 +198,11 @@ n16_stage_kernel(const N16Args a) {
         const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * nto;
         // a tile whose window and halo lie inside the sequence needs no per-position checks in the epilogues
         const bool edge = n0 - N16_H2 < 0 || n0 - N16_H2 + W > L;
-        __syncthreads();                                                        // the previous tile's stores have read the scratch
+        n16_lds_barrier();                                                        // the previous tile's stores have read the scratch
         V2W_STAMP(0);
         commit_x(n0 - N16_H1 - N16_H2);                                         // (position of x row 0: a multiple of 4)
         V2W_STAMP(1);
-        __syncthreads();
+        n16_lds_barrier();
         V2W_STAMP(2);
 
         f32x4 oacc[NB];
@@ -193,7 +218,7 @@ n16_stage_kernel(const N16Args a) {
             // conv1_j: window column col <-> x row col + 5
             conv(k_c, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, p_c, acc1, XB, col0 + N16_H1 - h1);
             V2W_STAMP(3 + 5 * JB);
-            __syncthreads();                                                    // conv2 of the previous branch has read the t1 tile
+            n16_lds_barrier();                                                    // conv2 of the previous branch has read the t1 tile
             V2W_STAMP(4 + 5 * JB);
             // t1 = acc + x (the r tile); the running output takes t1 in fp32, the t1 tile lrelu(t1) as bf16.  Registers 0 .. 3 of block cb
             // <-> channels 4 kg .. 4 kg + 3 at column 16 cb + j of this wave
@@ -219,7 +244,7 @@ n16_stage_kernel(const N16Args a) {
                 *reinterpret_cast<u32x2*>(smem_n + TB + col * RB + 8 * kg) = u32x2{n16_pack2(t1v[0], t1v[1]), n16_pack2(t1v[2], t1v[3])};
             }
             V2W_STAMP(5 + 5 * JB);
-            __syncthreads();
+            n16_lds_barrier();
             V2W_STAMP(6 + 5 * JB);
             // conv2_j on the same window (taps that reach past the t1 tile read the x tile / the slack behind it: columns that are never stored)
             conv(k_c, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, p_c, oacc, TB, col0 - h2);
@@ -231,7 +256,7 @@ n16_stage_kernel(const N16Args a) {
 
         // ---- the nto valid columns (window columns 15 .. 15 + nto) through an fp32 scratch [16][SRS] over the dead tiles: scratch column
         // = window column + 1 (output quads 16-byte aligned), then 8-byte bf16 stores along positions
-        __syncthreads();
+        n16_lds_barrier();
         V2W_STAMP(18);
         {
             float* const scr = reinterpret_cast<float*>(smem_n);
@@ -243,7 +268,7 @@ n16_stage_kernel(const N16Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scr[(4 * kg + r) * SRS + col + 1] = oacc[cb][r];
             }
-            __syncthreads();
+            n16_lds_barrier();
             V2W_STAMP(19);
             // the next tile's x: in flight under this tile's stores (unconditional - past the end the last tile again, never committed: under
             // a condition the old values would stay live through the whole iteration as the other input of the join)
