@@ -402,14 +402,20 @@ class Generator(nn.Module):
             out[name] = (wpsb, scb)
             if wide:
                 self._split_wide.add(name)
-        if batch:
-            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in batch) + (self.precision,)
-            plan = self._fold_key.get('split_plan')
+        # two batches: conv_pre alone on the calling stream (the forward needs it at once), every other layer on `ups_stream` beside conv_pre
+        first = [q for (nm, _m, _w), q in zip(picked, batch) if nm == 'conv_pre'] if ups_stream is not None else batch
+        rest = [q for (nm, _m, _w), q in zip(picked, batch) if nm != 'conv_pre'] if ups_stream is not None else []
+        for slot, sub, strm in (('split_plan', first, None), ('split_plan_rest', rest, ups_stream)):
+            if not sub:
+                continue
+            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in sub) + (self.precision,)
+            plan = self._fold_key.get(slot)
             if plan is None or plan.key != key:
-                plan = hipops.SplitPlan(batch, device, bf16=self.precision == 'bf16')
+                plan = hipops.SplitPlan(sub, device, bf16=self.precision == 'bf16')
                 plan.key = key
-                self._fold_key['split_plan'] = plan
-            plan.run()
+                self._fold_key[slot] = plan
+            with (torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()):
+                plan.run()
         if self.precision == 'bf16':      # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd)
             with (torch.cuda.stream(ups_stream) if ups_stream is not None else contextlib.nullcontext()):
                 for i, m in enumerate(self.ups):
