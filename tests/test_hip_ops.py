@@ -70,6 +70,10 @@ CONV_CASES = [
     (2, 16, 16, 5, 7, 3),         # shorter than the receptive field
     (1, 16, 16, 1, 3, 1),         # single sample
     (2, 24, 40, 100, 5, 2),       # shape with no MFMA tile config -> direct kernel
+    (2, 8, 8, 1999, 11, 3),       # the 8-channel stage of a six-stage generator: all output channels per thread (conv1d_small_kernel, exact width)
+    (3, 16, 8, 70, 7, 1),
+    (2, 6, 5, 333, 5, 2),         # ... and its guarded form (C_out < 8)
+    (1, 8, 2, 9, 3, 1),
 ]
 
 
@@ -99,6 +103,22 @@ def test_conv1d_fused(dev, algo, B, cin, cout, L, k, dil):
                   accumulate=True, out_div=3.0, algo=a, wp=hipops.pack_mfma(wf))
     err = (out.cpu() - want).abs().max().item()
     assert err <= 2e-5, f'max err {err}'
+
+
+@pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 16, 8, 700, 4, 2), (3, 16, 8, 1, 4, 2), (2, 12, 5, 333, 8, 4), (1, 8, 8, 50, 4, 4), (2, 10, 3, 77, 6, 2)])
+def test_convt1d_few_output_channels(dev, B, cin, cout, L, k, u):
+    """leaky_relu -> ConvTranspose1d(k, stride u, padding (k - u) / 2) with C_out <= 8 (the last upsampler of a six-stage generator): one
+    thread per input position, its u outputs of every channel as one vector store (convt1d_small_kernel) - against torch."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(17)
+    x = torch.from_numpy(r.standard_normal((B, cin, L), dtype=np.float32))
+    w = torch.from_numpy((r.standard_normal((cin, cout, k)) / np.sqrt(cin * k)).astype(np.float32))
+    bias = torch.from_numpy(r.standard_normal(cout).astype(np.float32))
+    want = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, bias, stride=u, padding=(k - u) // 2)
+    wf = w.permute(2, 0, 1).contiguous().to(dev)          # [k][C_in][C_out]
+    out = torch.full((B, cout, L * u), float('nan'), device=dev)
+    hipops.convt1d(x.to(dev), wf, bias.to(dev), out, k=k, u=u, slope=0.1)
+    assert (out.cpu() - want).abs().max().item() <= 2e-5
 
 
 SPLIT_CASES = [

@@ -45,6 +45,108 @@ conv1d_direct_kernel(const v2w_conv1d_args a) {
     a.out[o] = v;
 }
 
+// Few output channels (C_out <= 8: the last stage of a six-stage x640 generator has 8 channels, below every MFMA tile): one thread per
+// position computes ALL CO output channels - the activated input value is loaded once per (channel, tap) and feeds CO FMAs, the CO weights
+// of a (tap, channel) are one uniform (scalar) load.  conv1d_direct_kernel launches a block row per output channel instead: C_out times the
+// input reads and a global weight load per FMA (0.9 - 1.6 ms per conv of the 8-channel stage at B = 16 x 163 840 positions, against 84 MB of
+// tensor).  Same arguments and flags.
+// EXACT: C_out == CO (no per-channel guards: the CO weights of a (tap, channel) are ONE s_load_dwordx8; with guards hipcc emitted a branch,
+// a one-dword scalar load and a wait per FMA).
+template <int CO, bool EXACT>
+__global__ void __launch_bounds__(256)
+conv1d_small_kernel(const v2w_conv1d_args a) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (l >= a.L) return;
+    const int pad = a.pad_left >= 0 ? a.pad_left : a.dil * (a.k - 1) / 2;
+    const int istr = a.in_stride > 0 ? a.in_stride : 1;
+    const int cit = a.in_ct > 0 ? a.in_ct : a.C_in, cot = a.out_ct > 0 ? a.out_ct : a.C_out;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+    for (int ci = 0; ci < a.C_in; ++ci) {
+        const float* src = a.in + ((size_t)b * cit + ci) * a.L * istr + a.in_phase;
+        const float av = a.in_a ? a.in_a[b * a.C_in + ci] : 1.f;
+        const float sv = a.in_s ? a.in_s[b * a.C_in + ci] : 0.f;
+#pragma unroll 4
+        for (int t = 0; t < a.k; ++t) {
+            const int li = l + t * a.dil - pad;
+            const bool in = li >= 0 && li < a.L;
+            const float raw = src[(size_t)min(max(li, 0), a.L - 1) * istr];      // (clamped, unconditional: no branch around the load)
+            const float x = in ? v2w_lrelu(fmaf(av, raw, sv), a.slope) : 0.f;
+            const float* w = a.wf + ((size_t)t * a.C_in + ci) * a.C_out;          // (uniform: scalar loads)
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+                if (EXACT || co < a.C_out) acc[co] = fmaf(w[co], x, acc[co]);
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (!EXACT && co >= a.C_out) break;
+        const size_t o = ((size_t)b * cot + co) * a.L + l;
+        float v = acc[co];
+        if (a.mask_src) {
+            const float ma = a.mask_a ? a.mask_a[b * a.C_out + co] : 1.f, ms = a.mask_a ? a.mask_s[b * a.C_out + co] : 0.f;
+            v = fmaf(ma, a.mask_src[o], ms) > 0.f ? v : v * a.mask_slope;
+        }
+        v += a.bias ? a.bias[co] : 0.f;
+        if (a.res) {
+            const float ra = a.res_a ? a.res_a[b * a.C_out + co] : 1.f;
+            const float rs = a.res_s ? a.res_s[b * a.C_out + co] : 0.f;
+            v += fmaf(ra, a.res[o], rs);
+        }
+        if (a.add1) v += a.add0[o] + a.add1[o];
+        else if (a.add0) v += a.add0[o];
+        else if (a.accumulate) v += a.out[o];
+        if (a.out_div != 0.f) v = v / a.out_div;
+        if (a.out_slope != 0.f && a.out_slope != 1.f) v = v > 0.f ? v : v * a.out_slope;
+        a.out[o] = v;
+    }
+}
+
+// Transposed counterpart: one thread per INPUT position q computes its u output positions u q .. u q + u - 1 of all CO channels (u <= 4):
+// the taps of a phase are uniform, the u outputs of a channel leave as one 8- / 16-byte store.
+template <int CO, int U, bool EXACT>
+__global__ void __launch_bounds__(256)
+convt1d_small_kernel(const v2w_convt1d_args a) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (q >= a.L) return;
+    const int pad = (a.k - U) / 2;
+    float acc[CO][U];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int r = 0; r < U; ++r) acc[co][r] = 0.f;
+    for (int ci = 0; ci < a.C_in; ++ci) {
+        const float* src = a.in + ((size_t)b * a.C_in + ci) * a.L;
+        // out[U q + r] = sum_t in[(U q + r + pad - t) / U] w[t] over the taps t = (r + pad) mod U, + U, ...: input offset c - m, c = (r + pad) / U
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+            const int t0 = (r + pad) % U, c = (r + pad) / U;
+            for (int m = 0; t0 + m * U < a.k; ++m) {
+                const int i = q + c - m;
+                const bool in = i >= 0 && i < a.L;
+                const float raw = src[min(max(i, 0), a.L - 1)];
+                const float x = in ? v2w_lrelu(raw, a.slope) : 0.f;
+                const float* w = a.wf + ((size_t)(t0 + m * U) * a.C_in + ci) * a.C_out;
+#pragma unroll
+                for (int co = 0; co < CO; ++co)
+                    if (EXACT || co < a.C_out) acc[co][r] = fmaf(w[co], x, acc[co][r]);
+            }
+        }
+    }
+    const size_t Lout = (size_t)a.L * U;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (!EXACT && co >= a.C_out) break;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        float* dst = a.out + ((size_t)b * a.C_out + co) * Lout + (size_t)U * q;
+        if constexpr (U == 2) *reinterpret_cast<f32x2*>(dst) = f32x2{acc[co][0] + bv, acc[co][1] + bv};
+        else *reinterpret_cast<f32x4*>(dst) = f32x4{acc[co][0] + bv, acc[co][1] + bv, acc[co][2] + bv, acc[co][3] + bv};
+    }
+}
+
 // C_out = 1 (the discriminators' conv_post, models.py:171,230): a reduction over C_in * k, HBM-bound on reading the input once.
 // One block = 32 output positions of one batch item; 8 channel groups of 32 lanes split the input channels (4 independent
 // accumulation chains each) and meet in LDS.
@@ -201,12 +303,26 @@ int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
         hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((a->L + 31) / 32, a->B), dim3(256), 0, stream, *a);
         return v2w_launch_status();
     }
+    if (a->C_out >= 2 && a->C_out <= 8 && a->B <= 65535) {
+        if (a->C_out == 8) hipLaunchKernelGGL((conv1d_small_kernel<8, true>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
+        else hipLaunchKernelGGL((conv1d_small_kernel<8, false>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
+        return v2w_launch_status();
+    }
     dim3 grid((a->L + 255) / 256, a->C_out, a->B);
     hipLaunchKernelGGL(conv1d_direct_kernel, grid, dim3(256), 0, stream, *a);
     return v2w_launch_status();
 }
 
 int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream) {
+    if (a->C_out >= 2 && a->C_out <= 8 && a->B <= 65535 && (a->u == 2 || a->u == 4) && a->k >= a->u && ((a->k - a->u) & 1) == 0 &&
+        (reinterpret_cast<uintptr_t>(a->out) & 15) == 0) {
+        const dim3 grid((a->L + 255) / 256, a->B);
+        if (a->u == 2 && a->C_out == 8) hipLaunchKernelGGL((convt1d_small_kernel<8, 2, true>), grid, dim3(256), 0, stream, *a);
+        else if (a->u == 2) hipLaunchKernelGGL((convt1d_small_kernel<8, 2, false>), grid, dim3(256), 0, stream, *a);
+        else if (a->C_out == 8) hipLaunchKernelGGL((convt1d_small_kernel<8, 4, true>), grid, dim3(256), 0, stream, *a);
+        else hipLaunchKernelGGL((convt1d_small_kernel<8, 4, false>), grid, dim3(256), 0, stream, *a);
+        return v2w_launch_status();
+    }
     dim3 grid((a->L * a->u + 255) / 256, a->C_out, a->B);
     hipLaunchKernelGGL(convt1d_direct_kernel, grid, dim3(256), 0, stream, *a);
     return v2w_launch_status();
