@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 26
+#define V2W_ABI_VERSION 27
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -202,6 +202,10 @@ typedef struct {
     float slope, out_div;
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
+/* The same section for an 8-channel stage (the sixth stage of a x640 generator, upsample_rates (5,4,4,2,2,2); ABI v27), fp32 on the
+ * vector ALU: C == 8, odd kernel sizes, halos <= 32, nk <= 4.  HERE wp1[j] / wp2[j] are the FOLDED weights [k][C][C] of
+ * v2w_wn_fold_conv (there is no fragment stream for 8 channels).  V2W_E_SHAPE otherwise. */
+int v2w_resblock2_stage_small_fwd(const v2w_stage_args* a, void* stream);
 
 /* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16 - and, with bf16 != 0 on bf16 tensors
  * (io_bf16 == 3), for the wide stages C == 64 / 128 / 256 as well (csrc/v2w_stage_bf16_wide.hip: x and t1_j resident in LDS, one kernel): wps / sc from v2w_pack_split or

@@ -432,6 +432,39 @@ def test_resblock2_wide_stage_bf16_storage(dev, B, C, L):
     assert err.mean().item() <= 4e-3
 
 
+@pytest.mark.parametrize('ks,d1,d2', [([3, 7, 11], [1, 1, 1], [3, 3, 3]), ([5], [2], [1]), ([3, 5, 7, 9], [1, 3, 1, 4], [2, 1, 5, 1])])
+@pytest.mark.parametrize('B,L,affine', [(2, 1000, True), (3, 1, True), (1, 473, False), (2, 2051, True)])
+def test_resblock2_stage_small_8_channels(dev, B, L, affine, ks, d1, d2):
+    """v2w_resblock2_stage_small_fwd: the residual section of an 8-channel stage (the sixth stage of a x640 generator) as one fp32 FMA kernel,
+    folded weights [k][C][C] - against fp64 torch; rows shorter than the receptive field, tile ends inside a row, with and without the
+    conditional-BatchNorm affine, one to four branches."""
+    from wavthruvec_pytorch_amd import hipops
+    C = 8
+    g = torch.Generator().manual_seed(11 + L + len(ks))
+    x = torch.randn(B, C, L, generator=g)
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    xa = (a[:, :, None] * x + s[:, :, None]).double() if affine else x.double()
+    tot = 0
+    for j, k in enumerate(ks):
+        t1 = xa + F.conv1d(F.leaky_relu(xa, 0.1), w1[j].double(), b1[j].double(), dilation=d1[j], padding=d1[j] * (k - 1) // 2)
+        tot = tot + t1 + F.conv1d(F.leaky_relu(t1, 0.1), w2[j].double(), b2[j].double(), dilation=d2[j], padding=d2[j] * (k - 1) // 2)
+    want = tot / len(ks)
+    br = [dict(wf1=w1[j].permute(2, 1, 0).contiguous().to(dev), b1=b1[j].to(dev), wf2=w2[j].permute(2, 1, 0).contiguous().to(dev), b2=b2[j].to(dev),
+               k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(len(ks))]
+    out = torch.full((B, C, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage_small(x.to(dev), (a.to(dev), s.to(dev)) if affine else None, br, out, slope=0.1, out_div=float(len(ks)))
+    assert (out.cpu().double() - want).abs().max().item() <= 2e-5
+    # other channel counts are declined, not mis-run
+    x16 = torch.zeros(1, 16, 8, device=dev)
+    assert hipops.resblock2_stage_small(x16, None, [dict(wf1=torch.zeros(3, 16, 16, device=dev), b1=None, wf2=torch.zeros(3, 16, 16, device=dev), b2=None,
+                                                          k=3, dil1=1, dil2=1)], torch.empty_like(x16), slope=0.1, out_div=1.0) is False
+
+
 @pytest.mark.parametrize('C', [16, 32, 64])
 def test_resblock2_stage_kernels_random_lengths(dev, C):
     """Seeded random (B, L) for the one-kernel stages - persistent workgroups with fewer tiles than CUs, rows of a few positions, tile counts

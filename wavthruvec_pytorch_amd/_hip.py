@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -137,6 +137,7 @@ SIGNATURES = {
     'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
     'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
+    'v2w_resblock2_stage_small_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_branch_convs_bf16_fwd': (C.c_int, [C.POINTER(BranchConvsArgs), _fp]),
     'v2w_convt1d_fwd': (C.c_int, [C.POINTER(ConvT1dArgs), _fp]),
     'v2w_pack_bf16_convt': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -539,6 +539,27 @@ def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
     return True
 
 
+def resblock2_stage_small(x, in_affine, branches, out, *, slope, out_div):
+    """The same section for an 8-channel stage (v2w_resblock2_stage_small_fwd: fp32 FMAs, x read once, t1_j in LDS).  `branches`: list of
+    dicts(wf1, b1, wf2, b2, k, dil1, dil2) with the FOLDED weights [k][C][C].  Returns False when the shape is not taken."""
+    B, Cc, L = x.shape
+    a = _hip.StageArgs()
+    a.in_ = x.data_ptr()
+    a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
+    for j, br in enumerate(branches):
+        a.wp1[j] = br['wf1'].data_ptr(); a.bias1[j] = _hip.ptr(br['b1'])
+        a.wp2[j] = br['wf2'].data_ptr(); a.bias2[j] = _hip.ptr(br['b2'])
+        a.k[j], a.dil1[j], a.dil2[j] = br['k'], br['dil1'], br['dil2']
+    a.out = out.data_ptr()
+    a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
+    a.slope = slope; a.out_div = out_div
+    rc = _hip.load().v2w_resblock2_stage_small_fwd(C.byref(a), _stream(x))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_resblock2_stage_small_fwd')
+    return True
+
+
 def wgrad(x, dy, *, k, dil=1, u=1, slope=1.0, x_affine=None, out=None):
     """Weight gradient dwf [k][C_in][C_out] of a fused lrelu -> Conv1d (u = 1) or lrelu -> ConvTranspose1d (stride u).
     x (B, C_in, Lq) is the forward conv's input (before the affine / activation), dy (B, C_out, u*Lq) the output gradient."""

@@ -199,7 +199,7 @@ class Generator(nn.Module):
         self.always_refold = True             # train mode: fold weight norm every forward, as the reference's hook does
         self.fuse_pairs = (16,)               # stage widths whose conv pairs run as ONE fused kernel (measured: pays at C=16,
                                               # ties at C=32 where the per-layer tiles are already MFMA-bound)
-        self.fuse_stage = (16, 32)            # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
+        self.fuse_stage = (8, 16, 32)         # ResBlock2 stage widths whose WHOLE residual section runs as one kernel
         self.precision = 'f32'                # 'f32': exact fp32 MFMA everywhere (default).  'bf16': bf16 operands, one MFMA per
                                               # product (BASELINE configs[2]).  'f16x3': Conv1d layers with
                                               # C_out >= split_min_channels run on the f16 matrix pipe with split operands
@@ -672,6 +672,14 @@ class Generator(nn.Module):
                             ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage, xr, aff,
                                              [dict(wp1=wp[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                                    wp2=wp[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                   dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                              for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk))
+                        if (not ok and C == 8 and 8 in fuse_stage and not st and nk <= 4
+                                and all(wf[f'{nm}.convs.{c}'] is not None for nm in names for c in (0, 1))):
+                            # 8 channels (the sixth stage of a x640 generator): below every MFMA tile - the whole section as one FMA kernel
+                            ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_small, xr, aff,
+                                             [dict(wf1=wf[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                   wf2=wf[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                                    dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
                                               for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk))
                         if not ok and fused_pair:
