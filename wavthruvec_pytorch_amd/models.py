@@ -561,7 +561,7 @@ class Generator(nn.Module):
                 Lo = L * up.stride
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
                 xr = self._buf(f'act.up{i}', (B, C, Lo), dtype=adt, device=dev)
-                if not cond_joined:       # the side stream: this upsampler's packed weights (bf16 mode) and, for its BatchNorm, gamma / beta
+                if not cond_joined and f'ups.{i}' in wps:      # the side stream holds this upsampler's packed weights (bf16 / f16x3 modes)
                     main.wait_stream(side)
                     cond_joined = True
                 cbn = self.cbns[i]
@@ -596,6 +596,9 @@ class Generator(nn.Module):
                         self._timed(f'stat_sync.{i}', self.stat_sync, stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
                 s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
+                if not cond_joined:       # (fp32: the side stream only carries gamma / beta - joined as late as their first use, which
+                    main.wait_stream(side)    # matters at B = 1, where conv_pre is shorter than the conditioning chain)
+                    cond_joined = True
                 hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                    training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
