@@ -74,8 +74,8 @@ def cpu_baseline(h):
       * cfg1 (BASELINE configs[0]: B=1, T=50, the reference's own CPU-runnable case): 1 thread and all usable cores, train and eval
         mode, median of 10 after 3 warm-ups (SURVEY 8(d) / BASELINE.md 4);
       * the cfg2 sample B=4 x T=256 (1/8 of the cfg2 batch, same per-sample work) in train mode: short sweep over thread counts,
-        best median of 3 -> `value` / `cores` (more threads than the problem can feed are slower);
-      * cfg2 ITSELF (B=32 x T=256) once at all usable cores after one warm-up: `cfg2_full_samples_per_s`."""
+        best median of 3 -> `cfg2_sample_B4` (more threads than the problem can feed are slower);
+      * cfg2 ITSELF (B=32 x T=256) once at all usable cores after one warm-up -> `value` / `cores`."""
     from oracle import vec2wav_oracle as O
     from wavthruvec_pytorch_amd import synthetic
     sd = synthetic.make_state_dict(h, seed=0)
@@ -100,17 +100,17 @@ def cpu_baseline(h):
         if time.time() > t_end:
             break
     med, th = best
-    full = None
-    if time.time() < t_end + 30.0:
-        inpf = synthetic.make_inputs(h, 32, 256, seed=1234)
-        tf = _timed_oracle(O, sd, h, inpf, True, ncpu, 1, warmups=1)
-        full = dict(value=32 * 256 * up / tf, unit='samples/s', cores=ncpu, seconds_per_forward=tf,
-                    sample='one full cfg2 forward (B=32, T=256, train mode) after one warm-up')
-    return dict(value=B * T * up / med, unit='samples/s', cores=th, kind='port',
-                sample=f'oracle (torch CPU fp32 restatement of the reference forward), train mode, B={B} T={T} 768-d, '
-                       f'median of 3 at {th} threads (best of thread counts {cands}; {ncpu} usable CPUs)',
-                cfg1_B1_T50_samples_per_s=cfg1, cfg1_protocol='median of 10 after 3 warm-ups (BASELINE.md 4)',
-                cfg2_full_samples_per_s=full)
+    small = dict(value=B * T * up / med, unit='samples/s', cores=th,
+                 sample=f'train mode, B={B} T={T} 768-d (1/8 of the cfg2 batch), median of 3 at {th} threads (best of thread counts {cands})')
+    # `value` is the bench line's OWN workload: one full cfg2 forward (B=32, T=256, train mode) at all usable cores after one warm-up
+    # (~5 s each); the B=4 sample - which a smaller thread count serves better - stays beside it
+    inpf = synthetic.make_inputs(h, 32, 256, seed=1234)
+    tf = _timed_oracle(O, sd, h, inpf, True, ncpu, 1, warmups=1)
+    return dict(value=32 * 256 * up / tf, unit='samples/s', cores=ncpu, kind='port', seconds_per_forward=tf,
+                sample=f'oracle (torch CPU fp32 restatement of the reference forward), the bench line\'s workload itself: ONE full cfg2 forward '
+                       f'(B=32, T=256, 768-d, train mode) at {ncpu} threads after one warm-up ({ncpu} usable CPUs)',
+                cfg2_sample_B4=small,
+                cfg1_B1_T50_samples_per_s=cfg1, cfg1_protocol='median of 10 after 3 warm-ups (BASELINE.md 4)')
 
 
 def self_launch(args) -> int:
@@ -119,7 +119,7 @@ def self_launch(args) -> int:
     import torch
     have = torch.cuda.device_count()
     pinned = os.environ.get('V2W_BENCH_DEVICE') is not None      # test hook: every rank on one device
-    if have < (1 if pinned else args.gpus):
+    if not args.dry_run and have < (1 if pinned else args.gpus):
         print(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible', file=sys.stderr)
         return 3
     with socket.socket() as sk:
@@ -205,7 +205,7 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
 
     def kernel_of(l, nprob=1):
         if l['name'] == 'conv_post':
-            if bf16_run and act_bytes == 2 and l['cin'] in (8, 16) and l['k'] <= 9 and l['L'] % 4 == 0:
+            if bf16_run and act_bytes == 2 and l['cin'] in (8, 16) and l['k'] <= 9 and l['L'] % 8 == 0 and l['L'] >= 8:   # (the kernel's own condition)
                 return 'conv_post_tanh_mfma_kernel<%d>' % l['cin']            # v2w_conv_post_bf16.hip
             return 'conv_post_tanh_vec4_kernel'
         direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
@@ -344,7 +344,7 @@ def stat_sync_overhead(g, inp, dev, steps):
     g.stat_sync = None
     with_ms, without_ms = [], []
     from wavthruvec_pytorch_amd.distributed import BNStatSync
-    sync = BNStatSync()
+    sync = BNStatSync(single_rank_collective=True)     # (a one-rank group skips the exchange unless asked: here it is what is timed)
     for _ in range(3):
         for on in (True, False):
             g.stat_sync = sync if on else None
@@ -369,6 +369,109 @@ def stat_sync_overhead(g, inp, dev, steps):
                      'at N ranks each adds the xGMI all-reduce latency of <= 4 KiB')
 
 
+def config_block(hp, B, T, precision, steps, warmup, dev, workload, parity, traffic_suffix=None):
+    """One more single-GPU BASELINE configuration as a first-class block of the bench line: its own generator, its own timed steps
+    (wall clock + event median), priced against both ceilings with ITS byte count, and the roofline of its dominant kernel."""
+    from wavthruvec_pytorch_amd import Generator, synthetic, workmodel
+    h = synthetic.make_hparams(**hp)
+    g = Generator(h)
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+    g = g.to(dev).train()
+    g.precision = precision
+    inp = synthetic.make_inputs(h, B, T, seed=4, device=dev)
+    el, ms = run_steps(g, inp, steps, warmup)
+    act = 2 if precision == 'bf16' else 4
+    fl, by = workmodel.totals(h, B, T, act)
+    st = el / steps
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == 'bf16' else PEAK_FP32_MFMA_TFLOPS
+    roof = roofline_block(g, h, inp, B, T, precision, 'auto', st, traffic_suffix)
+    up = synthetic.total_upsample(h)
+    del g
+    torch.cuda.empty_cache()
+    return dict(workload=workload, dtype=precision, steps=steps, ms_per_step=st * 1e3, ms_per_step_event_median=median(ms),
+                value=B * T * up / st, unit='samples/s', flops=fl, algorithmic_bytes=by,
+                hbm_frac=by / st / 1e9 / PEAK_HBM_GBS, mfma_frac=fl / st / 1e12 / peak,
+                peaks=dict(hbm_gbs=PEAK_HBM_GBS, mfma_tflops=peak), roofline=roof, parity=parity)
+
+
+def train_step_block(dev, B, T, steps):
+    """The generator half of a vec2wav/train.py:204-215 step at the cfg2 shape, exact fp32: forward (autograd schedule) + backward through
+    the C ABI + AdamW (train.py:100 betas / lr), a weighted-sum loss.  FLOPs = 3 x the forward's (input- and weight-gradient GEMMs)."""
+    from wavthruvec_pytorch_amd import Generator, synthetic, workmodel
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = Generator(h)
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+    g = g.to(dev).train()
+    opt = torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99))
+    inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
+    up = synthetic.total_upsample(h)
+    dy = torch.randn(B, 1, T * up, device=dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for it in range(steps + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            evs[0].record()
+        opt.zero_grad(set_to_none=True)
+        (g(*inp) * dy).sum().backward()
+        opt.step()
+        if it >= 2:
+            evs[it - 1].record()
+    torch.cuda.synchronize()
+    st = (time.perf_counter() - t0) / steps
+    fl, _by = workmodel.totals(h, B, T, 4)
+    del g, opt
+    torch.cuda.empty_cache()
+    return dict(workload=f'generator training step (vec2wav/train.py:204-215 without the discriminators): forward + backward + AdamW, B={B} x T={T}, '
+                         '768-d, x320, ResBlock2, exact fp32', dtype='f32', steps=steps, ms_per_step=st * 1e3,
+                ms_per_step_event_median=median(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)),
+                value=B * T * up / st, unit='trained samples/s', flops=3.0 * fl, tflops=3.0 * fl / st / 1e12,
+                mfma_frac=3.0 * fl / st / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                parity='tests/test_hip_generator.py::test_generator_backward_matches_oracle_autograd (every parameter gradient vs autograd through the oracle)')
+
+
+def dry_run(args, rank, world) -> int:
+    """`--dry-run`: everything of an N-rank run except the GPU work - process group over V2W_BENCH_BACKEND (gloo on a CPU box), the
+    per-rank input seeds and batch shards, barrier, max-over-ranks, ONE JSON line from rank 0 with `value` null.  What an 8-GPU node
+    meets first (rendezvous of 8 processes, rank -> seed / shard bookkeeping, stdout discipline) is checked without hardware."""
+    backend = os.environ.get('V2W_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and not torch.cuda.is_available():
+        raise SystemExit('--dry-run without a GPU needs V2W_BENCH_BACKEND=gloo')
+    redirect = stdout_to_stderr()
+    redirect.__enter__()
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    from wavthruvec_pytorch_amd import synthetic
+    from wavthruvec_pytorch_amd.distributed import shard_bounds
+    h = synthetic.make_hparams(num_wv_feat=768)
+    B, T = args.batch, args.frames
+    seed = 1234 + rank
+    x, spk, nz = synthetic.make_inputs(h, 1, 4, seed=seed)           # (a sliver of this rank's inputs: enough to tell the seeds apart)
+    mine = dict(rank=rank, seed=seed, shard=list(shard_bounds(B * world, rank, world)), x_checksum=float(x.double().sum()))
+    allr = [None] * world
+    if world > 1:
+        dist.barrier()
+        dist.all_gather_object(allr, mine)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+    else:
+        allr = [mine]
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    redirect.__exit__()
+    if rank == 0:
+        up = synthetic.total_upsample(h)
+        print(json.dumps({
+            'metric': baseline_metric(), 'value': None, 'unit': 'samples/s', 'n_gpus': world, 'rccl_ranks': None, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic', 'dry_run': dict(backend=backend, ranks=allr, samples_per_step=world * B * T * up),
+            'config': {'workload': f'DRY RUN (no GPU work) of BASELINE configs[1]: B={B}/GPU x T={T} frames', 'global_batch': B * world, 'frames': T,
+                       'parallelism': f'dp{world} (batch shards, all-reduce of CondBN stats)' if world > 1 else 'single GPU'}}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -384,6 +487,9 @@ def main():
     ap.add_argument('--resblock', default='2', choices=['1', '2'], help="'1': the ResBlock1 generator (h.resblock == '1'); default ResBlock2")
     ap.add_argument('--force-pg', action='store_true',
                     help='--gpus 1 only: create a ONE-rank RCCL process group and keep the CondBN statistics all-reduces inside the timed region')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='first-contact check of the N-rank plumbing WITHOUT a GPU: launcher, rendezvous (set V2W_BENCH_BACKEND=gloo), per-rank '
+                         'seeds and shards, barrier, max-over-ranks and the one JSON line are exercised; no forward runs and `value` is null')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -395,6 +501,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the run asked for is not the run that was launched')
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the Vec2Wav HIP path has no CPU fallback)')
     if os.environ.get('V2W_BENCH_DEVICE') is None and torch.cuda.device_count() < world:
@@ -426,7 +534,7 @@ def main():
     g.algo = hipops.ALGO_DIRECT if args.algo == 'direct' else hipops.ALGO_AUTO
     g.precision = args.precision
     if grouped:
-        g.enable_sync_batchnorm()
+        g.enable_sync_batchnorm(single_rank_collective=True if args.force_pg else None)
     x, spk, nz = synthetic.make_inputs(h, B, T, seed=1234 + rank, device=dev)
     inp = (x, spk, nz)
     up = synthetic.total_upsample(h)
@@ -510,29 +618,31 @@ def main():
         del g1
         torch.cuda.empty_cache()
 
-    # ---- BASELINE configs[2] (B = 64 x T = 512, bf16 compute / fp32 accumulate, bf16 activation storage): its own workload, priced
-    # against BOTH ceilings with ITS byte count (bf16 activations between layers), with its own dominant-kernel roofline
-    cfg3 = None
+    # ---- the other single-GPU BASELINE configurations as first-class blocks (their own workload, byte count and dominant-kernel roofline):
+    #   configs[2]  B = 64 x T = 512, bf16 compute / fp32 accumulate, bf16 activation storage          -> cfg3_bf16
+    #   the north_star's literal shape B = 32 x T = 256 in that arithmetic                              -> cfg2_bf16
+    #   configs[4]  1024-d latents, upsample (8,5,4,2,2) x640, B = 16 x T = 256, exact fp32             -> cfg5_f32
+    # and the generator training step at the cfg2 shape                            -> train_step
+    cfg3 = cfg2b = cfg5 = train = None
     if extras:
-        B3, T3 = 64, 512
-        g3 = Generator(h)
-        g3.load_state_dict(synthetic.make_state_dict(h, seed=0))
-        g3 = g3.to(dev).train()
-        g3.precision = 'bf16'
-        x3 = synthetic.make_inputs(h, B3, T3, seed=4, device=dev)
-        n3 = max(5, args.steps)
-        el3, ms3 = run_steps(g3, x3, n3, max(3, args.warmup))
-        f3, b3 = workmodel.totals(h, B3, T3, 2)
-        s3 = el3 / n3
-        r3 = roofline_block(g3, h, x3, B3, T3, 'bf16', 'auto', s3, '_cfg3_bf16_hbm_traffic.json')
-        cfg3 = dict(workload='BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
-                             'bf16 activation storage', dtype='bf16', steps=n3, ms_per_step=s3 * 1e3, ms_per_step_event_median=median(ms3),
-                    value=B3 * T3 * up / s3, unit='samples/s',
-                    flops=f3, algorithmic_bytes=b3, hbm_frac=b3 / s3 / 1e9 / PEAK_HBM_GBS, mfma_frac=f3 / s3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                    peaks=dict(hbm_gbs=PEAK_HBM_GBS, bf16_mfma_tflops=PEAK_BF16_MFMA_TFLOPS), roofline=r3,
-                    parity='tests/test_hip_generator.py::test_generator_cfg3_full_size_vs_oracle_train: no farther from the fp32 oracle than '
-                           "the reference's own bf16 autocast on the same inputs (max and rms)")
-        del g3
+        def guarded(fn, *a, **kw):
+            try:
+                return fn(*a, **kw)
+            except Exception as e:        # one extra block must not lose the bench line
+                return dict(error=f'{type(e).__name__}: {e}')
+        bf16_parity = ("no farther from the fp32 oracle than the reference's own bf16 autocast on the same inputs (max and rms): "
+                       'tests/test_hip_generator.py::test_generator_cfg3_full_size_vs_oracle_train')
+        cfg3 = guarded(config_block, dict(num_wv_feat=768), 64, 512, 'bf16', max(5, args.steps), max(3, args.warmup), dev,
+                       'BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
+                       'bf16 activation storage', bf16_parity, '_cfg3_bf16_hbm_traffic.json')
+        cfg2b = guarded(config_block, dict(num_wv_feat=768), 32, 256, 'bf16', max(5, args.steps), max(3, args.warmup), dev,
+                        'the north_star shape B=32 x T=256 (BASELINE configs[1]) in the configs[2] arithmetic: bf16 compute / fp32 accumulate, '
+                        'bf16 activation storage, train mode', bf16_parity, '_cfg2_bf16_hbm_traffic.json')
+        cfg5 = guarded(config_block, dict(num_wv_feat=1024, upsample_rates=[8, 5, 4, 2, 2], upsample_kernel_sizes=[16, 11, 8, 4, 4]), 16, 256, 'f32',
+                       max(5, args.steps // 2), max(2, args.warmup // 2), dev,
+                       'BASELINE configs[4]: 1024-d latents, upsample (8,5,4,2,2) x640, B=16 x T=256, train mode, exact fp32',
+                       'tests/test_hip_generator.py::test_generator_cfg5_full_size_vs_oracle_train (|dy| <= 1e-4 at this size)')
+        train = guarded(train_step_block, dev, B, T, max(4, args.steps // 4))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -555,6 +665,7 @@ def main():
                        'parallelism': (f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else
                                        'single GPU' + (', one-rank RCCL group: the CondBN all-reduces are inside the timed region' if args.force_pg else ''))},
             'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
+            'cfg2_bf16': cfg2b, 'cfg5_f32': cfg5, 'train_step': train,
         }
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 27
+#define V2W_ABI_VERSION 28
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -143,8 +143,19 @@ typedef struct {
                                    * rowsum_part[tile][C_out][2] - tiles = v2w_conv1d_tile_config()[9] - for v2w_bn_reduce_partials to add up:
                                    * the bias gradient of the layer whose output gradient this launch produces (backward of models.py:65-70)
                                    * without another pass over the tensor.  V2W_E_ARG when the launch cannot provide it. */
+    float*  splitk_ws;
+    int64_t splitk_ws_bytes;      /* optional CALLER-OWNED scratch for the f32 MFMA path (ABI v28; the library allocates nothing and keeps no
+                                   * state between calls): a launch that cannot fill the chip (<= 128 workgroups: inference at B = 1) is split
+                                   * over slices of C_in, every slice stores plain partial sums to its own slab of this buffer and a second
+                                   * kernel adds the slabs in slice order and applies bias / residual / addends / division (deterministic).
+                                   * v2w_conv1d_splitk_ws_bytes() says how many bytes this launch would use (0: it runs unsplit); NULL, or fewer
+                                   * bytes than that: the launch runs unsplit - same values up to the summation order over C_in.  Launches that
+                                   * share a buffer must be ordered on ONE stream (a module keeps one buffer per stream it launches on).
+                                   * _fwd_multi reads the fields of a[0]. */
 } v2w_conv1d_args;
 int v2w_conv1d_fwd(const v2w_conv1d_args* a, void* stream);   /* `a` is a HOST pointer, read before return */
+/* Bytes of `splitk_ws` the f32 MFMA launch of a[0..n) would use (sizes only are read; 0: no split / another kernel serves it). */
+long long v2w_conv1d_splitk_ws_bytes(const v2w_conv1d_args* a, int n);
 /* a[0..n) (n <= 4) convs that share B, C_in, C_out, L in ONE launch (MFMA path; V2W_E_SHAPE -> issue them one by one):
  * the residual branches of one generator stage, heaviest first. */
 int v2w_conv1d_fwd_multi(const v2w_conv1d_args* a, int n, void* stream);
@@ -210,8 +221,10 @@ int v2w_resblock2_stage_small_fwd(const v2w_stage_args* a, void* stream);
 /* Split-operand counterpart (V2W_ALGO_SPLIT / V2W_ALGO_BF16 arithmetic) for C == 32 or 16 - and, with bf16 != 0 on bf16 tensors
  * (io_bf16 == 3), for the wide stages C == 64 / 128 / 256 as well (csrc/v2w_stage_bf16_wide.hip: x and t1_j resident in LDS, one kernel): wps / sc from v2w_pack_split or
  * v2w_pack_bf16 (or the batch) of the (k, C, C) layers; bf16 != 0 selects the bf16 single-MFMA form.  V2W_E_SHAPE otherwise.
- * The 2*nk fragment streams must lie BACK TO BACK in execution order (wps1[0], wps2[0], wps1[1], ...; (C/16)*k units of 2 KiB each,
- * pack them into slices of one buffer): the kernel prefetches along one pointer; V2W_E_ARG if they do not. */
+ * Fragment streams: the fp32-tensor kernels (io_bf16 == 0: csrc/v2w_stage_split.hip) walk ONE weight stream - there the 2*nk streams must
+ * lie BACK TO BACK in execution order (wps1[0], wps2[0], wps1[1], ...; (C/16)*k units of 2 KiB each, slices of one buffer), V2W_E_ARG if
+ * they do not.  The bf16-tensor kernels (io_bf16 == 3: v2w_stage_bf16_wide.hip, v2w_stage_bf16_n16.hip, v2w_stage_bf16.hip) take every
+ * stream through its own pointer: any placement. */
 typedef struct {
     const float* in; const float* in_a; const float* in_s;
     const void*  wps1[4]; const float* sc1[4]; const float* bias1[4];
@@ -230,6 +243,10 @@ typedef struct {
     float post_slope;
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
+/* Shape query (ABI v28; host-only, nothing is launched or dereferenced): 0 when the call above would run this stage as one kernel, else the
+ * code it would return.  Read: B, C, L, nk, k, dil1, dil2, bf16, io_bf16, slope, post_* and the ALIGNMENT of `in` / `out` when they are set
+ * (NULL tensor and weight pointers count as aligned). */
+int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a);
 
 /* ---- the residual convolutions of a WIDE ResBlock2 stage (C % 64 == 0) on bf16 tensors (BASELINE configs[2]: bf16 compute / fp32
  * accumulate, bf16 activation storage), one launch per conv position of the block instead of one per branch group
@@ -264,8 +281,11 @@ typedef struct {
     int32_t algo;
     int32_t io_bf16;    /* v2w_convt1d_bf16_fwd only (else 0): bit 0 `in` is bf16, bit 1 `out` is bf16 (see v2w_conv1d_args) */
     int32_t _pad;
+    float*  splitk_ws;  /* v2w_convt1d_fwd only: caller-owned split-over-C_in scratch, as in v2w_conv1d_args (NULL: unsplit) */
+    int64_t splitk_ws_bytes;
 } v2w_convt1d_args;
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
+long long v2w_convt1d_splitk_ws_bytes(const v2w_convt1d_args* a);   /* as v2w_conv1d_splitk_ws_bytes */
 
 /* bf16 counterpart (V2W_ALGO_BF16 arithmetic: bf16 operands, fp32 accumulate - BASELINE configs[2]) of v2w_convt1d_fwd for the
  * transposed convs of models.py:128-129.  The transposed conv runs as a Conv1d over UP * C_out virtual output channels on the bf16

@@ -439,6 +439,39 @@ def test_graph_capture_matches_eager(dev):
     assert gt.cbns[0].batch_nrom.num_batches_tracked.item() == ge.cbns[0].batch_nrom.num_batches_tracked.item() == 2
 
 
+def test_two_captured_generators_replay_concurrently(dev):
+    """ABI v28: the split-over-C_in scratch belongs to the module (Generator._slab), not to the library.  Two generators with different
+    weights, captured at the inference size whose conv_pre / ups.0 / stage-0 launches ARE split (B = 1, T = 50), replay at the same time
+    on two streams, many times over: every replay equals the module's own eager result bit for bit (with the library's old
+    per-(device, stream) slab both graphs wrote one buffer)."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    gens, runs, wants, inps = [], [], [], []
+    for seed in (0, 5):
+        sd = synthetic.make_state_dict(h, seed=seed)
+        inp = to_dev(synthetic.make_inputs(h, 1, 50, seed=20 + seed), dev)
+        O.calibrate_running_stats(sd, h, *synthetic.make_inputs(h, 1, 50, seed=20 + seed))
+        g = build_generator(h, sd, dev, training=False)
+        with torch.no_grad():
+            wants.append(g(*inp).clone())
+            runs.append(g.capture_graph(*inp))
+        assert any(sl.t is not None and sl.t.numel() > 0 for sl in g._slabs.values()), 'no launch of this size was split: the test would prove nothing'
+        gens.append(g); inps.append(inp)
+    ptrs = [{sl.t.data_ptr() for sl in g._slabs.values() if sl.t is not None} for g in gens]
+    assert not (ptrs[0] & ptrs[1])                                # one scratch per module
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for _ in range(20):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                runs[i].graph.replay()                            # (the static inputs still hold inps[i] from the capture)
+                outs[i].append(runs[i](*inps[i]).clone())
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        for y in outs[i]:
+            assert torch.equal(y, wants[i])
+
+
 def test_synthesize_entry_end_to_end(dev, tmp_path):
     """Checkpoint file + text2vec-format latents + speaker-embedding file -> wav, equal to the oracle's eval forward."""
     import os
@@ -772,7 +805,12 @@ def _rccl_single_rank_worker(rank, port, B, T, out_dir, use_ddp):
     g0 = build_generator(h, sd, dev, training=True)
     with torch.no_grad():
         y0 = g0(*to_dev(inp, dev))
-    g = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    gd = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    assert not gd.stat_sync.single_rank_collective                  # the product default: a one-rank group issues no collective
+    with torch.no_grad():
+        gd(*to_dev(inp, dev))
+    assert gd.stat_sync.calls == 0
+    g = build_generator(h, sd, dev, training=True).enable_sync_batchnorm(single_rank_collective=True)
     assert g.stat_sync.backend == 'nccl' and g.stat_sync.world_size == 1 and g.stat_sync.single_rank_collective
     with torch.no_grad():
         y = g(*to_dev(inp, dev))
@@ -782,7 +820,7 @@ def _rccl_single_rank_worker(rank, port, B, T, out_dir, use_ddp):
         if 'cbns' in k:
             assert torch.equal(v, g0.state_dict()[k]), k
     # forward + backward under autograd (train.py:167-214), optionally through DistributedDataParallel (train.py:92)
-    g2 = build_generator(h, sd, dev, training=True).enable_sync_batchnorm()
+    g2 = build_generator(h, sd, dev, training=True).enable_sync_batchnorm(single_rank_collective=True)
     model = g2
     if use_ddp:
         from torch.nn.parallel import DistributedDataParallel
@@ -898,6 +936,25 @@ def test_bench_self_launches_the_ranks_it_was_asked_for(dev):
     assert d1['n_gpus'] == 1 and d1['rccl_ranks'] == 1 and d1['metric'] == d['metric']
     too_many = _run_bench(['--gpus', str(ngpu + 1)] + small)
     assert too_many.returncode != 0 and not [l for l in too_many.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_first_contact(dev):
+    """The driver's 8-GPU command line, on whatever this box has: `bench.py --gpus 8` at the real per-rank workload (B = 32 x T = 256), eight
+    processes that each run the train-mode forward with the CondBN statistics all-reduced every stage.  On a box with fewer than 8 GPUs
+    the ranks share device 0 and meet over gloo (test hooks); the bookkeeping - one JSON line, n_gpus 8, global batch 256, weak scaling,
+    a throughput that counts all eight shards - is the same code an 8-GPU node runs."""
+    import json
+    ngpu = torch.cuda.device_count()
+    hooks = {} if ngpu >= 8 else {'V2W_BENCH_DEVICE': '0', 'V2W_BENCH_BACKEND': 'gloo'}
+    r = _run_bench(['--gpus', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-alt'], hooks, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1 and len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 256 and d['scaling'] == 'weak' and d['steps'] == 2
+    assert d['rccl_ranks'] == (8 if ngpu >= 8 else None)
+    assert abs(d['value'] - 8 * 32 * 256 * 320 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']      # whole-job samples / max-over-ranks time
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -276,12 +276,34 @@ def test_conv1d_split_over_cin_matches_the_unsplit_kernel(dev, B, cin, cout, L, 
     prev = _t(r.standard_normal((B, cout, L), dtype=np.float32), dev)
     kw = dict(k=k, dil=dil, slope=0.1, res=res, res_affine=(ra, rs), accumulate=True, out_div=3.0)
     outs = []
-    for algo, wp in ((hipops.ALGO_AUTO, hipops.pack_mfma(wf)), (hipops.ALGO_AUTO, hipops.pack_mfma(wf)), (hipops.ALGO_DIRECT, None)):
+    slab = hipops.SplitKSlab()       # caller-owned scratch (ABI v28: the library allocates nothing)
+    for algo, wp, ws in ((hipops.ALGO_AUTO, hipops.pack_mfma(wf), slab), (hipops.ALGO_AUTO, hipops.pack_mfma(wf), slab),
+                         (hipops.ALGO_DIRECT, None, None), (hipops.ALGO_AUTO, hipops.pack_mfma(wf), None)):
         o = prev.clone()
-        hipops.conv1d(x, wf, bias, o, algo=algo, wp=wp, **kw)
+        hipops.conv1d(x, wf, bias, o, algo=algo, wp=wp, splitk_ws=ws, **kw)
         outs.append(o)
+    assert slab.t is not None and slab.t.numel() > 0, 'the size query reported no split for a launch of <= 128 workgroups'
     assert torch.equal(outs[0], outs[1]), 'split launches are not run-to-run deterministic'
     assert (outs[0] - outs[2]).abs().max().item() <= 2e-5
+    assert (outs[3] - outs[2]).abs().max().item() <= 2e-5        # no slab handed over: the launch runs unsplit
+    # a slab smaller than the query's answer: unsplit as well (never a partial use of it)
+    small = hipops.SplitKSlab(); small.t = torch.full((16,), float('nan'), device=dev)
+    a = _hip_args_conv1d(x, wf, bias, prev.clone(), wp=hipops.pack_mfma(wf), small=small.t, **kw)
+    assert torch.isnan(small.t).all()
+    assert (a - outs[2]).abs().max().item() <= 2e-5
+
+
+def _hip_args_conv1d(x, wf, bias, out, *, wp, small, **kw):
+    """One v2w_conv1d_fwd call with an explicit (too small) splitk_ws buffer."""
+    import ctypes as C
+    from wavthruvec_pytorch_amd import _hip, hipops
+    a = _hip.Conv1dArgs()
+    hipops._conv1d_args(a, x, wf, bias, out, wp=wp, **kw)
+    need = _hip.load().v2w_conv1d_splitk_ws_bytes(C.byref(a), 1)
+    assert need > small.numel() * 4
+    a.splitk_ws, a.splitk_ws_bytes = small.data_ptr(), small.numel() * 4
+    _hip.check(_hip.load().v2w_conv1d_fwd(C.byref(a), hipops._stream(x)), 'v2w_conv1d_fwd')
+    return out
 
 
 @pytest.mark.parametrize('B,C,L,k,dil,nprob', [(4, 128, 1280, 7, 3, 3), (3, 64, 2052, 3, 1, 2), (2, 256, 520, 11, 1, 1), (4, 32, 4096, 7, 1, 3)])

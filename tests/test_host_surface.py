@@ -71,14 +71,38 @@ def test_library_exports_every_declared_symbol():
     assert loaded.v2w_build_arch() == b'gfx950'
 
 
-def test_struct_layouts_match_header_field_order():
-    header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
-    body = header[header.index('typedef struct {', header.index('K1/K5/K6/K7')):header.index('} v2w_conv1d_args;')]
+def _header_struct_fields(header, name):
+    """Field names of `typedef struct { ... } name;` in declaration order (comments stripped, array suffixes dropped)."""
+    end = header.index('} %s;' % name)
+    body = header[header.rindex('typedef struct {', 0, end):end]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
-    names = re.findall(r'\b(?:const\s+)?(?:float|int32_t|void)\s*\*?\s*([a-zA-Z_0-9]+(?:\s*,\s*[a-zA-Z_0-9]+)*)\s*;', body)
-    flat = [n.strip() for grp in names for n in grp.split(',')]
-    want = [f[0].rstrip('_') for f in _hip.Conv1dArgs._fields_]
+    groups = re.findall(r'\b(?:const\s+)?(?:float|int32_t|int64_t|void)\s*\*?\s*([a-zA-Z_0-9\[\]]+(?:\s*,\s*[a-zA-Z_0-9\[\]]+)*)\s*;', body)
+    return [re.sub(r'\[.*?\]', '', n).strip() for grp in groups for n in grp.split(',')]
+
+
+@pytest.mark.parametrize('cname,mirror', [('v2w_conv1d_args', 'Conv1dArgs'), ('v2w_convt1d_args', 'ConvT1dArgs'),
+                                          ('v2w_stage_split_args', 'StageSplitArgs')])
+def test_struct_layouts_match_header_field_order(cname, mirror):
+    """The ctypes mirrors list the header's fields in the header's order (ABI v28 added splitk_ws / splitk_ws_bytes to both conv structs)."""
+    header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
+    flat = _header_struct_fields(header, cname)
+    want = [f[0].rstrip('_') if f[0] != '_pad' else '_pad' for f in getattr(_hip, mirror)._fields_]
     assert flat == want, (flat, want)
+
+
+def test_library_keeps_no_allocations_or_process_state():
+    """SURVEY 8(b): the C ABI allocates nothing and keeps no mutable state - workspaces are the caller's (v2w_conv1d_args::splitk_ws,
+    the slab arguments of v2w_wgrad*).  Checked on the sources: no hipMalloc / hipFree and no function-local or file-level mutable static."""
+    csrc = os.path.join(ROOT, 'wavthruvec_pytorch_amd', 'csrc')
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(('.hip', '.h')):
+            continue
+        text = re.sub(r'//.*', '', open(os.path.join(csrc, fn)).read())
+        assert not re.search(r'\bhip(Malloc|Free|MallocAsync|HostMalloc)\b', text), fn
+        for m in re.finditer(r'^\s*static\s+(?!inline|constexpr|const\b|__device__|int\s+\w+\s*\(|bool\s+\w+\s*\(|\w+\s+\w+\s*\()([^;(]*);', text, flags=re.M):
+            if 'V2W_TIMELINE' in fn or 'g_tl' in m.group(0):      # diagnostic builds only (-DV2W_TIMELINE)
+                continue
+            raise AssertionError(f'{fn}: mutable static `{m.group(0).strip()}`')
 
 
 def test_workmodel_matches_survey_contract_figures():

@@ -1,3 +1,5 @@
+// EXPERIMENT, not part of the library (round 3; moved out of csrc/ in round 4: nothing in the default build reached it).  To try it again: copy it
+// back to wavthruvec_pytorch_amd/csrc/, add it to build.SOURCES and call v2w_resblock2_stage_bf16_n32 from v2w_resblock2_stage_bf16 for C == 32.
 // The 32-channel ResBlock2 stage of the generator on bf16 tensors (reference: vec2wav/models.py:135-141 with the reference's block set,
 // kernel sizes (3, 7, 11) x dilations (1, 3); anything else runs on v2w_stage_bf16_wide.hip):
 //   out = ( sum_j [ t1_j + conv_{k_j, 3}(lrelu(t1_j)) + b2_j ] ) / 3,   t1_j = x + conv_{k_j, 1}(lrelu(x)) + b1_j,   x = a * in + s.
@@ -382,12 +384,7 @@ int launch_n32(const v2w_stage_split_args* q, hipStream_t stream) {
     if ((long long)q->B * p.ntl > 0x7fffffffll) return V2W_E_SHAPE;
     p.ntiles = q->B * p.ntl;
     const size_t lds = (size_t)(2 * N32_XR + 2 * N32_W + 16) * 64 + (size_t)32 * N32_SRS * sizeof(float);
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    const int ncu = v2w_num_cus();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(n32_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     // persistent, one 8-wave workgroup per CU (151 KB of LDS; two waves per SIMD: one of each role)

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -29,13 +29,14 @@ class Conv1dArgs(C.Structure):
                 ('out_div', C.c_float), ('algo', C.c_int32), ('mask_slope', C.c_float),
                 ('in_stride', C.c_int32), ('in_phase', C.c_int32), ('pad_left', C.c_int32),
                 ('wps', _fp), ('winv', _fp), ('in_ct', C.c_int32), ('out_ct', C.c_int32), ('out_slope', C.c_float),
-                ('io_bf16', C.c_int32), ('rowsum_part', _fp)]
+                ('io_bf16', C.c_int32), ('rowsum_part', _fp), ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64)]
 
 
 class ConvT1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
-                ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32), ('io_bf16', C.c_int32), ('_pad', C.c_int32)]
+                ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32), ('io_bf16', C.c_int32), ('_pad', C.c_int32),
+                ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64)]
 
 
 class PairArgs(C.Structure):
@@ -129,12 +130,15 @@ SIGNATURES = {
     'v2w_mel_phases_bwd': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_packable': (C.c_int, [C.c_int, C.c_int]),
     'v2w_resblock2_stage_split_fwd': (C.c_int, [C.POINTER(StageSplitArgs), _fp]),
+    'v2w_resblock2_stage_split_config': (C.c_int, [C.POINTER(StageSplitArgs)]),
     'v2w_pack_bf16': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),
     'v2w_conv1d_fwd_multi': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, _fp]),
+    'v2w_conv1d_splitk_ws_bytes': (C.c_longlong, [C.POINTER(Conv1dArgs), C.c_int]),
+    'v2w_convt1d_splitk_ws_bytes': (C.c_longlong, [C.POINTER(ConvT1dArgs)]),
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
     'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_resblock2_stage_small_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),

@@ -1,8 +1,8 @@
 // extern "C" dispatch of the conv entry points declared in include/vec2wav_hip.h.
 #include "v2w_common.h"
 
-int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out);
-int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out);
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out, long long* ws_query = nullptr);
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out, long long* ws_query = nullptr);
 int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool bf16);
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream);
 int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream);
@@ -77,6 +77,18 @@ extern "C" int v2w_conv1d_tile_config(const v2w_conv1d_args* a, int32_t* cfg) {
 extern "C" int v2w_convt1d_tile_config(const v2w_convt1d_args* a, int32_t* cfg) {
     if (!a || !cfg) return V2W_E_ARG;
     return v2w_convt1d_mfma(a, nullptr, cfg);
+}
+
+// Bytes of caller scratch (v2w_conv1d_args::splitk_ws) the f32 MFMA launch of these problems would split into; 0: unsplit or not an MFMA launch
+extern "C" long long v2w_conv1d_splitk_ws_bytes(const v2w_conv1d_args* a, int n) {
+    if (!a || n < 1 || n > 4 || (a->algo != V2W_ALGO_AUTO && a->algo != V2W_ALGO_MFMA)) return 0;
+    long long bytes = 0;
+    return v2w_conv1d_mfma(a, n, nullptr, nullptr, &bytes) == 0 ? bytes : 0;
+}
+extern "C" long long v2w_convt1d_splitk_ws_bytes(const v2w_convt1d_args* a) {
+    if (!a || a->u <= 0 || a->k < a->u || (a->algo != V2W_ALGO_AUTO && a->algo != V2W_ALGO_MFMA)) return 0;
+    long long bytes = 0;
+    return v2w_convt1d_mfma(a, nullptr, nullptr, &bytes) == 0 ? bytes : 0;
 }
 
 // n (<= 4) fused convs that share B, C_in, C_out and L in ONE launch: the residual branches of a generator stage read the

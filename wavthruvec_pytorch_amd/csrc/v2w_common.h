@@ -15,6 +15,20 @@ static inline int v2w_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// Host-only "would this launch be taken?" queries run the launcher itself up to the launch with this sentinel for a stream: every shape
+// check the real call makes is made, nothing is launched, no attribute is set, no pointer is dereferenced.
+#define V2W_DRY_STREAM (reinterpret_cast<hipStream_t>(static_cast<intptr_t>(-1)))
+static inline bool v2w_dry(hipStream_t s) { return s == V2W_DRY_STREAM; }
+
+// Compute units of the CURRENT device (the device the caller's stream belongs to: every entry point runs with it made current).
+// Asked of the runtime at every launch of a persistent kernel - no process-wide cache: a value remembered from the first caller's
+// device would size the grids of every other device in the process.
+static inline int v2w_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
+
 __device__ __forceinline__ float v2w_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // v / d with r = 1.f / d precomputed (one true division per thread instead of one per element): q = v*r is within one ulp of the

@@ -890,7 +890,6 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* 
     if (p.hla > HMAX || p.hr > HMAX) return V2W_E_SHAPE;
     p.ntl = (p.L + NT - 1) / NT;
     p.ntiles = p.B * p.ntl;
-    if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
     p.xrows = (p.hla + NT + p.hr + 3) & ~3;
     p.vec4 = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.in) & 15) == 0);
     p.evec = (p.L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
@@ -899,14 +898,17 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* 
     if (tab < WM * WN * 2048) tab = WM * WN * 2048;
     p.atab_off = tab;
     const size_t lds = ((size_t)tab + 5 * MT + 2 * p.Cin + WN * (MT / p.up_p) * 2) * sizeof(float);
+    // every shape check stands in front of the query's answer: a configuration / tile-count query that says yes must mean the launch
+    // will not decline (Generator._bf16_storage_kernels_exist decides on it before the forward starts)
     if (lds > 160 * 1024) return V2W_E_SHAPE;
+    if (p.io_bf16 != 0 && p.io_bf16 != 3) return V2W_E_SHAPE;
+    if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
     MultiArgs m{};
     m.p[0] = p;
     m.start[0] = 0;
     const int grid = ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
     m.start[1] = grid;
     for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
-    if (p.io_bf16 != 0 && p.io_bf16 != 3) return V2W_E_SHAPE;
     if (VEC && !p.vec4) return V2W_E_ARG;
     auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true, V2W_BF_CK, VEC> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false, V2W_BF_CK, VEC>;
     if (lds > 64 * 1024) {

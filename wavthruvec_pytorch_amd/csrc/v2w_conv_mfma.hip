@@ -28,7 +28,6 @@
 // Waves        : WM x WN waves per workgroup, each owning (MF*MI) x (MF*NI) outputs for each of the U phases;
 //                64-lane fragments: lane&(MF-1) = row/col inside the MFMA tile, lane/MF = k index.
 #include <type_traits>
-#include <mutex>
 #include "v2w_tile.h"
 
 #ifdef V2W_TIMELINE   // diagnostic build only (see v2w_common.h)
@@ -642,28 +641,6 @@ splitk_reduce_kernel(const SplitEpiArgs a) {
     }
 }
 
-// One slab workspace per (device, stream) that ever needed one: allocated on first use (never while the stream is capturing - the
-// caller then launches unsplit), kept for the life of the process.
-#define V2W_SPLITK_WS_BYTES (32u << 20)
-static float* splitk_workspace(hipStream_t stream) {
-    struct Entry { int dev; hipStream_t stream; float* buf; };
-    static Entry table[32];
-    static int used = 0;
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < used; ++i)
-        if (table[i].dev == dev && table[i].stream == stream) return table[i].buf;
-    if (used == 32) return nullptr;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    void* buf = nullptr;
-    if (hipMalloc(&buf, V2W_SPLITK_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    table[used++] = Entry{dev, stream, static_cast<float*>(buf)};
-    return static_cast<float*>(buf);
-}
-
 // HMAX: largest halo (each side) the staging slots cover: 32 for the generator (k = 11, dilation 5 -> 25); the 48 variants serve
 // DiscriminatorP's dilation = period convs (k = 5, period 19 -> 38) at one more prefetch slot per thread.
 template <int MF, int U, int MI, int NI, int WM, int WN, int CK, int HMAX = 32>
@@ -741,9 +718,13 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
             vec = vec && (p.L * U) % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1);
             floats += n * s2;
         }
-        if (ok && floats * sizeof(float) <= V2W_SPLITK_WS_BYTES) {
-            float* ws = splitk_workspace(stream);
-            if (ws) {
+        if (m.p[0].ws_query) {                       // host-only query: bytes of caller scratch this launch would use
+            *m.p[0].ws_query = ok ? (long long)(floats * sizeof(float)) : 0;
+            return 0;
+        }
+        if (ok && m.p[0].splitk_ws && (long long)(floats * sizeof(float)) <= m.p[0].splitk_ws_bytes) {
+            float* ws = m.p[0].splitk_ws;           // caller-owned (v2w_conv1d_args::splitk_ws): nothing is allocated or kept here
+            {
                 S = s2;
                 red_vec = vec;
                 size_t off = 0;
@@ -768,6 +749,7 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
             }
         }
     }
+    if (m.p[0].ws_query) { *m.p[0].ws_query = 0; return 0; }
     bool vec = true;
     for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
     auto kern = vec ? (epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1, true>
@@ -957,7 +939,7 @@ extern "C" int v2w_pack_mfma_batch(const float* wf, float* wp, int k, int c_in, 
 
 // Called by v2w_api.hip.  Returns V2W_E_SHAPE when no tile configuration fits (caller falls back to the direct kernel).
 // n problems (1 <= n <= V2W_MAX_MULTI) that share B, C_in, C_out, L - hence the tile configuration - in ONE launch.
-int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out) {
+int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cfg_out, long long* ws_query) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
     const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, 1);
     if (!cfg.mf) return V2W_E_SHAPE;
@@ -966,7 +948,7 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
     for (int i = 0; i < n; ++i) {
         const v2w_conv1d_args* q = a + i;
         if (q->B != a->B || q->C_in != a->C_in || q->C_out != a->C_out || q->L != a->L) return V2W_E_SHAPE;
-        if (!q->wp && !cfg_out) return V2W_E_SHAPE;
+        if (!q->wp && !cfg_out && !ws_query) return V2W_E_SHAPE;
         TileArgs p{};
         p.cfg_out = cfg_out;
         p.in = q->in; p.in_a = q->in_a; p.in_s = q->in_s; p.wp = q->wp; p.bias = q->bias;
@@ -981,6 +963,7 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
         if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
         p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
+        p.splitk_ws = a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? a->splitk_ws_bytes : 0; p.ws_query = ws_query;
         ps[i] = p;
         tiles128 += (long)p.B * ((p.L + 127) / 128) * (p.Cout / 128);
     }
@@ -1008,11 +991,12 @@ int v2w_conv1d_mfma(const v2w_conv1d_args* a, int n, hipStream_t stream, int* cf
     return V2W_E_SHAPE;
 }
 
-int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out) {
+int v2w_convt1d_mfma(const v2w_convt1d_args* a, hipStream_t stream, int* cfg_out, long long* ws_query) {
     const LayerCfg cfg = v2w_layer_cfg(a->C_in, a->C_out, a->u);
-    if ((!a->wp && !cfg_out) || !cfg.mf) return V2W_E_SHAPE;
+    if ((!a->wp && !cfg_out && !ws_query) || !cfg.mf) return V2W_E_SHAPE;
     TileArgs p{};
     p.cfg_out = cfg_out;
+    p.splitk_ws = a->splitk_ws; p.splitk_ws_bytes = a->splitk_ws ? a->splitk_ws_bytes : 0; p.ws_query = ws_query;
     p.in = a->in; p.wp = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out; p.L = a->L; p.K = a->k; p.dil = 1;
     p.CinT = p.Cin; p.CoutT = p.Cout; p.out_slope = 1.f;

@@ -139,12 +139,7 @@ conv_post_tanh_mfma_kernel(const PostArgs a) {
 
 template <int C>
 int launch_post(const PostArgs& p, hipStream_t stream) {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    const int ncu = v2w_num_cus();
     // two resident workgroups per CU, each builds the operand image once and walks its jobs
     const int grid = p.njobs < V2W_PM_WGS * ncu ? p.njobs : V2W_PM_WGS * ncu;
     hipLaunchKernelGGL(conv_post_tanh_mfma_kernel<C>, dim3(grid), dim3(256), (size_t)C * 3 * 64 * sizeof(u32x4), stream, p);

@@ -423,6 +423,7 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
     if (lds < scr) lds = scr;
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (q->io_bf16 != 0 && q->io_bf16 != 3) return V2W_E_ARG;
+    if (v2w_dry(stream)) return 0;
     auto kern = q->io_bf16 ? stage_bf16_kernel<C, true> : stage_bf16_kernel<C, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -440,20 +441,10 @@ V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
 
 int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16_wide.hip
 int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
-int v2w_resblock2_stage_bf16_n32(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n32.hip
 
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
-#ifdef V2W_N32
-    // Opt-in (build with -DV2W_N32): the wave-specialised C = 32 kernel (v2w_stage_bf16_n32.hip: conv1 waves and conv2 waves, weights in
-    // registers).  Correct (same tests), 794 against 839 us standalone at configs[2], but no faster than the template inside the forward
-    // (742 - 768 against ~750 us): its conv1 role carries the three epilogues and the staging and is the critical path.
-    if (a->C == 32 && a->io_bf16 == 3 && !a->post_out) {
-        const int rc = v2w_resblock2_stage_bf16_n32(a, stream);
-        if (rc != V2W_E_SHAPE) return rc;
-    }
-#endif
 #ifndef V2W_NO_N16
     if (a->C == 16 && a->io_bf16 == 3 && !a->post_out) {      // the reference's block set on aligned bf16 tensors: weights in registers
         const int rc = v2w_resblock2_stage_bf16_n16(a, stream);

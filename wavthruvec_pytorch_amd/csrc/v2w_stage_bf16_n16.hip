@@ -311,12 +311,8 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
     // x, t1 (+ 16 rows of slack behind it: conv2's taps past its end) and r tiles; the store scratch [16][W + 12] floats overlays them
     const size_t tiles = (size_t)(XR + W + 16 + XR) * 32, scratch = (size_t)16 * (W + 12) * sizeof(float);
     const size_t lds = tiles > scratch ? tiles : scratch;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    if (v2w_dry(stream)) return 0;
+    const int ncu = v2w_num_cus();
     // persistent: the registers hold the stage's weights, so a workgroup walks tiles; 8 waves per CU (2 per SIMD: ~230 registers each)
     const int slots = ncu * (8 / WN);
     hipLaunchKernelGGL(n16_stage_kernel<WN>, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);

@@ -732,15 +732,11 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
 #endif
     auto kern = (std_cfg && CH == 32 && !WLDS) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, (CH == 32 && !WLDS)>
                                                : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false>;
+    if (v2w_dry(stream)) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     // V2W_WS_PERSIST: one residency of the chip (workgroups per CU as the configuration counts on), each workgroup walks its tiles
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    const int ncu = v2w_num_cus();
     const int slots = V2W_WS_PERSIST ? ncu * ((OCC * 4) / (WM * WN)) : p.ntiles;
     hipLaunchKernelGGL(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
     return v2w_launch_status();

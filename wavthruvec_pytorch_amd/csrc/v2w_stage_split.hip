@@ -356,9 +356,9 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
     p.wbase = p.w1[0];
     const unsigned char* expect = p.wbase;
     for (int j = 0; j < q->nk; ++j) {
-        if (p.w1[j] != expect) return V2W_E_ARG;
+        if (p.w1[j] != expect && !v2w_dry(stream)) return V2W_E_ARG;
         expect += (size_t)NCH * q->k[j] * 2048;
-        if (p.w2[j] != expect) return V2W_E_ARG;
+        if (p.w2[j] != expect && !v2w_dry(stream)) return V2W_E_ARG;
         expect += (size_t)NCH * q->k[j] * 2048;
         p.ntot += 2 * NCH * q->k[j];
     }
@@ -371,6 +371,7 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0);
     const size_t lds = (size_t)(p.xrows + W) * ROWB + (size_t)(2 * V2W_SS_MAXB + 2) * C * sizeof(float);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
+    if (v2w_dry(stream)) return 0;
     auto kern = q->bf16 ? stage_split_kernel<NCH, NI, WN, true> : stage_split_kernel<NCH, NI, WN, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -401,4 +402,23 @@ extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void
     if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
     if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
     return V2W_E_SHAPE;
+}
+
+// Shape query (ABI v28): 0 when v2w_resblock2_stage_split_fwd would run this stage as ONE kernel, V2W_E_SHAPE / V2W_E_ARG as the call itself
+// would answer.  Only the sizes (B, C, L, nk, k, dilations), the mode flags, slope and the ALIGNMENT of the tensor pointers that are set
+// are read; NULL tensor / weight pointers stand for "aligned".  Generator._bf16_storage_kernels_exist asks this before a forward starts
+// instead of restating the kernels' limits (tap count, halo) in Python.
+extern "C" int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a) {
+    if (!a) return V2W_E_ARG;
+    v2w_stage_split_args q = *a;
+    float* const dummy = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));     // aligned, never dereferenced
+    if (!q.in) q.in = dummy;
+    if (!q.out && !q.post_out) q.out = dummy;
+    for (int j = 0; j < q.nk && j < V2W_SS_MAXB; ++j) {
+        if (!q.wps1[j]) q.wps1[j] = dummy;
+        if (!q.wps2[j]) q.wps2[j] = dummy;
+        if (!q.sc1[j]) q.sc1[j] = dummy;
+        if (!q.sc2[j]) q.sc2[j] = dummy;
+    }
+    return v2w_resblock2_stage_split_fwd(&q, V2W_DRY_STREAM);
 }

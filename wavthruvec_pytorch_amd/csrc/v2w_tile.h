@@ -38,6 +38,8 @@ struct TileArgs {
                       // [s, s + 1) * (C_in / CK / ksplit) and stores its plain sums to out + s * B * CoutT * L * U (see launch_tile)
     int up_u, up_p;   // bf16 transposed conv run as a 3-tap conv over up_p * C_out virtual rows (row = co * up_p + phase): stride, padded phase count
     int* cfg_out; // host-only: when set, launch_tile reports its template configuration instead of launching
+    float* splitk_ws; long long splitk_ws_bytes;   // host-only (f32 tile kernel): the caller's split-over-C_in scratch (v2w_conv1d_args::splitk_ws)
+    long long* ws_query;                           // host-only: when set, launch_tile reports the bytes of splitk_ws it would use instead of launching
 };
 
 // The tile kernels pick their problem with a per-workgroup index into MultiArgs::p, so every `p.field` is a scalar load from the

@@ -296,14 +296,8 @@ template <int MF, int WCO, int WCI, int NT, int U, bool WIDE = false>
 static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t st) {
     if (!tiles) return true;                                       // dry run: "is this shape instantiated?"
     auto kern = wgrad_pipe_kernel<MF, WCO, WCI, NT, U, WIDE>;
-    // the > 64 KiB LDS opt-in is per device: one bit per device of this process (setting it twice is harmless, so a race is benign)
-    static unsigned long long attr_set = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
-    if (dev == 63 || !((attr_set >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set |= 1ull << dev;
-    }
+    // the > 64 KiB LDS opt-in is per device: set on the current device at every launch (idempotent, host-side only; the library keeps no state)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
     return true;
 }

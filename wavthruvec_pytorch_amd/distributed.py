@@ -41,10 +41,10 @@ class BNStatSync:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        # A one-rank group needs no exchange.  Over RCCL the collective is issued all the same (a legal one-rank all-reduce): it is
-        # the code a multi-GPU job runs, and on a one-GPU box the only way to execute and time it (bench.py --force-pg, the -m gpu
-        # tests).  gloo groups of one rank skip it unless asked.
-        self.single_rank_collective = (self.backend == 'nccl') if single_rank_collective is None else bool(single_rank_collective)
+        # A one-rank group needs no exchange and issues none (no collective, no stream joins around it) - unless asked to: a one-rank
+        # all-reduce is legal, it is the code a multi-GPU job runs, and on a one-GPU box the only way to execute and time it
+        # (bench.py --force-pg / its `stat_sync` block and the -m gpu tests pass single_rank_collective=True).
+        self.single_rank_collective = bool(single_rank_collective)
         self.calls = 0
 
     def __call__(self, stats: torch.Tensor) -> torch.Tensor:

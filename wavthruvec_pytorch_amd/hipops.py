@@ -182,15 +182,39 @@ def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, re
     a.slope = slope; a.accumulate = int(accumulate); a.out_div = out_div; a.algo = algo
 
 
-def conv1d(x, wf, bias, out, **kw):
-    """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out | + add0 (+ add1)] [/ out_div]; see the header."""
+class SplitKSlab:
+    """Caller-owned scratch of the split over C_in (v2w_conv1d_args::splitk_ws, ABI v28): launches too small to fill the chip - inference at
+    B = 1 - store per-slice partial sums here and a second kernel adds them.  The library allocates nothing: the OWNER of a slab (a
+    Generator, one slab per stream it launches on) passes it to conv1d / conv1d_multi / convt1d as `splitk_ws=`; launches that share a
+    slab must be ordered on one stream.  Grow-only, so a warmed-up module never allocates inside a HIP graph capture."""
+
+    def __init__(self):
+        self.t = None
+
+    def ensure(self, nbytes, device):
+        if self.t is None or self.t.device != device or self.t.numel() * 4 < nbytes:
+            self.t = torch.empty(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
+        return self.t
+
+
+def _attach_slab(a, slab, nbytes, device):
+    if slab is not None and nbytes > 0:
+        t = slab.ensure(int(nbytes), device)
+        a.splitk_ws, a.splitk_ws_bytes = t.data_ptr(), t.numel() * 4
+
+
+def conv1d(x, wf, bias, out, splitk_ws=None, **kw):
+    """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out | + add0 (+ add1)] [/ out_div]; see the header.
+    splitk_ws: a SplitKSlab (f32 MFMA path only; without one a small launch simply runs unsplit)."""
     a = _hip.Conv1dArgs()
     _conv1d_args(a, x, wf, bias, out, **kw)
+    if splitk_ws is not None:
+        _attach_slab(a, splitk_ws, _hip.load().v2w_conv1d_splitk_ws_bytes(C.byref(a), 1), x.device)
     _hip.check(_hip.load().v2w_conv1d_fwd(C.byref(a), _stream(x)), 'v2w_conv1d_fwd')
     return out
 
 
-def conv1d_multi(problems):
+def conv1d_multi(problems, splitk_ws=None):
     """`problems`: list of (x, wf, bias, out, kwargs) sharing B, C_in, C_out, L.  One launch when the MFMA path takes them
     (heaviest first), otherwise one launch each."""
     n = len(problems)
@@ -198,16 +222,18 @@ def conv1d_multi(problems):
         arr = (_hip.Conv1dArgs * n)()
         for a, (x, wf, bias, out, kw) in zip(arr, problems):
             _conv1d_args(a, x, wf, bias, out, **kw)
+        if splitk_ws is not None:
+            _attach_slab(arr[0], splitk_ws, _hip.load().v2w_conv1d_splitk_ws_bytes(arr, n), problems[0][0].device)
         rc = _hip.load().v2w_conv1d_fwd_multi(arr, n, _stream(problems[0][0]))
         if rc == 0:
             return
         if rc != -2:
             _hip.check(rc, 'v2w_conv1d_fwd_multi')
     for x, wf, bias, out, kw in problems:
-        conv1d(x, wf, bias, out, **kw)
+        conv1d(x, wf, bias, out, splitk_ws=splitk_ws, **kw)
 
 
-def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats_part=None):
+def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats_part=None, splitk_ws=None):
     """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias."""
     B, ci, L = x.shape
     a = _hip.ConvT1dArgs()
@@ -215,6 +241,8 @@ def convt1d(x, wf, bias, out, *, k, u, slope=1.0, algo=ALGO_AUTO, wp=None, stats
     a.stats_part = _hip.ptr(stats_part)
     a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
     a.slope = slope; a.algo = algo
+    if splitk_ws is not None:
+        _attach_slab(a, splitk_ws, _hip.load().v2w_convt1d_splitk_ws_bytes(C.byref(a)), x.device)
     _hip.check(_hip.load().v2w_convt1d_fwd(C.byref(a), _stream(x)), 'v2w_convt1d_fwd')
     return out
 
@@ -311,10 +339,11 @@ def conv_post_tanh(x, wf, bias, out, *, k, slope):
     return out
 
 
-def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
-    """Name PREFIX of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel).  The
-    instantiation's last template argument (VEC: vector staging) depends on the alignment and stride of the actual input, which a
-    shape query cannot know: kernel names of a trace are matched with `startswith`."""
+def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1, prefix=False):
+    """Name of the conv_tile_kernel instantiation the MFMA path picks for this problem, or None (direct kernel).  The instantiation's
+    last template argument (VEC: vector staging) depends on the alignment and stride of the actual input, which a shape query cannot
+    know: the name carries the value an aligned, unit-stride tensor of this length gets (L % 4 == 0); `prefix=True` returns the name
+    up to that argument, for `startswith` matching of trace names."""
     cfg = (C.c_int32 * 10)()
     if u == 1:
         a = _hip.Conv1dArgs(); a.B, a.C_in, a.C_out, a.L, a.k, a.dil = B, c_in, c_out, L, k, dil
@@ -326,7 +355,8 @@ def conv_tile_config(B, c_in, c_out, L, k, dil=1, u=1):
     if rc != 0:
         return None
     # forward instantiation (EPI = 0: no optional epilogue)
-    return 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, '
+    pre = 'conv_tile_kernel<' + ', '.join(str(v) for v in cfg[:9]) + ', 0, '
+    return pre if prefix else pre + ('true>' if L % 4 == 0 else 'false>')
 
 
 def conv_bf16_config(B, nprob, c_in, c_out, L, k, dil=1, u=1, io_bf16=3):
@@ -465,6 +495,17 @@ def resblock_pair_multi(problems):
         return False
     _hip.check(rc, 'v2w_resblock_pair_fwd')
     return True
+
+
+def resblock2_stage_split_ok(B, Cc, L, ks, dil1s, dil2s, *, slope, bf16=True, io_bf16=3) -> bool:
+    """Shape query: would resblock2_stage_split run this stage (nk branches of kernel sizes `ks`, dilations `dil1s` / `dil2s`) as one
+    kernel on aligned tensors?  Asked of the library (v2w_resblock2_stage_split_config), nothing is launched."""
+    a = _hip.StageSplitArgs()
+    for j, (k, d1, d2) in enumerate(zip(ks, dil1s, dil2s)):
+        a.k[j], a.dil1[j], a.dil2[j] = k, d1, d2
+    a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
+    a.slope, a.out_div, a.bf16, a.io_bf16 = slope, float(len(ks)), int(bf16), io_bf16
+    return _hip.load().v2w_resblock2_stage_split_config(C.byref(a)) == 0
 
 
 def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None):

@@ -212,14 +212,16 @@ class Generator(nn.Module):
                                               # (opt-in: measured 1162 us against 791 + 190 us for the two kernels at configs[2])
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
+        self._slabs: Dict[tuple, 'hipops.SplitKSlab'] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
 
     # -------------------------------------------------------------------------------------------
-    def enable_sync_batchnorm(self, group=None):
-        """Data-parallel CondBN: all-reduce the per-stage batch statistics over `group` (RCCL on GPUs)."""
+    def enable_sync_batchnorm(self, group=None, single_rank_collective=None):
+        """Data-parallel CondBN: all-reduce the per-stage batch statistics over `group` (RCCL on GPUs).  A one-rank group exchanges
+        nothing unless `single_rank_collective=True` (bench.py --force-pg and the -m gpu tests: the RCCL code path on a one-GPU box)."""
         from .distributed import BNStatSync
-        self.stat_sync = BNStatSync(group)
+        self.stat_sync = BNStatSync(group, single_rank_collective=single_rank_collective)
         return self
 
     def capture_graph(self, x, spk_emb, noise, warmup: int = 2):
@@ -228,15 +230,14 @@ class Generator(nn.Module):
         The forward is ~40-60 kernel launches; at inference sizes (B=1, T~50) it is launch-bound, and replaying one graph
         removes the per-launch host cost.  Inputs are copied into static buffers, the returned tensor is the graph's static
         output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured.
-        Graphs captured on one device share its capture stream and with it the library's split-over-C_in slab workspace (one
-        32 MiB slab per (device, stream), csrc/v2w_conv_mfma.hip): replays of DIFFERENT captured generators on that device must
-        be serialised on one stream - replaying two of them concurrently on different streams would race on the slab."""
+        Every buffer the captured launches touch - activations, folded weights, the split-over-C_in scratch (`_slab`) - belongs to
+        THIS module, so graphs of different generators may replay concurrently on different streams."""
         if self.stat_sync is not None:
             raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
         sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
         with torch.no_grad():
-            # warm-up and capture run on ONE per-device stream: the library keys its split-K slab workspace by (device, stream) and
-            # never allocates while a stream is capturing, so the capture must see the stream the warm-up ran on
+            # warm-up and capture run on ONE per-device stream: the module keys its split-over-C_in scratch by stream, and the warm-up
+            # must have sized it before the capture (nothing may be allocated while a stream is capturing)
             side = _CAPTURE_STREAMS.get(str(sx.device))
             if side is None:
                 side = _CAPTURE_STREAMS[str(sx.device)] = torch.cuda.Stream(device=sx.device)
@@ -280,6 +281,16 @@ class Generator(nn.Module):
             t = torch.empty(shape, device=device, dtype=dtype)
             self._ws[name] = t
         return t
+
+    def _slab(self, device):
+        """This module's split-over-C_in scratch for launches on the CURRENT stream of `device` (hipops.SplitKSlab; v2w_conv1d_args::splitk_ws).
+        One slab per (module, stream): two generators - or one generator on two streams - never share one, so captured graphs of
+        different modules may replay concurrently."""
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        slab = self._slabs.get(key)
+        if slab is None:
+            slab = self._slabs[key] = hipops.SplitKSlab()
+        return slab
 
     def _timed(self, tag, fn, *args, **kw):
         """Launch `fn`; when profiling is on, bracket it with events on the launching (current) stream."""
@@ -448,11 +459,14 @@ class Generator(nn.Module):
             ok = ok and hipops.conv_bf16_config(B, 1, up.in_channels, up.out_channels, L, up.kernel_size, 1, up.stride, io_bf16=3) is not None
             L *= up.stride
             C = up.out_channels
-            for rb in self.resblocks[i * nk:(i + 1) * nk]:
-                for c in rb.convs:
-                    if C in (16, 32):       # the fused narrow-stage kernel (v2w_stage_bf16.hip: V2W_SB_KMAX taps, halo <= 32)
-                        ok = ok and rb.kernel_size <= 11 and rb.kernel_size % 2 == 1 and c.dilation * (rb.kernel_size - 1) // 2 <= 32
-                    else:
+            rbs = self.resblocks[i * nk:(i + 1) * nk]
+            if C in (16, 32):       # the narrow stages exist as ONE fused kernel only: the library says whether it takes this block set
+                ok = ok and all(rb.kernel_size % 2 == 1 for rb in rbs) and hipops.resblock2_stage_split_ok(
+                    B, C, L, [rb.kernel_size for rb in rbs], [rb.convs[0].dilation for rb in rbs], [rb.convs[1].dilation for rb in rbs],
+                    slope=LRELU_SLOPE)
+            else:                   # a wide stage the one-kernel form declines runs conv by conv: every conv needs its bf16 tile kernel
+                for rb in rbs:
+                    for c in rb.convs:
                         ok = ok and rb.kernel_size % 2 == 1 and rb.kernel_size >= 3 and \
                             hipops.conv_bf16_config(B, 1, C, C, L, rb.kernel_size, c.dilation, 1, io_bf16=3) is not None
         self._fold_key['bf16_storage_ok'] = (key, bool(ok))
@@ -552,8 +566,9 @@ class Generator(nn.Module):
             y = None
             # ---- K1: conv_pre (no activation in front of it)
             cur = self._buf('act.pre', (B, c0, T), dtype=adt, device=dev)
+            slab = self._slab(dev)
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
-                        slope=1.0, **ck('conv_pre', io=2))        # (the latents arrive as fp32)
+                        slope=1.0, splitk_ws=slab, **ck('conv_pre', io=2))        # (the latents arrive as fp32)
             L = T
             for i in range(ns):
                 up = self.ups[i]
@@ -584,7 +599,7 @@ class Generator(nn.Module):
                     raise RuntimeError(f'bf16 storage: ups.{i} has no bf16 kernel (set generator.bf16_storage = False)')
                 else:
                     self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
-                                u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part)
+                                u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part, splitk_ws=slab)
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 if training:
                     if nt_stats:
@@ -618,7 +633,7 @@ class Generator(nn.Module):
                     def launch(tag_sfx, probs):
                         probs = [probs[j] for j in heavy_first if j in probs]
                         tag = '+'.join(f'{names[j]}.{tag_sfx}' for j, _ in probs)
-                        self._timed(tag, hipops.conv1d_multi, [pr for _, pr in probs])
+                        self._timed(tag, hipops.conv1d_multi, [pr for _, pr in probs], splitk_ws=slab)
 
                     def final_kw(j):
                         if j < nk - 1:
@@ -760,9 +775,9 @@ class Generator(nn.Module):
                         if isinstance(rb, ResBlock2):
                             c1, c2 = rb.convs[0], rb.convs[1]
                             self._timed(name + '.0', hipops.conv1d, xr, wf[name + '.convs.0'], c1.bias.detach(), t1, k=k,
-                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, **ck(name + '.convs.0'))
+                                        dil=c1.dilation, slope=LRELU_SLOPE, in_affine=aff, res=xr, res_affine=aff, splitk_ws=slab, **ck(name + '.convs.0'))
                             self._timed(name + '.1', hipops.conv1d, t1, wf[name + '.convs.1'], c2.bias.detach(), xs, k=k,
-                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, **ck(name + '.convs.1'), **last)
+                                        dil=c2.dilation, slope=LRELU_SLOPE, res=t1, splitk_ws=slab, **ck(name + '.convs.1'), **last)
                         else:
                             xa = self._buf(f'act.xa_{i}', (B, C, Lo), device=dev)
                             xb = self._buf(f'act.xb_{i}', (B, C, Lo), device=dev)
@@ -771,10 +786,10 @@ class Generator(nn.Module):
                             for n in range(3):
                                 c1, c2 = rb.convs1[n], rb.convs2[n]
                                 self._timed(f'{name}.{2 * n}', hipops.conv1d, src, wf[f'{name}.convs1.{n}'], c1.bias.detach(), t1,
-                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, **ck(f'{name}.convs1.{n}'))
+                                            k=k, dil=c1.dilation, slope=LRELU_SLOPE, in_affine=src_aff, splitk_ws=slab, **ck(f'{name}.convs1.{n}'))
                                 extra = last if n == 2 else {}
                                 self._timed(f'{name}.{2 * n + 1}', hipops.conv1d, t1, wf[f'{name}.convs2.{n}'], c2.bias.detach(),
-                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, **ck(f'{name}.convs2.{n}'), **extra)
+                                            dsts[n], k=k, dil=1, slope=LRELU_SLOPE, res=src, res_affine=src_aff, splitk_ws=slab, **ck(f'{name}.convs2.{n}'), **extra)
                                 src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
