@@ -246,10 +246,13 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             if staged and precision != 'f32':
                 # launch_wide configurations (v2w_stage_bf16_wide.hip; the trailing 'false, true': fragments through registers, the generator's
                 # own (k, dilation) set at compile time); C = 16 runs there only with the fused tail (fuse_post)
-                wide = {128: '<1, 4, 4, 2, 2, 32, false, true>', 64: '<2, 2, 1, 4, 2, 32, false, true>', 256: '<1, 4, 8, 1, 2, 32, false, true>',
-                        32: '<1, 4, 1, 2, 2, 32, false, true>'}
+                upf = 0                                      # the next stage's upsampler fused behind the stage (Generator.fuse_up): its stride
+                if names[-1].startswith('ups.'):
+                    upf = layers[names[-1]]['u']
+                wide = {128: f'<1, 4, 4, 2, 2, 32, false, true, {upf}>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}>',
+                        256: f'<1, 4, 8, 1, 2, 32, false, true, {upf}>', 32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}>'}
                 if names[-1] == 'conv_post':
-                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false>'
+                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false, 0>'
                 if ls[0]['cout'] == 16 and 16 not in wide and ls[0]['L'] % 4 == 0:
                     wide[16] = None                          # the reference's block set on 16 channels: v2w_stage_bf16_n16.hip
                 kname = (('n16_stage_kernel<4>' if wide[ls[0]['cout']] is None else 'wide_stage_bf16_kernel' + wide[ls[0]['cout']])
@@ -263,6 +266,9 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             nbytes = 2 * act + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
             if names[-1] == 'conv_post':          # the fused tail: the stage's output is not written, the fp32 audio is
                 nbytes += B * ls[0]['L'] * 4 - act
+            if names[-1].startswith('ups.'):      # the fused upsampler: the stage's output is not written, the next stage's input is
+                lu = ls[-1]
+                nbytes = act + B * lu['cout'] * lu['L'] * lu['u'] * act_bytes + sum(l['cin'] * l['cout'] * l['k'] * 4 for l in ls)
         launches[tag] = dict(kernel=kname, flops=sum(l['flops'] for l in ls), bytes=nbytes,
                              t=mean(ts), conv=all(l['name'] != 'conv_post' for l in ls))
     groups = {}

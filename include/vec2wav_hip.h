@@ -241,12 +241,24 @@ typedef struct {
     const float* post_w; const float* post_b; float* post_out;
     int32_t post_k;
     float post_slope;
+    /* optional fused UPSAMPLER of the next stage (ABI v28; bf16 != 0, io_bf16 == 3, the reference's block set k = (3, 7, 11), dilations (1, 3);
+     * models.py:128-129): when up_out != NULL the kernel does not write `out` (it may be NULL) but
+     *   up_out (B, C / 2, up_u L) bf16 = ConvTranspose1d(leaky_relu(stage output, up_slope); up_k = 2 up_u taps, stride up_u, padding up_u / 2) + up_bias
+     * and, when up_stats_part != NULL, the BatchNorm partial sums of those fp32 values as v2w_convt1d_bf16_fwd writes them
+     * ([v2w_resblock2_stage_up_tiles()][C / 2][2], for v2w_bn_reduce_partials).  up_wps: the fragments of v2w_pack_bf16_convt(k = up_k, C, C / 2,
+     * up_u).  Served: (C, up_u) = (256, 4), (128, 4), (64, 2), (32, 2); V2W_E_SHAPE otherwise (run the stage and v2w_convt1d_bf16_fwd). */
+    const void* up_wps; const float* up_bias; void* up_out; float* up_stats_part;
+    int32_t up_k, up_u;
+    float up_slope;
+    int32_t _pad;
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 /* Shape query (ABI v28; host-only, nothing is launched or dereferenced): 0 when the call above would run this stage as one kernel, else the
  * code it would return.  Read: B, C, L, nk, k, dil1, dil2, bf16, io_bf16, slope, post_* and the ALIGNMENT of `in` / `out` when they are set
  * (NULL tensor and weight pointers count as aligned). */
 int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a);
+/* Rows of up_stats_part a call with the fused upsampler (up_u != 0) fills; <= 0: that call would not run fused.  Host-only, as above. */
+int v2w_resblock2_stage_up_tiles(const v2w_stage_split_args* a);
 
 /* ---- the residual convolutions of a WIDE ResBlock2 stage (C % 64 == 0) on bf16 tensors (BASELINE configs[2]: bf16 compute / fp32
  * accumulate, bf16 activation storage), one launch per conv position of the block instead of one per branch group
@@ -331,6 +343,21 @@ typedef struct {
     int32_t n_stages, B, spk_dim, noise_dim, training;
 } v2w_cond_args;
 int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream);
+/* The spectral-norm half alone (ABI v28): sigma_ws[i] = u_i . (W_i v_i) of every stage (training != 0: after the power iteration, u / v
+ * updated in place).  Read: sn_w, sn_u, sn_v, C, n_stages, training, sigma_ws.  In eval mode sigma is a function of the parameters only. */
+int v2w_cond_sigma(const v2w_cond_args* a, void* stream);
+/* Eval mode (ABI v28), one launch for every stage: from (spk, noise) straight to the folded per-sample affine of the Conditional BatchNorm
+ * with its RUNNING statistics (modules.py:20-30 in eval; models.py:131-133):  z = fcs[i](cat(spk, noise)),
+ * [gamma | beta] = (W_i z) / sigma_ws[i] + b_i,  a_out[i][b][c] = gamma / sqrt(running_var[i][c] + eps[i]),
+ * s_out[i][b][c] = beta - a_out * running_mean[i][c].  c.sigma_ws must hold v2w_cond_sigma's result for the current parameters;
+ * c.gb / c.z_ws / c.sn_u / c.sn_v are not used.  Replaces v2w_cond_gamma_beta + n_stages x v2w_bn_finalize(training = 0). */
+typedef struct {
+    v2w_cond_args c;
+    const float* running_mean[V2W_MAX_STAGES]; const float* running_var[V2W_MAX_STAGES];
+    float* a_out[V2W_MAX_STAGES]; float* s_out[V2W_MAX_STAGES];
+    float eps[V2W_MAX_STAGES];
+} v2w_cond_eval_args;
+int v2w_cond_affine_eval(const v2w_cond_eval_args* e, void* stream);
 
 /* ---- K4: BatchNorm1d(affine=False) statistics and finalisation (modules.py:14,23).
  * v2w_bn_stats   : x (B,C,L) -> stats[2C] doubles = [sum_c | sumsq_c] over (B,L); deterministic two-level

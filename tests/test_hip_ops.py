@@ -454,6 +454,59 @@ def test_resblock2_wide_stage_bf16_storage(dev, B, C, L):
     assert err.mean().item() <= 4e-3
 
 
+@pytest.mark.parametrize('B,C,L,u', [(2, 128, 512, 4), (3, 128, 1004, 4), (1, 128, 20, 4), (2, 64, 1024, 2), (3, 64, 2000, 2), (2, 256, 256, 4),
+                                     (3, 256, 500, 4), (2, 32, 2000, 2), (3, 32, 4100, 2), (1, 32, 24, 2), (1, 64, 4, 2)])
+@pytest.mark.parametrize('with_stats', [True, False])
+def test_resblock2_wide_stage_with_the_next_upsampler_fused(dev, B, C, L, u, with_stats):
+    """resblock2_stage_split(up=...): the ResBlock2 section of a stage AND the next stage's leaky_relu -> ConvTranspose1d(2u, u) + bias
+    (models.py:135-141, then 128-129 of the following loop iteration) in one kernel, the stage's output never stored.  Against fp64 math
+    on the same bf16 operands - the transposed conv's operand is bf16(lrelu(stage output)), ONE rounding of the fp32 value - to the
+    rounding of the bf16 store; the BatchNorm partial sums (from the fp32 values) against the sums of the reference; tiles that straddle
+    the sequence ends, ragged tile counts, sequences shorter than a tile."""
+    from wavthruvec_pytorch_amd import hipops
+    g = torch.Generator().manual_seed(300 + C + L)
+    ks, d1, d2 = [3, 7, 11], [1, 1, 1], [3, 3, 3]
+    x = torch.randn(B, C, L, generator=g).bfloat16()
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    ku, cu = 2 * u, C // 2
+    wu = torch.randn(C, cu, ku, generator=g) / (C * ku / u) ** 0.5
+    bu = 0.3 * torch.randn(cu, generator=g)
+    stage, _ = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, True)
+    z = F.leaky_relu(stage.float(), 0.1).bfloat16().double()
+    want = F.conv_transpose1d(z, wu.bfloat16().double(), bu.double(), stride=u, padding=(ku - u) // 2)
+    br = [dict(wps1=hipops.pack_split(w1[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b1=b1[j].to(dev),
+               wps2=hipops.pack_split(w2[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b2=b2[j].to(dev),
+               k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(3)]
+    wpu = hipops.pack_bf16_convt(wu.permute(2, 0, 1).contiguous().to(dev), u)
+    assert wpu is not None
+    nt = hipops.resblock2_stage_up_tiles(B, C, L, ks, d1, d2, slope=0.1, up_k=ku, up_u=u, up_slope=0.1)
+    assert nt > 0, 'the library declined a fused shape it is built for'
+    out = torch.full((B, cu, L * u), float('nan'), device=dev, dtype=torch.bfloat16)
+    part = torch.full((nt * cu * 2,), float('nan'), device=dev) if with_stats else None
+    ok = hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, None, slope=0.1, out_div=3.0, bf16=True, io_bf16=3,
+                                      up=(wpu, bu.to(dev), out, part, ku, u, 0.1))
+    assert ok
+    assert torch.isfinite(out.float()).all(), 'positions left unwritten'
+    err = (out.cpu().double() - want).abs()
+    # a bf16 flip of one operand element (the fp32 stage value sits on a rounding boundary) moves an output by ~2^-9 |z| |w|
+    assert (err <= 2.0 ** -8 * want.abs() + 3e-2).all(), f'max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    assert err.mean().item() <= 5e-3
+    if with_stats:
+        assert torch.isfinite(part).all()
+        sums = part.view(nt, cu, 2).double().sum(0).cpu()
+        n = B * L * u
+        assert (sums[:, 0] - want.sum((0, 2))).abs().max().item() <= 5e-3 * n ** 0.5 + 1e-3 * want.sum((0, 2)).abs().max().item()
+        assert (sums[:, 1] - (want * want).sum((0, 2))).abs().max().item() <= 2e-3 * (want * want).sum((0, 2)).max().item()
+    # shapes the fused form does not exist for are declined by the query (the caller then runs the two kernels)
+    assert hipops.resblock2_stage_up_tiles(B, C, L, ks, d1, d2, slope=0.1, up_k=11, up_u=5, up_slope=0.1) == 0
+    assert hipops.resblock2_stage_up_tiles(B, C, L, [3, 5, 7], d1, d2, slope=0.1, up_k=ku, up_u=u, up_slope=0.1) == 0
+
+
 @pytest.mark.parametrize('ks,d1,d2', [([3, 7, 11], [1, 1, 1], [3, 3, 3]), ([5], [2], [1]), ([3, 5, 7, 9], [1, 3, 1, 4], [2, 1, 5, 1])])
 @pytest.mark.parametrize('B,L,affine', [(2, 1000, True), (3, 1, True), (1, 473, False), (2, 2051, True)])
 def test_resblock2_stage_small_8_channels(dev, B, L, affine, ks, d1, d2):
@@ -813,6 +866,58 @@ def test_cond_gamma_beta(dev, training):
         assert (gb[i].cpu() - want_gb[i]).abs().max().item() <= 2e-5 * max(1.0, scale)
         assert (sn_u[i].cpu() - want_u[i]).abs().max().item() <= 1e-6
         assert (sn_v[i].cpu() - want_v[i]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_cond_affine_eval_one_launch(dev, B):
+    """Eval mode: v2w_cond_sigma (once per weight version) + v2w_cond_affine_eval (ONE launch per forward, every stage) == the oracle's
+    fcs -> spectral-norm Linear -> eval-mode BatchNorm affine folded into (a, s) (models.py:120,131-133, modules.py:20-30), and == the
+    three-launch v2w_cond_gamma_beta + five v2w_bn_finalize(training = 0) path it replaces; u / v untouched."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(61)
+    Cs = [256, 128, 64, 32, 16, 8]
+    spk = r.standard_normal((B, 192), dtype=np.float32)
+    nz = r.standard_normal((B, 192), dtype=np.float32)
+    spk_noise = torch.from_numpy(np.concatenate([spk, nz], 1)).double()
+    fc_w, fc_b, sn_w, sn_b, sn_u, sn_v, rms, rvs, want_a, want_s = [], [], [], [], [], [], [], [], [], []
+    for C in Cs:
+        fw = (r.standard_normal((128, 384)) / np.sqrt(384)).astype(np.float32)
+        fb = (0.1 * r.standard_normal(128)).astype(np.float32)
+        w = (1 + 0.02 * r.standard_normal((2 * C, 128))).astype(np.float32)
+        b = (0.1 * r.standard_normal(2 * C)).astype(np.float32)
+        u = r.standard_normal(2 * C); u = (u / np.linalg.norm(u)).astype(np.float32)
+        v = r.standard_normal(128); v = (v / np.linalg.norm(v)).astype(np.float32)
+        rm = (0.3 * r.standard_normal(C)).astype(np.float32)
+        rv = r.uniform(0.3, 2.0, C).astype(np.float32)
+        z = F.linear(spk_noise, torch.from_numpy(fw).double(), torch.from_numpy(fb).double())
+        w_sn, _u2, _v2 = O.spectral_norm_weight(torch.from_numpy(w).double(), torch.from_numpy(u).double(), torch.from_numpy(v).double(), False)
+        gbw = F.linear(z, w_sn, torch.from_numpy(b).double())
+        rstd = 1.0 / torch.sqrt(torch.from_numpy(rv).double() + 1e-5)
+        aw = gbw[:, :C] * rstd
+        want_a.append(aw); want_s.append(gbw[:, C:] - aw * torch.from_numpy(rm).double())
+        fc_w.append(_t(fw, dev)); fc_b.append(_t(fb, dev)); sn_w.append(_t(w, dev)); sn_b.append(_t(b, dev))
+        sn_u.append(_t(u, dev)); sn_v.append(_t(v, dev)); rms.append(_t(rm, dev)); rvs.append(_t(rv, dev))
+    n = len(Cs)
+    u0 = [t.clone() for t in sn_u]
+    sg = torch.full((n,), float('nan'), device=dev)
+    hipops.cond_sigma(sn_w, sn_u, sn_v, sg, training=False)
+    a_out = [torch.full((B, C), float('nan'), device=dev) for C in Cs]
+    s_out = [torch.full((B, C), float('nan'), device=dev) for C in Cs]
+    hipops.cond_affine_eval(_t(spk, dev), _t(nz, dev), fc_w, fc_b, sn_w, sn_b, sg, rms, rvs, [1e-5] * n, a_out, s_out)
+    assert all(torch.equal(a, b) for a, b in zip(sn_u, u0))
+    # the path it replaces
+    gb = [torch.empty((B, 2 * C), device=dev) for C in Cs]
+    z_ws = torch.empty((n * B * 128,), device=dev)
+    sg2 = torch.empty((n,), device=dev)
+    hipops.cond_gamma_beta(_t(spk, dev), _t(nz, dev), fc_w, fc_b, sn_w, sn_b, sn_u, sn_v, gb, z_ws, sg2, False)
+    assert torch.equal(sg, sg2)
+    for i, C in enumerate(Cs):
+        a2, s2 = torch.empty((B, C), device=dev), torch.empty((B, C), device=dev)
+        hipops.bn_finalize(None, gb[i], rms[i], rvs[i], None, a2, s2, training=False, eps=1e-5)
+        sc = max(1.0, want_a[i].abs().max().item(), want_s[i].abs().max().item())
+        assert (a_out[i].cpu().double() - want_a[i]).abs().max().item() <= 2e-5 * sc
+        assert (s_out[i].cpu().double() - want_s[i]).abs().max().item() <= 2e-5 * sc
+        assert (a_out[i] - a2).abs().max().item() <= 2e-6 * sc and (s_out[i] - s2).abs().max().item() <= 2e-6 * sc
 
 
 @pytest.mark.parametrize('B,C,L', [(3, 256, 250), (2, 16, 100000), (1, 32, 1), (4, 64, 4097)])

@@ -120,7 +120,18 @@ def child_stage(C, variant):
                wps2=hipops.pack_split(torch.randn(k, C, C, device=dev) / (C * k) ** 0.5, bf16=True), b2=torch.zeros(C, device=dev),
                k=k, dil1=1, dil2=3) for k in ks]
     out = torch.empty_like(x)
-    run = lambda: hipops.resblock2_stage_split(x, (a, s), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
+    fused_up = os.environ.get('V2W_TL_UP') and C >= 32           # the stage with the next upsampler behind it (stride 4 after C >= 128, else 2)
+    if fused_up:
+        u = 4 if C >= 128 else 2
+        wpu = hipops.pack_bf16_convt(torch.randn(2 * u, C, C // 2, device=dev) / (C * 2) ** 0.5, u)
+        nt = hipops.resblock2_stage_up_tiles(B, C, L, ks, [1, 1, 1], [3, 3, 3], slope=0.1, up_k=2 * u, up_u=u, up_slope=0.1)
+        assert nt > 0
+        uout = torch.empty((B, C // 2, L * u), device=dev, dtype=torch.bfloat16)
+        part = torch.empty((nt * (C // 2) * 2,), device=dev)
+        run = lambda: hipops.resblock2_stage_split(x, (a, s), br, None, slope=0.1, out_div=3.0, bf16=True, io_bf16=3,
+                                                   up=(wpu, torch.zeros(C // 2, device=dev), uout, part, 2 * u, u, 0.1))
+    else:
+        run = lambda: hipops.resblock2_stage_split(x, (a, s), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
     assert run()
     fl = 2 * 2.0 * C * C * sum(ks) * L * B
     for _ in range(3):
@@ -170,6 +181,9 @@ def child_stage(C, variant):
         iss = k * nch * 2 * mi * ni * 32
         print(f'    branch {j} (k={k}): init {d(3 + 6 * j, 2 if j == 0 else 8 + 6 * (j - 1))}  conv1 {d(4 + 6 * j, 3 + 6 * j)} (issue alone {iss})  barrier {d(5 + 6 * j, 4 + 6 * j)}  '
               f't1 {d(6 + 6 * j, 5 + 6 * j)}  barrier {d(7 + 6 * j, 6 + 6 * j)}  conv2 {d(8 + 6 * j, 7 + 6 * j)}')
+    if fused_up:
+        print(f'    barrier {d(27, 20)}  z tile + barrier {d(21, 27)}  upsampler conv {d(22, 21)}  epilogue + stats {d(23, 22)}   tile total {d(23, 0)}')
+        return
     print(f'    barrier {d(27, 20)}  store {d(28, 27)}')
     clk = (t[:, 0, 28] - t[:, 0, 0])
     print(f'    clock: kernel {us:.1f} us; tiles per CU {t.shape[0] / 256:.2f}; sum of tile cycles per CU / kernel time = {np.sum(clk) / 256 / us / 1e3:.2f} GHz-equivalent')

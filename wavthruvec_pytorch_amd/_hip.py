@@ -70,7 +70,9 @@ class StageSplitArgs(C.Structure):
                 ('k', _I4), ('dil1', _I4), ('dil2', _I4), ('out', _fp),
                 ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
                 ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32),
-                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float)]
+                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float),
+                ('up_wps', _fp), ('up_bias', _fp), ('up_out', _fp), ('up_stats_part', _fp),
+                ('up_k', C.c_int32), ('up_u', C.c_int32), ('up_slope', C.c_float), ('_pad', C.c_int32)]
 
 
 class BranchConvsArgs(C.Structure):
@@ -94,6 +96,11 @@ class CondArgs(C.Structure):
                 ('gb', _PA), ('C', C.c_int32 * V2W_MAX_STAGES), ('z_ws', _fp), ('sigma_ws', _fp),
                 ('n_stages', C.c_int32), ('B', C.c_int32), ('spk_dim', C.c_int32), ('noise_dim', C.c_int32),
                 ('training', C.c_int32)]
+
+
+class CondEvalArgs(C.Structure):
+    _fields_ = [('c', CondArgs), ('running_mean', _PA), ('running_var', _PA), ('a_out', _PA), ('s_out', _PA),
+                ('eps', C.c_float * V2W_MAX_STAGES)]
 
 
 # name -> (restype, argtypes); must list every symbol include/vec2wav_hip.h declares
@@ -131,6 +138,7 @@ SIGNATURES = {
     'v2w_split_packable': (C.c_int, [C.c_int, C.c_int]),
     'v2w_resblock2_stage_split_fwd': (C.c_int, [C.POINTER(StageSplitArgs), _fp]),
     'v2w_resblock2_stage_split_config': (C.c_int, [C.POINTER(StageSplitArgs)]),
+    'v2w_resblock2_stage_up_tiles': (C.c_int, [C.POINTER(StageSplitArgs)]),
     'v2w_pack_bf16': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
@@ -153,6 +161,8 @@ SIGNATURES = {
     'v2w_conv1d_bf16_config': (C.c_int, [C.POINTER(Conv1dArgs), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_convt1d_bf16_config': (C.c_int, [C.POINTER(ConvT1dArgs), C.POINTER(C.c_int32)]),
     'v2w_cond_gamma_beta': (C.c_int, [C.POINTER(CondArgs), _fp]),
+    'v2w_cond_sigma': (C.c_int, [C.POINTER(CondArgs), _fp]),
+    'v2w_cond_affine_eval': (C.c_int, [C.POINTER(CondEvalArgs), _fp]),
     'v2w_bn_stats': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),
     'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,

@@ -105,6 +105,58 @@ cond_linear_kernel(const v2w_cond_args a) {
     }
 }
 
+// ---- eval mode, everything between (spk, noise) and the per-sample affine of EVERY stage in one launch (models.py:120,131 + modules.py:20-30
+// with the BatchNorm in eval mode): z = fcs[s](cat(spk, noise)), [gamma | beta] = (W z) / sigma + b, a = gamma * rstd(running_var),
+// s = beta - a * running_mean.  sigma_ws[s] = u . (W v) is a function of the parameters alone: v2w_cond_sigma computes it once per weight
+// version.  Grid (B, n_stages, channel groups of 32): a block recomputes z (128 x D MACs) and takes rows c and C + c of its 32 channels.
+__global__ void __launch_bounds__(256)
+cond_affine_eval_kernel(const v2w_cond_eval_args e) {
+    extern __shared__ float sn[];                  // cat(spk[b], noise[b])  [D]
+    __shared__ float z_s[128];
+    __shared__ float gbl[64];
+    const v2w_cond_args& a = e.c;
+    const int b = blockIdx.x, s = blockIdx.y, C = a.C[s];
+    const int cg = blockIdx.z * 32;
+    if (cg >= C) return;
+    const int D = a.spk_dim + a.noise_dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < D; i += 256)
+        sn[i] = i < a.spk_dim ? a.spk[(size_t)b * a.spk_dim + i] : a.noise[(size_t)b * a.noise_dim + (i - a.spk_dim)];
+    __syncthreads();
+    if (!a.fc_w[s]) {
+        if (tid < 128) z_s[tid] = sn[tid];
+    } else {
+        for (int j = wave; j < 128; j += 4) {      // one wave per output row: coalesced reads of the row, fixed-order wave sum
+            const float* w = a.fc_w[s] + (size_t)j * D;
+            float p = 0.f;
+            for (int i = lane; i < D; i += 64) p = fmaf(w[i], sn[i], p);
+            p = v2w_wave_sum(p);
+            if (lane == 0) z_s[j] = p + a.fc_b[s][j];
+        }
+    }
+    __syncthreads();
+    const float sigma = a.sigma_ws[s];
+    const float* W = a.sn_w[s];
+    const float z0 = z_s[lane], z1 = z_s[64 + lane];
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int c = cg + (rr & 31);
+        if (c >= C) continue;
+        const int r = (rr >> 5) * C + c;
+        float p = W[(size_t)r * 128 + lane] * z0 + W[(size_t)r * 128 + 64 + lane] * z1;
+        p = v2w_wave_sum(p);
+        if (lane == 0) gbl[rr] = p / sigma + a.sn_b[s][r];
+    }
+    __syncthreads();
+    if (tid < 32 && cg + tid < C) {
+        const int c = cg + tid;
+        const double mean = (double)e.running_mean[s][c], var = (double)e.running_var[s][c];
+        const float rstd = (float)(1.0 / sqrt(var + (double)e.eps[s]));
+        const float av = gbl[tid] * rstd;
+        e.a_out[s][(size_t)b * C + c] = av;
+        e.s_out[s][(size_t)b * C + c] = fmaf(-av, (float)mean, gbl[32 + tid]);
+    }
+}
+
 // ---- per-channel partial sums; grid (V2W_BN_SPLITS, C); each block covers a slice of L for every batch item: its four waves
 // take batch items round-robin (a slice may be as short as 64 positions), 64 lanes along the slice
 __global__ void __launch_bounds__(256)
@@ -234,6 +286,38 @@ extern "C" int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream) {
     hipLaunchKernelGGL(cond_fc_kernel, dim3(a->B, a->n_stages), dim3(128), lds_fc, st, *a);
     hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), st, *a);
     hipLaunchKernelGGL(cond_linear_kernel, dim3(a->B, a->n_stages, (maxR + 63) / 64), dim3(256), 0, st, *a);
+    return v2w_launch_status();
+}
+
+// sigma_ws[s] = u_s . (W_s v_s) of every stage (training != 0: after one power iteration, u and v updated in place) - the spectral-norm half
+// of v2w_cond_gamma_beta alone.  In eval mode sigma depends on the parameters only: call it once per weight version.
+extern "C" int v2w_cond_sigma(const v2w_cond_args* a, void* stream) {
+    if (!a || !a->sigma_ws || a->n_stages <= 0 || a->n_stages > V2W_MAX_STAGES) return V2W_E_ARG;
+    int maxR = 0;
+    for (int s = 0; s < a->n_stages; ++s) {
+        if (!a->sn_w[s] || !a->sn_u[s] || !a->sn_v[s] || a->C[s] <= 0) return V2W_E_ARG;
+        if (2 * a->C[s] > maxR) maxR = 2 * a->C[s];
+    }
+    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), (hipStream_t)stream, *a);
+    return v2w_launch_status();
+}
+
+extern "C" int v2w_cond_affine_eval(const v2w_cond_eval_args* e, void* stream) {
+    if (!e) return V2W_E_ARG;
+    const v2w_cond_args* a = &e->c;
+    if (!a->spk || (!a->noise && a->noise_dim > 0) || !a->sigma_ws) return V2W_E_ARG;
+    if (a->spk_dim <= 0 || a->noise_dim < 0 || a->n_stages <= 0 || a->n_stages > V2W_MAX_STAGES || a->B <= 0) return V2W_E_ARG;
+    int maxC = 0;
+    for (int s = 0; s < a->n_stages; ++s) {
+        if ((a->fc_w[s] == nullptr) != (a->fc_b[s] == nullptr)) return V2W_E_ARG;
+        if (!a->fc_w[s] && a->spk_dim + a->noise_dim != 128) return V2W_E_SHAPE;
+        if (!a->sn_w[s] || !a->sn_b[s] || a->C[s] <= 0) return V2W_E_ARG;
+        if (!e->running_mean[s] || !e->running_var[s] || !e->a_out[s] || !e->s_out[s]) return V2W_E_ARG;
+        if (a->C[s] > maxC) maxC = a->C[s];
+    }
+    const size_t lds = (size_t)(a->spk_dim + a->noise_dim) * sizeof(float);
+    if (lds > 48 * 1024) return V2W_E_SHAPE;
+    hipLaunchKernelGGL(cond_affine_eval_kernel, dim3(a->B, a->n_stages, (maxC + 31) / 32), dim3(256), lds, (hipStream_t)stream, *e);
     return v2w_launch_status();
 }
 

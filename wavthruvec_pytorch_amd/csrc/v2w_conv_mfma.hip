@@ -707,7 +707,9 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     if (epi == 0 && grid <= 128) {
         const int nch = m.p[0].Cin / CK;
         int s2 = 1;
-        while (s2 * 2 <= 8 && nch % (s2 * 2) == 0 && grid * s2 * 2 <= 512) s2 *= 2;
+        // (a launch whose serial chain is short - fewer than 24 (chunk, tap) steps: the narrow upsamplers, 64-channel convs - gains less
+        // from the split than the reduce launch behind it costs)
+        while (s2 * 2 <= 8 && nch % (s2 * 2) == 0 && grid * s2 * 2 <= 512 && nch * m.p[0].K >= 24) s2 *= 2;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         size_t floats = 0;
         bool ok = s2 > 1, vec = true;

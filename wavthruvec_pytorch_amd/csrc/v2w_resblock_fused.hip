@@ -767,7 +767,13 @@ extern "C" int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream) {
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (a->C == 32) return launch_stage<32, 2, 4>(a, st);
-    if (a->C == 16) return launch_stage<16, 4, 4>(a, st);
+    // latency sizes (inference at B = 1: fewer windows of 256 positions than CUs - a tile's six convs run one after the other on a
+    // quarter of the chip): windows of 128 positions, twice the workgroups for 23 % more halo work
+    int h2max = 0;
+    for (int j = 0; j < a->nk; ++j) { const int h2 = a->dil2[j] * (a->k[j] - 1) / 2; if (h2 > h2max) h2max = h2; }
+    const int nto = (256 - 2 * h2max) & ~3;
+    const bool small = nto > 0 && (long long)a->B * ((a->L + nto - 1) / nto) < 224 && 128 - 2 * h2max >= 64;
+    if (a->C == 32) return small ? launch_stage<32, 1, 4>(a, st) : launch_stage<32, 2, 4>(a, st);
+    if (a->C == 16) return small ? launch_stage<16, 2, 4>(a, st) : launch_stage<16, 4, 4>(a, st);
     return V2W_E_SHAPE;
 }

@@ -439,11 +439,15 @@ int launch_stage_bf16(const v2w_stage_split_args* q, hipStream_t stream) {
 V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
 #endif
 
-int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16_wide.hip
+int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out = nullptr);   // v2w_stage_bf16_wide.hip
 int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
 
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
-int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream) {
+int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out) {
+    if (a->up_out) {        // the stage + the next upsampler in one kernel: the resident-tile template only (C = 32 .. 256 on bf16 tensors)
+        if (a->io_bf16 != 3 || a->C < 32) return V2W_E_SHAPE;
+        return v2w_resblock2_stage_bf16_wide(a, stream, up_tiles_out);
+    }
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
 #ifndef V2W_NO_N16
     if (a->C == 16 && a->io_bf16 == 3 && !a->post_out) {      // the reference's block set on aligned bf16 tensors: weights in registers

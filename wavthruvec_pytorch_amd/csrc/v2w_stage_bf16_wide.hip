@@ -58,6 +58,12 @@ struct WideArgs {
     const float* post_w; const float* post_b; float* post_out;
     int post_k, hout;
     float post_slope;
+    // fused upsampler (UPF > 0 instantiations): leaky_relu(up_slope) -> ConvTranspose1d(2 UPF taps, stride UPF, C -> C / 2) + bias of the stage's
+    // output (models.py:128-129 of the NEXT stage) with its BatchNorm partial sums; `out` is not written.  up_w: the virtual 3-tap fragments of
+    // v2w_pack_bf16_convt; up_out (B, C / 2, UPF L) bf16; up_stats [ntiles][C / 2][2] or NULL.  hout = 1: a column of the valid window per
+    // side feeds the taps only.
+    const unsigned char* up_w; const float* up_bias; unsigned short* up_out; float* up_stats;
+    float up_slope;
 };
 
 __device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
@@ -68,6 +74,20 @@ __device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
 __device__ __forceinline__ float ws_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float ws_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 __device__ __forceinline__ int ws_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int CTRL> __device__ __forceinline__ float ws_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float ws_readlane(float v, int l) {           // (the builtin is typed int: a float argument would be CONVERTED)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row (fixed order): quad xor 1, quad xor 2, half mirror, mirror
+__device__ __forceinline__ float ws_row_sum(float v) {
+    v += ws_dpp<0xB1>(v);
+    v += ws_dpp<0x4E>(v);
+    v += ws_dpp<0x141>(v);
+    v += ws_dpp<0x140>(v);
+    return v;
+}
 template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); return v; }
 
 // MI x NI blocks of 32 x 32 per wave, WM x WN waves: C = 32 MI WM channels, window W = 32 NI WN positions
@@ -82,12 +102,14 @@ template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); ret
 // STD: the kernel is compiled for the generator's own residual blocks - three branches of 3 / 7 / 11 taps, dilation 1 in the first convs and 3 in
 // the second (hparams.py:42-43 with ResBlock2) - with every tap count and dilation a compile-time constant (conv_ct below); the launcher
 // checks the arguments against it.  !STD: any branch count / kernel size / dilation at run time.
-template <int MI, int NI, int WM, int WN, int OCC, int CH, bool WLDS, bool STD>
+// UPF: 0, or the stride (2 / 4) of the NEXT stage's transposed conv, run here on the stage's output while it is still on chip (STD only)
+template <int MI, int NI, int WM, int WN, int OCC, int CH, bool WLDS, bool STD, int UPF = 0>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 wide_stage_bf16_kernel(const WideArgs a) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     static_assert(CH == 32 || (CH == 16 && MI == 1 && WM == 1), "16 channels: one row block");
+    static_assert(UPF == 0 || ((UPF == 2 || UPF == 4) && STD && CH == 32), "fused upsampler: the compile-time block set, strides 2 and 4");
     constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32;
     constexpr int RB = 2 * CH;                                                  // bytes of a tile row (one position of one plane)
     constexpr int KS = CH / 16;                                                 // k-steps per (plane, tap)
@@ -405,19 +427,23 @@ wide_stage_bf16_kernel(const WideArgs a) {
             arp[3][i] = *gptr<const u32x4>(ap + (K + 1) * V2W_WS_UNIT);
         }
     };
-    auto conv_ct = [&](auto k_c, auto d_c, auto pre_c, acc_t (&acc)[MI][NI], unsigned base, int psz, int r0, const unsigned char* wps) {
+    // (acc: [MIX][NI] blocks, row block i of this wave = block rb0 + i of the weight stream: MIX = MI, rb0 = wm0 / 32 for the stage's own
+    // convs; the fused upsampler runs UPF / 2 times as many row blocks per wave)
+    auto conv_ct = [&](auto k_c, auto d_c, auto pre_c, auto& acc, int rb0, unsigned base, int psz, int r0, const unsigned char* wps) {
         constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value;
         constexpr bool PRE = decltype(pre_c)::value;
+        constexpr int MIX = (int)std::extent<std::remove_reference_t<decltype(acc)>, 0>::value;
         static_assert(KS == 2 && K >= 2, "64-byte rows");
-        const unsigned char* ap[MI];
+        static_assert(!PRE || MIX == MI, "the prefetched fragments are the stage's own");
+        const unsigned char* ap[MIX];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) ap[i] = wps + (size_t)(wm0 / 32 + i) * (KS * NCH * K) * V2W_WS_UNIT;
-        u32x4 ar[4][MI];                                      // fragments of two taps: slots 2 (g & 1) + s for global tap g
+        for (int i = 0; i < MIX; ++i) ap[i] = wps + (size_t)(rb0 + i) * (KS * NCH * K) * V2W_WS_UNIT;
+        u32x4 ar[4][MIX];                                     // fragments of two taps: slots 2 (g & 1) + s for global tap g
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));
-        auto frag = [&](u32x4 (&av)[MI], int foff) {          // foff: (uniform) byte offset of the fragment inside a row block's stream
+        auto frag = [&](u32x4 (&av)[MIX], int foff) {         // foff: (uniform) byte offset of the fragment inside a row block's stream
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = *gptr<const u32x4>(ap[i] + foff + l16);
+            for (int i = 0; i < MIX; ++i) av[i] = *gptr<const u32x4>(ap[i] + foff + l16);
         };
         auto addr = [&](unsigned pbase, int row) { return pbase + (unsigned)(row * RB + ((hk ^ swz(row)) << 4)); };
         // fragment (plane ch, k-step s, tap t) of a row block sits at ((2 ch + s) K + t) units
@@ -425,7 +451,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) ar[q][i] = arp[q][i];
+                for (int i = 0; i < MIX; ++i) ar[q][i] = arp[q][i];
         } else {
             frag(ar[0], 0);
             frag(ar[1], K * V2W_WS_UNIT);
@@ -466,7 +492,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
 #pragma unroll
-                        for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], ar[sl + sq][i], bb[sq][j]);
+                        for (int i = 0; i < MIX; ++i) acc[i][j] = mfma(acc[i][j], ar[sl + sq][i], bb[sq][j]);
                         bb[sq][j] = *reinterpret_cast<const u32x4*>(smem_w + (sq ? (xn ^ 32u) : xn) + j * CB);
                     }
                     frag(ar[sl + sq], f2 + sq * K * V2W_WS_UNIT);
@@ -516,7 +542,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                     for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
             }
         V2W_STAMP(3 + 6 * jb);
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, PRE1>{}, acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, PRE1>{}, acc1, wm0 / 32, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
         else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
         V2W_STAMP(4 + 6 * jb);
         if constexpr (PRE2) conv_pre(k_c, ws_uni(a.w2[jb]));          // conv2_j's first fragments: in flight under the barrier and the epilogue
@@ -557,7 +583,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
         __syncthreads();
         V2W_STAMP(7 + 6 * jb);
         // ---- conv2_j on the same window, onto the running accumulator
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, std::integral_constant<bool, PRE2>{}, oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, std::integral_constant<bool, PRE2>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
         else conv(oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), K, d2);
         V2W_STAMP(8 + 6 * jb);
     };
@@ -599,6 +625,134 @@ wide_stage_bf16_kernel(const WideArgs a) {
         for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{}, std::false_type{});
     }
 
+    if constexpr (UPF > 0) {
+        // ---- the NEXT stage's upsampler on this tile, while the stage's output is on chip (models.py:128-129: leaky_relu -> ConvTranspose1d
+        // (2 UPF taps, stride UPF) + bias): z = lrelu(out / nk) goes into the dead t1 tile as bf16 rows - the transposed conv's operand, written
+        // like a t1 epilogue, no transposition - and the polyphase 3-tap conv over the UPF * C / 2 virtual rows (v2w_convt_bf16_res.hip) runs on
+        // it: the phases of a channel are adjacent accumulator registers of one lane, so the output leaves straight from the accumulators with
+        // the BatchNorm partial sums of the fp32 values.  The stage's own output never exists in memory: one tensor written and one tensor
+        // read less per stage, one launch less, no staging of the upsampler's input.
+        constexpr int MIU = MI * UPF / 2;                     // 32-row blocks of virtual rows per wave
+        constexpr int CPB = 32 / UPF, CU = C / 2;             // channels per 32-row block; real output channels
+        __syncthreads();                                      // conv2 of the last branch has read the t1 tile
+        V2W_STAMP(27);
+        float* const ubias = reinterpret_cast<float*>(smem_w + xbase);           // over the dead x tile: bias [C / 2], partial sums [WN][C / 2][2]
+        float* const ured = ubias + CU;
+        for (int c = tid; c < CU; c += NTH) ubias[c] = a.up_bias ? a.up_bias[c] : 0.f;
+        {
+            const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
+            const float uslope = a.up_slope;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn0 + lr;
+                    asm volatile("" : "+v"(col));
+                    col += 32 * j;
+                    const int pos = n0 - h2max + col;
+                    const bool in_seq = pos >= 0 && pos < L;  // the transposed conv sees the L positions of the sequence only
+                    const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + col * RB + 8 * hk);
+                    const int tsw = swz(col);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        float z[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            float v = oacc[i][j][4 * g + x];
+                            if (a.out_div != 0.f) v = v2w_div_by(v, a.out_div, dinv);
+                            z[x] = in_seq ? fmaxf(v, v * uslope) : 0.f;
+                        }
+                        *reinterpret_cast<u32x2*>(smem_w + tq + ((g ^ tsw) << 4)) = u32x2{ws_pack2(z[0], z[1]), ws_pack2(z[2], z[3])};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        __syncthreads();
+        V2W_STAMP(21);
+        acc_t uacc[MIU][NI];
+#pragma unroll
+        for (int i = 0; i < MIU; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) uacc[i][j][e] = 0.f;
+        // virtual tap tv reads input position q + tv - 1 (2 U taps at stride U: one input position of halo per side)
+        conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::false_type{}, uacc, (wm0 / 32) * (UPF / 2), tbase, tpsz,
+                wn0 + lr - 1, ws_uni(a.up_w));
+        V2W_STAMP(22);
+        // epilogue (as convt_bf16_res_kernel): block (i, j), register quad g, lane (lr, hk): virtual rows 32 i + 8 g + 4 hk + {0..3} at input
+        // position q.  UPF = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};  UPF = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1}
+        const int Lout = L * UPF;
+        const bool stats = a.up_stats != nullptr;
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * CU * Lout * 2;
+        const int cw0 = (wm0 / 32) * (UPF / 2) * CPB;         // first channel of this wave
+        const int ncen = nto - 2;                             // input positions this tile is the centre of: window columns h2max + 1 ..
+#pragma unroll
+        for (int i = 0; i < MIU; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                constexpr int NC = UPF == 2 ? 2 : 1;          // channels of a register quad
+                const int cl = UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk;
+                float bias[NC], s1[NC], s2[NC];
+#pragma unroll
+                for (int n = 0; n < NC; ++n) { bias[n] = ubias[cw0 + CPB * i + cl + n]; s1[n] = s2[n] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int col = wn0 + lr;
+                    asm volatile("" : "+v"(col));
+                    col += 32 * j;
+                    const int cc = col - h2max - 1;           // index among the tile's centres
+                    const int q = n0 + 1 + cc;
+                    const bool ok = cc >= 0 && cc < ncen && q < L;
+                    float v[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        v[x] = uacc[i][j][4 * g + x] + bias[UPF == 2 ? (x >> 1) : 0];
+                        if (!ok) v[x] = 0.f;
+                        s1[UPF == 2 ? (x >> 1) : 0] += v[x];
+                        s2[UPF == 2 ? (x >> 1) : 0] = fmaf(v[x], v[x], s2[UPF == 2 ? (x >> 1) : 0]);
+                    }
+                    if (ok) {
+                        const int c = cw0 + CPB * i + cl;
+                        if constexpr (UPF == 2) {
+                            *gptr<unsigned>(obase + (unsigned)(c * Lout + 2 * q) * 2u) = ws_pack2(v[0], v[1]);
+                            *gptr<unsigned>(obase + (unsigned)((c + 1) * Lout + 2 * q) * 2u) = ws_pack2(v[2], v[3]);
+                        } else {
+                            *gptr<u32x2>(obase + (unsigned)(c * Lout + 4 * q) * 2u) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
+                        }
+                    }
+                }
+                if (stats) {
+                    // the 32 lanes that share hk hold one channel's columns: DPP row sums, then the rows of a half (and the halves) in a fixed order
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) {
+                        const float r1 = ws_row_sum(s1[n]), r2 = ws_row_sum(s2[n]);
+                        const float a1 = ws_readlane(r1, 0) + ws_readlane(r1, 16);
+                        const float b1 = ws_readlane(r1, 32) + ws_readlane(r1, 48);
+                        const float a2 = ws_readlane(r2, 0) + ws_readlane(r2, 16);
+                        const float b2 = ws_readlane(r2, 32) + ws_readlane(r2, 48);
+                        float* rd = ured + ((wave % WN) * CU + cw0 + CPB * i) * 2;
+                        if constexpr (UPF == 4) {
+                            if (lane == 0) { rd[2 * (2 * g)] = a1; rd[2 * (2 * g) + 1] = a2; rd[2 * (2 * g + 1)] = b1; rd[2 * (2 * g + 1) + 1] = b2; }
+                        } else {
+                            if (lane == 0) { rd[2 * (4 * g + n)] = a1; rd[2 * (4 * g + n) + 1] = a2; rd[2 * (4 * g + 2 + n)] = b1; rd[2 * (4 * g + 2 + n) + 1] = b2; }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (stats) {
+            __syncthreads();
+            for (int c = tid; c < CU; c += NTH) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { t1 += ured[(w * CU + c) * 2]; t2 += ured[(w * CU + c) * 2 + 1]; }
+                gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 0] = t1;
+                gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 1] = t2;
+            }
+        }
+        V2W_STAMP(23);
+    } else {
     // ---- the nto valid columns (window columns h2max .. h2max + nto) through an fp32 scratch [C][W + 8] in the dead tiles, shifted so that
     // output position quads are 16-byte aligned (all waves: quads cross the waves' columns), then either the stage's output - 8-byte bf16
     // stores along positions - or, fused, the generator's tail on it
@@ -685,11 +839,12 @@ wide_stage_bf16_kernel(const WideArgs a) {
         }
     }
     V2W_STAMP(28);
+    }     // (UPF == 0)
     }
 }
 
-template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32, bool WLDS = false>
-int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
+template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32, bool WLDS = false, int UPF = 0>
+int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles_out = nullptr) {
     constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32, RB = 2 * CH;
     WideArgs p{};
     p.in = reinterpret_cast<const unsigned short*>(q->in); p.in_a = q->in_a; p.in_s = q->in_s;
@@ -709,6 +864,14 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
         if (reinterpret_cast<uintptr_t>(q->post_out) & 15) return V2W_E_SHAPE;
         p.post_w = q->post_w; p.post_b = q->post_b; p.post_out = q->post_out; p.post_k = q->post_k; p.post_slope = q->post_slope;
         p.hout = (q->post_k - 1) / 2;
+    } else if (UPF > 0) {                      // the fused upsampler: 2 U taps at stride U = UPF (one input position of halo per side), C -> C / 2
+        if (q->up_u != UPF || q->up_k != 2 * UPF || !q->up_wps || !q->up_out) return V2W_E_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(q->up_out) & 15) || (reinterpret_cast<uintptr_t>(q->up_wps) & 15)) return V2W_E_SHAPE;
+        if (!(q->up_slope > 0.f && q->up_slope <= 1.f)) return V2W_E_SHAPE;
+        if ((long long)(C / 2) * q->L * UPF * 2 >= (1ll << 31)) return V2W_E_SHAPE;      // 32-bit offsets inside one batch item
+        p.up_w = static_cast<const unsigned char*>(q->up_wps); p.up_bias = q->up_bias; p.up_out = reinterpret_cast<unsigned short*>(q->up_out);
+        p.up_stats = q->up_stats_part; p.up_slope = q->up_slope;
+        p.hout = 1;
     } else if (!q->out) return V2W_E_ARG;
     p.nto = (W - 2 * p.h2max) & ~3;
     if (p.hout) p.nto = ((W - 2 * p.h2max - 2 * p.hout) & ~3) + 2 * p.hout;     // the tile advances by nto - 2 hout: a multiple of 4
@@ -730,8 +893,11 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream) {
 #ifdef V2W_WS_NOCT
     std_cfg = false;
 #endif
-    auto kern = (std_cfg && CH == 32 && !WLDS) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, (CH == 32 && !WLDS)>
-                                               : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false>;
+    if (UPF > 0 && !std_cfg) return V2W_E_SHAPE;             // the fused upsampler exists for the compile-time block set only
+    if (up_tiles_out) *up_tiles_out = p.ntiles;              // rows of up_stats_part
+    constexpr bool STDK = CH == 32 && !WLDS;
+    auto kern = (std_cfg && STDK) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, STDK, (STDK ? UPF : 0)>
+                                  : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false, 0>;
     if (v2w_dry(stream)) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -749,12 +915,23 @@ V2W_TL_SETTER(v2w_timeline_set_wide)
 #endif
 
 // Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for C >= 64 on bf16 tensors.  V2W_E_SHAPE: the caller issues the convs one by one.
-int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream) {
+// up_tiles_out: receives the rows of up_stats_part of a fused-upsampler call.
+int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out) {
     if (a->io_bf16 != 3 || a->nk > V2W_WS_MAXB) return V2W_E_SHAPE;
     if (a->post_out && a->C != 16) return V2W_E_SHAPE;
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
     if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out)) return V2W_E_SHAPE;
     if ((long long)a->C * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;           // 32-bit offsets inside one batch item
+    if (a->up_out) {
+        // the stage with the next stage's upsampler behind it (stride 4 after the 256- and 128-channel stages, stride 2 after 64 and 32: the
+        // generator's (5, 4, 4, 2, 2) and the x640 variant's (8, 5, 4, 2, 2) from the second / third upsampler on)
+        if (a->post_out || V2W_WS_CFG != 0) return V2W_E_SHAPE;
+        if (a->C == 256 && a->up_u == 4) return launch_wide<1, 4, 8, 1, 2, 32, false, 4>(a, stream, up_tiles_out);
+        if (a->C == 128 && a->up_u == 4) return launch_wide<1, 4, 4, 2, 2, 32, false, 4>(a, stream, up_tiles_out);
+        if (a->C == 64 && a->up_u == 2) return launch_wide<2, 2, 1, 4, 2, 32, false, 2>(a, stream, up_tiles_out);
+        if (a->C == 32 && a->up_u == 2) return launch_wide<1, 4, 1, 2, 2, 32, false, 2>(a, stream, up_tiles_out);
+        return V2W_E_SHAPE;
+    }
     // Measured (one MI355X, configs[2] shapes, us per stage): 8 waves of 64 x 64 outputs 1074 / 1225 / 1133 (C = 128 / 64 / 256) against 4 waves of
     // 64 x 128 with the whole register file 1227 / 1467 / 1199: the single wave per SIMD runs its bare MFMA loop at 89 % of the issue rate
     // but nothing covers its epilogues.  C = 64 fits twice per CU as 4-wave workgroups of 256 positions, which run out of phase.

@@ -383,11 +383,15 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
 
 }  // namespace
 
-int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream);   // v2w_stage_bf16.hip
+int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out = nullptr);   // v2w_stage_bf16.hip
 
-extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream) {
-    if (!a || !a->in || (!a->out && !a->post_out) || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+static int stage_split_dispatch(const v2w_stage_split_args* a, void* stream, int* up_tiles_out) {
+    if (!a || !a->in || (!a->out && !a->post_out && !a->up_out) || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
     if (a->post_out && !(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;                 // the fused tail exists on the bf16-tensor path only
+    if (a->up_out) {                                                                       // ... and so does the fused upsampler
+        if (a->post_out) return V2W_E_ARG;
+        if (!(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;
+    }
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
     for (int j = 0; j < a->nk; ++j) {
@@ -395,14 +399,15 @@ extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
     }
     if (a->bf16) {     // bf16 operands: the weights-in-registers kernel of v2w_stage_bf16.hip; shapes it does not take fall through
-        const int rc = v2w_resblock2_stage_bf16(a, (hipStream_t)stream);
+        const int rc = v2w_resblock2_stage_bf16(a, (hipStream_t)stream, up_tiles_out);
         if (rc != V2W_E_SHAPE) return rc;
     }
-    if (a->io_bf16) return V2W_E_SHAPE;       // this file's kernels read and write fp32 only
+    if (a->io_bf16 || a->up_out) return V2W_E_SHAPE;       // this file's kernels read and write fp32 only
     if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
     if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
     return V2W_E_SHAPE;
 }
+extern "C" int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream) { return stage_split_dispatch(a, stream, nullptr); }
 
 // Shape query (ABI v28): 0 when v2w_resblock2_stage_split_fwd would run this stage as ONE kernel, V2W_E_SHAPE / V2W_E_ARG as the call itself
 // would answer.  Only the sizes (B, C, L, nk, k, dilations), the mode flags, slope and the ALIGNMENT of the tensor pointers that are set
@@ -413,12 +418,34 @@ extern "C" int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a) {
     v2w_stage_split_args q = *a;
     float* const dummy = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));     // aligned, never dereferenced
     if (!q.in) q.in = dummy;
-    if (!q.out && !q.post_out) q.out = dummy;
+    if (!q.out && !q.post_out && !q.up_u) q.out = dummy;
+    if (q.up_u) {                      // a fused-upsampler query: up_u / up_k / up_slope are read
+        if (!q.up_out) q.up_out = dummy;
+        if (!q.up_wps) q.up_wps = dummy;
+    }
     for (int j = 0; j < q.nk && j < V2W_SS_MAXB; ++j) {
         if (!q.wps1[j]) q.wps1[j] = dummy;
         if (!q.wps2[j]) q.wps2[j] = dummy;
         if (!q.sc1[j]) q.sc1[j] = dummy;
         if (!q.sc2[j]) q.sc2[j] = dummy;
     }
-    return v2w_resblock2_stage_split_fwd(&q, V2W_DRY_STREAM);
+    return stage_split_dispatch(&q, V2W_DRY_STREAM, nullptr);
+}
+// Rows of up_stats_part ([rows][C / 2][2]) a fused-upsampler call (up_u != 0) fills; <= 0: the call would not run fused (error code or 0)
+extern "C" int v2w_resblock2_stage_up_tiles(const v2w_stage_split_args* a) {
+    if (!a || !a->up_u) return 0;
+    v2w_stage_split_args q = *a;
+    float* const dummy = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));
+    if (!q.in) q.in = dummy;
+    if (!q.up_out) q.up_out = dummy;
+    if (!q.up_wps) q.up_wps = dummy;
+    for (int j = 0; j < q.nk && j < V2W_SS_MAXB; ++j) {
+        if (!q.wps1[j]) q.wps1[j] = dummy;
+        if (!q.wps2[j]) q.wps2[j] = dummy;
+        if (!q.sc1[j]) q.sc1[j] = dummy;
+        if (!q.sc2[j]) q.sc2[j] = dummy;
+    }
+    int n = 0;
+    const int rc = stage_split_dispatch(&q, V2W_DRY_STREAM, &n);
+    return rc == 0 ? n : rc;
 }

@@ -305,6 +305,45 @@ def cond_gamma_beta(spk, noise, fc_w: Sequence, fc_b: Sequence, sn_w: Sequence, 
     _hip.check(_hip.load().v2w_cond_gamma_beta(C.byref(a), _stream(spk)), 'v2w_cond_gamma_beta')
 
 
+def _cond_args(a, spk, noise, fc_w, fc_b, sn_w, sn_b, sn_u, sn_v, sigma_ws):
+    n = len(sn_w)
+    if n > _hip.V2W_MAX_STAGES:
+        raise ValueError(f'at most {_hip.V2W_MAX_STAGES} upsample stages are supported')
+    a.spk = _hip.ptr(spk); a.noise = _hip.ptr(noise)
+    for i in range(n):
+        a.fc_w[i] = _hip.ptr(fc_w[i]) if fc_w is not None else None
+        a.fc_b[i] = _hip.ptr(fc_b[i]) if fc_b is not None else None
+        a.sn_w[i] = sn_w[i].data_ptr(); a.sn_b[i] = _hip.ptr(sn_b[i]) if sn_b is not None else None
+        a.sn_u[i] = _hip.ptr(sn_u[i]) if sn_u is not None else None
+        a.sn_v[i] = _hip.ptr(sn_v[i]) if sn_v is not None else None
+        a.C[i] = sn_w[i].shape[0] // 2
+    a.sigma_ws = sigma_ws.data_ptr()
+    a.n_stages = n
+    if spk is not None:
+        a.B = spk.shape[0]; a.spk_dim = spk.shape[1]; a.noise_dim = noise.shape[1]
+
+
+def cond_sigma(sn_w: Sequence, sn_u: Sequence, sn_v: Sequence, sigma_ws, training: bool = False):
+    """sigma_ws[i] = u_i . (W_i v_i) of every stage (eval: no power iteration - a function of the parameters alone)."""
+    a = _hip.CondArgs()
+    _cond_args(a, None, None, None, None, sn_w, None, sn_u, sn_v, sigma_ws)
+    a.training = int(training)
+    _hip.check(_hip.load().v2w_cond_sigma(C.byref(a), _stream(sigma_ws)), 'v2w_cond_sigma')
+
+
+def cond_affine_eval(spk, noise, fc_w: Sequence, fc_b: Sequence, sn_w: Sequence, sn_b: Sequence, sigma_ws,
+                     running_mean: Sequence, running_var: Sequence, eps: Sequence, a_out: Sequence, s_out: Sequence):
+    """Eval mode: the folded per-sample affine (a, s) of every stage's Conditional BatchNorm from (spk, noise) in ONE launch
+    (sigma_ws from cond_sigma for the current parameters)."""
+    e = _hip.CondEvalArgs()
+    _cond_args(e.c, spk, noise, fc_w, fc_b, sn_w, sn_b, None, None, sigma_ws)
+    for i in range(len(sn_w)):
+        e.running_mean[i] = running_mean[i].data_ptr(); e.running_var[i] = running_var[i].data_ptr()
+        e.a_out[i] = a_out[i].data_ptr(); e.s_out[i] = s_out[i].data_ptr()
+        e.eps[i] = eps[i]
+    _hip.check(_hip.load().v2w_cond_affine_eval(C.byref(e), _stream(spk)), 'v2w_cond_affine_eval')
+
+
 def bn_stats(x, stats, partial_ws):
     """x (B,C,L) -> stats[2C+1] fp64 = [sum | sumsq | count]."""
     B, Cc, L = x.shape
@@ -508,11 +547,29 @@ def resblock2_stage_split_ok(B, Cc, L, ks, dil1s, dil2s, *, slope, bf16=True, io
     return _hip.load().v2w_resblock2_stage_split_config(C.byref(a)) == 0
 
 
-def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None):
+def resblock2_stage_up_tiles(B, Cc, L, ks, dil1s, dil2s, *, slope, up_k, up_u, up_slope) -> int:
+    """Rows of the `stats_part` array the stage kernel WITH the next stage's upsampler fused behind it fills (resblock2_stage_split(up=...)),
+    or 0 when the library does not run this stage fused (shape query, nothing is launched)."""
+    a = _hip.StageSplitArgs()
+    for j, (k, d1, d2) in enumerate(zip(ks, dil1s, dil2s)):
+        a.k[j], a.dil1[j], a.dil2[j] = k, d1, d2
+    a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
+    a.slope, a.out_div, a.bf16, a.io_bf16 = slope, float(len(ks)), 1, 3
+    a.up_k, a.up_u, a.up_slope = up_k, up_u, up_slope
+    n = _hip.load().v2w_resblock2_stage_up_tiles(C.byref(a))
+    return n if n > 0 else 0
+
+
+def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None, up=None):
     """Split-operand (f16x3 / bf16) form of resblock2_stage for C == 32.  `branches`: list of dicts(wps1, b1, wps2, b2, k, dil1, dil2)
-    with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken."""
+    with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken.
+    up = (wps of pack_bf16_convt, bias, out (B, C / 2, u L) bf16, stats_part | None, k, u, slope): the NEXT stage's upsampler run on the
+    stage's output inside the same kernel (`out` may be None: it is not written)."""
     B, Cc, L = x.shape
     a = _hip.StageSplitArgs()
+    if up is not None:
+        a.up_wps, a.up_bias, a.up_out, a.up_stats_part = up[0].data_ptr(), _hip.ptr(up[1]), up[2].data_ptr(), _hip.ptr(up[3])
+        a.up_k, a.up_u, a.up_slope = up[4], up[5], up[6]
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
     for j, q in enumerate(branches):

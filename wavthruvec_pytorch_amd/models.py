@@ -208,6 +208,8 @@ class Generator(nn.Module):
         self.bf16_storage = True              # precision == 'bf16': keep activations in bf16 between layers (no-grad forwards)
         self.fuse_wide = True                 # bf16 storage: the residual convs of the wide stages (C >= 64) as one launch per conv position
         self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
+        self.fuse_up = True                   # bf16 storage: the NEXT stage's transposed conv (stride 2 / 4) inside the kernel of a stage (C = 32 .. 256):
+                                              # the stage's output never leaves the chip, one launch less per stage
         self.fuse_post = False                # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage
                                               # (opt-in: measured 1162 us against 791 + 190 us for the two kernels at configs[2])
         self._split_wide = set()
@@ -251,7 +253,10 @@ class Generator(nn.Module):
                 sy = self.forward(sx, ss, sn)
 
         def run(x, spk_emb, noise):
-            sx.copy_(x); ss.copy_(spk_emb); sn.copy_(noise)
+            if x.dtype == sx.dtype and spk_emb.dtype == ss.dtype and noise.dtype == sn.dtype and x.device == sx.device:
+                torch._foreach_copy_([sx, ss, sn], [x, spk_emb, noise])      # the three inputs into the static buffers: ONE launch
+            else:
+                sx.copy_(x); ss.copy_(spk_emb); sn.copy_(noise)
             graph.replay()
             return sy
 
@@ -554,13 +559,34 @@ class Generator(nn.Module):
             sigma_ws = self._buf('sigma_ws', (ns,), device=dev)
             # (depends on spk / noise and the conditioning weights only: three latency-bound launches, ~140 us, that run on the side
             # stream - behind the upsamplers' weight folds - beside the Conv1d weight batch and conv_pre; joined before the first upsampler)
+            # eval-mode inference: gamma / beta, the running statistics and the fold into (a, s) of EVERY stage are one launch
+            # (v2w_cond_affine_eval) - nothing between (spk, noise) and the affines depends on the activations; sigma = u^T W v depends on
+            # the parameters alone and is kept with the fold cache.  (A forward that will be back-propagated keeps gb / z for its backward.)
+            eval_fast = not training and save is None
+            affs = None
             with torch.cuda.stream(side):
-                hipops.cond_gamma_beta(
-                    spk, nz,
-                    [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
-                    [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
-                    [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
-                    gbs, z_ws, sigma_ws, training)
+                if eval_fast:
+                    sn_p = [q for c in self.cbns for q in (c.layer.weight_orig, c.layer.weight_u, c.layer.weight_v)]
+                    skey = (tuple((q.data_ptr(), q._version) for q in sn_p), str(dev))
+                    if self._fold_key.get('sigma') != skey:
+                        hipops.cond_sigma([c.layer.weight_orig.detach() for c in self.cbns], [c.layer.weight_u for c in self.cbns],
+                                          [c.layer.weight_v for c in self.cbns], sigma_ws, training=False)
+                        self._fold_key['sigma'] = skey
+                    affs = [(self._buf(f'bn.a{i}', (B, self.cbns[i].num_features), device=dev),
+                             self._buf(f'bn.s{i}', (B, self.cbns[i].num_features), device=dev)) for i in range(ns)]
+                    hipops.cond_affine_eval(
+                        spk, nz, [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                        [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns], sigma_ws,
+                        [c.batch_nrom.running_mean for c in self.cbns], [c.batch_nrom.running_var for c in self.cbns],
+                        [c.batch_nrom.eps for c in self.cbns], [q[0] for q in affs], [q[1] for q in affs])
+                else:
+                    self._fold_key.pop('sigma', None)        # (sigma_ws is about to hold this forward's own values)
+                    hipops.cond_gamma_beta(
+                        spk, nz,
+                        [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                        [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
+                        [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
+                        gbs, z_ws, sigma_ws, training)
             cond_joined = False
 
             y = None
@@ -570,6 +596,7 @@ class Generator(nn.Module):
             self._timed('conv_pre', hipops.conv1d, x, wf['conv_pre'], self.conv_pre.bias.detach(), cur, k=7, dil=1,
                         slope=1.0, splitk_ws=slab, **ck('conv_pre', io=2))        # (the latents arrive as fp32)
             L = T
+            up_done = None      # rows of bn.part{i} when the kernel of stage i - 1 already ran ups[i] (fuse_up)
             for i in range(ns):
                 up = self.ups[i]
                 C = up.out_channels
@@ -586,13 +613,17 @@ class Generator(nn.Module):
                 if training:
                     stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
                     # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
-                    if f'ups.{i}' in wps:
+                    if up_done is not None:
+                        nt_stats = up_done
+                    elif f'ups.{i}' in wps:
                         nt_stats = hipops.convt_bf16_stats_tiles(cur, xr, up.kernel_size, up.stride, io_bf16=3 if st else 0)
                     elif algo != hipops.ALGO_DIRECT and wp[f'ups.{i}'] is not None:
                         nt_stats = hipops.convt_stats_tiles(B, up.in_channels, C, L, up.kernel_size, up.stride)
                     if nt_stats:
                         part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
-                if f'ups.{i}' in wps and (nt_stats or not training):
+                if up_done is not None:
+                    pass        # the previous stage's kernel has written xr (and the partial sums): models.py:128-129 ran fused behind it
+                elif f'ups.{i}' in wps and (nt_stats or not training):
                     self._timed(f'ups.{i}', hipops.convt1d_bf16, cur, wps[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
                                 u=up.stride, slope=LRELU_SLOPE, stats_part=part, io_bf16=3 if st else 0)
                 elif st:
@@ -600,6 +631,7 @@ class Generator(nn.Module):
                 else:
                     self._timed(f'ups.{i}', hipops.convt1d, cur, wf[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
                                 u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part, splitk_ws=slab)
+                up_done = None
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 if training:
                     if nt_stats:
@@ -614,8 +646,9 @@ class Generator(nn.Module):
                 if not cond_joined:       # (fp32: the side stream only carries gamma / beta - joined as late as their first use, which
                     main.wait_stream(side)    # matters at B = 1, where conv_pre is shorter than the conditioning chain)
                     cond_joined = True
-                hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
-                                   training=training, momentum=bn.momentum, eps=bn.eps)
+                if affs is None:
+                    hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
+                                       training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
                 # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input.
                 # The branches are independent until the final sum, so conv n of ALL branches goes out as one launch
@@ -656,7 +689,28 @@ class Generator(nn.Module):
 
                     if isinstance(rbs[0], ResBlock2):
                         ok = False
-                        if C in (16, 32) and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
+                        # ---- the stage with the NEXT stage's upsampler behind it in one kernel (bf16 tensors): xs is never written, the
+                        # kernel stores act.up{i+1} and the BatchNorm partial sums of stage i + 1
+                        if (st and self.fuse_up and i + 1 < ns and C >= 32 and (C >= 64 and self.fuse_wide_stage or C in fuse_stage)
+                                and f'ups.{i + 1}' in wps and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1))):
+                            nup = self.ups[i + 1]
+                            if nup.kernel_size == 2 * nup.stride and nup.stride in (2, 4) and nup.out_channels * 2 == C:
+                                ntn = hipops.resblock2_stage_up_tiles(B, C, Lo, [rb.kernel_size for rb in rbs], [rb.convs[0].dilation for rb in rbs],
+                                                                      [rb.convs[1].dilation for rb in rbs], slope=LRELU_SLOPE,
+                                                                      up_k=nup.kernel_size, up_u=nup.stride, up_slope=LRELU_SLOPE)
+                                if ntn:
+                                    xr_n = self._buf(f'act.up{i + 1}', (B, nup.out_channels, Lo * nup.stride), dtype=adt, device=dev)
+                                    part_n = self._buf(f'bn.part{i + 1}', (ntn * nup.out_channels * 2,), device=dev) if training else None
+                                    ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names) + f'+ups.{i + 1}', hipops.resblock2_stage_split,
+                                                     xr, aff, [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
+                                                                    wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
+                                                                    dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
+                                                               for nm, rb in zip(names, rbs)], None, slope=LRELU_SLOPE, out_div=float(nk),
+                                                     bf16=True, io_bf16=3,
+                                                     up=(wps[f'ups.{i + 1}'], nup.bias.detach(), xr_n, part_n, nup.kernel_size, nup.stride, LRELU_SLOPE))
+                                    if ok:
+                                        up_done = ntn
+                        if not ok and C in (16, 32) and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
                             branches = [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                              wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                              dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation) for nm, rb in zip(names, rbs)]
