@@ -928,7 +928,7 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     p.in = a->in; p.wps = a->wp; p.bias = a->bias; p.out = a->out; p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.Cout = a->C_out * g.UP; p.L = a->L; p.K = g.KV; p.dil = 1;
     p.hl = g.hl; p.hr = g.hr; p.slope = a->slope; p.up_u = a->u; p.up_p = g.UP; p.io_bf16 = a->io_bf16;
-    if (a->io_bf16 == 3 && g.UP == a->u) {        // bf16 tensors, no padding phases: the resident-tile kernel (v2w_convt_bf16_res.hip)
+    if (a->io_bf16 == 3 && (g.UP == a->u || a->u == 5)) {   // bf16 tensors: the resident-tile kernel (v2w_convt_bf16_res.hip; stride 5: whole tiles)
         const int rc = v2w_convt1d_bf16_res(a, g.UP, g.hl, g.KV, stream, ntiles_out, cfg);
         if (rc != V2W_E_SHAPE) return rc;
     }

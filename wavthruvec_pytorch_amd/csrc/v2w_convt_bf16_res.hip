@@ -11,7 +11,11 @@
 //     output positions of a channel (or 4 of the 8), so the output leaves straight from the accumulators as 4- / 8-byte bf16 stores,
 //     consecutive lanes = consecutive addresses: no LDS scratch, no transposition;
 //   * the BatchNorm partial sums (sum, sum of squares of the fp32 values, before rounding) are reduced across the lanes of a column block
-//     with DPP adds in a fixed order, across the waves of a tile through LDS in a fixed order: one slot per (tile, channel) as before.
+//     with DPP adds in a fixed order, across the waves of a tile through LDS in a fixed order: one slot per (tile, channel) as before;
+//   * U = 5 (the generator's first upsampler, 8 virtual phases of which 5 exist): no register layout puts 5 consecutive outputs in a lane,
+//     so the accumulators pass through a wave-private fp32 scratch that IS the output block [channel][5 x 64 positions] (over the dead input
+//     tile) and leave as 8-byte bf16 stores along positions - the epilogue of the chunked kernel (v2w_conv_bf16.hip), without its 16
+//     barriers and exposed memory latencies per tile.
 #include <type_traits>
 #include "v2w_tile.h"
 
@@ -58,7 +62,8 @@ __device__ __forceinline__ float ct_row_sum(float v) {
 // workgroups (of 4 waves) per CU the register budget is cut for
 constexpr int ct_wgs(int mi, int ni) { return mi * ni >= 8 ? 2 : (mi * ni >= 4 ? 3 : 4); }
 
-template <int MI, int NI, int WM, int WN, int UP>
+// U: the stride (= UP, or 5 with UP = 8: whole tiles only, NI even)
+template <int MI, int NI, int WM, int WN, int UP, int U = UP>
 __global__ void __launch_bounds__(64 * WM * WN, ct_wgs(MI, NI))
 convt_bf16_res_kernel(const CtArgs a) {
     typedef Frag<32> F;
@@ -66,6 +71,7 @@ convt_bf16_res_kernel(const CtArgs a) {
     constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
     constexpr int NPF = (8 * ((NT + 16) / 4) + NTH - 1) / NTH;                 // staging items of one 32-channel plane per thread
     static_assert(UP == 2 || UP == 4 || UP == 8, "phases per channel");
+    static_assert(U == UP || (U == 5 && UP == 8 && NI % 2 == 0), "stride");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
 
@@ -240,8 +246,69 @@ convt_bf16_res_kernel(const CtArgs a) {
     //   UP = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};   UP = 8: channel 4 i + g, outputs 8 q + 4 hk + {0..3};
     //   UP = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1} each
     constexpr int CPB = 32 / UP;                                                // channels per 32-row block
-    const int Lout = L * UP;
+    const int Lout = L * U;
     const bool stats = a.stats_part != nullptr;
+    if constexpr (U != UP) {
+        // ---- U = 5: 64 input positions (two column blocks) of a 32-row block at a time -> scratch [4 channels][5 x 64 outputs] (the output's
+        // own layout: block (i, j), register quad eg, lane (lr, hk) holds phases 4 hk + {0..3} of channel eg at input position 32 j + lr)
+        // -> float4 number lane + 64 g of the scratch is 4 consecutive outputs of channel (lane + 64 g) / 80: + bias, sums, an 8-byte bf16 store.
+        constexpr int RW = 16 * U, G = CPB * U / 4, ORS = U * 64;               // float4s per channel row of a pass; float4s per lane; scratch row
+        constexpr int PARTS = 64 / (2 * CPB), NPER = RW / PARTS;
+        static_assert(CPB == 4 && G == 5 && RW % PARTS == 0, "U = 5 on 8 virtual phases");
+        __syncthreads();                                                        // every wave has left the MFMA loop: the input tile is dead
+        float* const scr = reinterpret_cast<float*>(smem_c) + wave * 2048;
+        unsigned char* const ob0 = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * CoutR * Lout * 2;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f32x4 sa[G], sq[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) sa[g] = sq[g] = zero4;
+            const int co0 = (m0 + wm0 + i * 32) / UP;
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += 2) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const acc_t& ac = acc[i][jh + jj];
+                    float* const sc = scr + U * (jj * 32 + lr);
+#pragma unroll
+                    for (int eg = 0; eg < 4; ++eg) {
+                        sc[eg * ORS + 4 * hk] = ac[4 * eg];
+                        if (hk == 0) { sc[eg * ORS + 1] = ac[4 * eg + 1]; sc[eg * ORS + 2] = ac[4 * eg + 2]; sc[eg * ORS + 3] = ac[4 * eg + 3]; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned ub = (unsigned)(co0 * Lout + U * (n0 + wn0 + jh * 32)) * 2u;      // (uniform)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int idx = lane + 64 * g;
+                    const int cl = (idx >= RW) + (idx >= 2 * RW) + (idx >= 3 * RW), c4 = idx - cl * RW;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + 4 * idx);
+                    const float bias = btab[(wm0 / UP) + CPB * i + cl];
+                    v += f32x4{bias, bias, bias, bias};
+                    if (stats) { sa[g] += v; sq[g] += v * v; }
+                    *gptr<u32x2>(ob0 + ub + (unsigned)(cl * Lout + 4 * c4) * 2u) = u32x2{ct_pack2(v[0], v[1]), ct_pack2(v[2], v[3])};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (stats) {
+                // per-lane sums -> scratch[g * 64 + lane] = (sum, sumsq): slot k belongs to channel k / RW; lane = (channel, part, stat) adds NPER
+                // slots in a fixed order, the parts of a channel meet in a fixed shuffle tree
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    *reinterpret_cast<f32x2*>(scr + 2 * (g * 64 + lane)) =
+                        f32x2{(sa[g][0] + sa[g][1]) + (sa[g][2] + sa[g][3]), (sq[g][0] + sq[g][1]) + (sq[g][2] + sq[g][3])};
+                const int stat = lane & 1, part = (lane >> 1) % PARTS, c = lane / (2 * PARTS);
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < NPER; ++k) t += scr[2 * (c * RW + part * NPER + (k + (lane >> 1)) % NPER) + stat];
+#pragma unroll
+                for (int off = 2; off < 2 * PARTS; off <<= 1) t += __shfl_xor(t, off, 64);
+                if (part == 0) red[((wave % WN) * (MT / UP) + (wm0 / UP) + CPB * i + c) * 2 + stat] = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
     unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * CoutR * Lout * 2;
     const int cw0 = (m0 + wm0) / UP;                                            // first channel of this wave (inside the tensor)
 #pragma unroll
@@ -300,6 +367,7 @@ convt_bf16_res_kernel(const CtArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }     // (U == UP)
     if (stats) {
         __syncthreads();
         for (int c = tid; c < MT / UP; c += NTH) {
@@ -312,10 +380,11 @@ convt_bf16_res_kernel(const CtArgs a) {
     }
 }
 
-template <int MI, int NI, int WM, int WN, int UP>
+template <int MI, int NI, int WM, int WN, int UP, int U = UP>
 int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
     if ((p.CoutR * UP) % MT != 0 || p.Cin % 32 != 0) return V2W_E_SHAPE;
+    if (U != UP && p.L % NT != 0) return V2W_E_SHAPE;                // the scratch epilogue of U = 5 serves whole tiles
     const int nch = p.Cin / 32;
     if (nch > 1 && (nch & 1)) return V2W_E_SHAPE;                    // planes are staged in pairs
     p.hla = (p.hl + 3) & ~3;
@@ -324,13 +393,14 @@ int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     p.ntl = (p.L + NT - 1) / NT;
     p.ntiles = p.B * p.ntl;
     p.xrows = (p.hla + NT + hr + 3) & ~3;
-    const size_t lds = (size_t)nch * p.xrows * 64 + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
+    size_t lds = (size_t)nch * p.xrows * 64 + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
+    if (U != UP && lds < (size_t)WM * WN * 2048 * sizeof(float)) lds = (size_t)WM * WN * 2048 * sizeof(float);      // the waves' scratch overlays the tile
     constexpr int WGS = ct_wgs(MI, NI);                              // workgroups per CU the register budget allows (4-wave workgroups)
     if (lds * (WGS > 2 ? 2 : WGS) > 160 * 1024) return V2W_E_SHAPE;
-    if (cfg) { const int32_t c[10] = {MI, NI, WM, WN, UP, 102 /* = this kernel */, 1, 1, 32, 1}; for (int i = 0; i < 10; ++i) cfg[i] = c[i]; }
+    if (cfg) { const int32_t c[10] = {MI, NI, WM, WN, UP, 102 /* = this kernel */, 1, 1, 32, U}; for (int i = 0; i < 10; ++i) cfg[i] = c[i]; }
     if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
     const int grid = ((p.ntiles + 7) / 8) * 8 * ((p.CoutR * UP) / MT);
-    auto kern = convt_bf16_res_kernel<MI, NI, WM, WN, UP>;
+    auto kern = convt_bf16_res_kernel<MI, NI, WM, WN, UP, U>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -344,7 +414,7 @@ int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
 // Called by the dispatcher of v2w_conv_bf16.hip for bf16 tensors (io_bf16 == 3), aligned, L % 4 == 0, U == UP in {2, 4, 8}.
 // hl / KV: the virtual conv's geometry (convt_geom).  V2W_E_SHAPE: the chunked kernel runs instead.
 int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
-    if (a->io_bf16 != 3 || a->u != UP || a->L % 4 != 0) return V2W_E_SHAPE;
+    if (a->io_bf16 != 3 || (a->u != UP && !(a->u == 5 && UP == 8)) || a->L % 4 != 0) return V2W_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(a->in) & 15) || (reinterpret_cast<uintptr_t>(a->out) & 15)) return V2W_E_SHAPE;    // (queries carry the pointers too)
     if ((long long)a->C_out * a->L * UP * 2 >= (1ll << 31) || (long long)a->C_in * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;
     if (!(a->slope > 0.f && a->slope <= 1.f)) return V2W_E_SHAPE;
@@ -353,6 +423,11 @@ int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipS
     p.out = reinterpret_cast<unsigned short*>(a->out); p.stats_part = a->stats_part;
     p.B = a->B; p.Cin = a->C_in; p.CoutR = a->C_out; p.L = a->L; p.KV = KV; p.hl = hl; p.slope = a->slope;
     const int rows = a->C_out * UP;
+    if (a->u == 5) {
+        // 256 virtual rows x 64 positions, 4 waves of 64 x 64: the 512-channel input tile of the generator's first upsampler fits twice per CU
+        if (rows % 256 == 0) return launch_ct<2, 2, 4, 1, 8, 5>(p, stream, ntiles_out, cfg);
+        return V2W_E_SHAPE;
+    }
     if (UP == 4) {
         if (rows % 256 == 0) return launch_ct<4, 2, 2, 2, 4>(p, stream, ntiles_out, cfg);       // 256 rows x 128 positions
         if (rows % 128 == 0) return launch_ct<2, 4, 2, 2, 4>(p, stream, ntiles_out, cfg);       // 128 rows x 256 positions

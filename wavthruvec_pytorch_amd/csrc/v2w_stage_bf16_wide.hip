@@ -669,79 +669,92 @@ wide_stage_bf16_kernel(const WideArgs a) {
         }
         __syncthreads();
         V2W_STAMP(21);
+        // Block (i, j), register quad g, lane (lr, hk): virtual rows 32 i + 8 g + 4 hk + {0..3} at input position q.
+        //   UPF = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};   UPF = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1}
+        // The accumulators start at the bias of their channel (no add in the epilogue).
+        constexpr int NC = UPF == 2 ? 2 : 1;                  // channels of a register quad
+        constexpr int CHW = MIU * CPB;                        // channels of this wave
+        const int cw0 = (wm0 / 32) * (UPF / 2) * CPB;         // its first channel
         acc_t uacc[MIU][NI];
 #pragma unroll
         for (int i = 0; i < MIU; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const int cl = CPB * i + (UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) uacc[i][j][e] = 0.f;
+                for (int x = 0; x < 4; ++x) {
+                    const float bv = ubias[cw0 + cl + (UPF == 2 ? (x >> 1) : 0)];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) uacc[i][j][4 * g + x] = bv;
+                }
+            }
         // virtual tap tv reads input position q + tv - 1 (2 U taps at stride U: one input position of halo per side)
         conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::false_type{}, uacc, (wm0 / 32) * (UPF / 2), tbase, tpsz,
                 wn0 + lr - 1, ws_uni(a.up_w));
         V2W_STAMP(22);
-        // epilogue (as convt_bf16_res_kernel): block (i, j), register quad g, lane (lr, hk): virtual rows 32 i + 8 g + 4 hk + {0..3} at input
-        // position q.  UPF = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};  UPF = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1}
+        // ---- epilogue: bf16 stores straight from the accumulators (the phases of a channel are adjacent registers of a lane, consecutive
+        // lanes = consecutive output positions).  BatchNorm partial sums of the fp32 values: a lane adds up its columns of a channel, the
+        // 32 lanes of a channel meet through a wave-private LDS scratch [channel][32][2] that ONE pass of the wave sums per (channel, stat)
+        // in a fixed order - instead of a DPP tree + readlanes per register quad (30 of the ~100 vector instructions of a quad).
         const int Lout = L * UPF;
         const bool stats = a.up_stats != nullptr;
         unsigned char* const obase = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * CU * Lout * 2;
-        const int cw0 = (wm0 / 32) * (UPF / 2) * CPB;         // first channel of this wave
         const int ncen = nto - 2;                             // input positions this tile is the centre of: window columns h2max + 1 ..
+        float* const ssc = ured + WN * CU * 2 + wave * (CHW * 64);       // this wave's scratch (over the dead x tile)
+        unsigned qo[NI];                                      // byte offset of output position U q inside a channel row; 0xffffffff: not stored
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) {
+            const int col = wn0 + 32 * jj + lr;
+            const int cc = col - h2max - 1;                   // index among the tile's centres
+            const int q = n0 + 1 + cc;
+            const bool ok = cc >= 0 && cc < ncen && q < L;
+            qo[jj] = ok ? (unsigned)(UPF * q) * 2u : 0xffffffffu;
+        }
 #pragma unroll
         for (int i = 0; i < MIU; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                constexpr int NC = UPF == 2 ? 2 : 1;          // channels of a register quad
-                const int cl = UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk;
-                float bias[NC], s1[NC], s2[NC];
+                const int cl = CPB * i + (UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk);       // channel inside the wave (+ 1: the second of UPF = 2)
+                float s1[NC], s2[NC];
 #pragma unroll
-                for (int n = 0; n < NC; ++n) { bias[n] = ubias[cw0 + CPB * i + cl + n]; s1[n] = s2[n] = 0.f; }
+                for (int n = 0; n < NC; ++n) s1[n] = s2[n] = 0.f;
+                const unsigned crow = (unsigned)((cw0 + cl) * Lout) * 2u;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    int col = wn0 + lr;
-                    asm volatile("" : "+v"(col));
-                    col += 32 * j;
-                    const int cc = col - h2max - 1;           // index among the tile's centres
-                    const int q = n0 + 1 + cc;
-                    const bool ok = cc >= 0 && cc < ncen && q < L;
+                for (int jj = 0; jj < NI; ++jj) {
                     float v[4];
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        v[x] = uacc[i][j][4 * g + x] + bias[UPF == 2 ? (x >> 1) : 0];
-                        if (!ok) v[x] = 0.f;
-                        s1[UPF == 2 ? (x >> 1) : 0] += v[x];
-                        s2[UPF == 2 ? (x >> 1) : 0] = fmaf(v[x], v[x], s2[UPF == 2 ? (x >> 1) : 0]);
+                        v[x] = uacc[i][jj][4 * g + x];
+                        // (columns outside the tile's centres / the sequence count 0 - a select, not a product: they may hold NaN patterns)
+                        const float vm = qo[jj] != 0xffffffffu ? v[x] : 0.f;
+                        s1[UPF == 2 ? (x >> 1) : 0] += vm;
+                        s2[UPF == 2 ? (x >> 1) : 0] = fmaf(vm, vm, s2[UPF == 2 ? (x >> 1) : 0]);
                     }
-                    if (ok) {
-                        const int c = cw0 + CPB * i + cl;
+                    if (qo[jj] != 0xffffffffu) {
                         if constexpr (UPF == 2) {
-                            *gptr<unsigned>(obase + (unsigned)(c * Lout + 2 * q) * 2u) = ws_pack2(v[0], v[1]);
-                            *gptr<unsigned>(obase + (unsigned)((c + 1) * Lout + 2 * q) * 2u) = ws_pack2(v[2], v[3]);
+                            *gptr<unsigned>(obase + crow + qo[jj]) = ws_pack2(v[0], v[1]);
+                            *gptr<unsigned>(obase + crow + (unsigned)Lout * 2u + qo[jj]) = ws_pack2(v[2], v[3]);
                         } else {
-                            *gptr<u32x2>(obase + (unsigned)(c * Lout + 4 * q) * 2u) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
+                            *gptr<u32x2>(obase + crow + qo[jj]) = u32x2{ws_pack2(v[0], v[1]), ws_pack2(v[2], v[3])};
                         }
                     }
                 }
                 if (stats) {
-                    // the 32 lanes that share hk hold one channel's columns: DPP row sums, then the rows of a half (and the halves) in a fixed order
 #pragma unroll
-                    for (int n = 0; n < NC; ++n) {
-                        const float r1 = ws_row_sum(s1[n]), r2 = ws_row_sum(s2[n]);
-                        const float a1 = ws_readlane(r1, 0) + ws_readlane(r1, 16);
-                        const float b1 = ws_readlane(r1, 32) + ws_readlane(r1, 48);
-                        const float a2 = ws_readlane(r2, 0) + ws_readlane(r2, 16);
-                        const float b2 = ws_readlane(r2, 32) + ws_readlane(r2, 48);
-                        float* rd = ured + ((wave % WN) * CU + cw0 + CPB * i) * 2;
-                        if constexpr (UPF == 4) {
-                            if (lane == 0) { rd[2 * (2 * g)] = a1; rd[2 * (2 * g) + 1] = a2; rd[2 * (2 * g + 1)] = b1; rd[2 * (2 * g + 1) + 1] = b2; }
-                        } else {
-                            if (lane == 0) { rd[2 * (4 * g + n)] = a1; rd[2 * (4 * g + n) + 1] = a2; rd[2 * (4 * g + 2 + n)] = b1; rd[2 * (4 * g + 2 + n) + 1] = b2; }
-                        }
-                    }
+                    for (int n = 0; n < NC; ++n) *reinterpret_cast<f32x2*>(ssc + ((cl + n) * 32 + lr) * 2) = f32x2{s1[n], s2[n]};
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         if (stats) {
+            // lane = (channel, stat) of this wave's CHW channels: the 32 column sums in an order that starts at the lane's own slot (LDS banks)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private scratch: the wave's own writes have landed)
+            if (lane < 2 * CHW) {
+                const int chl = lane >> 1, st = lane & 1;
+                float t = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) t += ssc[(chl * 32 + ((k + lane) & 31)) * 2 + st];
+                ured[((wave % WN) * CU + cw0 + chl) * 2 + st] = t;
+            }
             __syncthreads();
             for (int c = tid; c < CU; c += NTH) {
                 float t1 = 0.f, t2 = 0.f;

@@ -417,7 +417,7 @@ def conv_bf16_config(B, nprob, c_in, c_out, L, k, dil=1, u=1, io_bf16=3):
         return None
     v = list(cfg)
     if v[5] == 102:         # the resident-tile transposed conv (v2w_convt_bf16_res.hip)
-        return 'convt_bf16_res_kernel<' + ', '.join(str(x) for x in v[:5]) + '>'
+        return 'convt_bf16_res_kernel<' + ', '.join(str(x) for x in v[:5]) + f', {v[9]}>'      # (..., UP, U)
     tf = lambda b: 'true' if b else 'false'
     return 'conv_bf16_kernel<' + ', '.join(str(x) for x in v[:6]) + f', {tf(v[6])}, {tf(v[7])}, {v[8]}, {tf(v[9])}>'
 
