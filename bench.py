@@ -400,14 +400,17 @@ def config_block(hp, B, T, precision, steps, warmup, dev, workload, parity, traf
                 peaks=dict(hbm_gbs=PEAK_HBM_GBS, mfma_tflops=peak), roofline=roof, parity=parity)
 
 
-def train_step_block(dev, B, T, steps):
-    """The generator half of a vec2wav/train.py:204-215 step at the cfg2 shape, exact fp32: forward (autograd schedule) + backward through
-    the C ABI + AdamW (train.py:100 betas / lr), a weighted-sum loss.  FLOPs = 3 x the forward's (input- and weight-gradient GEMMs)."""
+def train_step_block(dev, B, T, steps, precision='f32'):
+    """The generator half of a vec2wav/train.py:204-215 step at the cfg2 shape: forward (autograd schedule) + backward through the C ABI +
+    AdamW (train.py:100 betas / lr), a weighted-sum loss.  FLOPs = 3 x the forward's (input- and weight-gradient GEMMs).  precision 'f32':
+    exact fp32 everywhere; 'f16x3': the wide convs of the forward and their input gradients on the f16 matrix pipe with split operands
+    (~22-bit products, fp32 accumulate), weight gradients exact fp32."""
     from wavthruvec_pytorch_amd import Generator, synthetic, workmodel
     h = synthetic.make_hparams(num_wv_feat=768)
     g = Generator(h)
     g.load_state_dict(synthetic.make_state_dict(h, seed=0))
     g = g.to(dev).train()
+    g.precision = precision
     opt = torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99))
     inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
     up = synthetic.total_upsample(h)
@@ -429,7 +432,9 @@ def train_step_block(dev, B, T, steps):
     del g, opt
     torch.cuda.empty_cache()
     return dict(workload=f'generator training step (vec2wav/train.py:204-215 without the discriminators): forward + backward + AdamW, B={B} x T={T}, '
-                         '768-d, x320, ResBlock2, exact fp32', dtype='f32', steps=steps, ms_per_step=st * 1e3,
+                         '768-d, x320, ResBlock2, ' + ('exact fp32' if precision == 'f32' else 'forward and input-gradient convs as f16 hi+lo '
+                                                        '(3 MFMA per product, fp32 accumulate), weight gradients exact fp32'),
+                dtype=precision, steps=steps, ms_per_step=st * 1e3,
                 ms_per_step_event_median=median(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)),
                 value=B * T * up / st, unit='trained samples/s', flops=3.0 * fl, tflops=3.0 * fl / st / 1e12,
                 mfma_frac=3.0 * fl / st / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -649,6 +654,9 @@ def main():
                        'BASELINE configs[4]: 1024-d latents, upsample (8,5,4,2,2) x640, B=16 x T=256, train mode, exact fp32',
                        'tests/test_hip_generator.py::test_generator_cfg5_full_size_vs_oracle_train (|dy| <= 1e-4 at this size)')
         train = guarded(train_step_block, dev, B, T, max(4, args.steps // 4))
+        if isinstance(train, dict) and 'error' not in train:
+            alt_t = guarded(train_step_block, dev, B, T, max(4, args.steps // 4), 'f16x3')
+            train['alt_precision_f16x3'] = {k: alt_t.get(k) for k in ('ms_per_step', 'value', 'tflops', 'workload', 'error') if k in alt_t}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -91,6 +91,11 @@ typedef struct {
     int32_t c_in, c_out, k, u, transposed;
     int32_t mf, ck;     /* filled by v2w_fold_plan */
     int32_t _pad;
+    float* wf;          /* optional (ABI v28): the folded weight in the plain layout [k][C_in][C_out] as well (what v2w_wn_fold_conv / _convt
+                         * write) - a forward that will be back-propagated needs it for the gradient kernels; NULL: not written */
+    float* wpd;         /* optional (ABI v28; Conv1d layers with C_in == C_out whose tile configuration has MF == CK only, else must be NULL):
+                         * the fragment stream of the layer's INPUT-GRADIENT conv (tap-reversed transpose, what v2w_pack_mfma_dgrad builds
+                         * from wf) in the same pass */
 } v2w_fold_desc;
 int v2w_fold_plan(v2w_fold_desc* descs, int n, int32_t* starts);
 int v2w_fold_pack_batch(const v2w_fold_desc* descs_dev, const int32_t* starts_dev, int n,

@@ -57,7 +57,7 @@ class StageArgs(C.Structure):
 class FoldDesc(C.Structure):
     _fields_ = [('v', _fp), ('g', _fp), ('wp', _fp), ('scale', _fp),
                 ('c_in', C.c_int32), ('c_out', C.c_int32), ('k', C.c_int32), ('u', C.c_int32), ('transposed', C.c_int32),
-                ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32)]
+                ('mf', C.c_int32), ('ck', C.c_int32), ('_pad', C.c_int32), ('wf', _fp), ('wpd', _fp)]
 
 
 _P4 = _fp * 4

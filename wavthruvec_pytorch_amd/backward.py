@@ -69,6 +69,12 @@ def _wn_grads(grads, name, m, dwf):
 def generator_backward(gen, sv, dy):
     """dy (B, 1, L_out) -> {parameter name: gradient}.  `sv` is the dict filled by `Generator._forward_hip(save=...)`."""
     ws, wf = sv['ws'], sv['wf']
+    # the folded weights live in module-owned buffers that the NEXT forward's fold overwrites: harmless while the parameters are unchanged
+    # (the same values again); parameters that changed in between - an optimizer step between this graph's forward and its backward -
+    # are what autograd itself refuses ("modified by an inplace operation")
+    if sv.get('vers') is not None and gen._fold_key.get('vers') is not None and gen._fold_key['vers'] != sv['vers']:
+        raise RuntimeError('Generator (HIP) backward: the generator\'s weights were modified and re-folded by a later forward before this '
+                           'backward ran (the saved forward used the earlier weights)')
     x, spk, nz, y, training = sv['x'], sv['spk'], sv['nz'], sv['y'], sv['training']
     B = sv['B']
     dev = x.device
@@ -105,7 +111,7 @@ def generator_backward(gen, sv, dy):
             # dr is never materialised on this path: the gradient convs read dxs through the per-(b, c) affine (1/nk, 0) - operand and
             # residual - and the quantities that are linear in dr (conv2's weight and bias gradients) are scaled afterwards
             dr = dxs
-            db2 = hipops.channel_sum(dxs) * (1.0 / nk)
+            db2 = None          # (the per-channel sum of dxs: a memory-bound pass nothing downstream waits for - side stream, below)
         else:
             dr = hipops.affine_apply(dxs, inv, zero, torch.empty_like(dxs))
             db2 = hipops.channel_sum(dr)
@@ -120,8 +126,12 @@ def generator_backward(gen, sv, dy):
             t1s = [ws[f'act.t1_{i}_{j}'] for j in range(nk)]
             dt1s = [torch.empty_like(dxs) for _ in range(nk)]
             # fragment streams of the gradient convs straight from the forward-layout weights (no transposed copies: C -> C layers)
-            p2 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1']) for j in range(nk)]
-            p1 = [hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0']) for j in range(nk)]
+            # (built by the forward's batched weight fold, beside the forward streams, when the layer is one of its C -> C residual convs)
+            wpd = sv.get('wpd', {})
+            p2 = [wpd.get(names[j] + '.convs.1') if wpd.get(names[j] + '.convs.1') is not None else hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1'])
+                  for j in range(nk)]
+            p1 = [wpd.get(names[j] + '.convs.0') if wpd.get(names[j] + '.convs.0') is not None else hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0'])
+                  for j in range(nk)]
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
             # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
             # (the launch's tile shape follows its WIDEST halo - the wide-halo tile variants are other shapes: probe with that branch)
@@ -144,26 +154,38 @@ def generator_backward(gen, sv, dy):
             # weight / bias gradients: nothing downstream waits for them - side stream, beside the next stage's gradient convs
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
+            def branch_grads(j, db2):
+                c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
+                k = rbs[j].kernel_size
+                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
+                grads[names[j] + '.convs.1.bias'] = db2
+                _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+                if ntile:
+                    st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
+                    hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
+                    grads[names[j] + '.convs.0.bias'] = st[:C].float()
+                else:
+                    grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+
+            # The LAST stage of the walk (stage 0: the widest convs) leaves the side stream a backlog the main stream has nothing left to
+            # run beside (it waited ~2.5 ms for it at the end of the backward): its heaviest branch's weight gradients go to the main stream
+            on_main = [order[0]] if i == 0 and nk > 1 else []
             with torch.cuda.stream(side):
                 made = []
+                db2 = hipops.channel_sum(dxs) * (1.0 / nk)
+                made.append(db2)
                 for j in range(nk):
-                    c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
-                    k = rbs[j].kernel_size
+                    if j in on_main:
+                        continue
                     g0 = dict(grads)
-                    _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
-                    grads[names[j] + '.convs.1.bias'] = db2
-                    _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
-                    if ntile:
-                        st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
-                        hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
-                        grads[names[j] + '.convs.0.bias'] = st[:C].float()
-                    else:
-                        grads[names[j] + '.convs.0.bias'] = hipops.channel_sum(dt1s[j])
+                    branch_grads(j, db2)
                     made += [v for kk, v in grads.items() if kk not in g0]
             for t in [dxs, xr, aff[0], aff[1]] + dt1s + t1s + [r_ for r_ in rsp if r_ is not None]:
                 t.record_stream(side)
             for t in made:
                 t.record_stream(main)
+            for j in on_main:       # (db2 is only handed on as the bias gradient here: no kernel of the main stream reads it)
+                branch_grads(j, db2)
         for j in range(nk if not merged else 0):
             rb = gen.resblocks[i * nk + j]
             name = f'resblocks.{i * nk + j}'
@@ -227,14 +249,16 @@ def generator_backward(gen, sv, dy):
         with torch.cuda.stream(side):
             d_w, d_b, d_fw, d_fb = hipops.cond_backward(dgb, z_all[i].contiguous(), ly.weight_orig.detach(), sn_u, sn_v,
                                                         ws['sigma_ws'][i:i + 1], spk, nz)
+            d_ub = hipops.channel_sum(dxr)       # the upsampler's bias gradient: a memory-bound pass beside the gradient convs
         dgb.record_stream(side)
-        for t in (d_w, d_b, d_fw, d_fb):
+        dxr.record_stream(side)
+        for t in (d_w, d_b, d_fw, d_fb, d_ub):
             t.record_stream(main)
         grads[f'cbns.{i}.layer.weight_orig'], grads[f'cbns.{i}.layer.bias'] = d_w, d_b
         grads[f'fcs.{i}.weight'], grads[f'fcs.{i}.bias'] = d_fw, d_fb
 
         # ---- leaky_relu -> ConvTranspose1d (models.py:128-129)
-        grads[f'ups.{i}.bias'] = hipops.channel_sum(dxr)
+        grads[f'ups.{i}.bias'] = d_ub
         _wn_grads(grads, f'ups.{i}', up,
                   hipops.wgrad(cur_in, dxr, k=up.kernel_size, u=up.stride, slope=LRELU_SLOPE))
         dxs = torch.empty_like(cur_in)

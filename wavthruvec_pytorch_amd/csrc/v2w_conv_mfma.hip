@@ -883,6 +883,27 @@ fold_pack_batch_kernel(const v2w_fold_desc* __restrict__ descs, const int32_t* _
         const int c = gg * CKG + j * KSTEP + lane / MF, co = lane % MF;
         dst[o] = d.transposed ? tile[c * rstride + co * K + t] : tile[co * rstride + c * K + t];
     }
+    // ---- the same sub-block in the plain layout wf [k][C_in][C_out] (a training forward: the gradient kernels read it), coalesced along C_out
+    if (d.wf) {
+        for (int idx = threadIdx.x; idx < K * CK * MF; idx += 256) {
+            const int col = idx % MF, c = (idx / MF) % CK, t = idx / (MF * CK);
+            d.wf[((size_t)t * d.c_in + ch * CK + c) * d.c_out + mb * MF + col] =
+                d.transposed ? tile[c * rstride + col * K + t] : tile[col * rstride + c * K + t];
+        }
+    }
+    // ---- ... and as block (row block ch, chunk mb) of the INPUT-GRADIENT conv's fragment stream (C -> C Conv1d layers, MF == CK): that conv
+    // has rows = this layer's input channels, k-channels = its output channels and tap ts = tap K - 1 - ts of this layer
+    if (d.wpd) {
+        const int nchd = d.c_out / CK;                      // chunks of the gradient conv (over this layer's C_out)
+        float* dd = d.wpd + (size_t)(ch * nchd + mb) * K * GPC * 256;
+        for (int o = threadIdx.x; o < K * GPC * 256; o += 256) {
+            const int j = o & 3, lane = (o >> 2) & 63;
+            const int rest = o >> 8;
+            const int gg = rest % GPC, ts = rest / GPC;
+            const int kc = gg * CKG + j * KSTEP + lane / MF, row = lane % MF;      // k-channel (this layer's C_out index), row (its C_in index)
+            dd[o] = tile[kc * rstride + row * K + (K - 1 - ts)];
+        }
+    }
 }
 
 }  // namespace
@@ -1031,6 +1052,7 @@ extern "C" int v2w_fold_plan(v2w_fold_desc* descs, int n, int32_t* starts) {
         const LayerCfg cfg = v2w_layer_cfg(d.c_in, d.c_out, d.transposed ? d.u : 1);
         if (!cfg.mf) return V2W_E_SHAPE;
         d.mf = cfg.mf; d.ck = cfg.ck;
+        if (d.wpd && (d.transposed || d.c_in != d.c_out || cfg.mf != cfg.ck)) return V2W_E_ARG;   // the gradient stream comes from the same LDS block only then
         starts[i] = bs; starts[n + 1 + i] = bp;
         bs += d.transposed ? d.c_in : d.c_out;
         bp += (d.c_out / cfg.mf) * (d.c_in / cfg.ck);

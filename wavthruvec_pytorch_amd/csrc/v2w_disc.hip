@@ -32,6 +32,29 @@ phase_split_kernel(const float* __restrict__ x, float* __restrict__ out, int C, 
     }
 }
 
+// The same for inner == 1, one group, dense rows whose phase length is a multiple of 4 (the generator's transposed-conv input gradients:
+// B x C rows of S * U floats): a thread reads the 4 S consecutive floats of four output positions as S float4s (coalesced) and writes one
+// float4 to each of the S phase rows (coalesced) - the element-wise form above reads with stride S and ran at 1.3 TB/s.
+template <int S>
+__global__ void __launch_bounds__(256)
+phase_split_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int U) {
+    const int row = blockIdx.y;                        // b * C + c
+    const int b = row / C, c = row - b * C;
+    const float* src = x + (size_t)row * S * U;
+    float* dst = out + ((size_t)b * S * C + c) * U;    // phase r of channel c: row r * C + c of batch item b
+    for (int q = blockIdx.x * 256 + threadIdx.x; 4 * q < U; q += gridDim.x * 256) {
+        float v[4 * S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + (size_t)4 * S * q + 4 * i);
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+        }
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+            *reinterpret_cast<f32x4*>(dst + (size_t)r * C * U + 4 * q) = f32x4{v[r], v[S + r], v[2 * S + r], v[3 * S + r]};
+    }
+}
+
 // x (B, T) single-channel audio, read as (H, inner) rows with a reflect pad on the right up to H*inner samples
 // (models.py:176-181) -> out (B, rows, U*inner): out[b][j][u*inner + w] = xpad[(s*u + j - pad)*inner + w] for j < k and
 // 0 <= s*u + j - pad < H, else 0.  Turns the C_in = 1 first layers into rows-channel 1-tap convs.
@@ -103,6 +126,19 @@ extern "C" int v2w_phase_split(const float* x, float* out, int B, int C, int Cg,
     if (opitch <= 0) opitch = U * inner;
     if (ipitch < L * inner || opitch < U * inner) return V2W_E_ARG;
     const size_t total = (size_t)s * C * opitch;
+    if (inner == 1 && Cg == C && L == s * U && U % 4 == 0 && ipitch == L && opitch == U && (long long)B * C <= 65535 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (s == 2 || s == 4 || s == 5 || s == 8)) {
+        int gx = (U / 4 + 255) / 256; if (gx > 64) gx = 64;
+        const dim3 grid(gx, B * C);
+        hipStream_t st = (hipStream_t)stream;
+        switch (s) {
+            case 2: hipLaunchKernelGGL(phase_split_vec_kernel<2>, grid, dim3(256), 0, st, x, out, C, U); break;
+            case 4: hipLaunchKernelGGL(phase_split_vec_kernel<4>, grid, dim3(256), 0, st, x, out, C, U); break;
+            case 5: hipLaunchKernelGGL(phase_split_vec_kernel<5>, grid, dim3(256), 0, st, x, out, C, U); break;
+            default: hipLaunchKernelGGL(phase_split_vec_kernel<8>, grid, dim3(256), 0, st, x, out, C, U); break;
+        }
+        return v2w_launch_status();
+    }
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U, ipitch, opitch);
     return v2w_launch_status();

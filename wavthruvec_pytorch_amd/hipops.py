@@ -449,15 +449,18 @@ class FoldPlan:
     """Device-resident descriptor table for v2w_fold_pack_batch: every MFMA layer folded + packed in two launches."""
 
     def __init__(self, layers, device):
-        """layers: list of (v, g|None, wp, c_in, c_out, k, u, transposed) with tensors already on `device`."""
+        """layers: list of (v, g|None, wp, c_in, c_out, k, u, transposed[, wf|None[, wpd|None]]) with tensors already on `device`; wf: the plain
+        layout [k][C_in][C_out] as well, wpd: the fragment stream of the layer's input-gradient conv as well (training forwards)."""
         n = len(layers)
         self.n = n
-        rows = [(ci if tr else co) for (_, _, _, ci, co, _, _, tr) in layers]
+        layers = [tuple(l) + (None,) * (10 - len(l)) for l in layers]
+        rows = [(l[3] if l[7] else l[4]) for l in layers]
         self.scale = torch.empty((sum(rows),), device=device, dtype=torch.float32)
         descs = (_hip.FoldDesc * n)()
         off = 0
-        for d, (v, g, wp, ci, co, k, u, tr), r in zip(descs, layers, rows):
+        for d, (v, g, wp, ci, co, k, u, tr, wf, wpd), r in zip(descs, layers, rows):
             d.v = v.data_ptr(); d.g = _hip.ptr(g); d.wp = wp.data_ptr()
+            d.wf = _hip.ptr(wf); d.wpd = _hip.ptr(wpd)
             d.scale = self.scale.data_ptr() + 4 * off
             d.c_in, d.c_out, d.k, d.u, d.transposed = ci, co, k, u, int(tr)
             off += r

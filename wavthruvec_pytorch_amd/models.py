@@ -215,6 +215,7 @@ class Generator(nn.Module):
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._slabs: Dict[tuple, 'hipops.SplitKSlab'] = {}
+        self._wts: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
 
@@ -297,6 +298,17 @@ class Generator(nn.Module):
             slab = self._slabs[key] = hipops.SplitKSlab()
         return slab
 
+    def _wbuf(self, name, shape, dtype=torch.float32, device=None):
+        """Folded / packed WEIGHT buffers: like `_buf`, but they stay with the module when a training forward hands its activation
+        buffers to the autograd graph - the batched fold's descriptor table (pointers) then survives from step to step instead of being
+        rebuilt and copied to the device in front of every training forward.  A backward whose forward's weights have since been
+        modified AND re-folded by a later forward is refused (backward.py), as autograd refuses an in-place modified saved tensor."""
+        t = self._wts.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, device=device, dtype=dtype)
+            self._wts[name] = t
+        return t
+
     def _timed(self, tag, fn, *args, **kw):
         """Launch `fn`; when profiling is on, bracket it with events on the launching (current) stream."""
         if self._profile is None:
@@ -343,6 +355,7 @@ class Generator(nn.Module):
         if not force and self._fold_key.get('state') == state:
             return self._fold_key['wf'], self._fold_key['wp']
         wf, wp, batch = {}, {}, []
+        wpd = {}        # need_wf: fragment streams of the input-gradient convs of the C -> C residual convs (backward.py), from the same pass
         for name, m in layers:
             if bf16_only and name != 'conv_post':      # bf16 activation storage: every other layer runs on its bf16 fragments (_split_weights):
                 wf[name], wp[name] = None, None        # no fp32 fold / fragment stream is read, none is built
@@ -352,29 +365,34 @@ class Generator(nn.Module):
             mfma_ok = (self.algo != hipops.ALGO_DIRECT and name != 'conv_post' and
                        hipops.conv_tile_config(1, m.in_channels, m.out_channels, 64, m.kernel_size,
                                                1 if m.transposed else m.dilation, u) is not None)
-            if mfma_ok and need_wf:     # a forward that will be back-propagated: dgrad / wgrad also read the plain layout
-                wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
-                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
-                (hipops.fold_convt_weight if m.transposed else hipops.fold_conv_weight)(v, g, wfb, scratch)
-                wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
-                wf[name], wp[name] = wfb, hipops.pack_mfma(wfb, wpb, u=u)
+            if mfma_ok and need_wf:     # a forward that will be back-propagated: dgrad / wgrad also read the plain layout - written by the
+                # same batched fold (was: three launches per layer, ~100 host-bound launches and 1.6 ms in front of every training forward)
+                n_el = m.kernel_size * m.in_channels * m.out_channels
+                wfb = self._wbuf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                wpb = self._wbuf('wp.' + name, (n_el,), device=device)
+                wdb = None
+                if not m.transposed and m.in_channels == m.out_channels and name.startswith('resblocks.'):
+                    wdb = wpd[name] = self._wbuf('wpd.' + name, (n_el,), device=device)
+                batch.append((v, g, wpb, m.in_channels, m.out_channels, m.kernel_size, u, m.transposed, wfb, wdb))
+                wf[name], wp[name] = wfb, wpb
             elif mfma_ok:
-                wpb = self._buf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
+                wpb = self._wbuf('wp.' + name, (m.kernel_size * m.in_channels * m.out_channels,), device=device)
                 batch.append((v, g, wpb, m.in_channels, m.out_channels, m.kernel_size, u, m.transposed))
                 wf[name], wp[name] = None, wpb
             else:
-                wfb = self._buf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
-                scratch = self._buf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
+                wfb = self._wbuf('wf.' + name, (m.kernel_size, m.in_channels, m.out_channels), device=device)
+                scratch = self._wbuf('wf_scratch', (max(2048, m.out_channels, m.in_channels),), device=device)
                 (hipops.fold_convt_weight if m.transposed else hipops.fold_conv_weight)(v, g, wfb, scratch)
                 wf[name], wp[name] = wfb, None
         if batch:
-            key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, *_r) in batch)
+            key = tuple((q[0].data_ptr(), 0 if q[1] is None else q[1].data_ptr(), q[2].data_ptr(),
+                         0 if len(q) < 9 or q[8] is None else q[8].data_ptr()) for q in batch)
             plan = self._fold_key.get('plan')
             if plan is None or plan.key != key:
                 plan = hipops.FoldPlan(batch, device)
                 self._fold_key['plan'] = plan
             plan.run()
-        self._fold_key.update(state=state, wf=wf, wp=wp, gen=self._fold_key.get('gen', 0) + 1)
+        self._fold_key.update(state=state, wf=wf, wp=wp, wpd=wpd, vers=tuple(vers), gen=self._fold_key.get('gen', 0) + 1)
         return wf, wp
 
     def _split_weights(self, device, all_ups=False, ups_stream=None):
@@ -859,7 +877,8 @@ class Generator(nn.Module):
             # the spectral-norm vectors AS THIS FORWARD LEFT THEM: the backward of sigma = u^T W v must not see a later forward's
             # power-iteration step (two micro-batches before one backward, a DDP buffer broadcast)
             save['sn_uv'] = [(c.layer.weight_u.detach().clone(), c.layer.weight_v.detach().clone()) for c in self.cbns]
-            save.update(ws=self._ws, wf=wf, wp=wp, y=y, x=x, spk=spk, nz=nz, training=training, B=B, T=T)
+            save.update(ws=self._ws, wf=wf, wp=wp, wpd=self._fold_key.get('wpd', {}), vers=self._fold_key.get('vers'),
+                        y=y, x=x, spk=spk, nz=nz, training=training, B=B, T=T)
             self._ws = keep_ws
             self._fold_key.pop('state', None)     # the cached fold pointed into the handed-over buffers
         return y
