@@ -251,11 +251,13 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                     upf = layers[names[-1]]['u']
                 wide = {128: f'<1, 4, 4, 2, 2, 32, false, true, {upf}>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}>',
                         256: f'<1, 4, 8, 1, 2, 32, false, true, {upf}>', 32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}>'}
-                if names[-1] == 'conv_post':
+                tail7 = names[-1] == 'conv_post' and layers['conv_post']['k'] == 7
+                if names[-1] == 'conv_post' and not tail7:
                     wide[16] = '<1, 4, 1, 2, 2, 16, false, false, 0>'
                 if ls[0]['cout'] == 16 and 16 not in wide and ls[0]['L'] % 4 == 0:
-                    wide[16] = None                          # the reference's block set on 16 channels: v2w_stage_bf16_n16.hip
-                kname = (('n16_stage_kernel<4>' if wide[ls[0]['cout']] is None else 'wide_stage_bf16_kernel' + wide[ls[0]['cout']])
+                    wide[16] = None                          # the reference's block set on 16 channels: v2w_stage_bf16_n16.hip (+ the 7-tap tail)
+                kname = ((('n16_stage_kernel<4, true>' if tail7 else 'n16_stage_kernel<4, false>') if wide[ls[0]['cout']] is None
+                          else 'wide_stage_bf16_kernel' + wide[ls[0]['cout']])
                          if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         nbytes = sum(l['bytes'] for l in ls)

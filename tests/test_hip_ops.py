@@ -606,10 +606,12 @@ def test_resblock2_wide_stage_other_block_sets(dev, B, C, L, ks, d1, d2):
     assert err.mean().item() <= 4e-3
 
 
-@pytest.mark.parametrize('B,L', [(2, 1000), (3, 4100), (1, 24), (2, 216), (2, 220), (2, 224)])
-def test_resblock2_stage16_with_the_fused_tail(dev, B, L):
+@pytest.mark.parametrize('kp', [7, 9])
+@pytest.mark.parametrize('B,L', [(2, 1000), (3, 4100), (1, 24), (2, 216), (2, 220), (2, 224), (2, 468), (2, 472), (2, 476), (1, 948)])
+def test_resblock2_stage16_with_the_fused_tail(dev, B, L, kp):
     """The last (C = 16) stage with leaky_relu(0.01) -> conv_post -> tanh (models.py:143-145) inside the same kernel: the stage's output is
-    not written, the fp32 audio is - against fp64 math on the same bf16 operands; lengths around the tile advance (220 outputs)."""
+    not written, the fp32 audio is - against fp64 math on the same bf16 operands.  kp = 7 (the reference's conv_post): the weights-in-
+    registers kernel (v2w_stage_bf16_n16.hip, tiles advance by 472 outputs); kp = 9: the resident-tile template (220 outputs per tile)."""
     from wavthruvec_pytorch_amd import hipops
     C = 16
     g = torch.Generator().manual_seed(300 + L)
@@ -621,16 +623,16 @@ def test_resblock2_stage16_with_the_fused_tail(dev, B, L):
     w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
     b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
     b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
-    wpost = torch.randn(1, C, 7, generator=g) / (C * 7) ** 0.5
+    wpost = torch.randn(1, C, kp, generator=g) / (C * kp) ** 0.5
     bpost = 0.1 * torch.randn(1, generator=g)
     out_want, _ = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, True)
-    y_want = torch.tanh(F.conv1d(F.leaky_relu(out_want, 0.01), wpost.double(), bpost.double(), padding=3))
+    y_want = torch.tanh(F.conv1d(F.leaky_relu(out_want, 0.01), wpost.double(), bpost.double(), padding=(kp - 1) // 2))
     br = [dict(wps1=hipops.pack_split(w1[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b1=b1[j].to(dev),
                wps2=hipops.pack_split(w2[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b2=b2[j].to(dev),
                k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(3)]
     y = torch.full((B, 1, L), float('nan'), device=dev)
     ok = hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, None, slope=0.1, out_div=3.0, bf16=True, io_bf16=3,
-                                      post=(wpost.permute(2, 1, 0).contiguous().to(dev), bpost.to(dev), y, 7, 0.01))
+                                      post=(wpost.permute(2, 1, 0).contiguous().to(dev), bpost.to(dev), y, kp, 0.01))
     assert ok, 'the fused tail was declined'
     assert torch.isfinite(y).all()
     err = (y.cpu().double() - y_want).abs()
@@ -639,7 +641,7 @@ def test_resblock2_stage16_with_the_fused_tail(dev, B, L):
     out = torch.empty((B, C, L), device=dev, dtype=torch.bfloat16)
     assert hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)
     y2 = torch.empty_like(y)
-    hipops.conv_post_tanh(out, wpost.permute(2, 1, 0).contiguous().to(dev), bpost.to(dev), y2, k=7, slope=0.01)
+    hipops.conv_post_tanh(out, wpost.permute(2, 1, 0).contiguous().to(dev), bpost.to(dev), y2, k=kp, slope=0.01)
     assert (y2 - y).abs().max().item() <= 2e-2
 
 

@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 if sys.argv[1] == 'child':
     v = sys.argv[2]
+    flags = v.split(':')[1:]          # 'main:nopost', '_variant:noup': Generator switches
+    v = v.split(':')[0]
     if v != 'main':
         os.environ['V2W_LIB'] = os.path.join(ROOT, 'tools', 'exp', f'libv2w_res{v}.so')
     import torch
@@ -12,6 +14,9 @@ if sys.argv[1] == 'child':
     dev = torch.device('cuda:0')
     h = synthetic.make_hparams(num_wv_feat=768)
     g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train(); g.precision = 'bf16'
+    if 'nopost' in flags: g.fuse_post = False
+    if 'noup' in flags: g.fuse_up = False
+    v = ':'.join([v] + flags)
     inp = tuple(t.to(dev) for t in synthetic.make_inputs(h, 64, 512, seed=1))
     per = {}
     with torch.no_grad():

@@ -450,7 +450,7 @@ int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, 
     }
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
 #ifndef V2W_NO_N16
-    if (a->C == 16 && a->io_bf16 == 3 && !a->post_out) {      // the reference's block set on aligned bf16 tensors: weights in registers
+    if (a->C == 16 && a->io_bf16 == 3) {      // the reference's block set on aligned bf16 tensors: weights in registers (+ the 7-tap tail)
         const int rc = v2w_resblock2_stage_bf16_n16(a, stream);
         if (rc != V2W_E_SHAPE) return rc;
     }

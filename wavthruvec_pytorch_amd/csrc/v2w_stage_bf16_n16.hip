@@ -32,6 +32,12 @@ struct N16Args {
     unsigned short* out;
     int B, L, nto, ntl, ntiles;
     float slope, inv_slope, out_div;
+    // fused tail (POST instantiation; models.py:143-145): y = tanh(conv_post(leaky_relu(out, post_slope))) with 7 taps, written as fp32 (B, 1, L);
+    // `out` is not written.  A tile then advances by nadv = nto - 2 hout positions and starts hout = 4 positions early (3 feed the taps, 4
+    // keep the output quads 16-byte aligned).
+    const float* post_w; const float* post_b; float* post_out;
+    float post_slope;
+    int nadv, hout;
 };
 
 __device__ __forceinline__ unsigned int n16_pack2(float lo, float hi) {
@@ -53,7 +59,7 @@ constexpr int N16_NB = 8;                        // 16-column blocks per wave (1
 
 // WN waves per workgroup: a window of W = 128 WN columns (positions n0 - 15 .. n0 - 15 + W), of which the middle nto = (W - 30) & ~3 are
 // valid outputs; x tile rows = positions n0 - 20 .. (W + 12 rows), t1 tile rows = window columns.
-template <int WN>
+template <int WN, bool POST = false>
 __global__ void __launch_bounds__(64 * WN, 2)
 n16_stage_kernel(const N16Args a) {
     constexpr int NTH = 64 * WN, W = 128 * WN, XR = W + 12, RB = 32, NB = N16_NB;
@@ -147,7 +153,7 @@ n16_stage_kernel(const N16Args a) {
     float av[4], sv[4];
     const int cq = tid & 3;                                                     // (NTH % 4 == 0: a thread keeps its channel quad)
     auto issue_x = [&](int tile) {
-        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * nto;
+        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * a.nadv - a.hout;
         const int pos0 = n0 - N16_H1 - N16_H2;
         const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * 16 * L * 2;
 #pragma unroll
@@ -193,9 +199,14 @@ n16_stage_kernel(const N16Args a) {
         }
     };
 
+    // the tail's weights, transposed to [channel][8] behind the tiles (never overlaid): a channel's 7 taps are two broadcast float4 reads
+    float* const wl = reinterpret_cast<float*>(smem_n + (2 * XR + W + 16) * RB);       // (behind the x, t1 and r tiles)
+    if constexpr (POST) {
+        if (tid < 128) wl[tid] = (tid & 7) < 7 ? a.post_w[(tid & 7) * 16 + (tid >> 3)] : 0.f;
+    }
     issue_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * nto;
+        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * a.nadv - a.hout;
         // a tile whose window and halo lie inside the sequence needs no per-position checks in the epilogues
         const bool edge = n0 - N16_H2 < 0 || n0 - N16_H2 + W > L;
         n16_lds_barrier();                                                        // the previous tile's stores have read the scratch
@@ -260,6 +271,24 @@ n16_stage_kernel(const N16Args a) {
         V2W_STAMP(18);
         {
             float* const scr = reinterpret_cast<float*>(smem_n);
+            if constexpr (POST) {
+                // the tail's operand z = leaky_relu(out / nk, post_slope), exactly 0 outside the sequence (conv_post zero-pads): fp32, never rounded
+                const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f, ps = a.post_slope;
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    int col = col0;
+                    asm volatile("" : "+v"(col));
+                    col += 16 * cb;
+                    const int pos = n0 - N16_H2 + col;
+                    const bool in_seq = pos >= 0 && pos < L;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = oacc[cb][r];
+                        if (a.out_div != 0.f) v = v2w_div_by(v, a.out_div, dinv);
+                        scr[(4 * kg + r) * SRS + col + 1] = in_seq ? fmaxf(v, v * ps) : 0.f;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
                 int col = col0;
@@ -268,11 +297,55 @@ n16_stage_kernel(const N16Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scr[(4 * kg + r) * SRS + col + 1] = oacc[cb][r];
             }
+            }
             n16_lds_barrier();
             V2W_STAMP(19);
             // the next tile's x: in flight under this tile's stores (unconditional - past the end the last tile again, never committed: under
             // a condition the old values would stay live through the whole iteration as the other input of the join)
             issue_x(min(tile + (int)gridDim.x, a.ntiles - 1));
+            if constexpr (POST) {
+                // y[p] = tanh(b + sum_c sum_t w[t][c] z[c][p + t - 3]) for the nadv positions p = n0 + hout + m: window column of z[c][p + t - 3] is
+                // 15 + hout + m + t - 3, scratch column one more = 17 + m + t (hout = 4).  A thread takes 4 consecutive outputs (m = 4 q ..) of 8
+                // of the 16 channels: per channel the three aligned float4s from scratch column 16 + 4 q hold the 10 values it needs; the two
+                // channel halves (threads tid and tid + NTH / 2) meet through LDS.
+                constexpr int HALF = NTH / 2;
+                const int q = tid % HALF, hf = tid / HALF;
+                float* const part = scr + 16 * SRS;                       // [HALF] float4 behind the scratch rows
+                const bool act = 4 * q < a.nadv;
+                f32x4 y = {0.f, 0.f, 0.f, 0.f};
+                if (act) {
+#pragma unroll 1
+                    for (int cc = 0; cc < 8; ++cc) {       // (rolled: unrolled, hipcc hoists the 24 float4 reads - 96 registers beside the 96 of weights)
+                        const int c = 8 * hf + cc;
+                        const float* zr = scr + c * SRS + 16 + 4 * q;
+                        float z[12];
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 4 * u);
+                            z[4 * u] = zz[0]; z[4 * u + 1] = zz[1]; z[4 * u + 2] = zz[2]; z[4 * u + 3] = zz[3];
+                        }
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + 8 * c), w1 = *reinterpret_cast<const f32x4*>(wl + 8 * c + 4);
+                        const float wv[7] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2]};
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) y[x] = fmaf(wv[t], z[1 + x + t], y[x]);
+                        }
+                    }
+                    if (hf == 1) *reinterpret_cast<f32x4*>(part + 4 * q) = y;
+                }
+                n16_lds_barrier();
+                if (act && hf == 0) {
+                    const int p0 = n0 + a.hout + 4 * q;
+                    if (p0 < L) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(part + 4 * q);
+                        const float pb = a.post_b ? a.post_b[0] : 0.f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) y[x] = tanhf((y[x] + o[x]) + pb);
+                        *gptr<f32x4>(a.post_out + (size_t)b * L + p0) = y;
+                    }
+                }
+            } else {
             const int nq = nto >> 2;
             const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
             const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
@@ -288,6 +361,7 @@ n16_stage_kernel(const N16Args a) {
                 }
                 *gptr<u32x2>(obase + (unsigned)(row * L + pos) * 2u) = u32x2{n16_pack2(v[0], v[1]), n16_pack2(v[2], v[3])};
             }
+            }     // (!POST)
         }
         V2W_STAMP(20);
     }
@@ -305,17 +379,25 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
     }
     p.B = q->B; p.L = q->L; p.slope = q->slope; p.inv_slope = 1.f / q->slope; p.out_div = q->out_div;
     p.nto = (W - 2 * N16_H2) & ~3;
-    p.ntl = (q->L + p.nto - 1) / p.nto;
+    p.nadv = p.nto; p.hout = 0;
+    const bool post = q->post_out != nullptr;
+    if (post) {                     // the generator's tail behind the stage: 7 taps, 16 -> 1 channels, fp32 output
+        p.post_w = q->post_w; p.post_b = q->post_b; p.post_out = q->post_out; p.post_slope = q->post_slope;
+        p.hout = 4; p.nadv = (p.nto - 2 * p.hout) & ~3;
+    }
+    p.ntl = (q->L + p.nadv - 1) / p.nadv;
     if ((long long)q->B * p.ntl > 0x7fffffffll) return V2W_E_SHAPE;
     p.ntiles = q->B * p.ntl;
     // x, t1 (+ 16 rows of slack behind it: conv2's taps past its end) and r tiles; the store scratch [16][W + 12] floats overlays them
-    const size_t tiles = (size_t)(XR + W + 16 + XR) * 32, scratch = (size_t)16 * (W + 12) * sizeof(float);
-    const size_t lds = tiles > scratch ? tiles : scratch;
+    const size_t tiles = (size_t)(XR + W + 16 + XR) * 32, scratch = (size_t)16 * (W + 12) * sizeof(float) + (post ? (size_t)(NTH / 2) * 16 : 0);
+    if (scratch > tiles) return V2W_E_SHAPE;                                    // (the scratch overlays the tiles)
+    const size_t lds = tiles + (post ? 512 : 0);
     if (v2w_dry(stream)) return 0;
     const int ncu = v2w_num_cus();
     // persistent: the registers hold the stage's weights, so a workgroup walks tiles; 8 waves per CU (2 per SIMD: ~230 registers each)
     const int slots = ncu * (8 / WN);
-    hipLaunchKernelGGL(n16_stage_kernel<WN>, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    if (post) hipLaunchKernelGGL((n16_stage_kernel<WN, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    else hipLaunchKernelGGL((n16_stage_kernel<WN, false>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 
@@ -332,11 +414,12 @@ V2W_TL_SETTER(v2w_timeline_set_n16)
 // Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for C = 16 on bf16 tensors.  V2W_E_SHAPE: not the reference's block set / not
 // aligned - the caller runs its own kernels.
 int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream) {
-    if (a->C != 16 || a->io_bf16 != 3 || !a->bf16 || a->nk != 3 || a->post_out) return V2W_E_SHAPE;
+    if (a->C != 16 || a->io_bf16 != 3 || !a->bf16 || a->nk != 3 || a->up_out) return V2W_E_SHAPE;
+    if (a->post_out && (a->post_k != 7 || !a->post_w || (reinterpret_cast<uintptr_t>(a->post_out) & 15))) return V2W_E_SHAPE;     // the fused tail: 7 taps
     for (int j = 0; j < 3; ++j)
         if (a->k[j] != 3 + 4 * j || a->dil1[j] != 1 || a->dil2[j] != 3 || !a->wps1[j] || !a->wps2[j]) return V2W_E_SHAPE;
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
-    if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out) || !a->out) return V2W_E_SHAPE;
+    if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out) || (!a->out && !a->post_out)) return V2W_E_SHAPE;
     if ((long long)16 * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;            // 32-bit offsets inside one batch item
     if (!(a->slope > 0.f && a->slope < 1.f)) return V2W_E_SHAPE;                // lrelu as max(v, slope v), undone as min(a, a / slope)
     return launch_n16<V2W_N16_WN>(a, stream);

@@ -210,8 +210,8 @@ class Generator(nn.Module):
         self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
         self.fuse_up = True                   # bf16 storage: the NEXT stage's transposed conv (stride 2 / 4) inside the kernel of a stage (C = 32 .. 256):
                                               # the stage's output never leaves the chip, one launch less per stage
-        self.fuse_post = False                # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage
-                                              # (opt-in: measured 1162 us against 791 + 190 us for the two kernels at configs[2])
+        self.fuse_post = True                 # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage: the stage's
+                                              # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._slabs: Dict[tuple, 'hipops.SplitKSlab'] = {}
@@ -732,7 +732,11 @@ class Generator(nn.Module):
                             branches = [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                              wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                              dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation) for nm, rb in zip(names, rbs)]
-                            if st and self.fuse_post and i == ns - 1 and C == 16 and self.conv_post.kernel_size <= 9:
+                            # (the reference's block set and 7-tap tail: the weights-in-registers kernel takes them; any other set / k <= 9 tail
+                            # would run on the resident-tile template, measured slower than the two kernels: only with fuse_post = 'any')
+                            std_set = [(rb.kernel_size, rb.convs[0].dilation, rb.convs[1].dilation) for rb in rbs] == [(3, 1, 3), (7, 1, 3), (11, 1, 3)]
+                            if st and self.fuse_post and i == ns - 1 and C == 16 and self.conv_post.kernel_size <= 9 and \
+                                    ((std_set and self.conv_post.kernel_size == 7) or self.fuse_post == 'any'):
                                 # the last stage with the generator's tail behind it in ONE kernel (models.py:143-145): the stage's output never
                                 # leaves the chip, y is written instead
                                 y = torch.empty((B, 1, Lo), device=dev, dtype=torch.float32)
