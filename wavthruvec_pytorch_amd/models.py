@@ -390,6 +390,7 @@ class Generator(nn.Module):
             plan = self._fold_key.get('plan')
             if plan is None or plan.key != key:
                 plan = hipops.FoldPlan(batch, device)
+                plan.key = key
                 self._fold_key['plan'] = plan
             plan.run()
         self._fold_key.update(state=state, wf=wf, wp=wp, wpd=wpd, vers=tuple(vers), gen=self._fold_key.get('gen', 0) + 1)
