@@ -240,6 +240,7 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
         kname = kernel_of(ls[0], len(tag.split('+')))
         if bconv:
             kname = 'conv_bf16_res_kernel<%s, %d>' % ('2, 4, 2, 2' if ls[0]['cout'] % 128 == 0 else '1, 4, 2, 2', int(tag[5]))
+        rb1 = tag.startswith('rb1:')              # ResBlock1 pairs on bf16 tensors: the run-time form of the resident-tile kernel, one launch per pair position
         if fused:
             kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
                     ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
@@ -260,6 +261,10 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                           else 'wide_stage_bf16_kernel' + wide[ls[0]['cout']])
                          if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
+        if rb1:
+            kname = 'wide_stage_bf16_kernel' + {256: '<1, 4, 8, 1, 2, 32, false, false, 0>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0>',
+                                                64: '<2, 2, 1, 4, 2, 32, false, false, 0>', 32: '<1, 4, 1, 2, 2, 32, false, false, 0>',
+                                                16: '<1, 4, 1, 2, 2, 16, false, false, 0>'}[ls[0]['cout']]
         nbytes = sum(l['bytes'] for l in ls)
         if fused:                              # the intermediate is neither written nor re-read
             nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])

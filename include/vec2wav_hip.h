@@ -255,7 +255,15 @@ typedef struct {
     const void* up_wps; const float* up_bias; void* up_out; float* up_stats_part;
     int32_t up_k, up_u;
     float up_slope;
-    int32_t _pad;
+    /* ResBlock1 pair mode (ABI v28; rb1 != 0, bf16 != 0, io_bf16 == 3; models.py:37-44 on bf16 tensors): the nk entries are independent PROBLEMS -
+     * branch p of a stage at one of its three (dilated conv, conv) pairs - run in one launch:
+     *   out_b[p] = ( x_p + conv_{k[p], dil2[p]}(lrelu(conv_{k[p], dil1[p]}(lrelu x_p) + bias1[p])) + bias2[p] ) [ + add0 + add1 ] / out_div ,
+     *   x_p = in_a * in_b[p] + in_s (in_b[p] == NULL: `in`; in_a / in_s as above, NULL for the second and third pair).
+     * add0 / add1 (bf16 (B, C, L) or NULL): added, add0 + add1 first, by the LAST problem of the launch before the division - the final pair of
+     * the last branch takes the other branches' results: ((r0 + r1) + r2) / nk.  `out`, post_*, up_* are not used.  C = 16 .. 256. */
+    int32_t rb1;
+    const void* in_b[4]; void* out_b[4];
+    const void* add0; const void* add1;
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 /* Shape query (ABI v28; host-only, nothing is launched or dereferenced): 0 when the call above would run this stage as one kernel, else the

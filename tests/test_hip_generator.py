@@ -159,6 +159,36 @@ def test_generator_bf16_storage_ragged_lengths(dev, B, T):
     assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
 
 
+@pytest.mark.parametrize('B,T,rates,ks', [(3, 64, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]), (2, 40, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]),
+                                          (2, 20, [8, 5, 4, 2, 2], [16, 11, 8, 4, 4])])
+@pytest.mark.parametrize('training', [True, False])
+def test_generator_resblock1_bf16_storage(dev, B, T, rates, ks, training):
+    """h.resblock == '1' with precision='bf16': bf16 tensors between ALL layers - every (dilated conv, conv) pair of
+    models.py:37-44 as one resident-tile launch per pair position (v2w_stage_split_args::rb1), the branch mean in the last one - against
+    the fp32 oracle at the small-size bf16 bar, train and calibrated-eval mode."""
+    nf = 768 if rates[0] == 5 else 1024
+    h = synthetic.make_hparams(num_wv_feat=nf, resblock='1', upsample_rates=rates, upsample_kernel_sizes=ks)
+    sd = synthetic.make_state_dict(h, seed=5)
+    inp_cpu = synthetic.make_inputs(h, B, T, seed=9)
+    if not training:
+        O.calibrate_running_stats(sd, h, *inp_cpu)
+    want, _ = O.generator_forward({k: v.clone() for k, v in sd.items()}, h, *inp_cpu, training=training)
+    g = build_generator(h, sd, dev, training=training)
+    g.precision = 'bf16'
+    with torch.no_grad():
+        y = g(*to_dev(inp_cpu, dev))
+    assert g._ws['act.xa_0_0'].dtype == torch.bfloat16 and g._ws['act.rb4'].dtype == torch.bfloat16, 'the activations are not stored as bf16'
+    assert y.shape == want.shape and torch.isfinite(y).all()
+    d = (y.cpu() - want).abs().max().item()
+    assert 1e-6 < d <= 6e-3, f'max|dy| = {d}'
+    # ... and no farther from the oracle than fp32 storage with the same bf16 operands is, by more than the storage rounding allows
+    g2 = build_generator(h, sd, dev, training=training)
+    g2.precision = 'bf16'; g2.bf16_storage = False
+    with torch.no_grad():
+        y2 = g2(*to_dev(inp_cpu, dev))
+    assert (y2.cpu() - want).abs().max().item() <= 6e-3
+
+
 def test_generator_bf16_storage_falls_back_when_a_layer_has_no_bf16_kernel(dev):
     """precision='bf16' with the default bf16 activation storage on a configuration the bf16-tensor kernels do not cover (a residual
     kernel of 13 taps: the fused narrow-stage kernel stops at 11): the forward must run - with fp32 tensors between the layers -
@@ -716,6 +746,14 @@ def test_generator_resblock1_full_size_vs_oracle_train(dev):
     B=32 x T=256, fp32, train mode: |dy| <= 1e-4 against the pinned oracle, buffers equal (bench.py reports it as resblock1_f32)."""
     h = synthetic.make_hparams(num_wv_feat=768, resblock='1')
     _full_size_case(dev, h, 32, 256, 1234, [('f32', TOL)])
+
+
+@pytest.mark.timeout(1800)
+def test_generator_resblock1_bf16_full_size_vs_oracle_train(dev):
+    """The ResBlock1 generator at the cfg2 shape in the configs[2] arithmetic (bf16 compute / fp32 accumulate, bf16 tensors between the layers):
+    held, like cfg3, to the reference's own bf16-autocast deviation on the same inputs (max and rms)."""
+    h = synthetic.make_hparams(num_wv_feat=768, resblock='1')
+    _full_size_case(dev, h, 32, 256, 1234, [('bf16', 'ref-bf16')])
 
 
 @pytest.mark.timeout(900)

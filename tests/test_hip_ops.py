@@ -606,6 +606,58 @@ def test_resblock2_wide_stage_other_block_sets(dev, B, C, L, ks, d1, d2):
     assert err.mean().item() <= 4e-3
 
 
+@pytest.mark.parametrize('B,C,L', [(2, 128, 512), (3, 64, 1000), (2, 256, 260), (2, 32, 2000), (3, 16, 4100), (1, 32, 24), (1, 128, 8)])
+@pytest.mark.parametrize('dil', [1, 3, 5])
+def test_resblock1_pairs_bf16(dev, B, C, L, dil):
+    """resblock1_pairs_bf16 (v2w_stage_split_args::rb1): three independent ResBlock1 pairs - kernel sizes 3 / 7 / 11, first conv at dilation
+    `dil`, second at 1, each on its OWN input tensor - in one launch, then the summing form (the last problem adds the others' results and
+    divides): against fp64 math on the same bf16 operands (models.py:37-44: xt = c2(lrelu(c1(lrelu x))); x = xt + x)."""
+    from wavthruvec_pytorch_amd import hipops
+    g = torch.Generator().manual_seed(500 + C + L + dil)
+    ks = [3, 7, 11]
+    xs = [torch.randn(B, C, L, generator=g).bfloat16() for _ in ks]
+    a = 1 + 0.2 * torch.randn(B, C, generator=g)
+    s_ = 0.2 * torch.randn(B, C, generator=g)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    b1 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) for _ in ks]
+
+    def ref(x, j, affine):
+        xa = (a[:, :, None] * x.float() + s_[:, :, None]) if affine else x.float()
+        xact = F.leaky_relu(xa, 0.1).bfloat16().double()
+        xres = torch.where(xact > 0, xact, xact / 0.1)            # the kernel rebuilds the residual from the activated operand
+        u = F.conv1d(xact, w1[j].bfloat16().double(), b1[j].double(), dilation=dil, padding=dil * (ks[j] - 1) // 2)
+        uact = F.leaky_relu(u.float(), 0.1).bfloat16().double()
+        return xres + F.conv1d(uact, w2[j].bfloat16().double(), b2[j].double(), padding=(ks[j] - 1) // 2)
+
+    br = [dict(wps1=hipops.pack_split(w1[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b1=b1[j].to(dev),
+               wps2=hipops.pack_split(w2[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b2=b2[j].to(dev),
+               k=ks[j], dil1=dil, dil2=1) for j in range(3)]
+    fits = not (C == 256 and dil == 5)      # 256 channels at dilation 5: 94 KB of x beside 66 KB of intermediate exceed the LDS - the generator
+    assert hipops.resblock1_pairs_ok(B, C, L, ks, [dil] * 3, [1] * 3, slope=0.1) == fits      # then runs that pair conv by conv
+    if not fits:
+        return
+    xd = [x.to(dev) for x in xs]
+    for affine in (True, False):
+        outs = [torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16) for _ in ks]
+        ok = hipops.resblock1_pairs_bf16(xd, (a.to(dev), s_.to(dev)) if affine else None, br, outs, slope=0.1)
+        assert ok
+        for j in range(3):
+            want = ref(xs[j], j, affine)
+            err = (outs[j].cpu().double() - want).abs()
+            assert torch.isfinite(outs[j].float()).all()
+            assert (err <= 2.0 ** -8 * want.abs() + 2e-2).all(), f'branch {j}: max err {err.max().item()} (|want| max {want.abs().max().item()})'
+    # the last pair of a stage: branches 0 and 1 first, then branch 2 takes their (bf16) results and divides
+    o01 = [torch.empty((B, C, L), device=dev, dtype=torch.bfloat16) for _ in range(2)]
+    assert hipops.resblock1_pairs_bf16(xd[:2], None, br[:2], o01, slope=0.1)
+    tot = torch.full((B, C, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    assert hipops.resblock1_pairs_bf16(xd[2:], None, br[2:], [tot], slope=0.1, out_div=3.0, add=o01)
+    want = ((o01[0].cpu().double() + o01[1].cpu().double()) + ref(xs[2], 2, False)) / 3.0
+    err = (tot.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 1e-2).all(), f'sum: max err {err.max().item()}'
+
+
 @pytest.mark.parametrize('kp', [7, 9])
 @pytest.mark.parametrize('B,L', [(2, 1000), (3, 4100), (1, 24), (2, 216), (2, 220), (2, 224), (2, 468), (2, 472), (2, 476), (1, 948)])
 def test_resblock2_stage16_with_the_fused_tail(dev, B, L, kp):

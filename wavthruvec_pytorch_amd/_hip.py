@@ -72,7 +72,8 @@ class StageSplitArgs(C.Structure):
                 ('slope', C.c_float), ('out_div', C.c_float), ('bf16', C.c_int32), ('io_bf16', C.c_int32),
                 ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float),
                 ('up_wps', _fp), ('up_bias', _fp), ('up_out', _fp), ('up_stats_part', _fp),
-                ('up_k', C.c_int32), ('up_u', C.c_int32), ('up_slope', C.c_float), ('_pad', C.c_int32)]
+                ('up_k', C.c_int32), ('up_u', C.c_int32), ('up_slope', C.c_float), ('rb1', C.c_int32),
+                ('in_b', _P4), ('out_b', _P4), ('add0', _fp), ('add1', _fp)]
 
 
 class BranchConvsArgs(C.Structure):

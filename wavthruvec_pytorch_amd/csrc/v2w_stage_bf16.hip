@@ -448,6 +448,10 @@ int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, 
         if (a->io_bf16 != 3 || a->C < 32) return V2W_E_SHAPE;
         return v2w_resblock2_stage_bf16_wide(a, stream, up_tiles_out);
     }
+    if (a->rb1) {           // ResBlock1 pair mode: the resident-tile template's run-time form (bf16 tensors, C = 16 .. 256)
+        if (a->io_bf16 != 3) return V2W_E_SHAPE;
+        return v2w_resblock2_stage_bf16_wide(a, stream);
+    }
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
 #ifndef V2W_NO_N16
     if (a->C == 16 && a->io_bf16 == 3) {      // the reference's block set on aligned bf16 tensors: weights in registers (+ the 7-tap tail)

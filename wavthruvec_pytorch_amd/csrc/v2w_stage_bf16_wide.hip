@@ -64,6 +64,13 @@ struct WideArgs {
     // side feeds the taps only.
     const unsigned char* up_w; const float* up_bias; unsigned short* up_out; float* up_stats;
     float up_slope;
+    // ResBlock1 pair mode (rb1 != 0; run-time block sets only; models.py:37-44): nk independent PROBLEMS, one conv pair each, in one launch -
+    //   out_b[p] = ( x_p + conv_{k_p, d2_p}(lrelu(conv_{k_p, d1_p}(lrelu x_p) + b1_p)) + b2_p  [+ add0 + add1] ) / out_div ,  x_p = a * in_b[p] + s
+    // - the p-th branch of a stage at one of its three (dilated conv, conv) pairs: the residual goes to the OUTPUT, not to the intermediate.
+    // Tiles [p * ntiles1, (p + 1) * ntiles1) belong to problem p; add0 / add1 (the last pair of the last branch: the other branches' results).
+    int rb1, ntiles1;
+    const unsigned short* in_b[V2W_WS_MAXB]; unsigned short* out_b[V2W_WS_MAXB];
+    const unsigned short* add0; const unsigned short* add1;
 };
 
 __device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
@@ -147,6 +154,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
     const int wn0 = (wave % WN) * (32 * NI);
     const int xc0 = ws_uni(a.xoff) + h1max;                                     // x row of window column 0 (position n0 - h2max)
     auto tile_origin = [&](int tile, int& tb, int& tn0, int& tpos0) {
+        if constexpr (!STD) { if (a.rb1) tile %= a.ntiles1; }
         tb = tile / a.ntl;
         tn0 = (tile % a.ntl) * (nto - 2 * hout) - hout;
         tpos0 = tn0 - h2max - h1max - ws_uni(a.xoff);                           // (a multiple of 4)
@@ -162,7 +170,9 @@ wide_stage_bf16_kernel(const WideArgs a) {
     auto issue_x = [&](int tile) {
         int tb, tn0, tpos0;
         tile_origin(tile, tb, tn0, tpos0);
-        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)tb * C * L * 2;
+        const unsigned short* src = a.in;
+        if constexpr (!STD) { if (a.rb1) src = a.in_b[tile / a.ntiles1]; }
+        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(src) + (size_t)tb * C * L * 2;
 #pragma unroll
         for (int s = 0; s < NPF; ++s) {
             const int idx = tid + s * NTH;
@@ -527,6 +537,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
             }
     };
 
+    bool rb1 = false;
+    if constexpr (!STD) rb1 = ws_uni(a.rb1) != 0;
     auto branch = [&](int jb, auto k_c, auto pre1_c) {
         constexpr int KC = decltype(k_c)::value;             // > 0: the tap count at compile time (dilations 1 and 3), 0: run-time arguments
         constexpr bool PRE1 = decltype(pre1_c)::value && V2W_WS_PRE, PRE2 = KC > 0 && V2W_WS_PRE;      // conv1 / conv2 start from `arp`
@@ -579,10 +591,12 @@ wide_stage_bf16_kernel(const WideArgs a) {
                         const f32x2 xa = {ws_lo(w[h]), ws_hi(w[h])};
                         const f32x2 xi = xa * isl2;
                         const f32x2 xr = {ws_min(xa[0], xi[0]), ws_min(xa[1], xi[1])};       // lrelu undone (slope < 1)
-                        f32x2 t = f32x2{acc1[i][j][4 * g + 2 * h], acc1[i][j][4 * g + 2 * h + 1]} + xr;
+                        f32x2 t = f32x2{acc1[i][j][4 * g + 2 * h], acc1[i][j][4 * g + 2 * h + 1]};
+                        if (!rb1) t = t + xr;                // ResBlock2: t1 = x + conv1(..); ResBlock1: the intermediate carries no residual
                         t = t * msk;
-                        oacc[i][j][4 * g + 2 * h] += t[0];
-                        oacc[i][j][4 * g + 2 * h + 1] += t[1];
+                        const f32x2 radd = rb1 ? xr : t;     // ... its residual x (0 outside the sequence) joins the OUTPUT instead
+                        oacc[i][j][4 * g + 2 * h] += radd[0];
+                        oacc[i][j][4 * g + 2 * h + 1] += radd[1];
                         const f32x2 ts = t * sl2;
                         packed[h] = ws_pack2(fmaxf(t[0], ts[0]), fmaxf(t[1], ts[1]));
                     }
@@ -615,9 +629,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
         const int j = i / C, c = i - j * C;
         btab[i] = a.bias1[j] ? a.bias1[j][c] : 0.f;
     }
+    const int prob = rb1 ? tile / ws_uni(a.ntiles1) : 0;          // ResBlock1 pair mode: this tile's problem = its one branch
     for (int c = tid; c < C; c += NTH) {
         float v = 0.f;
-        for (int j = 0; j < nk; ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
+        for (int j = rb1 ? prob : 0; j < (rb1 ? prob + 1 : nk); ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
         b2tab[c] = v;
         atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
         atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
@@ -633,7 +648,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
         branch(1, std::integral_constant<int, 7>{}, std::false_type{});
         branch(2, std::integral_constant<int, 11>{}, std::false_type{});
     } else {
-        for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{}, std::false_type{});
+        if (rb1) branch(prob, std::integral_constant<int, 0>{}, std::false_type{});
+        else for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{}, std::false_type{});
     }
 
     if constexpr (UPF > 0) {
@@ -825,12 +841,25 @@ wide_stage_bf16_kernel(const WideArgs a) {
         if (!tail) {
             const int nq = nto >> 2;
             const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
-            unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * C * L * 2;
+            unsigned short* dstp = a.out;
+            if constexpr (!STD) { if (rb1) dstp = a.out_b[prob]; }
+            unsigned char* const obase = reinterpret_cast<unsigned char*>(dstp) + (size_t)b * C * L * 2;
+            const bool adds = !STD && rb1 && a.add0 != nullptr && prob == nk - 1;      // (the summing problem is the last one)
             for (int idx = tid; idx < C * nq; idx += NTH) {
                 const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
                 const int pos = n0 + 4 * q;
                 if (pos >= L) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + soff + 4 * q);
+                if (adds) {        // ((r0 + r1) + r2) / nk in the reference's order (models.py:135-141): the other branches' bf16 results first
+                    const size_t eo = ((size_t)b * C * L + (size_t)row * L + pos) * 2;
+                    const u32x2 w0 = *gptr<const u32x2>(reinterpret_cast<const unsigned char*>(a.add0) + eo);
+                    f32x4 s4 = {ws_lo(w0[0]), ws_hi(w0[0]), ws_lo(w0[1]), ws_hi(w0[1])};
+                    if (a.add1) {
+                        const u32x2 w1 = *gptr<const u32x2>(reinterpret_cast<const unsigned char*>(a.add1) + eo);
+                        s4 += f32x4{ws_lo(w1[0]), ws_hi(w1[0]), ws_lo(w1[1]), ws_hi(w1[1])};
+                    }
+                    v = s4 + v;
+                }
                 if (a.out_div != 0.f) {
 #pragma unroll
                     for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], a.out_div, dinv);
@@ -905,6 +934,16 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
         p.up_w = static_cast<const unsigned char*>(q->up_wps); p.up_bias = q->up_bias; p.up_out = reinterpret_cast<unsigned short*>(q->up_out);
         p.up_stats = q->up_stats_part; p.up_slope = q->up_slope;
         p.hout = 1;
+    } else if (q->rb1) {                       // ResBlock1 pair mode: one problem per branch, each with its own input / output tensor
+        if (q->up_out || q->post_out || UPF > 0) return V2W_E_ARG;
+        for (int j = 0; j < q->nk; ++j) {
+            if (!q->out_b[j]) return V2W_E_ARG;
+            const void* ib = q->in_b[j] ? q->in_b[j] : static_cast<const void*>(q->in);
+            if ((reinterpret_cast<uintptr_t>(ib) & 15) || (reinterpret_cast<uintptr_t>(q->out_b[j]) & 15)) return V2W_E_SHAPE;
+            p.in_b[j] = reinterpret_cast<const unsigned short*>(ib); p.out_b[j] = reinterpret_cast<unsigned short*>(q->out_b[j]);
+        }
+        if ((reinterpret_cast<uintptr_t>(q->add0) & 15) || (reinterpret_cast<uintptr_t>(q->add1) & 15) || (q->add1 && !q->add0)) return V2W_E_ARG;
+        p.rb1 = 1; p.add0 = reinterpret_cast<const unsigned short*>(q->add0); p.add1 = reinterpret_cast<const unsigned short*>(q->add1);
     } else if (!q->out) return V2W_E_ARG;
     p.nto = (W - 2 * p.h2max) & ~3;
     if (p.hout) p.nto = ((W - 2 * p.h2max - 2 * p.hout) & ~3) + 2 * p.hout;     // the tile advances by nto - 2 hout: a multiple of 4
@@ -915,6 +954,7 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     p.trows = W;                                      // (no halo rows: conv2's taps read up to h2max rows around the plane, see conv)
     p.ntl = (q->L + (p.nto - 2 * p.hout) - 1) / (p.nto - 2 * p.hout);
     p.ntiles = q->B * p.ntl;
+    if (p.rb1) { p.ntiles1 = p.ntiles; p.ntiles = q->nk * p.ntiles1; }
     const size_t tiles = (size_t)NCH * (p.xrows + p.trows) * RB;
     // (+ 32 rows of slack: conv2's taps past the last plane of the t1 tile stay inside the allocation)
     const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float) + (WLDS ? (size_t)3 * (C / 32) * (CH / 16) * 1024 : 0) + 32 * RB;
@@ -926,6 +966,7 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
 #ifdef V2W_WS_NOCT
     std_cfg = false;
 #endif
+    if (p.rb1) std_cfg = false;
     if (UPF > 0 && !std_cfg) return V2W_E_SHAPE;             // the fused upsampler exists for the compile-time block set only
     if (up_tiles_out) *up_tiles_out = p.ntiles;              // rows of up_stats_part
     constexpr bool STDK = CH == 32 && !WLDS;
@@ -955,6 +996,7 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
     auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
     if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out)) return V2W_E_SHAPE;
     if ((long long)a->C * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;           // 32-bit offsets inside one batch item
+    if (a->rb1 && a->C == 16) return launch_wide<1, 4, 1, 2, 2, 16>(a, stream);  // ResBlock1 pairs on 16 channels: the resident-tile form (one k-step per tap)
     if (a->up_out) {
         // the stage with the next stage's upsampler behind it (stride 4 after the 256- and 128-channel stages, stride 2 after 64 and 32: the
         // generator's (5, 4, 4, 2, 2) and the x640 variant's (8, 5, 4, 2, 2) from the second / third upsampler on)

@@ -386,7 +386,11 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out = nullptr);   // v2w_stage_bf16.hip
 
 static int stage_split_dispatch(const v2w_stage_split_args* a, void* stream, int* up_tiles_out) {
-    if (!a || !a->in || (!a->out && !a->post_out && !a->up_out) || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+    if (!a || (!a->in && !a->rb1) || (!a->out && !a->post_out && !a->up_out && !a->rb1) || a->nk < 1 || a->nk > V2W_SS_MAXB) return V2W_E_ARG;
+    if (a->rb1) {                                                                          // ResBlock1 pair mode: bf16 tensors only
+        if (!(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;
+        for (int j = 0; j < a->nk; ++j) if (!a->in_b[j] && !a->in) return V2W_E_ARG;
+    }
     if (a->post_out && !(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;                 // the fused tail exists on the bf16-tensor path only
     if (a->up_out) {                                                                       // ... and so does the fused upsampler
         if (a->post_out) return V2W_E_ARG;
@@ -402,7 +406,7 @@ static int stage_split_dispatch(const v2w_stage_split_args* a, void* stream, int
         const int rc = v2w_resblock2_stage_bf16(a, (hipStream_t)stream, up_tiles_out);
         if (rc != V2W_E_SHAPE) return rc;
     }
-    if (a->io_bf16 || a->up_out) return V2W_E_SHAPE;       // this file's kernels read and write fp32 only
+    if (a->io_bf16 || a->up_out || a->rb1) return V2W_E_SHAPE;       // this file's kernels read and write fp32 only
     if (a->C == 32) return launch_stage_split<2, 2, 4>(a, (hipStream_t)stream);      // 32 channels x 256 positions per workgroup
     if (a->C == 16) return launch_stage_split<1, 2, 4>(a, (hipStream_t)stream);      // 16 channels (MFMA rows zero-padded) x 256 positions
     return V2W_E_SHAPE;
@@ -418,7 +422,8 @@ extern "C" int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a) {
     v2w_stage_split_args q = *a;
     float* const dummy = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));     // aligned, never dereferenced
     if (!q.in) q.in = dummy;
-    if (!q.out && !q.post_out && !q.up_u) q.out = dummy;
+    if (!q.out && !q.post_out && !q.up_u && !q.rb1) q.out = dummy;
+    if (q.rb1) for (int j = 0; j < q.nk && j < V2W_SS_MAXB; ++j) { if (!q.in_b[j]) q.in_b[j] = dummy; if (!q.out_b[j]) q.out_b[j] = dummy; }
     if (q.up_u) {                      // a fused-upsampler query: up_u / up_k / up_slope are read
         if (!q.up_out) q.up_out = dummy;
         if (!q.up_wps) q.up_wps = dummy;

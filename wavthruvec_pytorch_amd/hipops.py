@@ -539,6 +539,17 @@ def resblock_pair_multi(problems):
     return True
 
 
+def resblock1_pairs_ok(B, Cc, L, ks, dil1s, dil2s, *, slope) -> bool:
+    """Shape query: would resblock1_pairs_bf16 take these problems (kernel sizes `ks`, dilations of the first / second conv of the pair)?"""
+    a = _hip.StageSplitArgs()
+    a.rb1 = 1
+    for j, (k, d1, d2) in enumerate(zip(ks, dil1s, dil2s)):
+        a.k[j], a.dil1[j], a.dil2[j] = k, d1, d2
+    a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
+    a.slope, a.out_div, a.bf16, a.io_bf16 = slope, 0.0, 1, 3
+    return _hip.load().v2w_resblock2_stage_split_config(C.byref(a)) == 0
+
+
 def resblock2_stage_split_ok(B, Cc, L, ks, dil1s, dil2s, *, slope, bf16=True, io_bf16=3) -> bool:
     """Shape query: would resblock2_stage_split run this stage (nk branches of kernel sizes `ks`, dilations `dil1s` / `dil2s`) as one
     kernel on aligned tensors?  Asked of the library (v2w_resblock2_stage_split_config), nothing is launched."""
@@ -561,6 +572,32 @@ def resblock2_stage_up_tiles(B, Cc, L, ks, dil1s, dil2s, *, slope, up_k, up_u, u
     a.up_k, a.up_u, a.up_slope = up_k, up_u, up_slope
     n = _hip.load().v2w_resblock2_stage_up_tiles(C.byref(a))
     return n if n > 0 else 0
+
+
+def resblock1_pairs_bf16(ins, in_affine, branches, outs, *, slope, out_div=0.0, add=None):
+    """ResBlock1 on bf16 tensors (v2w_stage_split_args::rb1): len(branches) independent problems in one launch, problem p computing
+    outs[p] = (x_p + conv2_p(lrelu(conv1_p(lrelu x_p) + b1_p)) + b2_p [+ add[0] + add[1]]) / out_div with x_p = a * ins[p] + s.  `branches`:
+    dicts(wps1, b1, wps2, b2, k, dil1, dil2) as for resblock2_stage_split; `add`: up to two bf16 tensors the LAST problem adds before the
+    division.  Returns False when the shape is not taken."""
+    B, Cc, L = ins[0].shape
+    a = _hip.StageSplitArgs()
+    a.rb1 = 1
+    a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
+    for j, q in enumerate(branches):
+        a.wps1[j], a.sc1[j], a.bias1[j] = q['wps1'][0].data_ptr(), q['wps1'][1].data_ptr(), _hip.ptr(q['b1'])
+        a.wps2[j], a.sc2[j], a.bias2[j] = q['wps2'][0].data_ptr(), q['wps2'][1].data_ptr(), _hip.ptr(q['b2'])
+        a.k[j], a.dil1[j], a.dil2[j] = q['k'], q['dil1'], q['dil2']
+        a.in_b[j] = ins[j].data_ptr(); a.out_b[j] = outs[j].data_ptr()
+    add = list(add or [])
+    a.add0 = _hip.ptr(add[0]) if len(add) > 0 else None
+    a.add1 = _hip.ptr(add[1]) if len(add) > 1 else None
+    a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
+    a.slope, a.out_div, a.bf16, a.io_bf16 = slope, out_div, 1, 3
+    rc = _hip.load().v2w_resblock2_stage_split_fwd(C.byref(a), _stream(ins[0]))
+    if rc == -2:
+        return False
+    _hip.check(rc, 'v2w_resblock2_stage_split_fwd (rb1)')
+    return True
 
 
 def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None, up=None):

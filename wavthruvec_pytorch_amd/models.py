@@ -417,7 +417,7 @@ class Generator(nn.Module):
                 continue
             # wide layers: the per-layer split kernel; the C = 32 / 16 ResBlock2 stages: the fused split stage kernel
             stage32 = (m.in_channels == m.out_channels and m.out_channels in (16, 32) and m.out_channels in self.fuse_stage
-                       and name.startswith('resblocks.') and '.convs.' in name)
+                       and name.startswith('resblocks.') and ('.convs.' in name or (all_ups and self.precision == 'bf16')))   # (ResBlock1 pairs on bf16 tensors: narrow stages too)
             wide = (m.out_channels >= self.split_min_channels and hipops.split_supported(m.in_channels, m.out_channels)
                     and m.kernel_size % 2 == 1 and m.kernel_size >= 3)       # the split kernel pipelines over an odd tap count
             if wide or stage32:
@@ -484,7 +484,15 @@ class Generator(nn.Module):
             L *= up.stride
             C = up.out_channels
             rbs = self.resblocks[i * nk:(i + 1) * nk]
-            if C in (16, 32):       # the narrow stages exist as ONE fused kernel only: the library says whether it takes this block set
+            if isinstance(rbs[0], ResBlock1):      # ResBlock1 on bf16 tensors: every (dilated conv, conv) pair of every branch on the pair kernel,
+                for n in range(3):                 # or - wide stages - both convs of the pair on the chunked bf16 tile kernel
+                    pair = hipops.resblock1_pairs_ok(B, C, L, [rb.kernel_size for rb in rbs], [rb.convs1[n].dilation for rb in rbs],
+                                                     [1] * len(rbs), slope=LRELU_SLOPE)
+                    convs = C >= 64 and all(rb.kernel_size >= 3 and
+                                            hipops.conv_bf16_config(B, 1, C, C, L, rb.kernel_size, rb.convs1[n].dilation, 1, io_bf16=3) is not None and
+                                            hipops.conv_bf16_config(B, 1, C, C, L, rb.kernel_size, 1, 1, io_bf16=3) is not None for rb in rbs)
+                    ok = ok and all(rb.kernel_size % 2 == 1 for rb in rbs) and (pair or convs)
+            elif C in (16, 32):       # the narrow stages exist as ONE fused kernel only: the library says whether it takes this block set
                 ok = ok and all(rb.kernel_size % 2 == 1 for rb in rbs) and hipops.resblock2_stage_split_ok(
                     B, C, L, [rb.kernel_size for rb in rbs], [rb.convs[0].dilation for rb in rbs], [rb.convs[1].dilation for rb in rbs],
                     slope=LRELU_SLOPE)
@@ -547,8 +555,9 @@ class Generator(nn.Module):
         # and writes bf16 tensors when all of them run on the bf16 kernels - default ResBlock2 generator, wide stages C % 32 == 0
         # (>= 64), narrow stages 32 / 16 fused.  fp32 accumulate, fp32 BatchNorm statistics from the accumulators, fp32 output.
         adt = torch.float32
+        rb1_net = all(isinstance(rb, ResBlock1) for rb in self.resblocks)
         if (self.precision == 'bf16' and self.bf16_storage and save is None and algo == hipops.ALGO_AUTO and nk <= 3
-                and all(isinstance(rb, ResBlock2) for rb in self.resblocks) and x.shape[2] % 4 == 0 and self.h.num_wv_feat % 32 == 0
+                and (all(isinstance(rb, ResBlock2) for rb in self.resblocks) or rb1_net) and x.shape[2] % 4 == 0 and self.h.num_wv_feat % 32 == 0
                 and all((up.out_channels >= 64 and up.out_channels % 64 == 0) or up.out_channels in fuse_stage for up in self.ups)
                 and all(up.in_channels % 32 == 0 and 2 <= up.stride <= 8 for up in self.ups)
                 and self._bf16_storage_kernels_exist(B, T)):
@@ -813,14 +822,35 @@ class Generator(nn.Module):
                                 launch('1', {j: conv2[j] for j in range(nk - 1)})
                             launch('1', {nk - 1: conv2[nk - 1]})
                     else:
-                        xas = [self._buf(f'act.xa_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
-                        xbs = [self._buf(f'act.xb_{i}_{j}', (B, C, Lo), device=dev) for j in range(nk)]
+                        xas = [self._buf(f'act.xa_{i}_{j}', (B, C, Lo), dtype=adt, device=dev) for j in range(nk)]
+                        xbs = [self._buf(f'act.xb_{i}_{j}', (B, C, Lo), dtype=adt, device=dev) for j in range(nk)]
                         srcs, src_aff = [xr] * nk, aff
                         for n in range(3):
                             dsts = [xas, xbs, outs][n]
                             if save is not None:   # backward needs every sub-block's conv1 output: one buffer per n
                                 t1s = [self._buf(f'act.t1_{i}_{j}_{n}', (B, C, Lo), device=dev) for j in range(nk)]
                             ok = False
+                            if st and hipops.resblock1_pairs_ok(B, C, Lo, [rb.kernel_size for rb in rbs], [rb.convs1[n].dilation for rb in rbs],
+                                                                [1] * nk, slope=LRELU_SLOPE):
+                                # (a pair whose resident tiles do not fit - 256 channels at dilation 5: 94 KB of x beside 66 KB of intermediate -
+                                # runs conv by conv on the chunked bf16 kernel below, still on bf16 tensors)
+                                # ResBlock1 on bf16 tensors (models.py:37-44): pair n of every branch as one resident-tile launch - the dilated
+                                # conv's output stays in LDS, the pair's residual joins the output - and the last pair of the last branch adds
+                                # the other branches' results in the reference's order ((r0 + r1) + r2) / nk
+                                brs = [dict(wps1=wps[f'{names[j]}.convs1.{n}'], b1=rbs[j].convs1[n].bias.detach(),
+                                            wps2=wps[f'{names[j]}.convs2.{n}'], b2=rbs[j].convs2[n].bias.detach(), k=rbs[j].kernel_size,
+                                            dil1=rbs[j].convs1[n].dilation, dil2=1) for j in range(nk)]
+                                sets = [list(range(nk))] if n < 2 or nk == 1 else [list(range(nk - 1)), [nk - 1]]
+                                for js in sets:
+                                    last = n == 2 and js[-1] == nk - 1
+                                    tag = 'rb1:' + '+'.join(f'{names[j]}.{2 * n}&{2 * n + 1}' for j in js)
+                                    ok = self._timed(tag, hipops.resblock1_pairs_bf16, [srcs[j] for j in js], src_aff, [brs[j] for j in js],
+                                                     [dsts[j] for j in js], slope=LRELU_SLOPE, out_div=float(nk) if last else 0.0,
+                                                     add=outs[:nk - 1] if last and nk > 1 else None)
+                                    if not ok:
+                                        raise RuntimeError('bf16 storage: the ResBlock1 pair kernel declined a shape its query accepted')
+                                srcs, src_aff = dsts, None
+                                continue
                             if fused_pair:
                                 ok = launch_pairs(f'{2 * n}&{2 * n + 1}',
                                                   {j: dict(x=srcs[j], in_affine=src_aff, wp1=wp[f'{names[j]}.convs1.{n}'],
