@@ -641,7 +641,7 @@ def main():
     #   the north_star's literal shape B = 32 x T = 256 in that arithmetic                              -> cfg2_bf16
     #   configs[4]  1024-d latents, upsample (8,5,4,2,2) x640, B = 16 x T = 256, exact fp32             -> cfg5_f32
     # and the generator training step at the cfg2 shape                            -> train_step
-    cfg3 = cfg2b = cfg5 = train = None
+    cfg3 = cfg2b = cfg5 = train = rb1b = None
     if extras:
         def guarded(fn, *a, **kw):
             try:
@@ -660,6 +660,10 @@ def main():
                        max(5, args.steps // 2), max(2, args.warmup // 2), dev,
                        'BASELINE configs[4]: 1024-d latents, upsample (8,5,4,2,2) x640, B=16 x T=256, train mode, exact fp32',
                        'tests/test_hip_generator.py::test_generator_cfg5_full_size_vs_oracle_train (|dy| <= 1e-4 at this size)')
+        rb1b = guarded(config_block, dict(num_wv_feat=768, resblock='1'), 32, 256, 'bf16', max(5, args.steps // 2), max(2, args.warmup // 2), dev,
+                       "Generator.forward with ResBlock1 (h.resblock == '1') at B=32 x T=256 in the configs[2] arithmetic: bf16 compute / fp32 "
+                       'accumulate, bf16 tensors between all layers, train mode',
+                       'tests/test_hip_generator.py::test_generator_resblock1_bf16_full_size_vs_oracle_train (the reference autocast bar)')
         train = guarded(train_step_block, dev, B, T, max(4, args.steps // 4))
         if isinstance(train, dict) and 'error' not in train:
             alt_t = guarded(train_step_block, dev, B, T, max(4, args.steps // 4), 'f16x3')
@@ -686,7 +690,7 @@ def main():
                        'parallelism': (f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else
                                        'single GPU' + (', one-rank RCCL group: the CondBN all-reduces are inside the timed region' if args.force_pg else ''))},
             'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
-            'cfg2_bf16': cfg2b, 'cfg5_f32': cfg5, 'train_step': train,
+            'cfg2_bf16': cfg2b, 'cfg5_f32': cfg5, 'train_step': train, 'resblock1_bf16': rb1b,
         }
     if dist.is_initialized():
         dist.destroy_process_group()
