@@ -289,7 +289,7 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disc, x, *params):
         xd = x.detach().contiguous().float()
-        st = disc._run(xd, keep=True)
+        st = disc._run(xd, keep=False)        # (the phase-stacked layer inputs are rebuilt in the backward from the maps below them: -11 GB)
         ctx.disc, ctx.st, ctx.x = disc, st, xd
         ctx.need_dx = x.requires_grad
         ctx.need_dw = any(p.requires_grad for p in params)
@@ -331,17 +331,30 @@ class _DiscFn(torch.autograd.Function):
             if ctx.need_dw:
                 db = torch.empty((C,), device=dev)
                 _hip.check(lib.v2w_rowsum_reduce(rowsum.data_ptr(), db.data_ptr(), B, C, stream), 'v2w_rowsum_reduce')
-            # the layer's stride-1 input: kept by the forward (the 16-row unfold of the first layer is rebuilt)
-            xs = _unfold_first(layer, x, T, H, inner)[0] if l == 0 else st['xss'][l]
+            # the layer's stride-1 input (the phases of the map below stacked along the channels; the 16-row unfold of the first layer): rebuilt
+            # here, one streaming pass, and only when a weight gradient reads it - the forward keeps the feature maps alone
             G = layer.groups
-            cigp, cog = xs.shape[1] // G, C // G
+            if l == 0:
+                xs_c = _UNFOLD_ROWS
+            else:
+                xs_c = layer.c_in * (layer.stride if layer.stride > 1 and not layer.unfolded else (layer.k if layer.stride > 1 else 1))
+            xs = None
+            if ctx.need_dw:
+                if st['xss'] is not None and l > 0:
+                    xs = st['xss'][l]
+                elif l == 0:
+                    xs = _unfold_first(layer, x, T, H, inner)[0]
+                else:
+                    xs = _stacked_input(layer, st['bufs'][l - 1][0], st['bufs'][l - 1][1], inner)[0]
+                assert xs.shape[1] == xs_c and xs.shape[2] == P
+            cigp, cog = xs_c // G, C // G
             kp, Q = rec['kp'], rec['Q']
             dil = 1 if kp == 1 else inner
             # ---- weight gradient in the stacked form, then back to the reference's (C_out, C_in / groups, k)
             if ctx.need_dw:                   # (frozen discriminators - `frozen()` around the G step - skip all of this)
                 if C == 1:
-                    dwp = torch.empty((kp, xs.shape[1], 1), device=dev)
-                    _hip.check(lib.v2w_cout1_wgrad(xs.data_ptr(), dz.data_ptr(), dwp.data_ptr(), B, xs.shape[1], P, kp, dil, Q, stream),
+                    dwp = torch.empty((kp, xs_c, 1), device=dev)
+                    _hip.check(lib.v2w_cout1_wgrad(xs.data_ptr(), dz.data_ptr(), dwp.data_ptr(), B, xs_c, P, kp, dil, Q, stream),
                                'v2w_cout1_wgrad')
                     dws = [dwp]
                 else:
@@ -357,13 +370,13 @@ class _DiscFn(torch.autograd.Function):
                         slab = torch.empty((ns * kp * cigp * cog,), device=dev)
                         for gi in range(G):
                             _hip.check(lib.v2w_wgrad_slice(xs.data_ptr() + gi * cigp * P * 4, dz.data_ptr() + gi * cog * P * 4,
-                                                           dwg[gi].data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs.shape[1], C,
+                                                           dwg[gi].data_ptr(), slab.data_ptr(), B, cigp, cog, P, kp, dil, Q, xs_c, C,
                                                            stream), 'v2w_wgrad_slice')
                     dws = list(dwg.unbind(0))
                 grads[l] = layer.param_grads(db, dws, st['sn'][l])
             # ---- input gradient: the forward conv kernel with the transposed, tap-flipped weights
             if l > 0 or ctx.need_dx:
-                dxs = torch.empty((B, xs.shape[1], P), device=dev)
+                dxs = torch.empty((B, xs_c, P), device=dev)
                 if 'wT' not in rec:                                            # shared by the y / y_hat calls of one step
                     packable = cog % 16 == 0 and (cigp % 32 == 0 or cigp == 16)
                     wT4 = rec['w4'].flip(1).transpose(2, 3).contiguous()        # [G][kp][cog][cigp], taps reversed
@@ -515,9 +528,27 @@ class frozen:
         return False
 
 
+class _L1MeanFn(torch.autograd.Function):
+    """mean |real - fake| of one feature-map pair.  torch's own graph for `torch.mean(torch.abs(real - fake))` keeps the difference and its
+    absolute value alive until the backward - two more tensors per feature map, 18 GB over the 2 x 48 maps of a generator step at
+    B = 32 x 81 920 samples; here nothing but the two maps (alive anyway: they are what the discriminators return) is saved, the sign is
+    rebuilt in the backward."""
+
+    @staticmethod
+    def forward(ctx, real, fake):
+        ctx.save_for_backward(real, fake)
+        return (real - fake).abs_().mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        real, fake = ctx.saved_tensors
+        d = torch.sign(real - fake).mul_(g / real.numel())
+        return (d if ctx.needs_input_grad[0] else None), (d.neg() if ctx.needs_input_grad[1] else None)
+
+
 def feature_loss(fmap_r, fmap_g):
     """2 x the sum over every feature map of mean |real - generated| (models.py:278-284)."""
-    terms = [torch.mean(torch.abs(real - fake)) for maps_r, maps_g in zip(fmap_r, fmap_g) for real, fake in zip(maps_r, maps_g)]
+    terms = [_L1MeanFn.apply(real, fake) for maps_r, maps_g in zip(fmap_r, fmap_g) for real, fake in zip(maps_r, maps_g)]
     return 2 * sum(terms)
 
 
