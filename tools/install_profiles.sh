@@ -19,4 +19,5 @@ cp $O/cfg3_bf16_per_layer.txt $P/${T}_cfg3_bf16_per_layer.txt
 cp $O/latency.txt $P/${T}_latency.txt
 cp $O/train_step.txt $P/${T}_train_step.txt
 cp $O/sync_overhead.txt $P/${T}_sync_overhead.txt
+cp $O/gan_iteration.txt $P/${T}_gan_iteration.txt
 ls -la $P/${T}_*

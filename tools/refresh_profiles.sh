@@ -46,5 +46,9 @@ for k, v in s.items():
     print(f'  {k}: {v}')
 PYEOF
 python3 tools/config_bench.py > $O/all_configs.txt 2>&1
+# one full GAN iteration (vec2wav/train.py:160-215) at the cfg2 shape and at the reference's own batch_size = 2
+python3 tools/gan_step_bench.py 32 256 3 > $O/gan_iteration.txt 2>&1
+python3 tools/gan_step_bench.py 2 256 3 >> $O/gan_iteration.txt 2>&1
+python3 tools/gan_step_bench.py 32 256 3 frozen >> $O/gan_iteration.txt 2>&1
 tail -c 600 $O/bench.json; grep ms/step $O/ks_train.log
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
