@@ -391,6 +391,14 @@ int v2w_bn_finalize(const double* stats, const float* gb,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* a_out, float* s_out, int B, int C, int training,
                     float momentum, float eps, void* stream);
+/* Two-level form for layers with thousands of partial rows (ABI v28; the fused stage kernels write one row per 224 positions):
+ * v2w_bn_reduce_slices adds slice s of the rows of `part` ([ntiles][C][2] floats) into slices[s][2 C] fp64 ([sum | sumsq], nslices <= 1024
+ * blocks reading whole rows), v2w_bn_finalize_slices is v2w_bn_finalize(training = 1) on those slices, added in slice order, with the element
+ * count given.  Deterministic; same values as the one-level form up to the order of the fp64 additions. */
+int v2w_bn_reduce_slices(const float* part, int ntiles, int C, double* slices, int nslices, void* stream);
+int v2w_bn_finalize_slices(const double* slices, int nslices, double count, const float* gb,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream);
 
 /* ---- K5 (standalone form): out = a[b,c]*x + s[b,c] over (B,C,L).  Only ConditionalBatchNorm1d.forward used on
  * its own (modules.py:20-30) materialises the normalised tensor; Generator.forward folds the affine into its

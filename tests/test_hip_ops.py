@@ -1508,3 +1508,35 @@ def test_disc_dz_and_merge_and_zero_tail(dev):
     t = torch.ones((B * C, P), device=dev)
     _hip.check(lib.v2w_zero_tail(t.data_ptr(), B * C, P, valid, st), 'v2w_zero_tail')
     assert torch.equal(t.cpu()[:, :valid], torch.ones(B * C, valid)) and torch.equal(t.cpu()[:, valid:], torch.zeros(B * C, P - valid))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,nt,B', [(16, 23424, 32), (32, 4100, 8), (64, 2049, 3), (256, 1024, 2), (24, 1500, 2)])
+def test_bn_two_level_reduce_matches_one_level(C, nt, B):
+    """v2w_bn_reduce_slices + v2w_bn_finalize_slices (two short launches for layers with thousands of partial rows) == v2w_bn_reduce_partials +
+    v2w_bn_finalize: same fp64 sums up to their order, same (a, s) and running statistics (models.py:59-70 of the reference in train mode)."""
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(C * 7 + nt)
+    part = torch.randn(nt, C, 2, generator=g).abs_().mul_(50).to(dev)
+    part[..., 1] += part[..., 0] ** 2 / 100
+    count = nt * 224
+    gb = torch.randn(B, 2 * C, generator=g).to(dev)
+    outs = []
+    for two_level in (False, True):
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nb = torch.zeros((), dtype=torch.int64, device=dev)
+        a, s = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+        if two_level:
+            sl = torch.full((hipops.BN_SLICES * 2 * C,), float('nan'), dtype=torch.float64, device=dev)
+            hipops.bn_reduce_finalize_slices(part, nt, count, sl, gb, rm, rv, nb, a, s, momentum=0.1, eps=1e-5)
+        else:
+            st = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+            hipops.bn_reduce_partials(part, nt, C, count, st)
+            hipops.bn_finalize(st, gb, rm, rv, nb, a, s, training=True, momentum=0.1, eps=1e-5)
+        outs.append((a, s, rm, rv, nb))
+    for x, y in zip(*outs):
+        assert torch.isfinite(y.float()).all()
+        torch.testing.assert_close(y, x, rtol=1e-6, atol=1e-7)
+    ref = part.double().sum(0)                                   # and against torch in fp64
+    mean = ref[:, 0] / count
+    torch.testing.assert_close(outs[1][2].double(), 0.1 * mean, rtol=1e-6, atol=1e-9)

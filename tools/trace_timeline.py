@@ -10,7 +10,7 @@ import sys
 def main(path):
     f = glob.glob(os.path.join(path, '**', '*_kernel_trace.csv'), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'cond_fc' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if 'cond_fc' in r['Kernel_Name'] or 'cond_affine_eval' in r['Kernel_Name']]
     s, e = idx[-2], idx[-1]
     t0 = int(rows[s]['Start_Timestamp'])
     busy = 0

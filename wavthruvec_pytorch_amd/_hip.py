@@ -168,6 +168,8 @@ SIGNATURES = {
     'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),
     'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, _fp]),
+    'v2w_bn_reduce_slices': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
+    'v2w_bn_finalize_slices': (C.c_int, [_fp, C.c_int, C.c_double, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_float, _fp]),
     'v2w_affine_apply': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_wgrad_slabs': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'v2w_wgrad': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

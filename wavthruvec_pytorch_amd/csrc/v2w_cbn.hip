@@ -219,15 +219,52 @@ bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ s
     }
 }
 
+// ---- level 1 of the two-level form of bn_reduce_partials for the many-tile layers (the fused stage kernels write one row of partial sums
+// per 224 positions: 23 424 rows at BASELINE configs[2]; one block per channel read them with a stride of 2 C floats - 8 useful bytes per
+// 128-byte line - in 10-30 us): slice s of the rows, whole rows at a time (coalesced), fp64 sums in a fixed order -> slices[s][2 C].
+// bn_finalize_kernel adds the slices (fixed order) itself: two short launches, bit-reproducible.
+__global__ void __launch_bounds__(256)
+bn_reduce_slices_kernel(const float* __restrict__ part, double* __restrict__ slices, int ntiles, int C) {
+    __shared__ double red[256];
+    const int ns = gridDim.x, s = blockIdx.x;
+    const int lo = (int)((long long)ntiles * s / ns), hi = (int)((long long)ntiles * (s + 1) / ns);
+    const int W = 2 * C;                                   // floats per row
+    for (int j0 = 0; j0 < W; j0 += 256) {                  // (C = 256: two column passes)
+        const int cols = W - j0 < 256 ? W - j0 : 256;      // a power of two for the generator's widths; any width works
+        const int lanes = 256 / cols > 0 ? 256 / cols : 1; // rows in flight per step
+        const int j = threadIdx.x % cols, tl = threadIdx.x / cols;
+        double acc = 0.0;
+        if (tl < lanes)
+            for (int t = lo + tl; t < hi; t += lanes) acc += (double)part[(size_t)t * W + j0 + j];
+        red[threadIdx.x] = tl < lanes ? acc : 0.0;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            double tot = 0.0;
+            for (int q = 0; q < lanes; ++q) tot += red[q * cols + threadIdx.x];     // fixed order
+            // row layout [c][2] = (sum, sumsq) pairs -> slices[s][stat][c]
+            const int col = j0 + threadIdx.x;
+            slices[(size_t)s * W + (col & 1) * C + (col >> 1)] = tot;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gb,
                                    float* running_mean, float* running_var, int64_t* nbt,
                                    float* __restrict__ a_out, float* __restrict__ s_out,
-                                   int B, int C, int training, float momentum, float eps) {
+                                   int B, int C, int training, float momentum, float eps, int nslices, double slice_count) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
     double mean, var, count = 1.0;
-    if (training) {
+    if (training && nslices > 0) {      // `stats` = slices[nslices][2 C] of bn_reduce_slices_kernel: summed here, in slice order
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < nslices; ++q) { s1 += stats[(size_t)q * 2 * C + c]; s2 += stats[(size_t)q * 2 * C + C + c]; }
+        count = slice_count;
+        mean = s1 / count;
+        var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else if (training) {
         count = stats[2 * C];
         mean = stats[c] / count;
         var = stats[C + c] / count - mean * mean;   // biased (normalisation) variance
@@ -345,6 +382,24 @@ extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
     if (training && !stats) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
-                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps);
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps, 0, 0.0);
+    return v2w_launch_status();
+}
+
+// The two-level form for layers with thousands of partial rows (ABI v28): v2w_bn_reduce_slices sums slice s of the rows into
+// slices[s][2 C] fp64 (nslices blocks, whole rows at a time); v2w_bn_finalize_slices is v2w_bn_finalize in train mode reading those slices
+// (added in slice order) instead of the [sum | sumsq | count] array.  Same values as v2w_bn_reduce_partials + v2w_bn_finalize up to the
+// order of the fp64 additions; a data-parallel run, which all-reduces the array, keeps the one-level form.
+extern "C" int v2w_bn_reduce_slices(const float* part, int ntiles, int C, double* slices, int nslices, void* stream) {
+    if (!part || !slices || ntiles <= 0 || C <= 0 || nslices <= 0 || nslices > 1024) return V2W_E_ARG;
+    hipLaunchKernelGGL(bn_reduce_slices_kernel, dim3(nslices), dim3(256), 0, (hipStream_t)stream, part, slices, ntiles, C);
+    return v2w_launch_status();
+}
+extern "C" int v2w_bn_finalize_slices(const double* slices, int nslices, double count, const float* gb,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream) {
+    if (!slices || nslices <= 0 || !(count > 0.0) || !gb || !a_out || !s_out || !running_mean || !running_var || B <= 0 || C <= 0) return V2W_E_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slices, gb,
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, 1, momentum, eps, nslices, count);
     return v2w_launch_status();
 }

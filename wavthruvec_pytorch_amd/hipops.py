@@ -360,6 +360,22 @@ def bn_finalize(stats, gb, running_mean, running_var, num_batches_tracked, a_out
                                            B, C2 // 2, int(training), momentum, eps, _stream(gb)), 'v2w_bn_finalize')
 
 
+BN_SLICES = 64
+
+
+def bn_reduce_finalize_slices(part, ntiles, count, slices, gb, running_mean, running_var, num_batches_tracked, a_out, s_out, *,
+                              momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm statistics of a layer whose producer left `ntiles` rows of partial sums, and their fold into (a, s), as two short
+    launches: slices of whole rows -> fp64 sums per slice (`slices`: >= BN_SLICES * 2 C doubles), then the finalize kernel adds the slices."""
+    B, C2 = gb.shape
+    Cc = C2 // 2
+    lib, st = _hip.load(), _stream(part)
+    _hip.check(lib.v2w_bn_reduce_slices(part.data_ptr(), ntiles, Cc, slices.data_ptr(), BN_SLICES, st), 'v2w_bn_reduce_slices')
+    _hip.check(lib.v2w_bn_finalize_slices(slices.data_ptr(), BN_SLICES, float(count), gb.data_ptr(), running_mean.data_ptr(),
+                                          running_var.data_ptr(), _hip.ptr(num_batches_tracked), a_out.data_ptr(), s_out.data_ptr(),
+                                          B, Cc, momentum, eps, st), 'v2w_bn_finalize_slices')
+
+
 def affine_apply(x, a, s, out):
     B, Cc, L = x.shape
     _hip.check(_hip.load().v2w_affine_apply(x.data_ptr(), a.data_ptr(), s.data_ptr(), out.data_ptr(), B, Cc, L, _stream(x)),

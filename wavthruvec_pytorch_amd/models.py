@@ -661,7 +661,10 @@ class Generator(nn.Module):
                                 u=up.stride, slope=LRELU_SLOPE, algo=algo, wp=wp[f'ups.{i}'], stats_part=part, splitk_ws=slab)
                 up_done = None
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
-                if training:
+                sliced = training and nt_stats >= 1024 and self.stat_sync is None and save is None
+                if sliced:
+                    pass        # (thousands of partial rows, nothing to all-reduce, no backward that reads the array: the two-level form below)
+                elif training:
                     if nt_stats:
                         hipops.bn_reduce_partials(part, nt_stats, C, B * Lo, stats)
                     else:
@@ -674,7 +677,11 @@ class Generator(nn.Module):
                 if not cond_joined:       # (fp32: the side stream only carries gamma / beta - joined as late as their first use, which
                     main.wait_stream(side)    # matters at B = 1, where conv_pre is shorter than the conditioning chain)
                     cond_joined = True
-                if affs is None:
+                if sliced:
+                    sl = self._buf(f'bn.slices{i}', (hipops.BN_SLICES * 2 * C,), dtype=torch.float64, device=dev)
+                    hipops.bn_reduce_finalize_slices(part, nt_stats, B * Lo, sl, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                     a_t, s_t, momentum=bn.momentum, eps=bn.eps)
+                elif affs is None:
                     hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                        training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
