@@ -1515,6 +1515,7 @@ def test_disc_dz_and_merge_and_zero_tail(dev):
 def test_bn_two_level_reduce_matches_one_level(C, nt, B):
     """v2w_bn_reduce_slices + v2w_bn_finalize_slices (two short launches for layers with thousands of partial rows) == v2w_bn_reduce_partials +
     v2w_bn_finalize: same fp64 sums up to their order, same (a, s) and running statistics (models.py:59-70 of the reference in train mode)."""
+    from wavthruvec_pytorch_amd import hipops
     dev = 'cuda'
     g = torch.Generator(device='cpu').manual_seed(C * 7 + nt)
     part = torch.randn(nt, C, 2, generator=g).abs_().mul_(50).to(dev)
