@@ -219,10 +219,11 @@ bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ s
     }
 }
 
-// ---- level 1 of the two-level form of bn_reduce_partials for the many-tile layers (the fused stage kernels write one row of partial sums
-// per 224 positions: 23 424 rows at BASELINE configs[2]; one block per channel read them with a stride of 2 C floats - 8 useful bytes per
-// 128-byte line - in 10-30 us): slice s of the rows, whole rows at a time (coalesced), fp64 sums in a fixed order -> slices[s][2 C].
-// bn_finalize_kernel adds the slices (fixed order) itself: two short launches, bit-reproducible.
+// ---- the two-level form of bn_reduce_partials + bn_finalize for the many-tile layers (the fused stage kernels write one row of partial
+// sums per 224 positions: 23 424 rows at BASELINE configs[2]; one block per channel read them with a stride of 2 C floats - 8 useful bytes
+// per 128-byte line - in 10-30 us).  Level 1: slice s of the rows, whole rows at a time (coalesced, four rows in flight per thread), fp64
+// sums in a fixed order -> slices[s][2 C].  Level 2 (bn_finalize_slices_kernel): 16 channels per block - the slices are added in a fixed
+// order by 16 x 16 threads through LDS, then the block writes (a, s) of its channels for every sample.  Two short launches, bit-reproducible.
 __global__ void __launch_bounds__(256)
 bn_reduce_slices_kernel(const float* __restrict__ part, double* __restrict__ slices, int ntiles, int C) {
     __shared__ double red[256];
@@ -234,8 +235,15 @@ bn_reduce_slices_kernel(const float* __restrict__ part, double* __restrict__ sli
         const int lanes = 256 / cols > 0 ? 256 / cols : 1; // rows in flight per step
         const int j = threadIdx.x % cols, tl = threadIdx.x / cols;
         double acc = 0.0;
-        if (tl < lanes)
-            for (int t = lo + tl; t < hi; t += lanes) acc += (double)part[(size_t)t * W + j0 + j];
+        if (tl < lanes) {
+            const float* p = part + j0 + j;
+            int t = lo + tl;
+            for (; t + 3 * lanes < hi; t += 4 * lanes) {   // four independent loads, added in row order
+                const float v0 = p[(size_t)t * W], v1 = p[(size_t)(t + lanes) * W], v2 = p[(size_t)(t + 2 * lanes) * W], v3 = p[(size_t)(t + 3 * lanes) * W];
+                acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+            }
+            for (; t < hi; t += lanes) acc += (double)p[(size_t)t * W];
+        }
         red[threadIdx.x] = tl < lanes ? acc : 0.0;
         __syncthreads();
         if (threadIdx.x < cols) {
@@ -249,22 +257,59 @@ bn_reduce_slices_kernel(const float* __restrict__ part, double* __restrict__ sli
     }
 }
 
+__global__ void __launch_bounds__(256)
+bn_finalize_slices_kernel(const double* __restrict__ slices, int nslices, double count, const float* __restrict__ gb,
+                          float* running_mean, float* running_var, int64_t* nbt,
+                          float* __restrict__ a_out, float* __restrict__ s_out, int B, int C, float momentum, float eps) {
+    __shared__ double red[2][16][16];
+    __shared__ double tot[2][16];
+    __shared__ float mr[2][16];
+    const int tid = threadIdx.x, cl = tid & 15, g = tid >> 4;
+    const int c0 = blockIdx.x * 16, c = c0 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int q = g; q < nslices; q += 16) { s1 += slices[(size_t)q * 2 * C + c]; s2 += slices[(size_t)q * 2 * C + C + c]; }
+    red[0][g][cl] = s1; red[1][g][cl] = s2;
+    __syncthreads();
+    if (tid < 32) {
+        const int st = tid >> 4;
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[st][q][cl];
+        tot[st][cl] = t;
+    }
+    __syncthreads();
+    if (tid < 16 && c < C) {
+        const double mean = tot[0][cl] / count;
+        double var = tot[1][cl] / count - mean * mean;        // biased (normalisation) variance
+        if (var < 0.0) var = 0.0;
+        mr[0][cl] = (float)mean;
+        mr[1][cl] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        if (c == 0 && nbt) *nbt += 1;
+    }
+    __syncthreads();
+    if (c < C) {
+        const float mean = mr[0][cl], rstd = mr[1][cl];
+        for (int b = g; b < B; b += 16) {
+            const float gamma = gb[(size_t)b * 2 * C + c], beta = gb[(size_t)b * 2 * C + C + c];
+            const float av = gamma * rstd;
+            a_out[(size_t)b * C + c] = av;
+            s_out[(size_t)b * C + c] = fmaf(-av, mean, beta);
+        }
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gb,
                                    float* running_mean, float* running_var, int64_t* nbt,
                                    float* __restrict__ a_out, float* __restrict__ s_out,
-                                   int B, int C, int training, float momentum, float eps, int nslices, double slice_count) {
+                                   int B, int C, int training, float momentum, float eps) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
     double mean, var, count = 1.0;
-    if (training && nslices > 0) {      // `stats` = slices[nslices][2 C] of bn_reduce_slices_kernel: summed here, in slice order
-        double s1 = 0.0, s2 = 0.0;
-        for (int q = 0; q < nslices; ++q) { s1 += stats[(size_t)q * 2 * C + c]; s2 += stats[(size_t)q * 2 * C + C + c]; }
-        count = slice_count;
-        mean = s1 / count;
-        var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-    } else if (training) {
+    if (training) {
         count = stats[2 * C];
         mean = stats[c] / count;
         var = stats[C + c] / count - mean * mean;   // biased (normalisation) variance
@@ -382,7 +427,7 @@ extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
     if (training && !stats) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
-                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps, 0, 0.0);
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps);
     return v2w_launch_status();
 }
 
@@ -399,7 +444,7 @@ extern "C" int v2w_bn_finalize_slices(const double* slices, int nslices, double 
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream) {
     if (!slices || nslices <= 0 || !(count > 0.0) || !gb || !a_out || !s_out || !running_mean || !running_var || B <= 0 || C <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slices, gb,
-                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, 1, momentum, eps, nslices, count);
+    hipLaunchKernelGGL(bn_finalize_slices_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, slices, nslices, count, gb,
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, momentum, eps);
     return v2w_launch_status();
 }

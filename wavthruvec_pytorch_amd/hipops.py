@@ -360,7 +360,7 @@ def bn_finalize(stats, gb, running_mean, running_var, num_batches_tracked, a_out
                                            B, C2 // 2, int(training), momentum, eps, _stream(gb)), 'v2w_bn_finalize')
 
 
-BN_SLICES = 64
+BN_SLICES = 128
 
 
 def bn_reduce_finalize_slices(part, ntiles, count, slices, gb, running_mean, running_var, num_batches_tracked, a_out, s_out, *,

@@ -568,7 +568,9 @@ class Generator(nn.Module):
             main = torch.cuda.current_stream(dev)
             side = self._side_stream(dev)
             side.wait_stream(main)
-            wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
+            # (bf16 storage: the only fp32 fold is conv_post's, first read by the last stage - it runs on the side stream, not in front of conv_pre)
+            with (torch.cuda.stream(side) if st else contextlib.nullcontext()):
+                wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
             wps = self._split_weights(dev, all_ups=st, ups_stream=side)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
 
             def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
