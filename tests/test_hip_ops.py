@@ -376,11 +376,14 @@ def test_convt1d_bf16_operands(dev, B, cin, cout, L, k, u):
 @pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 256, 128, 264, 8, 4), (3, 128, 64, 1000, 8, 4), (2, 64, 32, 2052, 4, 2),
                                               (2, 32, 16, 4100, 4, 2), (1, 64, 32, 36, 4, 2), (2, 128, 64, 72, 16, 8),
                                               (2, 512, 256, 52, 11, 5), (2, 64, 32, 37, 4, 2),
-                                              (2, 512, 256, 128, 11, 5), (3, 256, 128, 192, 11, 5), (1, 512, 256, 64, 11, 5)])
+                                              (2, 512, 256, 128, 11, 5), (3, 256, 128, 192, 11, 5), (1, 512, 256, 64, 11, 5),
+                                              (2, 256, 96, 128, 11, 5), (2, 512, 256, 192, 15, 5), (5, 64, 384, 64, 5, 5), (2, 64, 96, 64, 5, 5),
+                                              (2, 64, 96, 64, 11, 5), (5, 64, 96, 64, 11, 5)])
 def test_convt1d_bf16_activation_storage(dev, B, cin, cout, L, k, u):
     """io_bf16 = 3: the transposed conv on bf16 TENSORS (models.py:128-129 under BASELINE configs[2] with bf16 activation storage).  Strides
     2 / 4 / 8 at L % 4 == 0 run on the resident-tile kernel (v2w_convt_bf16_res.hip: stores straight from the accumulators), stride 5 at
-    L % 64 == 0 on its scratch-epilogue form, stride 5 otherwise and ragged lengths on the chunked kernel: both against an fp64 ConvTranspose1d of the same bf16 operands to the rounding of the bf16
+    L % 64 == 0 on its exact-phase form (C_out in steps of 128: rows co * 5 + phase, no MFMA on padding phases) or its scratch-epilogue form
+    (8 virtual phases; C_out = 96 here), stride 5 otherwise and ragged lengths on the chunked kernel: all against an fp64 ConvTranspose1d of the same bf16 operands to the rounding of the bf16
     store, and the fused BatchNorm partial sums (taken from the fp32 values before rounding) against the reference's sums.  The rows of
     `stats_part` are asked for with the same tensors and io_bf16 (the tile width follows the kernel)."""
     from wavthruvec_pytorch_amd import hipops

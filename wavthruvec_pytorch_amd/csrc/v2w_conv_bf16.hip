@@ -877,6 +877,9 @@ static ConvtGeom convt_geom(int k, int u) {
     return g;
 }
 
+// v2w_pack_bf16_convt's buffer carries a second region (rows co * u + phase, no padding phases) when the stride is no power of two
+static bool convt_exact_region(int c_out, int u, int UP) { return UP != u && (c_out * u) % 32 == 0; }
+
 template <int MI, int NI, int WM, int WN, bool VEC = true>
 int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg = nullptr) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, HMAX = 32;
@@ -996,6 +999,14 @@ extern "C" int v2w_pack_bf16_convt(const float* wf, void* wps, int k, int c_in, 
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_bf16_convt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), k, c_in, c_out, u,
                        g.UP, g.hl, g.KV);
+    if (convt_exact_region(c_out, u, g.UP)) {
+        // a stride that is no power of two (5): the same taps again over the EXACT phases, rows co * u + phase, behind the padded rows - the
+        // resident kernel of v2w_convt_bf16_res.hip then spends no MFMA on the dead phases
+        const size_t total2 = (size_t)(c_out * u / 32) * (c_in / 16) * g.KV * 64;
+        int grid2 = (int)((total2 + 255) / 256); if (grid2 > 4096) grid2 = 4096;
+        hipLaunchKernelGGL(pack_bf16_convt_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, wf,
+                           reinterpret_cast<b8*>(reinterpret_cast<unsigned char*>(wps) + total / 64 * V2W_BF_UNIT), k, c_in, c_out, u, u, g.hl, g.KV);
+    }
     return v2w_launch_status();
 }
 // bytes of the fragment buffer of v2w_pack_bf16_convt (0: shape not supported)
@@ -1003,7 +1014,7 @@ extern "C" long long v2w_pack_bf16_convt_bytes(int k, int c_in, int c_out, int u
     if (k <= 0 || c_in <= 0 || c_out <= 0 || u <= 1 || k < u || ((k - u) & 1) || u > 8 || c_in % 32 != 0) return 0;
     const ConvtGeom g = convt_geom(k, u);
     if ((c_out * g.UP) % 32 != 0) return 0;
-    return (long long)(c_out * g.UP / 32) * (c_in / 16) * g.KV * V2W_BF_UNIT;
+    return (long long)(c_out * g.UP / 32 + (convt_exact_region(c_out, u, g.UP) ? c_out * u / 32 : 0)) * (c_in / 16) * g.KV * V2W_BF_UNIT;
 }
 extern "C" int v2w_convt1d_bf16_fwd(const v2w_convt1d_args* a, void* stream) {
     if (!a || !a->in || !a->wp || !a->out) return V2W_E_ARG;

@@ -16,6 +16,11 @@
 //     so the accumulators pass through a wave-private fp32 scratch that IS the output block [channel][5 x 64 positions] (over the dead input
 //     tile) and leave as 8-byte bf16 stores along positions - the epilogue of the chunked kernel (v2w_conv_bf16.hip), without its 16
 //     barriers and exposed memory latencies per tile.
+//   * U = UP = 5 (round 4): the EXACT five phases - virtual rows co * 5 + phase, the second region of v2w_pack_bf16_convt's buffer - instead of
+//     8 of which 3 are zero (37.5 % of the MFMA work of the kernel above).  160 rows = 32 channels per wave, 4 waves = 128 channels x 64
+//     positions per workgroup, ONE workgroup per CU (the 512-channel input tile is 74 KB) with the whole register file: 10 accumulator blocks
+//     per wave, every weight fragment feeds two MFMAs, every staged input tile serves 128 channels instead of 32.  Accumulators start at the
+//     bias; the epilogue passes 32 positions at a time through a wave-private scratch [32 channels][5 x 32 outputs] (over the dead tile).
 #include <type_traits>
 #include "v2w_tile.h"
 
@@ -61,16 +66,17 @@ __device__ __forceinline__ float ct_row_sum(float v) {
 
 // workgroups (of 4 waves) per CU the register budget is cut for
 constexpr int ct_wgs(int mi, int ni) { return mi * ni >= 8 ? 2 : (mi * ni >= 4 ? 3 : 4); }
+#define V2W_CT5_SCRATCH (4 * 16 * 160 * 4)      // UP = 5: four waves x [16 channels][160 outputs] fp32
 
 // U: the stride (= UP, or 5 with UP = 8: whole tiles only, NI even)
 template <int MI, int NI, int WM, int WN, int UP, int U = UP>
-__global__ void __launch_bounds__(64 * WM * WN, ct_wgs(MI, NI))
+__global__ void __launch_bounds__(64 * WM * WN, UP == 5 ? 1 : ct_wgs(MI, NI))
 convt_bf16_res_kernel(const CtArgs a) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
     constexpr int NPF = (8 * ((NT + 16) / 4) + NTH - 1) / NTH;                 // staging items of one 32-channel plane per thread
-    static_assert(UP == 2 || UP == 4 || UP == 8, "phases per channel");
+    static_assert(UP == 2 || UP == 4 || UP == 8 || (UP == 5 && MI == 5 && WM == 4 && WN == 1), "phases per channel");
     static_assert(U == UP || (U == 5 && UP == 8 && NI % 2 == 0), "stride");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
@@ -78,7 +84,10 @@ convt_bf16_res_kernel(const CtArgs a) {
     const int Cin = ct_uni(a.Cin), L = ct_uni(a.L), xrows = ct_uni(a.xrows), hla = ct_uni(a.hla), KV = ct_uni(a.KV);
     const int CoutR = ct_uni(a.CoutR);
     const int nch = Cin >> 5, psz = xrows * 64;
-    float* const btab = reinterpret_cast<float*>(smem_c + nch * psz);         // bias of this M-tile's channels [MT / UP]
+    // bias of this M-tile's channels [MT / UP]: behind the tile - and behind the waves' scratch of the U = 5 epilogue, which reads it (a tile
+    // of few input channels is smaller than that scratch)
+    constexpr int SCR8 = (U != UP) ? WM * WN * 2048 * 4 : 0;
+    float* const btab = reinterpret_cast<float*>(smem_c + (nch * psz > SCR8 ? nch * psz : SCR8));
     float* const red = btab + MT / UP;                                          // [WN][MT / UP][2] partial sums of the waves
     const float slope = a.slope;
 
@@ -146,6 +155,7 @@ convt_bf16_res_kernel(const CtArgs a) {
                 }
             }
         };
+        {
         u32x2 pf0[NPF][4], pf1[NPF][4];
         prefetch(0, pf0);
         if (nch > 1) prefetch(1, pf1);
@@ -161,6 +171,7 @@ convt_bf16_res_kernel(const CtArgs a) {
         }
         commit(ch, pf0);
         if (ch + 1 < nch) commit(ch + 1, pf1);
+        }
     }
     __syncthreads();
 
@@ -171,7 +182,10 @@ convt_bf16_res_kernel(const CtArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                if constexpr (UP == 5) acc[i][j][e] = btab[32 * wave + (32 * i + 8 * (e >> 2) + 4 * hk + (e & 3)) / 5];    // (the bias)
+                else acc[i][j][e] = 0.f;
+            }
     {
         const unsigned lane16 = (unsigned)lane * 16u;
         auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
@@ -183,7 +197,8 @@ convt_bf16_res_kernel(const CtArgs a) {
         const unsigned char* ap[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) ap[i] = a.wps + (size_t)((m0 + wm0) / 32 + i) * nst * V2W_CT_UNIT;
-        u32x4 ar[4][MI];
+        constexpr int RD = 2;                                                   // taps of weight fragments in flight (2 k-steps each)
+        u32x4 ar[2 * RD][MI];
         auto load_frag = [&](u32x4 (&av)[MI], int ch, int s, int t) {
             unsigned l16 = lane16;
             asm volatile("" : "+v"(l16));
@@ -192,15 +207,15 @@ convt_bf16_res_kernel(const CtArgs a) {
             for (int i = 0; i < MI; ++i)
                 av[i] = *gptr<const u32x4>(ap[i] + (size_t)((2 * chc + s) * K + t) * V2W_CT_UNIT + l16);
         };
-        load_frag(ar[0], 0, 0, 0);
-        load_frag(ar[1], 0, 1, 0);
-        {
-            const int c1 = K > 1 ? 0 : 1, t1 = K > 1 ? 1 : 0;
-            load_frag(ar[2], c1, 0, t1);
-            load_frag(ar[3], c1, 1, t1);
+#pragma unroll
+        for (int d = 0; d < RD; ++d) {
+            int c1 = 0, t1 = d;
+            while (t1 >= K) { t1 -= K; ++c1; }
+            load_frag(ar[2 * d], c1, 0, t1);
+            load_frag(ar[2 * d + 1], c1, 1, t1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        int ch = 0, t = 0, qc = 0, qt = 2;
+        int ch = 0, t = 0, qc = 0, qt = RD;
         while (qt >= K) { qt -= K; ++qc; }
         const int r0 = hla - ct_uni(a.hl) + wn0 + lr;
         unsigned xt = baddr(0, r0);
@@ -235,7 +250,11 @@ convt_bf16_res_kernel(const CtArgs a) {
             if (++qt >= K) { qt = 0; ++qc; }
             ch = nch_; t = nt_; xt = xn;
         };
+#ifdef V2W_CT_EXP_NOMFMA
+        const int TT = UP == 5 ? 0 : nch * K;
+#else
         const int TT = nch * K;
+#endif
         int g = 0;
         for (; g + 1 < TT; g += 2) { tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); }
         if (g < TT) tap(std::integral_constant<int, 0>{});
@@ -248,7 +267,67 @@ convt_bf16_res_kernel(const CtArgs a) {
     constexpr int CPB = 32 / UP;                                                // channels per 32-row block
     const int Lout = L * U;
     const bool stats = a.stats_part != nullptr;
-    if constexpr (U != UP) {
+    if constexpr (UP == 5) {
+        // ---- the exact five phases: block (i, j), register e, lane (lr, hk) = row 32 i + 8 (e / 4) + 4 hk + e % 4 of this wave's 160 =
+        // (channel row / 5, phase row % 5) at input position 32 j + lr.  Sixteen channels (rows 0..79 / 80..159: whole register quads) of 32
+        // positions at a time -> scratch[channel][5 lr + phase] (10 KB a wave: two workgroups' tiles fit a CU); float4 number lane + 64 g of
+        // the scratch = 4 consecutive outputs of channel (lane + 64 g) / 40: an 8-byte bf16 store; lane (channel, quarter) adds a quarter row
+        __syncthreads();                                                        // every wave has left the MFMA loop: the input tile is dead
+        float* const scr = reinterpret_cast<float*>(smem_c) + wave * (16 * 160);
+        const int co0 = (m0 + wm0) / 5;
+        unsigned char* const ob0 = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * CoutR * Lout * 2;
+        const int cS = lane & 15, qS = lane >> 4;
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#ifdef V2W_CT_EXP_NOEPI
+        if (a.slope > 5.f)
+#endif
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r0_ = 32 * i + 8 * (e >> 2) + (e & 3), r1_ = r0_ + 4;
+                        if (r0_ / 80 != h) continue;                             // (r0_ and r0_ + 4 share the half: quads of 8 rows)
+                        const int o0 = (r0_ / 5 - 16 * h) * 160 + r0_ % 5, o1 = (r1_ / 5 - 16 * h) * 160 + r1_ % 5;
+                        scr[(hk ? o1 : o0) + 5 * lr] = acc[i][j][e];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned ub = (unsigned)((co0 + 16 * h) * Lout + 5 * (n0 + 32 * j)) * 2u;       // (uniform)
+#pragma unroll
+                for (int g = 0; g < 10; ++g) {
+                    const int idx = lane + 64 * g;
+                    const int c = idx / 40, q4 = idx - 40 * c;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(scr + 4 * idx);
+                    *gptr<u32x2>(ob0 + ub + (unsigned)(c * Lout + 4 * q4) * 2u) = u32x2{ct_pack2(v[0], v[1]), ct_pack2(v[2], v[3])};
+                }
+                if (stats) {
+                    const float* row = scr + cS * 160 + qS * 40;
+#pragma unroll 8
+                    for (int k = 0; k < 40; ++k) {
+                        int kk = k + 2 * cS; kk = kk >= 40 ? kk - 40 : kk;     // rotated start: the 16 channels x 4 quarters read 64 banks
+                        const float v = row[kk];
+                        s1[h] += v; s2[h] = fmaf(v, v, s2[h]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (stats) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float t1 = s1[h] + __shfl_xor(s1[h], 16, 64), t2 = s2[h] + __shfl_xor(s2[h], 16, 64);
+                t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+                if (lane < 16) {
+                    gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 0] = t1;
+                    gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 1] = t2;
+                }
+            }
+        }
+        return;
+    } else if constexpr (U != UP) {
         // ---- U = 5: 64 input positions (two column blocks) of a 32-row block at a time -> scratch [4 channels][5 x 64 outputs] (the output's
         // own layout: block (i, j), register quad eg, lane (lr, hk) holds phases 4 hk + {0..3} of channel eg at input position 32 j + lr)
         // -> float4 number lane + 64 g of the scratch is 4 consecutive outputs of channel (lane + 64 g) / 80: + bias, sums, an 8-byte bf16 store.
@@ -384,7 +463,7 @@ template <int MI, int NI, int WM, int WN, int UP, int U = UP>
 int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     constexpr int NTH = 64 * WM * WN, MT = 32 * MI * WM, NT = 32 * NI * WN;
     if ((p.CoutR * UP) % MT != 0 || p.Cin % 32 != 0) return V2W_E_SHAPE;
-    if (U != UP && p.L % NT != 0) return V2W_E_SHAPE;                // the scratch epilogue of U = 5 serves whole tiles
+    if ((U != UP || UP == 5) && p.L % NT != 0) return V2W_E_SHAPE;   // the scratch epilogues of U = 5 serve whole tiles
     const int nch = p.Cin / 32;
     if (nch > 1 && (nch & 1)) return V2W_E_SHAPE;                    // planes are staged in pairs
     p.hla = (p.hl + 3) & ~3;
@@ -393,8 +472,10 @@ int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     p.ntl = (p.L + NT - 1) / NT;
     p.ntiles = p.B * p.ntl;
     p.xrows = (p.hla + NT + hr + 3) & ~3;
-    size_t lds = (size_t)nch * p.xrows * 64 + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
-    if (U != UP && lds < (size_t)WM * WN * 2048 * sizeof(float)) lds = (size_t)WM * WN * 2048 * sizeof(float);      // the waves' scratch overlays the tile
+    size_t tile_b = (size_t)nch * p.xrows * 64;
+    if (U != UP && tile_b < (size_t)WM * WN * 2048 * sizeof(float)) tile_b = (size_t)WM * WN * 2048 * sizeof(float);   // the waves' scratch overlays the tile
+    size_t lds = tile_b + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
+    if (UP == 5 && lds < V2W_CT5_SCRATCH) lds = V2W_CT5_SCRATCH;     // (bias table and tile are dead by then)
     constexpr int WGS = ct_wgs(MI, NI);                              // workgroups per CU the register budget allows (4-wave workgroups)
     if (lds * (WGS > 2 ? 2 : WGS) > 160 * 1024) return V2W_E_SHAPE;
     if (cfg) { const int32_t c[10] = {MI, NI, WM, WN, UP, 102 /* = this kernel */, 1, 1, 32, U}; for (int i = 0; i < 10; ++i) cfg[i] = c[i]; }
@@ -424,6 +505,14 @@ int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipS
     p.B = a->B; p.Cin = a->C_in; p.CoutR = a->C_out; p.L = a->L; p.KV = KV; p.hl = hl; p.slope = a->slope;
     const int rows = a->C_out * UP;
     if (a->u == 5) {
+        // the exact five phases (fragments: the second region of v2w_pack_bf16_convt's buffer, behind the C_out * 8 virtual rows): 128 channels x 64
+        // positions per workgroup; whole tiles, C_out in steps of 128
+        if (a->C_out % 128 == 0 && a->L % 64 == 0 && a->C_in % 32 == 0) {
+            CtArgs q = p;
+            q.wps = p.wps + (size_t)(a->C_out * 8 / 32) * (a->C_in / 16) * KV * V2W_CT_UNIT;
+            const int rc = launch_ct<5, 2, 4, 1, 5, 5>(q, stream, ntiles_out, cfg);
+            if (rc != V2W_E_SHAPE) return rc;
+        }
         // 256 virtual rows x 64 positions, 4 waves of 64 x 64: the 512-channel input tile of the generator's first upsampler fits twice per CU
         if (rows % 256 == 0) return launch_ct<2, 2, 4, 1, 8, 5>(p, stream, ntiles_out, cfg);
         return V2W_E_SHAPE;
