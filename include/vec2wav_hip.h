@@ -184,8 +184,9 @@ typedef struct {
     int32_t c_in, c_out, k;
     int32_t mode;                     /* 0: split f16 (hi, lo) fragments; 1: bf16 fragments for V2W_ALGO_BF16 */
 } v2w_split_desc;
+/* all_bf16 != 0: every descriptor has mode 1 (no scale record is kept: two launches instead of three) */
 int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32_t* starts_dev, int n, int nblk_rows, int nblk_pack,
-                         int k_max, void* stream);
+                         int k_max, int all_bf16, void* stream);
 
 /* ---- K6 fused pair for the narrow stages (C == 32 or 16; MFMA path): two chained convs of one residual block in ONE kernel,
  * the intermediate stays in LDS (these layers are HBM-bound as separate launches).

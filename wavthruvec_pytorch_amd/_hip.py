@@ -141,7 +141,7 @@ SIGNATURES = {
     'v2w_resblock2_stage_split_config': (C.c_int, [C.POINTER(StageSplitArgs)]),
     'v2w_resblock2_stage_up_tiles': (C.c_int, [C.POINTER(StageSplitArgs)]),
     'v2w_pack_bf16': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
-    'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'v2w_split_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_fold_plan': (C.c_int, [C.POINTER(FoldDesc), C.c_int, C.POINTER(C.c_int32)]),
     'v2w_fold_pack_batch': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'v2w_conv1d_fwd': (C.c_int, [C.POINTER(Conv1dArgs), _fp]),

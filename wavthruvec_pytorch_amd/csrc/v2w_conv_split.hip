@@ -631,7 +631,25 @@ split_rowscale_batch_kernel(const v2w_split_desc* __restrict__ descs, const int3
     const float* src = d.v + (size_t)row * inner;
     double acc = 0.0;
     float mx = 0.f;
-    for (int i = threadIdx.x; i < inner; i += 256) { const float x = src[i]; acc += (double)x * x; mx = fmaxf(mx, fabsf(x)); }
+    if ((inner & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {       // 16-byte loads, two in flight (a row of conv_pre: 5 376 floats)
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        const int n4 = inner >> 2;
+        int i = threadIdx.x;
+        for (; i + 256 < n4; i += 512) {
+            const f32x4 x = s4[i], y = s4[i + 256];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc += (double)x[e] * x[e]; mx = fmaxf(mx, fabsf(x[e])); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc += (double)y[e] * y[e]; mx = fmaxf(mx, fabsf(y[e])); }
+        }
+        if (i < n4) {
+            const f32x4 x = s4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc += (double)x[e] * x[e]; mx = fmaxf(mx, fabsf(x[e])); }
+        }
+    } else {
+        for (int i = threadIdx.x; i < inner; i += 256) { const float x = src[i]; acc += (double)x * x; mx = fmaxf(mx, fabsf(x)); }
+    }
     const double n2 = v2w_block_sum(acc, red);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -641,7 +659,8 @@ split_rowscale_batch_kernel(const v2w_split_desc* __restrict__ descs, const int3
         const float sc = d.g ? (float)((double)d.g[row] / sqrt(n2)) : 1.f;
         d.rowscale[row] = sc;
         mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])) * fabsf(sc);
-        atomicMax(reinterpret_cast<unsigned int*>(d.sc) + 2, __float_as_uint(mx));   // order of non-negative floats = order of their bits
+        if (d.mode != 1)            // (bf16 fragments carry no scale record)
+            atomicMax(reinterpret_cast<unsigned int*>(d.sc) + 2, __float_as_uint(mx));   // order of non-negative floats = order of their bits
     }
 }
 
@@ -774,13 +793,14 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
 
 // Batched form of (v2w_wn_fold_conv + v2w_pack_split) for n Conv1d layers: descs / starts live in DEVICE memory;
 // starts[0..n] = prefix sums of c_out (rows), starts[n+1 .. 2n+1] = prefix sums of (c_out/32)*(c_in/16) (pack blocks).
+// all_bf16 != 0: every descriptor has mode 1 - no scale record is kept, the launch that zeroes the records is left out (two launches)
 extern "C" int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32_t* starts_dev, int n, int nblk_rows, int nblk_pack,
-                                    int k_max, void* stream) {
+                                    int k_max, int all_bf16, void* stream) {
     if (!descs_dev || !starts_dev || n <= 0 || nblk_rows <= 0 || nblk_pack <= 0 || k_max <= 0) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int lds = 32 * (V2W_SPLIT_CK * k_max + 1) * (int)sizeof(float);
     if (lds > 64 * 1024) return V2W_E_SHAPE;
-    hipLaunchKernelGGL(split_zero_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, st, descs_dev, n);
+    if (!all_bf16) hipLaunchKernelGGL(split_zero_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, st, descs_dev, n);
     hipLaunchKernelGGL(split_rowscale_batch_kernel, dim3(nblk_rows), dim3(256), 0, st, descs_dev, starts_dev, n);
     hipLaunchKernelGGL(split_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds, st, descs_dev, starts_dev + n + 1, n);
     return v2w_launch_status();

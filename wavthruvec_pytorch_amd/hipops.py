@@ -504,6 +504,7 @@ class SplitPlan:
         """layers: list of (v (C_out, C_in, k), g|None, wps, sc) with tensors already on `device`; bf16: fragments for ALGO_BF16."""
         n = len(layers)
         self.n = n
+        self.bf16 = bool(bf16)
         self.rowscale = torch.empty((sum(v.shape[0] for v, *_ in layers),), device=device, dtype=torch.float32)
         descs = (_hip.SplitDesc * n)()
         starts = [0] * (2 * (n + 1))
@@ -525,7 +526,7 @@ class SplitPlan:
 
     def run(self):
         _hip.check(_hip.load().v2w_split_pack_batch(self.descs_dev.data_ptr(), self.starts_dev.data_ptr(), self.n,
-                                                    self.nblk_rows, self.nblk_pack, self.k_max,
+                                                    self.nblk_rows, self.nblk_pack, self.k_max, int(self.bf16),
                                                     torch.cuda.current_stream(self.rowscale.device).cuda_stream),
                    'v2w_split_pack_batch')
 
