@@ -151,11 +151,8 @@ typedef struct {
     float*  splitk_ws;
     int64_t splitk_ws_bytes;      /* optional CALLER-OWNED scratch for the f32 MFMA path (ABI v28; the library allocates nothing and keeps no
                                    * state between calls): a launch that cannot fill the chip (<= 128 workgroups: inference at B = 1) is split
-                                   * over slices of C_in, every slice stores plain partial sums to its own slab of this buffer and the LAST
-                                   * workgroup of an output tile to arrive (one ticket word per tile at the start of the buffer) adds the
-                                   * slabs in slice order and applies bias / residual / addends / division: deterministic, one launch.
-                                   * The buffer must be 16-byte aligned and ZERO-FILLED ONCE by its owner when allocated; every launch
-                                   * leaves the ticket words at zero again (the rest is scratch).
+                                   * over slices of C_in, every slice stores plain partial sums to its own slab of this buffer and a second
+                                   * kernel adds the slabs in slice order and applies bias / residual / addends / division (deterministic).
                                    * v2w_conv1d_splitk_ws_bytes() says how many bytes this launch would use (0: it runs unsplit); NULL, or fewer
                                    * bytes than that: the launch runs unsplit - same values up to the summation order over C_in.  Launches that
                                    * share a buffer must be ordered on ONE stream (a module keeps one buffer per stream it launches on).

@@ -263,10 +263,9 @@ def test_resblock2_stage_bf16_storage(dev, C, L):
 
 @pytest.mark.parametrize('B,cin,cout,L,k,dil', [(1, 768, 512, 50, 7, 1), (1, 256, 256, 250, 11, 3), (2, 128, 128, 1000, 3, 1), (1, 512, 512, 64, 7, 1)])
 def test_conv1d_split_over_cin_matches_the_unsplit_kernel(dev, B, cin, cout, L, k, dil):
-    """Launches of at most 128 workgroups are split over C_in chunks (slabs in the caller's scratch; the last workgroup of a tile to arrive
-    adds them): same result as the direct kernel to fp32 summation order, bitwise identical from run to run (whichever
-    slice arrives last), with every epilogue operand (residual affine, running sum, division), for sequence lengths that are and are not
-    multiples of 4; the ticket words at the head of the scratch are back at zero after every launch."""
+    """Launches of at most 128 workgroups are split over C_in chunks (slabs + splitk_reduce_kernel): same result as
+    the direct kernel to fp32 summation order, bitwise identical from run to run, with every epilogue operand (residual affine,
+    running sum, division), for sequence lengths that are and are not multiples of 4."""
     from wavthruvec_pytorch_amd import hipops
     r = _rng(41)
     x = _t(r.standard_normal((B, cin, L), dtype=np.float32), dev)
@@ -287,13 +286,6 @@ def test_conv1d_split_over_cin_matches_the_unsplit_kernel(dev, B, cin, cout, L, 
     expect_split = (cin // 32) * k >= 24
     assert (slab.t is not None and slab.t.numel() > 0) == expect_split, 'the size query and the split rule disagree'
     assert torch.equal(outs[0], outs[1]), 'split launches are not run-to-run deterministic'
-    if expect_split:
-        for _ in range(5):
-            o = prev.clone()
-            hipops.conv1d(x, wf, bias, o, algo=hipops.ALGO_AUTO, wp=hipops.pack_mfma(wf), splitk_ws=slab, **kw)
-            assert torch.equal(o, outs[0])
-        ntick = 64 * ((B * ((L + 63) // 64) * (cout // 64) + 63) // 64)       # an upper bound of the ticket words of this launch
-        assert (slab.t[:min(ntick, slab.t.numel())].view(torch.int32)[:64] == 0).all(), 'ticket words not returned to zero'
     assert (outs[0] - outs[2]).abs().max().item() <= 2e-5
     assert (outs[3] - outs[2]).abs().max().item() <= 2e-5        # no slab handed over: the launch runs unsplit
     if expect_split:   # a slab smaller than the query's answer: unsplit as well (never a partial use of it)

@@ -55,7 +55,6 @@ template <int MF, int CK> struct TileGeom {
 // EPI: which optional epilogue is compiled in.  0 = none (the generator's forward kernels).  1 = the backward-only leaky_relu-
 // derivative mask (+ out_slope): it costs 8 VGPRs (one occupancy step on the 128 x 128 tile, 5-12 % of a layer's time), so it is
 // its own instantiation.  2 = out_slope only (the discriminators' activated feature maps): no extra registers.
-// 3 = the partial pass of a split over C_in with the reduction fused behind it (launch_tile; the code at the kernel's end).
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 128 x 128 conv tile runs three
 // workgroups per CU - its LDS footprint allows exactly that - and would otherwise drift to 2 through the epilogue's temporaries)
 // VEC: every problem of the launch has float4-aligned, unit-stride input (the vector staging path).  A template parameter, not a
@@ -405,7 +404,7 @@ conv_tile_kernel(const MultiArgs m) {
                         float t = v[x] + bias;
                         if (p.res) t += fmaf(ra, rall[g][x], rs);
                         if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
-                        if constexpr (EPI == 1 || EPI == 2)
+                        if constexpr (EPI != 0)
                             if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                         v[x] = t;
                     }
@@ -450,7 +449,7 @@ conv_tile_kernel(const MultiArgs m) {
                             if (p.add1) t += ov[g][x] + o2[g][x];      // (add0 + add1) + value: the reference's `xs += ...` order
                             else if (p.accumulate || p.add0) t += ov[g][x];
                             if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
-                            if constexpr (EPI == 1 || EPI == 2)
+                            if constexpr (EPI != 0)
                                 if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                             v[x] = t;
                         }
@@ -483,7 +482,7 @@ conv_tile_kernel(const MultiArgs m) {
                     else if (p.accumulate) t += outp[goff];
                     else if (p.add0) t += p.add0[goff];
                     if (p.out_div != 0.f) t = v2w_div_by(t, p.out_div, dinv);
-                    if constexpr (EPI == 1 || EPI == 2)
+                    if constexpr (EPI != 0)
                         if (p.out_slope != 1.f) t = t > 0.f ? t : t * p.out_slope;
                     outp[goff] = t;
                 }
@@ -572,79 +571,75 @@ conv_tile_kernel(const MultiArgs m) {
             }
         }
     }
-
-    // ---- EPI 3 = the partial pass of a split over C_in with the reduction fused behind it: the workgroup that finds the tile's ticket at
-    // ksplit - 1 is the last of the tile's slices to have stored (release fence before the ticket, acquire fence behind it): it adds the
-    // slabs in slice order and applies the epilogue in the arithmetic order of the unsplit kernel, then leaves the ticket at zero.
-    // Deterministic (the order of the additions is the slice order whoever arrives last); no second launch.
-    if constexpr (EPI == 3) {
-        const SplitFin& f = m.fin[pq];
-        __shared__ int last_ws;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) last_ws = atomicAdd(f.cnt + tile * mtiles + mt, 1) == p.ksplit - 1;
-        __syncthreads();
-        if (!last_ws) return;
-        __threadfence();
-        if (tid == 0) f.cnt[tile * mtiles + mt] = 0;
-        const int Lo = L * U, o0 = n0 * U;
-        const int ow = Lo - o0 < NT * U ? Lo - o0 : NT * U;       // output positions of this tile
-        const int S = p.ksplit;
-        const float dinv = f.out_div != 0.f ? 1.f / f.out_div : 1.f;
-        if (f.vec) {
-            constexpr int Q = NT * U / 4;
-            for (int idx = tid; idx < MT * Q; idx += NTHREADS) {
-                const int r = idx / Q, c4 = idx - r * Q;
-                if (4 * c4 >= ow) continue;
-                const size_t row = (size_t)b * p.Cout + m0 + r;
-                const size_t off = row * Lo + o0 + 4 * c4;
-                f32x4 v = *gptr<const f32x4>(f.slab + off);
-                for (int sl = 1; sl < S; ++sl) v += *gptr<const f32x4>(f.slab + (size_t)sl * f.slice_stride + off);
-                const float bias = f.bias ? f.bias[m0 + r] : 0.f;
-                f32x4 rr = {0.f, 0.f, 0.f, 0.f}, ov = rr, o2 = rr;
-                float ra = 1.f, rs = 0.f;
-                if (f.res) { rr = *gptr<const f32x4>(f.res + off); if (f.res_a) { ra = f.res_a[row]; rs = f.res_s[row]; } }
-                if (f.accumulate) ov = *gptr<const f32x4>(f.out + off);
-                else if (f.add0) ov = *gptr<const f32x4>(f.add0 + off);
-                if (f.add1) o2 = *gptr<const f32x4>(f.add1 + off);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    float t2 = v[x] + bias;
-                    if (f.res) t2 += fmaf(ra, rr[x], rs);
-                    if (f.add1) t2 += ov[x] + o2[x];
-                    else if (f.accumulate || f.add0) t2 += ov[x];
-                    if (f.out_div != 0.f) t2 = v2w_div_by(t2, f.out_div, dinv);
-                    v[x] = t2;
-                }
-                *gptr<f32x4>(f.out + off) = v;
-            }
-        } else {
-            for (int idx = tid; idx < MT * NT * U; idx += NTHREADS) {
-                const int r = idx / (NT * U), c = idx - r * (NT * U);
-                if (c >= ow) continue;
-                const size_t row = (size_t)b * p.Cout + m0 + r;
-                const size_t off = row * Lo + o0 + c;
-                float v = f.slab[off];
-                for (int sl = 1; sl < S; ++sl) v += f.slab[(size_t)sl * f.slice_stride + off];
-                float t2 = v + (f.bias ? f.bias[m0 + r] : 0.f);
-                if (f.res) t2 += f.res_a ? fmaf(f.res_a[row], f.res[off], f.res_s[row]) : f.res[off];
-                if (f.add1) t2 += f.add0[off] + f.add1[off];
-                else if (f.accumulate) t2 += f.out[off];
-                else if (f.add0) t2 += f.add0[off];
-                if (f.out_div != 0.f) t2 = v2w_div_by(t2, f.out_div, dinv);
-                f.out[off] = t2;
-            }
-        }
-    }
 }
 
 // ---- split over C_in for launches that cannot fill the chip (inference at B = 1: conv_pre at T = 50 is 64 workgroups walking
 // 24 chunks x 7 taps one after the other, 176 us).  The launch is repeated over `ksplit` slices of the chunks, every slice writes its
-// plain partial sums to its own slab of the CALLER's scratch (same (B, C_out, L_out) layout as the output), and the last workgroup of a
-// tile to arrive adds the slabs in slice order and applies the epilogue - bias, residual, addends, division - in the main kernel's
-// arithmetic order (conv_tile_kernel, EPI 3): deterministic, one launch (rounds 2-3 ran a second kernel for the reduction: at B = 1 eleven
-// of the forward's thirty launches).  The scratch starts with one ticket word per output tile; the caller zero-fills the scratch once
-// when it allocates it, every launch leaves the words at zero.
+// plain partial sums to its own slab of a per-(device, stream) workspace (same (B, C_out, L_out) layout as the output), and
+// splitk_reduce_kernel adds the slabs in slice order and applies the epilogue - bias, residual, addends, division - in the main
+// kernel's arithmetic order: deterministic, no atomics, visibility from the kernel boundary.
+struct SplitEpi {
+    const float* slab; float* out;
+    const float* bias; const float* res; const float* res_a; const float* res_s; const float* add0; const float* add1;
+    int accumulate; float out_div;
+    int Cout, Lout;
+    size_t slice_stride;      // floats between the slabs of consecutive slices
+};
+struct SplitEpiArgs {
+    SplitEpi e[V2W_MAX_MULTI];
+    long long start[V2W_MAX_MULTI + 1];     // first float4 of problem i in the flat index space
+    int n, S;
+};
+
+// VEC: float4 per thread (every L_out a multiple of 4, every pointer 16-byte aligned); else one element per thread
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const SplitEpiArgs a) {
+    constexpr int W = VEC ? 4 : 1;
+    typedef typename std::conditional<VEC, f32x4, float>::type vec_t;
+    const long long total = a.start[a.n];
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int q = 0;
+#pragma unroll
+        for (int i = 1; i < V2W_MAX_MULTI; ++i) q += (i < a.n && idx >= a.start[i]) ? 1 : 0;
+        const SplitEpi& e = a.e[q];
+        const size_t off = (size_t)(idx - a.start[q]) * W;
+        const size_t row = off / e.Lout;                  // b * Cout + co (VEC: Lout % 4 == 0, a float4 never crosses rows)
+        const int co = (int)(row % e.Cout);
+        float v[W], r[W], ov[W], o2[W];
+        auto ld = [&](const float* src, float (&dst)[W]) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(src + off);
+            if constexpr (VEC) { dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3]; } else dst[0] = t;
+        };
+        ld(e.slab, v);
+        for (int s = 1; s < a.S; ++s) {
+            float t[W];
+            ld(e.slab + (size_t)s * e.slice_stride, t);
+#pragma unroll
+            for (int x = 0; x < W; ++x) v[x] += t[x];
+        }
+        const float bias = e.bias ? e.bias[co] : 0.f;
+#pragma unroll
+        for (int x = 0; x < W; ++x) r[x] = ov[x] = o2[x] = 0.f;
+        float ra = 1.f, rs = 0.f;
+        if (e.res) { ld(e.res, r); if (e.res_a) { ra = e.res_a[row]; rs = e.res_s[row]; } }
+        if (e.accumulate) ld(e.out, ov);
+        else if (e.add0) ld(e.add0, ov);
+        if (e.add1) ld(e.add1, o2);
+        const float dinv = e.out_div != 0.f ? 1.f / e.out_div : 1.f;
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            float t2 = v[x] + bias;
+            if (e.res) t2 += fmaf(ra, r[x], rs);
+            if (e.add1) t2 += ov[x] + o2[x];
+            else if (e.accumulate || e.add0) t2 += ov[x];
+            if (e.out_div != 0.f) t2 = v2w_div_by(t2, e.out_div, dinv);
+            v[x] = t2;
+        }
+        if constexpr (VEC) *reinterpret_cast<f32x4*>(e.out + off) = f32x4{v[0], v[1], v[2], v[3]};
+        else e.out[off] = v[0];
+    }
+}
 
 // HMAX: largest halo (each side) the staging slots cover: 32 for the generator (k = 11, dilation 5 -> 25); the 48 variants serve
 // DiscriminatorP's dilation = period convs (k = 5, period 19 -> 38) at one more prefetch slot per thread.
@@ -706,15 +701,17 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
     }
     // split over C_in chunks (see splitk_reduce_kernel) when the launch is at most half a workgroup per CU and every problem has the
     // plain epilogue: S = the largest power of two that divides the chunk count and keeps the grid within two workgroups per CU
+    SplitEpiArgs red{};
     int S = 1;
+    bool red_vec = true;
     if (epi == 0 && grid <= 128) {
         const int nch = m.p[0].Cin / CK;
         int s2 = 1;
         // (a launch whose serial chain is short - fewer than 24 (chunk, tap) steps: the narrow upsamplers, 64-channel convs - gains less
-        // from the split than it costs)
+        // from the split than the reduce launch behind it costs)
         while (s2 * 2 <= 8 && nch % (s2 * 2) == 0 && grid * s2 * 2 <= 512 && nch * m.p[0].K >= 24) s2 *= 2;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        size_t floats = 0, tickets = 0;
+        size_t floats = 0;
         bool ok = s2 > 1, vec = true;
         for (int i = 0; i < nprob && ok; ++i) {
             const TileArgs& p = m.p[i];
@@ -722,53 +719,59 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
             ok = !p.stats_part && p.CoutT == p.Cout && p.Cin / CK == nch;
             vec = vec && (p.L * U) % 4 == 0 && al16(p.out) && al16(p.res) && al16(p.add0) && al16(p.add1);
             floats += n * s2;
-            tickets += (size_t)p.ntiles * (p.Cout / MT);
         }
-        tickets = (tickets + 63) & ~(size_t)63;     // (the slabs stay 256-byte aligned behind the ticket words)
         if (m.p[0].ws_query) {                       // host-only query: bytes of caller scratch this launch would use
-            *m.p[0].ws_query = ok ? (long long)((tickets + floats) * sizeof(float)) : 0;
+            *m.p[0].ws_query = ok ? (long long)(floats * sizeof(float)) : 0;
             return 0;
         }
-        if (ok && m.p[0].splitk_ws && (long long)((tickets + floats) * sizeof(float)) <= m.p[0].splitk_ws_bytes
-            && al16(m.p[0].splitk_ws)) {
-            int* cnt = reinterpret_cast<int*>(m.p[0].splitk_ws);   // caller-owned (v2w_conv1d_args::splitk_ws): nothing is allocated or kept here
-            float* ws = m.p[0].splitk_ws + tickets;
-            S = s2;
-            size_t off = 0, coff = 0;
-            grid = 0;
-            for (int i = 0; i < nprob; ++i) {
-                TileArgs& p = m.p[i];
-                const size_t n = (size_t)p.B * p.Cout * p.L * U;
-                m.fin[i] = SplitFin{ws + off, p.out, p.bias, p.res, p.res_a, p.res_s, p.add0, p.add1, cnt + coff, p.accumulate, vec ? 1 : 0,
-                                    p.out_div, (unsigned long long)n};
-                p.out = ws + off; p.bias = nullptr; p.res = p.res_a = p.res_s = nullptr; p.add0 = p.add1 = nullptr;
-                p.accumulate = 0; p.out_div = 0.f; p.ksplit = S;
-                p.evec = U == 1 && p.L % 4 == 0;
-                off += n * S;
-                coff += (size_t)p.ntiles * (p.Cout / MT);
-                m.start[i] = grid;
-                grid += ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT) * S;
+        if (ok && m.p[0].splitk_ws && (long long)(floats * sizeof(float)) <= m.p[0].splitk_ws_bytes) {
+            float* ws = m.p[0].splitk_ws;           // caller-owned (v2w_conv1d_args::splitk_ws): nothing is allocated or kept here
+            {
+                S = s2;
+                red_vec = vec;
+                size_t off = 0;
+                long long f4 = 0;
+                grid = 0;
+                for (int i = 0; i < nprob; ++i) {
+                    TileArgs& p = m.p[i];
+                    const size_t n = (size_t)p.B * p.Cout * p.L * U;
+                    red.e[i] = SplitEpi{ws + off, p.out, p.bias, p.res, p.res_a, p.res_s, p.add0, p.add1, p.accumulate, p.out_div, p.Cout, p.L * U, n};
+                    red.start[i] = f4;
+                    f4 += vec ? (long long)(n / 4) : (long long)p.B * p.Cout * p.L * U;
+                    p.out = ws + off; p.bias = nullptr; p.res = p.res_a = p.res_s = nullptr; p.add0 = p.add1 = nullptr;
+                    p.accumulate = 0; p.out_div = 0.f; p.ksplit = S;
+                    p.evec = U == 1 && p.L % 4 == 0;
+                    off += n * S;
+                    m.start[i] = grid;
+                    grid += ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT) * S;
+                }
+                m.start[nprob] = grid;
+                red.start[nprob] = f4;
+                red.n = nprob; red.S = S;
             }
-            m.start[nprob] = grid;
-            epi = 3;
         }
     }
     if (m.p[0].ws_query) { *m.p[0].ws_query = 0; return 0; }
     bool vec = true;
     for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
     auto kern = vec ? (epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1, true>
-                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, true>
-                          : (epi == 3 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 3, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, true>)))
+                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, true> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, true>))
                     : (epi == 1 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 1, false>
-                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, false>
-                          : (epi == 3 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 3, false> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, false>)));
+                       : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, false> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, false>));
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    (void)S;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    if (S > 1) {
+        const int rc = v2w_launch_status();
+        if (rc != 0) return rc;
+        long long blocks = (red.start[nprob] + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        if (red_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, red);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, red);
+    }
     return v2w_launch_status();
 }
 

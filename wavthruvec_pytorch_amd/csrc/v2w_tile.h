@@ -75,20 +75,9 @@ __device__ __forceinline__ TileArgs pinned_tile_args(const TileArgs& g) {
 #define V2W_MAX_MULTI 4
 // Up to V2W_MAX_MULTI problems of identical tile configuration in one launch (the residual branches of a stage):
 // blocks [start[q], start[q+1]) belong to problem q; heaviest problem first so the tail of the launch is made of light tiles.
-// f32 tile kernel, split over C_in (TileArgs::ksplit > 1): what the LAST workgroup of an output tile to arrive (ticket word `cnt[tile * mtiles +
-// mt]`, left at zero again) needs to add the slices' partial sums and apply the layer's epilogue (launch_tile)
-struct SplitFin {
-    const float* slab; float* out;
-    const float* bias; const float* res; const float* res_a; const float* res_s; const float* add0; const float* add1;
-    int* cnt;
-    int accumulate, vec;
-    float out_div;
-    unsigned long long slice_stride;      // floats between the slabs of consecutive slices
-};
 struct MultiArgs {
     TileArgs p[V2W_MAX_MULTI];
     int start[V2W_MAX_MULTI + 1];
-    SplitFin fin[V2W_MAX_MULTI];
 };
 
 }  // namespace

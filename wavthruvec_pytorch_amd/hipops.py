@@ -184,18 +184,16 @@ def _conv1d_args(a, x, wf, bias, out, *, k, dil=1, slope=1.0, in_affine=None, re
 
 class SplitKSlab:
     """Caller-owned scratch of the split over C_in (v2w_conv1d_args::splitk_ws, ABI v28): launches too small to fill the chip - inference at
-    B = 1 - store per-slice partial sums here and the last workgroup of every output tile adds them.  The library allocates nothing: the
-    OWNER of a slab (a Generator, one slab per stream it launches on) passes it to conv1d / conv1d_multi / convt1d as `splitk_ws=`;
-    launches that share a slab must be ordered on one stream.  ZERO-FILLED when allocated (the header's contract: the scratch starts with
-    the tiles' ticket words, which every launch leaves at zero).  Grow-only, so a warmed-up module never allocates inside a HIP graph
-    capture."""
+    B = 1 - store per-slice partial sums here and a second kernel adds them.  The library allocates nothing: the OWNER of a slab (a
+    Generator, one slab per stream it launches on) passes it to conv1d / conv1d_multi / convt1d as `splitk_ws=`; launches that share a
+    slab must be ordered on one stream.  Grow-only, so a warmed-up module never allocates inside a HIP graph capture."""
 
     def __init__(self):
         self.t = None
 
     def ensure(self, nbytes, device):
         if self.t is None or self.t.device != device or self.t.numel() * 4 < nbytes:
-            self.t = torch.zeros(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
+            self.t = torch.empty(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
         return self.t
 
 
