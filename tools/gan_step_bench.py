@@ -99,9 +99,14 @@ def main():
     y_mel = mel_spectrogram(y.squeeze(1), *margs)
     times = {}
 
+    peaks, live = {}, {}
+
     def tick(name, t0):
         torch.cuda.synchronize()
         times[name] = times.get(name, 0.0) + time.perf_counter() - t0
+        peaks[name] = max(peaks.get(name, 0), torch.cuda.max_memory_allocated())      # per phase: reset below
+        live[name] = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
         return time.perf_counter()
 
     for it in range(steps + 2):          # two untimed iterations: the caching allocator reaches its working set (tens of GB)
@@ -133,12 +138,28 @@ def main():
         optim_g.step()
         t0 = tick('G step: backward (D, mel, G) + AdamW', t0)
     torch.cuda.synchronize()
+    if os.environ.get('V2W_LIVE_TENSORS'):      # diagnostic: what is still allocated after an iteration (storages, largest first)
+        import gc
+        seen, rows = set(), []
+        for o in gc.get_objects():
+            try:
+                if torch.is_tensor(o) and o.is_cuda:
+                    st = o.untyped_storage()
+                    if st.data_ptr() not in seen:
+                        seen.add(st.data_ptr())
+                        rows.append((st.nbytes(), tuple(o.shape), str(o.dtype), o.grad_fn is not None or o.requires_grad))
+            except Exception:
+                pass
+        rows.sort(reverse=True)
+        print(f'live storages: {len(rows)}, {sum(r[0] for r in rows) / 2 ** 30:.1f} GiB of {torch.cuda.memory_allocated() / 2 ** 30:.1f} GiB allocated')
+        for r in rows[:40]:
+            print(f'   {r[0] / 2 ** 20:9.1f} MiB  {r[1]}  {r[2]}  graph={r[3]}')
     dt = (time.perf_counter() - t_all) / steps
     print(f'{"stock torch discriminators" if stock else "HIP discriminators"}{" (frozen in the G step)" if freeze else ""}  B={B} T={T}: {dt * 1e3:.1f} ms per GAN iteration '
           f'({B * T * 320 / dt / 1e6:.2f} M samples/s trained), loss_gen {loss_gen_all.item():.4f}')
     for k, v in times.items():
-        print(f'    {k:45s} {v / steps * 1e3:8.1f} ms')
-    print(f'    peak device memory (torch allocator)          {torch.cuda.max_memory_allocated() / 2 ** 30:8.1f} GiB')
+        print(f'    {k:45s} {v / steps * 1e3:8.1f} ms   peak {peaks[k] / 2 ** 30:6.1f} GiB, live at its end {live[k] / 2 ** 30:6.1f} GiB')
+    print(f'    peak device memory (torch allocator)          {max(peaks.values()) / 2 ** 30:8.1f} GiB')
 
 
 if __name__ == '__main__':

@@ -290,15 +290,25 @@ class _DiscFn(torch.autograd.Function):
     def forward(ctx, disc, x, *params):
         xd = x.detach().contiguous().float()
         st = disc._run(xd, keep=False)        # (the phase-stacked layer inputs are rebuilt in the backward from the maps below them: -11 GB)
-        ctx.disc, ctx.st, ctx.x = disc, st, xd
+        views = tuple(disc._views(st, xd.shape[0]))
+        # the maps go through save_for_backward, not a ctx attribute: autograd then releases them when the backward has run (unless
+        # retain_graph) - as a plain attribute they lived as long as ANY tensor downstream of this call (train.py keeps `loss_disc_*` and the
+        # score lists until the next iteration assigns them: the D step's 19.5 GB of maps stayed allocated through the whole G step)
+        ctx.save_for_backward(xd, *[f for f, _u in st['bufs']])
+        ctx.rows = [u for _f, u in st['bufs']]
+        st['bufs'] = None
+        ctx.disc, ctx.st = disc, st
         ctx.need_dx = x.requires_grad
         ctx.need_dw = any(p.requires_grad for p in params)
-        return tuple(disc._views(st, xd.shape[0]))
+        return views
 
     @staticmethod
     @_hip.on_tensor_device
     def backward(ctx, *gouts):
-        disc, st, x = ctx.disc, ctx.st, ctx.x
+        disc = ctx.disc
+        x, *maps = ctx.saved_tensors
+        st = dict(ctx.st, bufs=list(zip(maps, ctx.rows)))
+        del maps
         lib, stream = _hip.load(), _stream(x)
         layers = disc._layers()
         inner, H, T = st['inner'], st['H'], st['T']
