@@ -126,25 +126,41 @@ cond_affine_eval_kernel(const v2w_cond_eval_args e) {
     if (!a.fc_w[s]) {
         if (tid < 128) z_s[tid] = sn[tid];
     } else {
-        for (int j = wave; j < 128; j += 4) {      // one wave per output row: coalesced reads of the row, fixed-order wave sum
-            const float* w = a.fc_w[s] + (size_t)j * D;
-            float p = 0.f;
-            for (int i = lane; i < D; i += 64) p = fmaf(w[i], sn[i], p);
-            p = v2w_wave_sum(p);
-            if (lane == 0) z_s[j] = p + a.fc_b[s][j];
+        // one wave per output row: coalesced reads of the row, fixed-order wave sum - four rows at a time, so that their loads are in flight
+        // together (at B = 1 this kernel is on the critical path: 32 dependent row round trips per wave took 60 of its 96 us)
+        for (int j0 = wave * 4; j0 < 128; j0 += 16) {
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = lane; i < D; i += 64) {
+                const float x = sn[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[q] = fmaf(a.fc_w[s][(size_t)(j0 + q) * D + i], x, p[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t = v2w_wave_sum(p[q]);
+                if (lane == 0) z_s[j0 + q] = t + a.fc_b[s][j0 + q];
+            }
         }
     }
     __syncthreads();
     const float sigma = a.sigma_ws[s];
     const float* W = a.sn_w[s];
     const float z0 = z_s[lane], z1 = z_s[64 + lane];
-    for (int rr = wave; rr < 64; rr += 4) {
-        const int c = cg + (rr & 31);
-        if (c >= C) continue;
-        const int r = (rr >> 5) * C + c;
-        float p = W[(size_t)r * 128 + lane] * z0 + W[(size_t)r * 128 + 64 + lane] * z1;
-        p = v2w_wave_sum(p);
-        if (lane == 0) gbl[rr] = p / sigma + a.sn_b[s][r];
+    for (int r0 = wave * 4; r0 < 64; r0 += 16) {   // (four rows of loads in flight, as above)
+        float p[4];
+        int rows[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = r0 + q, c = cg + (rr & 31);
+            rows[q] = c < C ? (rr >> 5) * C + c : -1;
+            const int r = rows[q] < 0 ? 0 : rows[q];
+            p[q] = W[(size_t)r * 128 + lane] * z0 + W[(size_t)r * 128 + 64 + lane] * z1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = v2w_wave_sum(p[q]);
+            if (lane == 0 && rows[q] >= 0) gbl[r0 + q] = t / sigma + a.sn_b[s][rows[q]];
+        }
     }
     __syncthreads();
     if (tid < 32 && cg + tid < C) {
