@@ -159,6 +159,40 @@ def test_generator_bf16_storage_ragged_lengths(dev, B, T):
     assert 1e-6 < d <= 4e-3, f'max|dy| = {d}'
 
 
+@pytest.mark.parametrize('B,T,feat,rates,ks', [(2, 64, 1024, [8, 5, 4, 2, 2], [16, 11, 8, 4, 4]), (3, 18, 1024, [8, 5, 4, 2, 2], [16, 11, 8, 4, 4]),
+                                               (2, 128, 768, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4])])
+@pytest.mark.parametrize('training', [True, False])
+def test_generator_bf16_storage_other_rates_and_fusion_switches(dev, B, T, feat, rates, ks, training):
+    """bf16 activation storage on the x640 generator of BASELINE configs[4] (stride 8 first, the stride-5 upsampler in SECOND place: the
+    stage-0 kernel cannot carry it - `fuse_up` declines that stage and the exact-phase / chunked stride-5 kernels run standalone) and on
+    the default generator at a length that puts whole 64-position tiles on ups.0: train and eval mode against the fp32 oracle at the
+    small-size bf16 bar, and the fused schedule (next upsampler and tail inside the stage kernels) against the unfused one - the same bf16
+    operands in both, so they differ by accumulation order and the rounding of the tensors the fusion no longer stores.  Bar: the
+    small-size bf16 bar (4e-3) or the reference's own bf16-autocast deviation on the same inputs, whichever is larger."""
+    h = synthetic.make_hparams(num_wv_feat=feat, upsample_rates=rates, upsample_kernel_sizes=ks)
+    sd = synthetic.make_state_dict(h, seed=7)
+    inp_cpu = synthetic.make_inputs(h, B, T, seed=3)
+    if not training:
+        O.calibrate_running_stats(sd, h, *inp_cpu)      # (a fresh-init eval forward is ill-conditioned, SURVEY 8(c): running statistics := these inputs')
+    want, _ = O.generator_forward({k: v.clone() for k, v in sd.items()}, h, *inp_cpu, training=training)
+    with torch.autocast('cpu', dtype=torch.bfloat16):       # the reference's own bf16 arithmetic on these inputs, in this mode
+        yb, _ = O.generator_forward({k: v.clone() for k, v in sd.items()}, h, *inp_cpu, training=training)
+    bar = max(4e-3, (yb.float() - want).abs().max().item())
+    outs = []
+    for fused in (True, False):
+        g = build_generator(h, sd, dev, training=training)
+        g.precision = 'bf16'
+        g.fuse_up = g.fuse_post = fused
+        assert g.bf16_storage
+        with torch.no_grad():
+            y = g(*to_dev(inp_cpu, dev))
+        assert y.shape == want.shape and torch.isfinite(y).all()
+        d = (y.cpu() - want).abs().max().item()
+        assert 1e-6 < d <= bar, f'fused={fused}: max|dy| = {d} (bar {bar})'
+        outs.append(y)
+    assert (outs[0] - outs[1]).abs().max().item() <= bar
+
+
 @pytest.mark.parametrize('B,T,rates,ks', [(3, 64, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]), (2, 40, [5, 4, 4, 2, 2], [11, 8, 8, 4, 4]),
                                           (2, 20, [8, 5, 4, 2, 2], [16, 11, 8, 4, 4])])
 @pytest.mark.parametrize('training', [True, False])
