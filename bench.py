@@ -650,7 +650,7 @@ def main():
                 return dict(error=f'{type(e).__name__}: {e}')
         bf16_parity = ("no farther from the fp32 oracle than the reference's own bf16 autocast on the same inputs (max and rms): "
                        'tests/test_hip_generator.py::test_generator_cfg3_full_size_vs_oracle_train')
-        cfg3 = guarded(config_block, dict(num_wv_feat=768), 64, 512, 'bf16', max(5, 2 * args.steps), max(8, args.warmup), dev,
+        cfg3 = guarded(config_block, dict(num_wv_feat=768), 64, 512, 'bf16', max(5, 5 * args.steps), max(8, args.warmup), dev,
                        'BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
                        'bf16 activation storage', bf16_parity, '_cfg3_bf16_hbm_traffic.json')
         cfg2b = guarded(config_block, dict(num_wv_feat=768), 32, 256, 'bf16', max(5, args.steps), max(3, args.warmup), dev,
