@@ -396,11 +396,14 @@ class Generator(nn.Module):
         self._fold_key.update(state=state, wf=wf, wp=wp, wpd=wpd, vers=tuple(vers), gen=self._fold_key.get('gen', 0) + 1)
         return wf, wp
 
-    def _split_weights(self, device, all_ups=False, ups_stream=None):
+    def _split_weights(self, device, all_ups=False, ups_stream=None, events=None, between=None):
         """precision == 'f16x3': (hi, lo) half-precision fragments + scale record of every Conv1d layer the split kernel
         serves.  Follows the fold cache: rebuilt whenever `_fold_weights` rebuilt (train mode: every forward).
         `ups_stream`: the upsamplers' fold + pack launches (ten latency-bound kernels, ~55 us at five stages) go to that stream - the
-        caller joins it before the first upsampler; they then run beside the Conv1d batch and conv_pre."""
+        caller joins it before the first upsampler; they then run beside the Conv1d batch and conv_pre.
+        `events` (a dict) + `between` (a callable): the order on `ups_stream` becomes ups.0 -> between() -> every Conv1d but conv_pre ->
+        ups.1 .. ups.n, with an event recorded behind each step ('ups.i', 'rest'): the caller waits for exactly what its next launch
+        reads instead of for the whole stream (at B = 32 x T = 256 the stream's 230 us of small kernels outlast conv_pre by 90 us)."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
         if self.precision not in ('f16x3', 'bf16'):
@@ -440,9 +443,15 @@ class Generator(nn.Module):
         # two batches: conv_pre alone on the calling stream (the forward needs it at once), every other layer on `ups_stream` beside conv_pre
         first = [q for (nm, _m, _w), q in zip(picked, batch) if nm == 'conv_pre'] if ups_stream is not None else batch
         rest = [q for (nm, _m, _w), q in zip(picked, batch) if nm != 'conv_pre'] if ups_stream is not None else []
-        for slot, sub, strm in (('split_plan', first, None), ('split_plan_rest', rest, ups_stream)):
+        def mark(name):
+            if events is not None and ups_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(ups_stream)
+                events[name] = ev
+
+        def run_plan(slot, sub, strm):
             if not sub:
-                continue
+                return
             key = tuple((v.data_ptr(), 0 if g is None else g.data_ptr(), w.data_ptr()) for (v, g, w, _s) in sub) + (self.precision,)
             plan = self._fold_key.get(slot)
             if plan is None or plan.key != key:
@@ -451,20 +460,32 @@ class Generator(nn.Module):
                 self._fold_key[slot] = plan
             with (torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()):
                 plan.run()
-        if self.precision == 'bf16':      # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd)
+
+        def fold_up(i, m):
+            v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
+            wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
+            # (its own scratch: `wf_scratch` is in use by the folds of the main stream)
+            scratch = self._buf('wf_scratch_ups', (max(2048, m.out_channels, m.in_channels),), device=device)
             with (torch.cuda.stream(ups_stream) if ups_stream is not None else contextlib.nullcontext()):
-                for i, m in enumerate(self.ups):
-                    if m.out_channels < 64 and not all_ups:   # the narrow upsamplers are memory-side: with fp32 tensors the f32 kernel's epilogue
-                        continue                              # moves their bytes faster; with bf16 storage every upsampler runs here
-                    v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
-                    wfb = self._buf(f'wfbf.ups.{i}', (m.kernel_size, m.in_channels, m.out_channels), device=device)
-                    # (its own scratch: `wf_scratch` is in use by the folds of the main stream)
-                    scratch = self._buf('wf_scratch_ups', (max(2048, m.out_channels, m.in_channels),), device=device)
-                    hipops.fold_convt_weight(v, g, wfb, scratch)
-                    w = hipops.pack_bf16_convt(wfb, m.stride, out=self._ws.get(f'wpsbf.ups.{i}'))
-                    if w is not None:
-                        self._ws[f'wpsbf.ups.{i}'] = w
-                        out[f'ups.{i}'] = w
+                hipops.fold_convt_weight(v, g, wfb, scratch)
+                w = hipops.pack_bf16_convt(wfb, m.stride, out=self._ws.get(f'wpsbf.ups.{i}'))
+            if w is not None:
+                self._ws[f'wpsbf.ups.{i}'] = w
+                out[f'ups.{i}'] = w
+            mark(f'ups.{i}')
+
+        # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd); the narrow upsamplers are memory-side: with fp32
+        # tensors the f32 kernel's epilogue moves their bytes faster; with bf16 storage every upsampler runs there
+        ups_bf = [(i, m) for i, m in enumerate(self.ups) if self.precision == 'bf16' and (m.out_channels >= 64 or all_ups)]
+        run_plan('split_plan', first, None)
+        if ups_bf and ups_bf[0][0] == 0:       # what the forward needs first: conv_pre's fragments (above, on its own stream), then ups.0's
+            fold_up(*ups_bf.pop(0))
+        if between is not None:
+            between()
+        run_plan('split_plan_rest', rest, ups_stream)
+        mark('rest')
+        for i, m in ups_bf:
+            fold_up(i, m)
         self._fold_key['wps'] = (gen, out)
         return out
 
@@ -568,20 +589,8 @@ class Generator(nn.Module):
             main = torch.cuda.current_stream(dev)
             side = self._side_stream(dev)
             side.wait_stream(main)
-            # (bf16 storage: the only fp32 fold is conv_post's, first read by the last stage - it runs on the side stream, not in front of conv_pre)
-            with (torch.cuda.stream(side) if st else contextlib.nullcontext()):
-                wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
-            wps = self._split_weights(dev, all_ups=st, ups_stream=side)   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
-
-            def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
-                if nm in wps and nm in self._split_wide:
-                    if st:       # bf16 storage: io bit 0 = the input tensor is bf16, bit 1 = out / res / addends are bf16
-                        return dict(algo=hipops.ALGO_BF16, wps=wps[nm], io_bf16=io)
-                    return dict(algo=hipops.ALGO_BF16 if self.precision == 'bf16' else hipops.ALGO_SPLIT, wps=wps[nm])
-                if st:
-                    raise RuntimeError(f'bf16 storage: layer {nm} has no bf16 kernel (set generator.bf16_storage = False)')
-                return dict(algo=algo, wp=wp[nm])
-
+            # bf16 storage: the side stream's work is ordered by first use and joined piecewise through events (`need`)
+            evs = {} if st else None
             # ---- K3: gamma/beta of every stage (depends on spk/noise only); spectral-norm u/v updated in train mode
             ns = self.num_upsamples
             gbs = [self._buf(f'gb.{i}', (B, 2 * self.cbns[i].num_features), device=dev) for i in range(ns)]
@@ -593,31 +602,72 @@ class Generator(nn.Module):
             # (v2w_cond_affine_eval) - nothing between (spk, noise) and the affines depends on the activations; sigma = u^T W v depends on
             # the parameters alone and is kept with the fold cache.  (A forward that will be back-propagated keeps gb / z for its backward.)
             eval_fast = not training and save is None
-            affs = None
-            with torch.cuda.stream(side):
-                if eval_fast:
-                    sn_p = [q for c in self.cbns for q in (c.layer.weight_orig, c.layer.weight_u, c.layer.weight_v)]
-                    skey = (tuple((q.data_ptr(), q._version) for q in sn_p), str(dev))
-                    if self._fold_key.get('sigma') != skey:
-                        hipops.cond_sigma([c.layer.weight_orig.detach() for c in self.cbns], [c.layer.weight_u for c in self.cbns],
-                                          [c.layer.weight_v for c in self.cbns], sigma_ws, training=False)
-                        self._fold_key['sigma'] = skey
-                    affs = [(self._buf(f'bn.a{i}', (B, self.cbns[i].num_features), device=dev),
-                             self._buf(f'bn.s{i}', (B, self.cbns[i].num_features), device=dev)) for i in range(ns)]
-                    hipops.cond_affine_eval(
-                        spk, nz, [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
-                        [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns], sigma_ws,
-                        [c.batch_nrom.running_mean for c in self.cbns], [c.batch_nrom.running_var for c in self.cbns],
-                        [c.batch_nrom.eps for c in self.cbns], [q[0] for q in affs], [q[1] for q in affs])
-                else:
-                    self._fold_key.pop('sigma', None)        # (sigma_ws is about to hold this forward's own values)
-                    hipops.cond_gamma_beta(
-                        spk, nz,
-                        [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
-                        [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
-                        [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
-                        gbs, z_ws, sigma_ws, training)
-            cond_joined = False
+            cond_state = {'done': False, 'affs': None}
+
+            def run_cond():        # on the side stream; bf16 storage: between ups.0's weights and the Conv1d batch (see _split_weights)
+                if cond_state['done']:
+                    return
+                cond_state['done'] = True
+                affs = None
+                with torch.cuda.stream(side):
+                    if eval_fast:
+                        sn_p = [q for c in self.cbns for q in (c.layer.weight_orig, c.layer.weight_u, c.layer.weight_v)]
+                        skey = (tuple((q.data_ptr(), q._version) for q in sn_p), str(dev))
+                        if self._fold_key.get('sigma') != skey:
+                            hipops.cond_sigma([c.layer.weight_orig.detach() for c in self.cbns], [c.layer.weight_u for c in self.cbns],
+                                              [c.layer.weight_v for c in self.cbns], sigma_ws, training=False)
+                            self._fold_key['sigma'] = skey
+                        affs = [(self._buf(f'bn.a{i}', (B, self.cbns[i].num_features), device=dev),
+                                 self._buf(f'bn.s{i}', (B, self.cbns[i].num_features), device=dev)) for i in range(ns)]
+                        hipops.cond_affine_eval(
+                            spk, nz, [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                            [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns], sigma_ws,
+                            [c.batch_nrom.running_mean for c in self.cbns], [c.batch_nrom.running_var for c in self.cbns],
+                            [c.batch_nrom.eps for c in self.cbns], [q[0] for q in affs], [q[1] for q in affs])
+                    else:
+                        self._fold_key.pop('sigma', None)        # (sigma_ws is about to hold this forward's own values)
+                        hipops.cond_gamma_beta(
+                            spk, nz,
+                            [f.weight.detach() for f in self.fcs], [f.bias.detach() for f in self.fcs],
+                            [c.layer.weight_orig.detach() for c in self.cbns], [c.layer.bias.detach() for c in self.cbns],
+                            [c.layer.weight_u for c in self.cbns], [c.layer.weight_v for c in self.cbns],
+                            gbs, z_ws, sigma_ws, training)
+                cond_state['affs'] = affs
+                if evs is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    evs['cond'] = ev
+
+            # (bf16 storage: the only fp32 fold is conv_post's, first read by the last stage - it runs on the side stream, not in front of conv_pre)
+            with (torch.cuda.stream(side) if st else contextlib.nullcontext()):
+                wf, wp = self._fold_weights(dev, need_wf=save is not None, bf16_only=st)
+            if st:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                evs['post'] = ev
+            # bf16 storage: the side stream's work is ordered by first use and joined piecewise through events (`need`)
+            wps = self._split_weights(dev, all_ups=st, ups_stream=side, events=evs,   # (the fused C = 32 stage is a no-grad schedule: fuse_stage is empty when saving)
+                                      between=run_cond if st else None)
+
+            def ck(nm, io=3):   # kernel choice of one Conv1d layer: split-f16 fragments when prepared, else the f32 MFMA stream
+                if nm in wps and nm in self._split_wide:
+                    if st:       # bf16 storage: io bit 0 = the input tensor is bf16, bit 1 = out / res / addends are bf16
+                        return dict(algo=hipops.ALGO_BF16, wps=wps[nm], io_bf16=io)
+                    return dict(algo=hipops.ALGO_BF16 if self.precision == 'bf16' else hipops.ALGO_SPLIT, wps=wps[nm])
+                if st:
+                    raise RuntimeError(f'bf16 storage: layer {nm} has no bf16 kernel (set generator.bf16_storage = False)')
+                return dict(algo=algo, wp=wp[nm])
+
+            run_cond()
+            affs = cond_state['affs']
+
+            def need(*names):     # the main stream waits for exactly these steps of the side stream (bf16 storage; no-op otherwise)
+                for nm in names:
+                    ev = evs.pop(nm, None) if evs is not None else None
+                    if ev is not None:
+                        main.wait_event(ev)
+
+            cond_joined = st     # (bf16 storage joins through `need`)
 
             y = None
             # ---- K1: conv_pre (no activation in front of it)
@@ -633,7 +683,10 @@ class Generator(nn.Module):
                 Lo = L * up.stride
                 # ---- K2: leaky_relu(0.1) -> ConvTranspose1d
                 xr = self._buf(f'act.up{i}', (B, C, Lo), dtype=adt, device=dev)
-                if not cond_joined and f'ups.{i}' in wps:      # the side stream holds this upsampler's packed weights (bf16 / f16x3 modes)
+                if st:
+                    if up_done is None:
+                        need(f'ups.{i}')                       # this upsampler's fragments (the side stream packed them)
+                elif not cond_joined and f'ups.{i}' in wps:    # the side stream holds this upsampler's packed weights (bf16 / f16x3 modes)
                     main.wait_stream(side)
                     cond_joined = True
                 cbn = self.cbns[i]
@@ -676,6 +729,7 @@ class Generator(nn.Module):
                         self._timed(f'stat_sync.{i}', self.stat_sync, stats)
                 a_t = self._buf(f'bn.a{i}', (B, C), device=dev)
                 s_t = self._buf(f'bn.s{i}', (B, C), device=dev)
+                need('cond')              # (bf16 storage: gamma / beta - or the eval-mode affines - are the side stream's second step)
                 if not cond_joined:       # (fp32: the side stream only carries gamma / beta - joined as late as their first use, which
                     main.wait_stream(side)    # matters at B = 1, where conv_pre is shorter than the conditioning chain)
                     cond_joined = True
@@ -687,6 +741,8 @@ class Generator(nn.Module):
                     hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                        training=training, momentum=bn.momentum, eps=bn.eps)
                 aff = (a_t, s_t)
+                # (bf16 storage: the fragments of the residual convs, of the upsampler a fused stage kernel runs, of the tail)
+                need('rest', *([f'ups.{i + 1}'] if i + 1 < ns else ['post']))
                 # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input.
                 # The branches are independent until the final sum, so conv n of ALL branches goes out as one launch
                 # (heaviest kernel size first); the first nk-1 branches end in their own buffers o_j and the last branch's
@@ -909,8 +965,8 @@ class Generator(nn.Module):
                                 src, src_aff = dsts[n], None
                 cur = xs
                 L = Lo
-            if not cond_joined:
-                main.wait_stream(side)
+            if not cond_joined or st:
+                main.wait_stream(side)        # (bf16 storage: whatever step nobody asked for; the side stream has long finished)
             # ---- K8: leaky_relu(0.01) -> conv_post -> tanh (unless the last stage's kernel has already done it)
             if y is None:
                 y = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
