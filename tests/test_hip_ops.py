@@ -378,7 +378,7 @@ def test_convt1d_bf16_operands(dev, B, cin, cout, L, k, u):
                                               (2, 512, 256, 52, 11, 5), (2, 64, 32, 37, 4, 2),
                                               (2, 512, 256, 128, 11, 5), (3, 256, 128, 192, 11, 5), (1, 512, 256, 64, 11, 5),
                                               (2, 256, 96, 128, 11, 5), (2, 512, 256, 192, 15, 5), (5, 64, 384, 64, 5, 5), (2, 64, 96, 64, 5, 5),
-                                              (2, 64, 96, 64, 11, 5), (5, 64, 96, 64, 11, 5)])
+                                              (2, 64, 96, 64, 11, 5), (5, 64, 96, 64, 11, 5), (1, 1024, 128, 64, 11, 5)])
 def test_convt1d_bf16_activation_storage(dev, B, cin, cout, L, k, u):
     """io_bf16 = 3: the transposed conv on bf16 TENSORS (models.py:128-129 under BASELINE configs[2] with bf16 activation storage).  Strides
     2 / 4 / 8 at L % 4 == 0 run on the resident-tile kernel (v2w_convt_bf16_res.hip: stores straight from the accumulators), stride 5 at

@@ -476,7 +476,7 @@ int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     if (U != UP && tile_b < (size_t)WM * WN * 2048 * sizeof(float)) tile_b = (size_t)WM * WN * 2048 * sizeof(float);   // the waves' scratch overlays the tile
     size_t lds = tile_b + (size_t)(MT / UP) * (1 + 2 * WN) * sizeof(float);
     if (UP == 5 && lds < V2W_CT5_SCRATCH) lds = V2W_CT5_SCRATCH;     // (bias table and tile are dead by then)
-    constexpr int WGS = ct_wgs(MI, NI);                              // workgroups per CU the register budget allows (4-wave workgroups)
+    constexpr int WGS = UP == 5 ? 1 : ct_wgs(MI, NI);                // workgroups per CU the register budget allows (4-wave workgroups)
     if (lds * (WGS > 2 ? 2 : WGS) > 160 * 1024) return V2W_E_SHAPE;
     if (cfg) { const int32_t c[10] = {MI, NI, WM, WN, UP, 102 /* = this kernel */, 1, 1, 32, U}; for (int i = 0; i < 10; ++i) cfg[i] = c[i]; }
     if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
