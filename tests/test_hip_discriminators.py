@@ -22,25 +22,36 @@ def dev():
     return torch.device('cuda:0')
 
 
-def build(kind, sd, dev, training=True):
-    from wavthruvec_pytorch_amd.discriminators import MultiPeriodDiscriminator, MultiScaleDiscriminator
+def build(kind, sd, dev, training=True, precision='f32'):
+    from wavthruvec_pytorch_amd.discriminators import MultiPeriodDiscriminator, MultiScaleDiscriminator, set_precision
     m = MultiPeriodDiscriminator(SimpleNamespace(periods=synthetic.DEFAULT_PERIODS)) if kind == 'mpd' else MultiScaleDiscriminator()
     m.load_state_dict(sd)
-    m = m.to(dev)
+    m = set_precision(m.to(dev), precision)
     return m.train() if training else m.eval()
 
 
+def _split_layers(m):
+    """Layers whose last call ran on the split-f16 kernel (their weight record carries the (hi, lo) fragments)."""
+    from wavthruvec_pytorch_amd.discriminators import _DiscConv
+    return [l for l in m.modules() if isinstance(l, _DiscConv) and l._cache is not None and 'wps' in l._cache[1]]
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 @pytest.mark.parametrize('name', golden_util.disc_golden_names())
-def test_discriminators_match_reference_goldens(dev, name):
+def test_discriminators_match_reference_goldens(dev, name, precision):
+    """The fixtures captured from the reference modules, in exact fp32 and with `set_precision(m, 'f16x3')` (the dense five-tap 1024 -> 1024
+    convs on the split-f16 kernel: the same 1e-4 bar)."""
     z, meta = golden_util.load_golden(name)
     sd, y, y_hat = golden_util.disc_case_setup(meta)
-    m = build(meta['kind'], sd, dev)
+    m = build(meta['kind'], sd, dev, precision=precision)
     with torch.no_grad():
         if meta['mode'] == 'traineval':
             m(y_hat.to(dev), y.to(dev))
             m.eval()
         outs = m(y.to(dev), y_hat.to(dev))
     golden_util.check_disc_outputs(z, outs, TOL)
+    nsplit = len(_split_layers(m))
+    assert nsplit == (0 if precision == 'f32' else 3), nsplit      # one such layer per discriminator (three periods, three scales)
     for k in z.files:          # spectral-norm buffers after the forward(s): two power iterations per training forward
         if k.startswith('buf_'):
             assert np.abs(m.state_dict()[k[4:]].cpu().numpy() - z[k]).max() <= 1e-5, k
@@ -82,8 +93,8 @@ def test_discriminator_losses_and_guards(dev):
         assert abs(generator_loss(got[1])[0].item() - generator_loss(want[1])[0].item()) <= 1e-4
 
 
-def _hip_grads(kind, sd, y, y_hat, dev, input_grad=True, loss=None):
-    m = build(kind, sd, dev)
+def _hip_grads(kind, sd, y, y_hat, dev, input_grad=True, loss=None, precision='f32'):
+    m = build(kind, sd, dev, precision=precision)
     yh = y_hat.to(dev).requires_grad_(input_grad)
     outs = m(y.to(dev), yh)
     (loss or D.mixed_loss)(outs).backward()
@@ -107,15 +118,17 @@ def test_discriminator_backward_tracks_reference_gradients(dev, name):
     golden_util.check_disc_grads(z, [(k, p.grad) for k, p in m.named_parameters()], gy, rtol=5e-2, head=False)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 @pytest.mark.parametrize('kind,B,T', [('mpd', 2, 3001), ('msd', 2, 3001), ('mpd', 1, 640), ('msd', 3, 1234)])
-def test_discriminator_backward_matches_oracle_autograd(dev, kind, B, T):
+def test_discriminator_backward_matches_oracle_autograd(dev, kind, B, T, precision):
     """EVERY entry of EVERY gradient (all parameters incl. the spectral-normed weight_orig, and dL/dy_hat) against torch autograd
     through the CPU oracle at ragged sizes.  The oracle's leaky_relu derivative masks are pinned to the signs of the HIP
     forward's own feature maps and the loss is smooth, so the comparison is exact up to fp32 rounding."""
     spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
     sd = synthetic.make_disc_state_dict(spec, seed=21)
     y, y_hat = synthetic.make_audio_pair(B, T, seed=6)
-    m, outs, gy = _hip_grads(kind, sd, y, y_hat, dev, loss=D.smooth_loss)
+    m, outs, gy = _hip_grads(kind, sd, y, y_hat, dev, loss=D.smooth_loss, precision=precision)
+    assert bool(_split_layers(m)) == (precision == 'f16x3')
     masks = {'r': [[t.detach().cpu() for t in fm] for fm in outs[2]], 'g': [[t.detach().cpu() for t in fm] for fm in outs[3]]}
     bufs = {k for k in sd if k.endswith('weight_u') or (k.endswith('weight_v') and k.replace('weight_v', 'weight_orig') in sd)}
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k not in bufs}

@@ -76,6 +76,8 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     stock = len(sys.argv) > 4 and sys.argv[4] == 'stock'
     freeze = 'frozen' in sys.argv[4:]      # discriminator parameters do not require grad during the G step (their grads are discarded anyway)
+    f16x3 = 'f16x3' in sys.argv[4:]        # the dense five-tap 1024 -> 1024 discriminator convs (forward + input gradient) and the generator's
+    #                                        forward / input-gradient convs as f16 hi + lo operands; every weight gradient exact
     dev = torch.device('cuda:0')
     torch.backends.cudnn.benchmark = os.environ.get("V2W_CUDNN_BENCHMARK", "1") == "1"          # train.py:24 sets True
     h = synthetic.make_hparams(num_wv_feat=768)
@@ -91,6 +93,9 @@ def main():
         msd = HD.MultiScaleDiscriminator()
         msd.load_state_dict(synthetic.make_disc_state_dict(synthetic.msd_state_dict_spec(), seed=0))
         mpd, msd = mpd.to(dev).train(), msd.to(dev).train()
+        if f16x3:
+            HD.set_precision(mpd, 'f16x3'); HD.set_precision(msd, 'f16x3')
+            g.precision = 'f16x3'
     optim_g = torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99))
     optim_d = torch.optim.AdamW(list(mpd.parameters()) + list(msd.parameters()), 2e-4, betas=(0.8, 0.99))
     inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
@@ -155,7 +160,7 @@ def main():
         for r in rows[:40]:
             print(f'   {r[0] / 2 ** 20:9.1f} MiB  {r[1]}  {r[2]}  graph={r[3]}')
     dt = (time.perf_counter() - t_all) / steps
-    print(f'{"stock torch discriminators" if stock else "HIP discriminators"}{" (frozen in the G step)" if freeze else ""}  B={B} T={T}: {dt * 1e3:.1f} ms per GAN iteration '
+    print(f'{"stock torch discriminators" if stock else "HIP discriminators"}{" (frozen in the G step)" if freeze else ""}{" [f16x3 convs]" if f16x3 else ""}  B={B} T={T}: {dt * 1e3:.1f} ms per GAN iteration '
           f'({B * T * 320 / dt / 1e6:.2f} M samples/s trained), loss_gen {loss_gen_all.item():.4f}')
     for k, v in times.items():
         print(f'    {k:45s} {v / steps * 1e3:8.1f} ms   peak {peaks[k] / 2 ** 30:6.1f} GiB, live at its end {live[k] / 2 ** 30:6.1f} GiB')

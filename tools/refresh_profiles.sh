@@ -50,5 +50,8 @@ python3 tools/config_bench.py > $O/all_configs.txt 2>&1
 python3 tools/gan_step_bench.py 32 256 3 > $O/gan_iteration.txt 2>&1
 python3 tools/gan_step_bench.py 2 256 3 >> $O/gan_iteration.txt 2>&1
 python3 tools/gan_step_bench.py 32 256 3 frozen >> $O/gan_iteration.txt 2>&1
+# the same iteration with the split-f16 convs (discriminators: the dense five-tap 1024 -> 1024 layers; generator: precision = 'f16x3'); weight gradients exact
+python3 tools/gan_step_bench.py 32 256 3 hip f16x3 >> $O/gan_iteration.txt 2>&1
+python3 tools/gan_step_bench.py 32 256 3 hip f16x3 frozen >> $O/gan_iteration.txt 2>&1
 tail -c 600 $O/bench.json; grep ms/step $O/ks_train.log
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete

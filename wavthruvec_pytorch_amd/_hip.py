@@ -187,7 +187,14 @@ _lib = None
 
 
 class HipLibraryError(RuntimeError):
-    pass
+    """A C-ABI call declined or failed; `code` is its return value (V2W_E_* < 0, hipError_t > 0)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+E_ARG, E_SHAPE, E_ALGO = -1, -2, -3
 
 
 def lib_path() -> str:
@@ -225,8 +232,8 @@ def check(rc: int, what: str) -> None:
         return
     if rc < 0:
         msg = {-1: 'bad argument', -2: 'unsupported shape for the requested algorithm', -3: 'unknown algorithm'}.get(rc, '?')
-        raise HipLibraryError(f'{what}: V2W error {rc} ({msg})')
-    raise HipLibraryError(f'{what}: hipError_t {rc}')
+        raise HipLibraryError(f'{what}: V2W error {rc} ({msg})', rc)
+    raise HipLibraryError(f'{what}: hipError_t {rc}', rc)
 
 
 def ptr(t):

@@ -51,7 +51,9 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4)));   // one 16-byte
 
 // BF = false: split f16x3 (three MFMAs per product).  BF = true: plain bf16 operands, ONE v_mfma_f32_32x32x16_bf16 per product
 // (BASELINE configs[2] 'bf16 compute / fp32 accumulate'): same tiles, same fragment layout with the lo halves unused.
-template <int MI, int NI, int WM, int WN, bool VEC, bool BF>
+// HM: the largest halo per side the staging slots cover (V2W_SPLIT_HMAX for the generator; 40 for the discriminators' dilation = period convs:
+// 2 x 17 / 2 x 19 positions)
+template <int MI, int NI, int WM, int WN, bool VEC, bool BF, int HM = V2W_SPLIT_HMAX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V2W_SPLIT_WPE, V2W_SPLIT_WPE)))
 conv_split_kernel(const MultiArgs m) {
     typedef Frag<32> F;
@@ -66,8 +68,8 @@ conv_split_kernel(const MultiArgs m) {
     // async 16-B copies per thread and stage; bf16 moves only the hi half of every unit (1 KiB = one wave copy per unit)
     constexpr int ADMA = BF ? (NMT + 3) / 4 : ASTAGE / (NTHREADS * 16);
     static_assert(ASTAGE % (NTHREADS * 16) == 0 && ADMA >= 1, "a stage is a whole number of workgroup copies");
-    constexpr int NS = ((NT + 2 * V2W_SPLIT_HMAX) / 4 + 63) / 64;    // position groups (4 positions) per lane
-    constexpr int NSIG = (CK * ((NT + 2 * V2W_SPLIT_HMAX) / 4) + NTHREADS - 1) / NTHREADS;   // async copies per thread of one raw signal chunk
+    constexpr int NS = ((NT + 2 * HM) / 4 + 63) / 64;    // position groups (4 positions) per lane
+    constexpr int NSIG = (CK * ((NT + 2 * HM) / 4) + NTHREADS - 1) / NTHREADS;   // async copies per thread of one raw signal chunk
     constexpr int RS = 72;                                      // floats per row of the epilogue transpose tile (32 x 64 per pass; 4*RS % 64 == 32)
     static_assert(NI % 2 == 0, "the epilogue works on pairs of 32-column blocks");
 
@@ -449,6 +451,7 @@ conv_split_kernel(const MultiArgs m) {
                             else if (p.accumulate) x += p.out[o + e];
                             else if (p.add0) x += p.add0[o + e];
                             if (p.out_div != 0.f) x = x / p.out_div;
+                            if (p.out_slope != 1.f) x = x > 0.f ? x : x * p.out_slope;
                             p.out[o + e] = x;
                         }
                         continue;
@@ -462,6 +465,7 @@ conv_split_kernel(const MultiArgs m) {
                         if (p.add1) x += ov[g][e] + o2[g][e];    // (add0 + add1) + value: the reference's `xs += ...` order
                         else if (p.accumulate || p.add0) x += ov[g][e];
                         if (p.out_div != 0.f) x = x / p.out_div;
+                        if (p.out_slope != 1.f) x = x > 0.f ? x : x * p.out_slope;      // (the discriminators' activated feature maps)
                         v[e] = x;
                     }
                     *reinterpret_cast<f32x4*>(p.out + o) = v;
@@ -479,7 +483,7 @@ conv_split_kernel(const MultiArgs m) {
     static_assert(MI <= 2 && NI <= 4, "epilogue passes are spelled out for MI <= 2, NI <= 4");
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, int HM = V2W_SPLIT_HMAX>
 int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
     constexpr int MT = 32 * MI * WM, NT = 32 * NI * WN, NTHREADS = 64 * WM * WN, CK = V2W_SPLIT_CK;
     constexpr int RS = 72;
@@ -492,7 +496,7 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
         if (p.Cout % MT != 0 || p.Cin % CK != 0 || !p.wps || !p.winv) return V2W_E_SHAPE;
         if (p.K < 3 || (p.K & 1) == 0) return V2W_E_SHAPE;            // the stage pipeline alternates register sets over an odd tap count
         p.hla = (p.hl + 3) & ~3;
-        if (p.hla > V2W_SPLIT_HMAX || p.hr > V2W_SPLIT_HMAX) return V2W_E_SHAPE;
+        if (p.hla > HM || p.hr > HM) return V2W_E_SHAPE;
         p.ntl = (p.L + NT - 1) / NT;
         p.ntiles = p.B * p.ntl;
         p.xcols = (p.hla + NT + p.hr + 3) & ~3;
@@ -518,8 +522,9 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
     bool vec = true;                                               // one staging flavour per launch: float4 only if every problem allows it
     for (int i = 0; i < nprob; ++i) vec = vec && m.p[i].vec4;
     for (int i = 0; i < nprob; ++i) m.p[i].vec4 = vec;
+    if (bf && HM != V2W_SPLIT_HMAX) return V2W_E_SHAPE;             // (the wide-halo form exists for the split-f16 operands only)
     auto kern = bf ? (vec ? conv_split_kernel<MI, NI, WM, WN, true, true> : conv_split_kernel<MI, NI, WM, WN, false, true>)
-                   : (vec ? conv_split_kernel<MI, NI, WM, WN, true, false> : conv_split_kernel<MI, NI, WM, WN, false, false>);
+                   : (vec ? conv_split_kernel<MI, NI, WM, WN, true, false, HM> : conv_split_kernel<MI, NI, WM, WN, false, false, HM>);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -773,8 +778,16 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
         if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
         p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;
         p.slope = q->slope; p.accumulate = q->accumulate; p.out_div = q->out_div;
+        p.out_slope = q->out_slope == 0.f ? 1.f : q->out_slope;
         ps[i] = p;
         tiles256 += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 128);
+    }
+    int hmax = 0;
+    for (int i = 0; i < n; ++i) { const int h = ((ps[i].hl + 3) & ~3) > ps[i].hr ? ((ps[i].hl + 3) & ~3) : ps[i].hr; if (h > hmax) hmax = h; }
+    if (hmax > V2W_SPLIT_HMAX) {      // DiscriminatorP's last conv at periods 17 / 19 (dilation = period on the flattened axis): the wide-halo instantiations
+        if (bf || hmax > 40) return V2W_E_SHAPE;
+        if (a->C_out % 128 == 0 && 2 * tiles256 >= 384) return launch_split<2, 2, 2, 2, 40>(ps, n, stream, false);
+        return launch_split<1, 2, 2, 2, 40>(ps, n, stream, false);
     }
     // two workgroups per CU are resident: prefer the largest tile that still gives every slot ~1 workgroup
     if (a->C_out % 128 == 0) {

@@ -61,6 +61,11 @@ class _DiscConv(nn.Module):
         self._last_sn = None
         self._jmap = None
         self._wpad = None
+        # 'f32' (exact) or 'f16x3': the forward and input-gradient convs of the layers the split-f16 kernel serves - dense, stride 1, an odd
+        # tap count: the 1024 -> 1024 five-tap convs that are 54 % of a period discriminator's and 30 % of a scale discriminator's FLOPs -
+        # run as f16 hi + lo operands (three MFMAs per product, fp32 accumulate: ~1e-6 of the fp32 result); weight gradients stay exact.
+        # Set through `set_precision(module, ...)`.
+        self.precision = 'f32'
         # optional form of the short strided ungrouped convs (DiscriminatorP k = 5, stride 3): taps unfolded into channels of a
         # 1-tap conv (exact MAC count, no halo).  Measured equal to the phase-stacked default (40.6 vs 40.4 ms per MPD forward):
         # one tap per staged chunk makes the kernel staging-bound, which cancels the 6/5 tap-slot saving.
@@ -127,8 +132,14 @@ class _DiscConv(nn.Module):
         packable = groups.shape[2] % 16 == 0 and (groups.shape[3] % 32 == 0 or groups.shape[3] == 16)
         rec = dict(w4=groups, wf=list(groups.unbind(0)), kp=kp, Q=Q,
                    wp=list(hipops.pack_mfma_batch(groups).unbind(0)) if packable else [None] * groups.shape[0])
+        if self.split_eligible(kp):
+            rec['wps'] = hipops.pack_split(rec['wf'][0])        # (hi, lo) f16 fragments + scale record of the forward conv
         self._cache = (key, rec)
         return rec
+
+    def split_eligible(self, kp):
+        return (self.precision == 'f16x3' and self.groups == 1 and self.stride == 1 and not self.unfolded and self.c_in > 1
+                and kp % 2 == 1 and kp >= 3 and hipops.split_supported(self.c_in, self.c_out))
 
     def param_grads(self, db, dws, sn):
         """Gradients of this layer's parameters (parameters() order) from the bias gradient and the per-group weight gradients
@@ -208,7 +219,15 @@ def _conv_layer(layer: _DiscConv, rec, x, L_in, inner, out_slope, keep=None):
     out = torch.empty((B, layer.c_out, xs.shape[2]), device=x.device)
     cig, cog = xs.shape[1] // G, layer.c_out // G
     kw = dict(k=rec['kp'], dil=1 if rec['kp'] == 1 else inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
-    if G == 1:
+    if G == 1 and 'wps' in rec:      # precision = 'f16x3': the split-f16 kernel (a shape it declines - a halo beyond its staging - runs exact)
+        try:
+            hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, algo=hipops.ALGO_SPLIT, wps=rec['wps'], **kw)
+        except _hip.HipLibraryError as e:
+            if e.code != _hip.E_SHAPE:
+                raise
+            del rec['wps']
+            hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
+    elif G == 1:
         hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
     else:
         bias = layer.bias.detach()
@@ -392,10 +411,16 @@ class _DiscFn(torch.autograd.Function):
                     wT4 = rec['w4'].flip(1).transpose(2, 3).contiguous()        # [G][kp][cog][cigp], taps reversed
                     rec['wT'] = list(wT4.unbind(0))
                     rec['wTp'] = list(hipops.pack_mfma_batch(wT4).unbind(0)) if packable else [None] * G
-                probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
-                                                             group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
-                for i in range(0, G, 4):
-                    hipops.conv1d_multi(probs[i:i + 4])
+                if 'wps' in rec and 'wTs' not in rec:
+                    rec['wTs'] = hipops.pack_split(rec['wT'][0])               # the same layer's input-gradient conv in split-f16 form
+                if 'wTs' in rec:
+                    hipops.conv1d(dz, rec['wT'][0], None, dxs, k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil,
+                                  algo=hipops.ALGO_SPLIT, wps=rec['wTs'])
+                else:
+                    probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
+                                                                 group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
+                    for i in range(0, G, 4):
+                        hipops.conv1d_multi(probs[i:i + 4])
                 if l == 0:
                     dx = torch.empty((B, 1, T), device=dev)
                     _hip.check(lib.v2w_fold1(dxs.data_ptr(), dx.data_ptr(), B, T, H, inner, layer.stride, layer.k, layer.padding,
@@ -554,6 +579,18 @@ class _L1MeanFn(torch.autograd.Function):
         real, fake = ctx.saved_tensors
         d = torch.sign(real - fake).mul_(g / real.numel())
         return (d if ctx.needs_input_grad[0] else None), (d.neg() if ctx.needs_input_grad[1] else None)
+
+
+def set_precision(module, precision):
+    """precision of the discriminator convs under `module` (a DiscriminatorP / DiscriminatorS / MultiPeriodDiscriminator /
+    MultiScaleDiscriminator): 'f32' (exact, default) or 'f16x3' (see _DiscConv.precision)."""
+    if precision not in ('f32', 'f16x3'):
+        raise ValueError(f"discriminator precision must be 'f32' or 'f16x3', got {precision!r}")
+    for m in module.modules():
+        if isinstance(m, _DiscConv):
+            m.precision = precision
+            m.invalidate_weight_cache()
+    return module
 
 
 def feature_loss(fmap_r, fmap_g):
