@@ -169,6 +169,12 @@ def test_discriminator_state_dict_surface():
         mpd(y, y)
     with pytest.raises(RuntimeError):              # under autograd too: CPU tensors are refused, nothing falls back to torch
         msd(y, y)
+    # set_precision: 'f32' / 'f16x3' on every conv of the module, anything else refused; the state_dict surface is untouched
+    from wavthruvec_pytorch_amd.discriminators import set_precision, _DiscConv
+    assert set_precision(mpd, 'f16x3') is mpd and all(l.precision == 'f16x3' for l in mpd.modules() if isinstance(l, _DiscConv))
+    assert list(mpd.state_dict().keys()) == [k for k, _, _ in synthetic.mpd_state_dict_spec()]
+    with pytest.raises(ValueError):
+        set_precision(msd, 'bf16')
 
 
 def test_bench_refuses_a_run_smaller_than_the_one_asked_for():
