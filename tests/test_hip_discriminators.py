@@ -51,7 +51,9 @@ def test_discriminators_match_reference_goldens(dev, name, precision):
         outs = m(y.to(dev), y_hat.to(dev))
     golden_util.check_disc_outputs(z, outs, TOL)
     nsplit = len(_split_layers(m))
-    assert nsplit == (0 if precision == 'f32' else 3), nsplit      # one such layer per discriminator (three periods, three scales)
+    # f16x3: per period discriminator its four C_in > 1 convs (the three two-tap phase-stacked ones with a zero third tap), per scale
+    # discriminator the grouped 512 -> 1024 / 1024 -> 1024 convs (64 output channels per group) and the dense 1024 -> 1024 one
+    assert nsplit == (0 if precision == 'f32' else (12 if meta['kind'] == 'mpd' else 9)), nsplit
     for k in z.files:          # spectral-norm buffers after the forward(s): two power iterations per training forward
         if k.startswith('buf_'):
             assert np.abs(m.state_dict()[k[4:]].cpu().numpy() - z[k]).max() <= 1e-5, k

@@ -32,8 +32,7 @@ static int check_conv1d(const v2w_conv1d_args* a) {
     if (a->io_bf16 != 0 && (a->algo != V2W_ALGO_BF16 || a->io_bf16 < 0 || a->io_bf16 > 3)) return V2W_E_ARG;   // bf16 storage: bf16 kernels only
     const bool ext_ct = (a->in_ct > 0 && a->in_ct != a->C_in) || (a->out_ct > 0 && a->out_ct != a->C_out);
     const bool ext_slope = a->out_slope != 0.f && a->out_slope != 1.f;
-    if (ext_ct && (a->algo == V2W_ALGO_SPLIT || a->algo == V2W_ALGO_BF16)) return V2W_E_SHAPE;     // channel slices: the f32 kernels only
-    if (ext_slope && a->algo == V2W_ALGO_BF16) return V2W_E_SHAPE;                                  // out_slope: f32 and split-f16 kernels
+    if ((ext_ct || ext_slope) && a->algo == V2W_ALGO_BF16) return V2W_E_SHAPE;      // channel slices, out_slope: the f32 and split-f16 kernels
     return 0;
 }
 

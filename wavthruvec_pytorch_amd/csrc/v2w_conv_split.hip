@@ -175,7 +175,7 @@ conv_split_kernel(const MultiArgs m) {
     }
     const unsigned r_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Rs);
     auto prefetch = [&](int ci0) __attribute__((always_inline)) {
-        const float* src = p.in + (size_t)(b * p.Cin + ci0) * L;
+        const float* src = p.in + (size_t)(b * p.CinT + ci0) * L;      // (CinT: channels of the tensor `in` points into - a group's slice)
 #pragma unroll
         for (int i = 0; i < NSIG; ++i) {
             unsigned m0_save;
@@ -230,7 +230,7 @@ conv_split_kernel(const MultiArgs m) {
     auto stage_scalar = [&](int ci0, unsigned char* Xs) __attribute__((always_inline)) {        // any L / alignment / input stride
         for (int c = wave; c < CK; c += 4) {
             const int ch = b * p.Cin + ci0 + c;
-            const float* src = p.in + (size_t)ch * L * p.in_stride + p.in_phase;
+            const float* src = p.in + (size_t)(b * p.CinT + ci0 + c) * L * p.in_stride + p.in_phase;
             const float av = p.in_a ? p.in_a[ch] : 1.f;
             const float sv = p.in_s ? p.in_s[ch] : 0.f;
             for (int j = lane; j < p.xcols; j += 64) {
@@ -421,7 +421,7 @@ conv_split_kernel(const MultiArgs m) {
                 for (int g = 0; g < EG; ++g) {
                     const int f = (g0 + g) * 64 + lane;
                     const int row = f / C4, q = n0 + wn0 + j0 * 32 + (f % C4) * 4;
-                    const size_t o = ((size_t)b * p.Cout + m0 + wm0 + i * 32 + row) * L + q;
+                    const size_t o = ((size_t)b * p.CoutT + m0 + wm0 + i * 32 + row) * L + q;
                     const bool in = p.evec && q < L;
                     rv[g] = (p.res && in) ? *reinterpret_cast<const f32x4*>(p.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
                     ov[g] = (p.accumulate && in) ? *reinterpret_cast<const f32x4*>(p.out + o)
@@ -435,7 +435,7 @@ conv_split_kernel(const MultiArgs m) {
                     const int row = f / C4, c4 = f % C4, q = n0 + wn0 + j0 * 32 + c4 * 4;
                     if (q >= L) continue;
                     const int col = wm0 + i * 32 + row;
-                    const size_t o = ((size_t)b * p.Cout + m0 + col) * L + q;
+                    const size_t o = ((size_t)b * p.CoutT + m0 + col) * L + q;
                     const float bias = etab[col], ra = etab[MT + col], rs = etab[2 * MT + col];
                     const float ma = etab[3 * MT + col], ms = etab[4 * MT + col];
                     f32x4 v = *reinterpret_cast<const f32x4*>(T + row * RS + c4 * 4);
@@ -774,6 +774,7 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
         p.add0 = q->add0; p.add1 = q->add1;
         p.mask_src = q->mask_src; p.mask_a = q->mask_a; p.mask_s = q->mask_s; p.mask_slope = q->mask_slope;
         p.B = q->B; p.Cin = q->C_in; p.Cout = q->C_out; p.L = q->L; p.K = q->k; p.dil = q->dil;
+        p.CinT = q->in_ct > 0 ? q->in_ct : q->C_in; p.CoutT = q->out_ct > 0 ? q->out_ct : q->C_out;   // one group of a grouped conv: channel slices
         p.pad = 0; p.hl = p.hr = q->dil * (q->k - 1) / 2;
         if (q->pad_left >= 0) { p.hl = q->pad_left; p.hr = q->dil * (q->k - 1) - q->pad_left; if (p.hr < 0) return V2W_E_ARG; }
         p.in_stride = q->in_stride > 0 ? q->in_stride : 1; p.in_phase = q->in_phase;

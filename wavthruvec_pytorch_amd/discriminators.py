@@ -132,14 +132,19 @@ class _DiscConv(nn.Module):
         packable = groups.shape[2] % 16 == 0 and (groups.shape[3] % 32 == 0 or groups.shape[3] == 16)
         rec = dict(w4=groups, wf=list(groups.unbind(0)), kp=kp, Q=Q,
                    wp=list(hipops.pack_mfma_batch(groups).unbind(0)) if packable else [None] * groups.shape[0])
-        if self.split_eligible(kp):
-            rec['wps'] = hipops.pack_split(rec['wf'][0])        # (hi, lo) f16 fragments + scale record of the forward conv
+        if self.split_eligible(kp, groups.shape[2], groups.shape[3]):
+            # (hi, lo) f16 fragments + scale record of the forward conv, per group.  The kernel pipelines over an odd tap count: the
+            # two-tap phase-stacked layers (k = 5, stride 3) get a zero third tap behind the others (same pad_left; 1.5 x the MFMAs at 2.2 x the rate)
+            ws = groups if kp % 2 == 1 else torch.cat([groups, torch.zeros_like(groups[:, :1])], 1)
+            rec['ws4'], rec['kps'] = ws, ws.shape[1]
+            rec['wps'] = [hipops.pack_split(ws[g]) for g in range(ws.shape[0])]
         self._cache = (key, rec)
         return rec
 
-    def split_eligible(self, kp):
-        return (self.precision == 'f16x3' and self.groups == 1 and self.stride == 1 and not self.unfolded and self.c_in > 1
-                and kp % 2 == 1 and kp >= 3 and hipops.split_supported(self.c_in, self.c_out))
+    def split_eligible(self, kp, cigp, cog):
+        """The split-f16 kernel serves this layer's stride-1 form: `cigp` stacked input channels and `cog` output channels per group."""
+        return (self.precision == 'f16x3' and not self.unfolded and self.c_in > 1 and kp >= 2
+                and hipops.split_supported(cigp, cog))
 
     def param_grads(self, db, dws, sn):
         """Gradients of this layer's parameters (parameters() order) from the bias gradient and the per-group weight gradients
@@ -219,21 +224,34 @@ def _conv_layer(layer: _DiscConv, rec, x, L_in, inner, out_slope, keep=None):
     out = torch.empty((B, layer.c_out, xs.shape[2]), device=x.device)
     cig, cog = xs.shape[1] // G, layer.c_out // G
     kw = dict(k=rec['kp'], dil=1 if rec['kp'] == 1 else inner, slope=1.0, pad_left=rec['Q'] * inner, out_slope=out_slope)
-    if G == 1 and 'wps' in rec:      # precision = 'f16x3': the split-f16 kernel (a shape it declines - a halo beyond its staging - runs exact)
+    bias = layer.bias.detach()
+
+    def problems(split):
+        if split:       # precision = 'f16x3': the split-f16 kernel on the (zero-padded to an odd tap count) stacked weights
+            kws = dict(kw, k=rec['kps'], algo=hipops.ALGO_SPLIT)
+            return [(xs, rec['ws4'][g], bias[g * cog:(g + 1) * cog], out,
+                     dict(kws, wps=rec['wps'][g], group=(g, cig, cog) if G > 1 else None)) for g in range(G)]
+        return [(xs, rec['wf'][g], bias[g * cog:(g + 1) * cog], out, dict(kw, wp=rec['wp'][g], group=(g, cig, cog) if G > 1 else None))
+                for g in range(G)]
+
+    def run(probs):
+        if G == 1:
+            x0, w0, b0, o0, k0 = probs[0]
+            hipops.conv1d(x0, w0, b0, o0, **k0)
+        else:
+            for i in range(0, G, 4):
+                hipops.conv1d_multi(probs[i:i + 4])
+
+    if 'wps' in rec:
         try:
-            hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, algo=hipops.ALGO_SPLIT, wps=rec['wps'], **kw)
-        except _hip.HipLibraryError as e:
+            run(problems(True))
+            return out, U
+        except _hip.HipLibraryError as e:       # a shape the split kernel declines (a halo beyond its staging slots): exact from here on
             if e.code != _hip.E_SHAPE:
                 raise
-            del rec['wps']
-            hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
-    elif G == 1:
-        hipops.conv1d(xs, rec['wf'][0], layer.bias.detach(), out, wp=rec['wp'][0], **kw)
-    else:
-        bias = layer.bias.detach()
-        probs = [(xs, rec['wf'][g], bias[g * cog:(g + 1) * cog], out, dict(kw, wp=rec['wp'][g], group=(g, cig, cog))) for g in range(G)]
-        for i in range(0, G, 4):
-            hipops.conv1d_multi(probs[i:i + 4])
+            for key in ('wps', 'ws4', 'kps'):
+                rec.pop(key, None)
+    run(problems(False))
     return out, U
 
 
@@ -411,11 +429,19 @@ class _DiscFn(torch.autograd.Function):
                     wT4 = rec['w4'].flip(1).transpose(2, 3).contiguous()        # [G][kp][cog][cigp], taps reversed
                     rec['wT'] = list(wT4.unbind(0))
                     rec['wTp'] = list(hipops.pack_mfma_batch(wT4).unbind(0)) if packable else [None] * G
-                if 'wps' in rec and 'wTs' not in rec:
-                    rec['wTs'] = hipops.pack_split(rec['wT'][0])               # the same layer's input-gradient conv in split-f16 form
+                if 'wps' in rec and 'wTs' not in rec and hipops.split_supported(cog, cigp):
+                    # the same layer's input-gradient conv in split-f16 form: transposed, tap-reversed (the zero pad tap comes first)
+                    wTs4 = rec['ws4'].flip(1).transpose(2, 3).contiguous()       # [G][kps][cog][cigp]
+                    rec['wTs4'], rec['wTs'] = wTs4, [hipops.pack_split(wTs4[gi]) for gi in range(G)]
                 if 'wTs' in rec:
-                    hipops.conv1d(dz, rec['wT'][0], None, dxs, k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil,
-                                  algo=hipops.ALGO_SPLIT, wps=rec['wTs'])
+                    kps = rec['kps']
+                    probs = [(dz, rec['wTs4'][gi], None, dxs, dict(k=kps, dil=dil, slope=1.0, pad_left=(kps - 1 - Q) * dil, algo=hipops.ALGO_SPLIT,
+                                                                   wps=rec['wTs'][gi], group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
+                    if G == 1:
+                        hipops.conv1d(dz, probs[0][1], None, dxs, **probs[0][4])
+                    else:
+                        for i in range(0, G, 4):
+                            hipops.conv1d_multi(probs[i:i + 4])
                 else:
                     probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
                                                                  group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
