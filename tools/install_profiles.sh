@@ -20,4 +20,5 @@ cp $O/latency.txt $P/${T}_latency.txt
 cp $O/train_step.txt $P/${T}_train_step.txt
 cp $O/sync_overhead.txt $P/${T}_sync_overhead.txt
 cp $O/gan_iteration.txt $P/${T}_gan_iteration.txt
+cp $O/ks_gan/ks_kernel_stats.csv $P/${T}_gan_iteration_kernel_stats.csv
 ls -la $P/${T}_*

@@ -18,6 +18,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_train 
 # BASELINE configs[2] in its own arithmetic (bf16 compute / fp32 accumulate, bf16 activation storage) and the cfg1 inference latency
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_cfg3 -o ks -- $B --precision bf16 --batch 64 --frames 512 > $O/ks_cfg3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ks_lat -o ks -- python3 $R/tools/latency_bench.py 1 50 > $O/ks_lat.log 2>&1
+# one train.py GAN iteration (generator, mel, D step, G step) at the cfg2 shape: kernel stats of 1 + 2 warm-up iterations
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_gan -o ks -- python3 $R/tools/gan_step_bench.py 32 256 1 > $O/ks_gan.log 2>&1
 B3C="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --precision bf16 --batch 64 --frames 512"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -o pf -- $B3C > $O/c3pf.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c3_write -o pw -- $B3C > $O/c3pw.log 2>&1
