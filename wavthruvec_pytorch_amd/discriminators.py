@@ -58,6 +58,7 @@ class _DiscConv(nn.Module):
             self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(c_out, *([1] * (len(wshape) - 1))).clone())
             self.weight_v = nn.Parameter(w)
         self._cache = None
+        self._pair_rec = None
         self._last_sn = None
         self._jmap = None
         self._wpad = None
@@ -103,6 +104,12 @@ class _DiscConv(nn.Module):
         # eval-mode optimisation only (`invalidate_weight_cache()` after a `.data` edit in eval mode)
         if self._cache is not None and self._cache[0] == key and not self.training:
             return self._cache[1]
+        # inside ONE forward(y, y_hat) of a multi-discriminator the weight-normed layers fold once for both inputs (`_pairwise`): nothing
+        # can change a parameter between the two calls, and at the reference's batch_size = 2 the ten-odd small launches of this function
+        # per layer and call are most of a discriminator forward's wall clock.  (Spectral norm iterates u, v on EVERY call, as the legacy
+        # hook does: never shared.)
+        if _PAIR['on'] and not self.spectral and self._pair_rec is not None and self._pair_rec[0] == key:
+            return self._pair_rec[1]
         k, s, P, G = self.k, self.stride, self.padding, self.groups
         cig, cog = self.c_in // G, self.c_out // G
         stacked = not self.unfolded and self.c_in > 1
@@ -139,6 +146,8 @@ class _DiscConv(nn.Module):
             rec['ws4'], rec['kps'] = ws, ws.shape[1]
             rec['wps'] = [hipops.pack_split(ws[g]) for g in range(ws.shape[0])]
         self._cache = (key, rec)
+        if _PAIR['on'] and not self.spectral:
+            self._pair_rec = (key, rec)
         return rec
 
     def split_eligible(self, kp, cigp, cog):
@@ -484,9 +493,19 @@ class DiscriminatorP(_DiscBase):
         return p, H
 
 
+_PAIR = {'on': False}       # True while a multi-discriminator runs its (y, y_hat) pairs: see _DiscConv.kernel_weights
+
+
 def _pairwise(discs, inputs):
     """Run every discriminator on its (y, y_hat) pair -> (scores_real, scores_generated, fmaps_real, fmaps_generated)."""
-    outs = [(d(y), d(y_hat)) for d, (y, y_hat) in zip(discs, inputs)]
+    _PAIR['on'] = True
+    try:
+        outs = [(d(y), d(y_hat)) for d, (y, y_hat) in zip(discs, inputs)]
+    finally:
+        _PAIR['on'] = False
+        for d in discs:
+            for l in d._layers():
+                l._pair_rec = None
     return ([r[0] for r, _ in outs], [g[0] for _, g in outs], [r[1] for r, _ in outs], [g[1] for _, g in outs])
 
 
