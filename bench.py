@@ -490,6 +490,98 @@ def dry_run(args, rank, world) -> int:
     return 0
 
 
+def _r(v, nd=4):
+    """Round floats for the compact line (the full-precision values are in the detail file / --verbose)."""
+    if isinstance(v, float):
+        return float(f'{v:.{nd}g}') if abs(v) < 1 else round(v, nd)
+    return v
+
+
+def compact_roofline(roof):
+    """The keys the contract names (bound, achieved, peak, unit, frac, traffic) + what identifies the kernel; the per-kernel table and
+    the launch tag lists stay in the detail file (`--verbose` puts them back into the line)."""
+    if not isinstance(roof, dict):
+        return roof
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'mfma_frac', 'hbm_frac', 'traffic', 'launches_per_step', 'avg_launch_us',
+            'algorithmic_bytes_per_launch_avg', 'flops_per_launch_avg', 'stat_sync_allreduce_us_mean')
+    out = {k: _r(roof[k]) for k in keep if k in roof}
+    src = roof.get('traffic_source')
+    if src:
+        out['traffic_source'] = src if len(src) <= 96 else src[:93] + '...'
+    wf = roof.get('whole_forward')
+    if wf:
+        out['whole_forward'] = {k: _r(wf[k]) for k in ('mfma_frac', 'hbm_frac', 'sum_conv_kernel_ms') if k in wf}
+    return out
+
+
+def compact_block(b):
+    """One extra block of the line: its step time, throughput, both roofline fractions and its dominant kernel's fraction."""
+    if not isinstance(b, dict) or 'error' in b:
+        return b
+    keep = ('dtype', 'steps', 'ms_per_step', 'ms_per_step_event_median', 'value', 'unit', 'hbm_frac', 'mfma_frac', 'tflops',
+            'ms_per_step_with_sync', 'ms_per_step_without_sync', 'stat_sync_ms_per_step', 'allreduce_us_event_mean', 'backend', 'ranks',
+            'precision', 'max_abs_diff_vs_f32_path', 'parity_bar')
+    out = {k: _r(b[k]) for k in keep if k in b}
+    r = b.get('roofline')
+    if isinstance(r, dict):
+        out['dominant'] = {k: _r(r[k]) for k in ('kernel', 'bound', 'frac', 'avg_launch_us', 'traffic') if k in r}
+        if b.get('dtype') == 'bf16' and 'resblock' not in str(b.get('workload', '')).lower()[:40] and isinstance(r.get('per_kernel'), dict):
+            # the bf16 pipeline's launches, largest first: [kernel, ms per step, TFLOP/s]
+            out['kernels'] = [[k.replace(' ', ''), _r(v['ms']), _r(v['tflops'])] for k, v in list(r['per_kernel'].items())[:7]]
+    alt = b.get('alt_precision_f16x3')
+    if isinstance(alt, dict):
+        out['alt_precision_f16x3'] = {k: _r(alt[k]) for k in ('ms_per_step', 'value', 'tflops', 'error') if k in alt}
+    return out
+
+
+def compact_cpu(c):
+    if not isinstance(c, dict):
+        return c
+    out = {k: _r(c[k]) for k in ('value', 'unit', 'cores', 'kind', 'seconds_per_forward') if k in c}
+    out['sample'] = f"oracle (torch CPU fp32 restatement of the reference forward): ONE full cfg2 forward (B=32, T=256, train mode) at {c.get('cores')} threads after one warm-up"
+    sm = c.get('cfg2_sample_B4')
+    if isinstance(sm, dict):
+        out['cfg2_sample_B4'] = {k: _r(sm[k]) for k in ('value', 'cores') if k in sm}
+    c1 = c.get('cfg1_B1_T50_samples_per_s')
+    if isinstance(c1, dict):
+        out['cfg1_B1_T50_samples_per_s'] = {k: _r(v) for k, v in c1.items()}
+    return out
+
+
+def summary_of(out, blocks):
+    """{block: [ms_per_step, hbm_frac, mfma_frac]} - the LAST key of the line, so that it survives a record that keeps only the tail."""
+    sm = {}
+    wf = (out.get('roofline') or {}).get('whole_forward') or {}
+    sm['cfg2_f32'] = [_r(out.get('ms_per_step')), _r(wf.get('hbm_frac')), _r(wf.get('mfma_frac'))]
+    for name in blocks:
+        b = out.get(name)
+        if not isinstance(b, dict):
+            continue
+        if 'error' in b:
+            sm[name] = 'error'
+        elif name == 'stat_sync':
+            sm[name] = [_r(b.get('stat_sync_ms_per_step')), _r(b.get('allreduce_us_event_mean')), None]
+        else:
+            sm[name] = [_r(b.get('ms_per_step')), _r(b.get('hbm_frac')), _r(b.get('mfma_frac'))]
+            alt = b.get('alt_precision_f16x3')
+            if isinstance(alt, dict) and 'ms_per_step' in alt:
+                sm[name + '.f16x3'] = [_r(alt['ms_per_step']), None, None]
+    return sm
+
+
+def write_detail(out):
+    """The full-precision line with every per-kernel table next to the run (best effort; never fails the bench)."""
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'bench_detail.json')
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -505,6 +597,9 @@ def main():
     ap.add_argument('--resblock', default='2', choices=['1', '2'], help="'1': the ResBlock1 generator (h.resblock == '1'); default ResBlock2")
     ap.add_argument('--force-pg', action='store_true',
                     help='--gpus 1 only: create a ONE-rank RCCL process group and keep the CondBN statistics all-reduces inside the timed region')
+    ap.add_argument('--verbose', action='store_true',
+                    help='print the full line (per-kernel tables, launch tags, every sub-measurement); default: the compact line '
+                         '(< 8 KB, ends in `summary`), the full one goes to gpurun_out/bench_detail.json')
     ap.add_argument('--dry-run', action='store_true',
                     help='first-contact check of the N-rank plumbing WITHOUT a GPU: launcher, rendezvous (set V2W_BENCH_BACKEND=gloo), per-rank '
                          'seeds and shards, barrier, max-over-ranks and the one JSON line are exercised; no forward runs and `value` is null')
@@ -692,6 +787,15 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
             'cfg2_bf16': cfg2b, 'cfg5_f32': cfg5, 'train_step': train, 'resblock1_bf16': rb1b,
         }
+        blocks = ('alt_precision', 'cfg3_bf16', 'cfg2_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync')
+        if not args.verbose:
+            detail = write_detail(out)
+            out['roofline'] = compact_roofline(roof)
+            out['cpu_baseline'] = compact_cpu(cpu)
+            for name in blocks:
+                out[name] = compact_block(out[name])
+            out['detail'] = detail
+        out['summary'] = summary_of(out, blocks)          # LAST key: [ms_per_step, hbm_frac, mfma_frac] of every block
     if dist.is_initialized():
         dist.destroy_process_group()
     redirect.__exit__()

@@ -195,3 +195,31 @@ def test_bench_refuses_a_run_smaller_than_the_one_asked_for():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, env=env2,
                         timeout=300)
     assert r2.returncode != 0 and 'WORLD_SIZE=2' in r2.stderr
+
+
+def test_bench_line_is_compact_and_ends_in_the_summary():
+    """The driver keeps the last ~8 KB of the bench line: the compact form of a full round-4 line (every block present) must fit, must keep
+    the contract's roofline / cpu_baseline keys, and must END in `summary` with one [ms, hbm_frac, mfma_frac] entry per block."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    with open(os.path.join(ROOT, 'profiles', 'r04_cfg2_bench.json')) as f:
+        out = json.load(f)
+    blocks = ('alt_precision', 'cfg3_bf16', 'cfg2_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync')
+    out['roofline'] = b.compact_roofline(out['roofline'])
+    out['cpu_baseline'] = b.compact_cpu(out['cpu_baseline'])
+    for n in blocks:
+        out[n] = b.compact_block(out.get(n))
+    out['summary'] = b.summary_of(out, blocks)
+    line = json.dumps(out)
+    assert len(line) < 7000, len(line)
+    assert list(out)[-1] == 'summary' and line.rstrip('}').count('"summary"') == 1
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in out['roofline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in out['cpu_baseline']
+    for n in ('cfg2_f32', 'cfg3_bf16', 'cfg2_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync'):
+        assert n in out['summary'], n
+    assert len(line[-2048:].split('"summary"')) == 2       # the summary sits inside the last 2 KB
