@@ -9,7 +9,7 @@ import torch
 
 from oracle import vec2wav_oracle as O
 from tests.golden_util import golden_names, load_golden, case_setup, probe_summary, tol_for
-from wavthruvec_pytorch_amd import synthetic
+from wavthruvec_pytorch_amd import synthetic, hipops
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # |dy| bar of BASELINE.json north_star (fp32)
@@ -221,6 +221,48 @@ def test_generator_resblock1_bf16_storage(dev, B, T, rates, ks, training):
     with torch.no_grad():
         y2 = g2(*to_dev(inp_cpu, dev))
     assert (y2.cpu() - want).abs().max().item() <= 6e-3
+
+
+@pytest.mark.parametrize('B,T', [(3, 64), (2, 128), (5, 16)])
+def test_generator_inline_batchnorm_statistics(dev, B, T):
+    """Statistics without launches (csrc/v2w_bnacc.h; train mode, bf16 storage): the producing kernels add their BatchNorm sums to an int64
+    fixed-point accumulator with integer atomics and every stage kernel folds the statistics of its own input - against the schedule with
+    the reduce / finalize launches between the stage kernels: the same tile sums either way, added exactly instead of in fp64, so outputs and
+    running statistics agree to rounding; num_batches_tracked advances once per forward; two runs are bit-identical (integer atomics are
+    order-independent); and the launches are really gone (no statistics entry points called)."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=5)
+    inp = to_dev(synthetic.make_inputs(h, B, T, seed=9), dev)
+    res = {}
+    for inline in (True, False):
+        g = build_generator(h, sd, dev, training=True)
+        g.precision = 'bf16'
+        g.inline_stats = inline
+        calls = []
+        keep = {}
+        for nm in ('bn_reduce_partials', 'bn_reduce_finalize_slices', 'bn_finalize', 'bn_stats'):
+            keep[nm] = getattr(hipops, nm)
+            setattr(hipops, nm, (lambda f, n: (lambda *a, **k: (calls.append(n), f(*a, **k))[1]))(keep[nm], nm))
+        try:
+            with torch.no_grad():
+                y1 = g(*inp).clone()
+                y2 = g(*inp).clone()
+        finally:
+            for nm, f in keep.items():
+                setattr(hipops, nm, f)
+        assert g._inline_stats_ok(B, T)
+        assert bool(calls) == (not inline), calls
+        res[inline] = (y1, y2, {k: v.clone() for k, v in g.state_dict().items() if 'batch_nrom' in k})
+        assert torch.isfinite(y1).all()
+    (a1, a2, sa), (b1, b2, sb) = res[True], res[False]
+    # the running statistics move between the two forwards of a generator, the batch statistics do not: y1 == y2 bit for bit
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert (a1 - b1).abs().max().item() <= 2e-5, (a1 - b1).abs().max().item()
+    for k in sa:
+        if k.endswith('num_batches_tracked'):
+            assert int(sa[k]) == int(sb[k]) == 2, (k, sa[k], sb[k])
+        else:
+            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-6), (k, (sa[k] - sb[k]).abs().max().item())
 
 
 def test_generator_bf16_storage_falls_back_when_a_layer_has_no_bf16_kernel(dev):

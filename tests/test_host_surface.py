@@ -76,7 +76,7 @@ def _header_struct_fields(header, name):
     end = header.index('} %s;' % name)
     body = header[header.rindex('typedef struct {', 0, end):end]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
-    groups = re.findall(r'\b(?:const\s+)?(?:float|int32_t|int64_t|void)\s*\*?\s*([a-zA-Z_0-9\[\]]+(?:\s*,\s*[a-zA-Z_0-9\[\]]+)*)\s*;', body)
+    groups = re.findall(r'\b(?:const\s+)?(?:float|double|int32_t|int64_t|void)\s*\*?\s*([a-zA-Z_0-9\[\]]+(?:\s*,\s*[a-zA-Z_0-9\[\]]+)*)\s*;', body)
     return [re.sub(r'\[.*?\]', '', n).strip() for grp in groups for n in grp.split(',')]
 
 

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -36,7 +36,7 @@ class ConvT1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32), ('io_bf16', C.c_int32), ('_pad', C.c_int32),
-                ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64)]
+                ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64), ('stats_acc', _fp)]
 
 
 class PairArgs(C.Structure):
@@ -73,7 +73,10 @@ class StageSplitArgs(C.Structure):
                 ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float),
                 ('up_wps', _fp), ('up_bias', _fp), ('up_out', _fp), ('up_stats_part', _fp),
                 ('up_k', C.c_int32), ('up_u', C.c_int32), ('up_slope', C.c_float), ('rb1', C.c_int32),
-                ('in_b', _P4), ('out_b', _P4), ('add0', _fp), ('add1', _fp)]
+                ('in_b', _P4), ('out_b', _P4), ('add0', _fp), ('add1', _fp),
+                ('up_stats_acc', _fp), ('in_stats_acc', _fp), ('in_gb', _fp),
+                ('in_running_mean', _fp), ('in_running_var', _fp), ('in_nbt', _fp),
+                ('in_count', C.c_double), ('in_eps', C.c_float), ('in_momentum', C.c_float)]
 
 
 class BranchConvsArgs(C.Structure):

@@ -935,6 +935,7 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
         const int rc = v2w_convt1d_bf16_res(a, g.UP, g.hl, g.KV, stream, ntiles_out, cfg);
         if (rc != V2W_E_SHAPE) return rc;
     }
+    if (a->stats_acc) return V2W_E_SHAPE;     // the statistics accumulator (v2w_bnacc.h) exists in the resident-tile kernels only: queries say so too
     const int rows = p.Cout;
     // the stats tiling (rows of stats_part) depends on the tile width only: every configuration here is 256 or 512 positions wide, the
     // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin

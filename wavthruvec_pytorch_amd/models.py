@@ -80,6 +80,16 @@ class ConvTranspose1d(_WNConvBase):
     transposed = True
 
 
+class _Shape:
+    """Shape carrier for the library's host-only queries (an aligned address that is never dereferenced)."""
+
+    def __init__(self, *shape):
+        self.shape = shape
+
+    def data_ptr(self):
+        return 4096
+
+
 def _fold_one(m, device):
     v, g = (m.weight_v.detach(), m.weight_g.detach()) if m.weight_normed else (m.weight.detach(), None)
     wf = hipops.fold_conv_weight(v, g)
@@ -212,6 +222,9 @@ class Generator(nn.Module):
                                               # the stage's output never leaves the chip, one launch less per stage
         self.fuse_post = True                 # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage: the stage's
                                               # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
+        self.inline_stats = True              # bf16 storage, train mode, no statistics exchange: the BatchNorm sums of a stage's input are added up by the
+                                              # PRODUCING kernel (integer atomics) and folded by the CONSUMING stage kernel - no reduce / finalize launches
+                                              # between the stage kernels (csrc/v2w_bnacc.h)
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._slabs: Dict[tuple, 'hipops.SplitKSlab'] = {}
@@ -525,6 +538,36 @@ class Generator(nn.Module):
         self._fold_key['bf16_storage_ok'] = (key, bool(ok))
         return bool(ok)
 
+    def _inline_stats_ok(self, B, T) -> bool:
+        """Statistics without launches need, for EVERY stage, a producer that adds its sums to the accumulator (the stand-alone bf16
+        transposed conv of stage 0, the fused upsampler behind every other stage) and a consumer that folds them (the resident-tile
+        stage kernels, the 16-channel kernel): asked of the library before the forward starts (shape queries only)."""
+        key = (B, T, self.num_kernels, tuple(self.fuse_stage), bool(self.fuse_up), bool(self.fuse_wide_stage), self.fuse_post)
+        hit = self._fold_key.get('inline_stats_ok')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        nk, ns = self.num_kernels, self.num_upsamples
+        ok = bool(self.fuse_up and self.fuse_wide_stage) and all(isinstance(rb, ResBlock2) for rb in self.resblocks)
+        L = T
+        for i, up in enumerate(self.ups):
+            if not ok:
+                break
+            Lo, C = L * up.stride, up.out_channels
+            rbs = self.resblocks[i * nk:(i + 1) * nk]
+            ks, d1, d2 = [rb.kernel_size for rb in rbs], [rb.convs[0].dilation for rb in rbs], [rb.convs[1].dilation for rb in rbs]
+            if i == 0:      # the producer of stage 0: the stand-alone transposed conv (bf16 in, bf16 out)
+                ok = ok and hipops.convt_bf16_stats_tiles(_Shape(B, up.in_channels, L), _Shape(B, C, Lo), up.kernel_size, up.stride, io_bf16=3, acc=True) > 0
+            if i + 1 < ns:  # the stage kernel folds its input's statistics and runs the next upsampler, which adds up the next stage's
+                nup = self.ups[i + 1]
+                ok = ok and C >= 32 and (C >= 64 or C in self.fuse_stage) and nup.kernel_size == 2 * nup.stride and nup.stride in (2, 4) \
+                    and nup.out_channels * 2 == C and hipops.resblock2_stage_up_tiles(
+                        B, C, Lo, ks, d1, d2, slope=LRELU_SLOPE, up_k=nup.kernel_size, up_u=nup.stride, up_slope=LRELU_SLOPE, fold=True) > 0
+            else:           # the last stage: any one-kernel form that folds (with the tail behind it when fuse_post takes it)
+                ok = ok and hipops.resblock2_stage_split_ok(B, C, Lo, ks, d1, d2, slope=LRELU_SLOPE, fold=True)
+            L = Lo
+        self._fold_key['inline_stats_ok'] = (key, bool(ok))
+        return bool(ok)
+
     # -------------------------------------------------------------------------------------------
     @_hip.on_tensor_device
     def forward(self, x, spk_emb=None, noise=None):
@@ -661,6 +704,22 @@ class Generator(nn.Module):
             run_cond()
             affs = cond_state['affs']
 
+            # ---- statistics without launches (csrc/v2w_bnacc.h): one zeroed accumulator per stage, filled by the producing kernel's atomics and
+            # folded by the consuming stage kernel; the memset is the side stream's (its events order it before the first producer)
+            inline = bool(training and st and self.inline_stats and self.stat_sync is None and save is None and self._inline_stats_ok(B, T))
+            accs = None
+            if inline:
+                offs = [0]
+                for c in self.cbns:
+                    offs.append(offs[-1] + 4 * c.num_features)
+                acc_all = self._buf('bn.acc', (offs[-1],), dtype=torch.int64, device=dev)
+                with torch.cuda.stream(side):
+                    acc_all.zero_()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    evs['acc'] = ev
+                accs = [acc_all[offs[i]:offs[i + 1]] for i in range(ns)]
+
             def need(*names):     # the main stream waits for exactly these steps of the side stream (bf16 storage; no-op otherwise)
                 for nm in names:
                     ev = evs.pop(nm, None) if evs is not None else None
@@ -693,7 +752,9 @@ class Generator(nn.Module):
                 bn = cbn.batch_nrom
                 stats = part = None
                 nt_stats = 0
-                if training:
+                if inline:
+                    need('acc')
+                elif training:
                     stats = self._buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64, device=dev)
                     # fused statistics: the MFMA transposed conv emits per-tile (sum, sumsq) from its accumulators
                     if up_done is not None:
@@ -706,6 +767,9 @@ class Generator(nn.Module):
                         part = self._buf(f'bn.part{i}', (nt_stats * C * 2,), device=dev)
                 if up_done is not None:
                     pass        # the previous stage's kernel has written xr (and the partial sums): models.py:128-129 ran fused behind it
+                elif inline:
+                    self._timed(f'ups.{i}', hipops.convt1d_bf16, cur, wps[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
+                                u=up.stride, slope=LRELU_SLOPE, io_bf16=3, stats_acc=accs[i])
                 elif f'ups.{i}' in wps and (nt_stats or not training):
                     self._timed(f'ups.{i}', hipops.convt1d_bf16, cur, wps[f'ups.{i}'], up.bias.detach(), xr, k=up.kernel_size,
                                 u=up.stride, slope=LRELU_SLOPE, stats_part=part, io_bf16=3 if st else 0)
@@ -717,7 +781,11 @@ class Generator(nn.Module):
                 up_done = None
                 # ---- K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s
                 sliced = training and nt_stats >= 1024 and self.stat_sync is None and save is None
-                if sliced:
+                fold = None
+                if inline:      # no launch here: the stage kernel below folds the totals (and updates the running statistics) itself
+                    fold = dict(acc=accs[i], gb=gbs[i], count=float(B) * float(Lo), eps=bn.eps, momentum=bn.momentum,
+                                running_mean=bn.running_mean, running_var=bn.running_var, nbt=bn.num_batches_tracked)
+                elif sliced:
                     pass        # (thousands of partial rows, nothing to all-reduce, no backward that reads the array: the two-level form below)
                 elif training:
                     if nt_stats:
@@ -733,14 +801,16 @@ class Generator(nn.Module):
                 if not cond_joined:       # (fp32: the side stream only carries gamma / beta - joined as late as their first use, which
                     main.wait_stream(side)    # matters at B = 1, where conv_pre is shorter than the conditioning chain)
                     cond_joined = True
-                if sliced:
+                if inline:
+                    pass
+                elif sliced:
                     sl = self._buf(f'bn.slices{i}', (hipops.BN_SLICES * 2 * C,), dtype=torch.float64, device=dev)
                     hipops.bn_reduce_finalize_slices(part, nt_stats, B * Lo, sl, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                                      a_t, s_t, momentum=bn.momentum, eps=bn.eps)
                 elif affs is None:
                     hipops.bn_finalize(stats, gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                        training=training, momentum=bn.momentum, eps=bn.eps)
-                aff = (a_t, s_t)
+                aff = None if inline else (a_t, s_t)
                 # (bf16 storage: the fragments of the residual convs, of the upsampler a fused stage kernel runs, of the tail)
                 need('rest', *([f'ups.{i + 1}'] if i + 1 < ns else ['post']))
                 # ---- K6/K7: the num_kernels residual blocks read the same x = a*xr + s; their mean is the next input.
@@ -790,19 +860,21 @@ class Generator(nn.Module):
                             if nup.kernel_size == 2 * nup.stride and nup.stride in (2, 4) and nup.out_channels * 2 == C:
                                 ntn = hipops.resblock2_stage_up_tiles(B, C, Lo, [rb.kernel_size for rb in rbs], [rb.convs[0].dilation for rb in rbs],
                                                                       [rb.convs[1].dilation for rb in rbs], slope=LRELU_SLOPE,
-                                                                      up_k=nup.kernel_size, up_u=nup.stride, up_slope=LRELU_SLOPE)
+                                                                      up_k=nup.kernel_size, up_u=nup.stride, up_slope=LRELU_SLOPE, fold=inline)
                                 if ntn:
                                     xr_n = self._buf(f'act.up{i + 1}', (B, nup.out_channels, Lo * nup.stride), dtype=adt, device=dev)
-                                    part_n = self._buf(f'bn.part{i + 1}', (ntn * nup.out_channels * 2,), device=dev) if training else None
+                                    part_n = self._buf(f'bn.part{i + 1}', (ntn * nup.out_channels * 2,), device=dev) if training and not inline else None
                                     ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names) + f'+ups.{i + 1}', hipops.resblock2_stage_split,
                                                      xr, aff, [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                                                     wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                                                     dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
                                                                for nm, rb in zip(names, rbs)], None, slope=LRELU_SLOPE, out_div=float(nk),
-                                                     bf16=True, io_bf16=3,
+                                                     bf16=True, io_bf16=3, fold=fold, up_acc=accs[i + 1] if inline else None,
                                                      up=(wps[f'ups.{i + 1}'], nup.bias.detach(), xr_n, part_n, nup.kernel_size, nup.stride, LRELU_SLOPE))
                                     if ok:
                                         up_done = ntn
+                        if inline and not ok and i + 1 < ns:
+                            raise RuntimeError('inline statistics: the fused stage kernel declined a shape its query accepted')
                         if not ok and C in (16, 32) and C in fuse_stage and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
                             branches = [dict(wps1=wps[nm + '.convs.0'], b1=rb.convs[0].bias.detach(),
                                              wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
@@ -816,14 +888,14 @@ class Generator(nn.Module):
                                 # leaves the chip, y is written instead
                                 y = torch.empty((B, 1, Lo), device=dev, dtype=torch.float32)
                                 ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names) + '+conv_post', hipops.resblock2_stage_split,
-                                                 xr, aff, branches, None, slope=LRELU_SLOPE, out_div=float(nk), bf16=True, io_bf16=3,
+                                                 xr, aff, branches, None, slope=LRELU_SLOPE, out_div=float(nk), bf16=True, io_bf16=3, fold=fold,
                                                  post=(wf['conv_post'], self.conv_post.bias.detach(), y, self.conv_post.kernel_size, 0.01))
                                 if not ok:
                                     y = None
                             if not ok:
                                 ok = self._timed('stage:' + '+'.join(f'{nm}.0&1' for nm in names), hipops.resblock2_stage_split, xr, aff,
                                                  branches, xs, slope=LRELU_SLOPE, out_div=float(nk),
-                                                 bf16=self.precision == 'bf16', io_bf16=3 if st else 0)
+                                                 bf16=self.precision == 'bf16', io_bf16=3 if st else 0, fold=fold)
                         if not ok and st and self.fuse_wide_stage and C >= 64 and all(f'{nm}.convs.{c}' in wps for nm in names for c in (0, 1)):
                             # wide stage on bf16 tensors: the WHOLE residual section in one kernel (v2w_stage_bf16_wide.hip): x read once,
                             # t1_j on chip, one fp32 accumulator over the branches
@@ -832,7 +904,9 @@ class Generator(nn.Module):
                                                    wps2=wps[nm + '.convs.1'], b2=rb.convs[1].bias.detach(), k=rb.kernel_size,
                                                    dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation)
                                               for nm, rb in zip(names, rbs)], xs, slope=LRELU_SLOPE, out_div=float(nk),
-                                             bf16=True, io_bf16=3)
+                                             bf16=True, io_bf16=3, fold=fold)
+                        if inline and not ok:
+                            raise RuntimeError('inline statistics: the stage kernel declined a shape its query accepted')
                         if st and not ok and C in (16, 32):
                             raise RuntimeError('bf16 storage: the fused narrow-stage kernel did not take this shape '
                                                '(set generator.bf16_storage = False)')
