@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 29
+#define V2W_ABI_VERSION 28
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -265,21 +265,6 @@ typedef struct {
     int32_t rb1;
     const void* in_b[4]; void* out_b[4];
     const void* add0; const void* add1;
-    /* BatchNorm statistics without launches of their own (ABI v29; bf16 != 0, io_bf16 == 3; modules.py:14,23 between two kernels of the bf16
-     * pipeline; csrc/v2w_bnacc.h).  PRODUCER side (fused upsampler only): up_stats_acc != NULL -> the per-tile (sum, sumsq) of up_out are
-     * ADDED to up_stats_acc [C / 2][4] int64 (two fixed-point words per sum; device-scope integer atomics: the totals do not depend on the
-     * order of the tiles) instead of / beside up_stats_part.  The caller zeroes the accumulator before the launch.
-     * CONSUMER side: in_stats_acc != NULL -> in_a / in_s are ignored; the kernel folds the statistics of ITS input itself,
-     *   a[b, c] = in_gb[b, c] * rstd[c],  s[b, c] = in_gb[b, C + c] - a[b, c] * mean[c]   (in_gb (B, 2 C) fp32 = gamma | beta of v2w_cond_gamma_beta)
-     * with mean / rstd from in_stats_acc [C][4] (as a producer filled it), in_count = B * L elements per channel and in_eps - the arithmetic
-     * of v2w_bn_finalize - and ONE workgroup updates in_running_mean / in_running_var (momentum in_momentum, unbiased variance) and
-     * increments in_nbt (all three may be NULL).  v2w_resblock2_stage_split_config() answers V2W_E_SHAPE when the kernel that would run
-     * cannot fold (then: v2w_bn_* launches and in_a / in_s). */
-    int64_t* up_stats_acc;
-    const int64_t* in_stats_acc; const float* in_gb;
-    float* in_running_mean; float* in_running_var; int64_t* in_nbt;
-    double in_count;
-    float in_eps, in_momentum;
 } v2w_stage_split_args;
 int v2w_resblock2_stage_split_fwd(const v2w_stage_split_args* a, void* stream);
 /* Shape query (ABI v28; host-only, nothing is launched or dereferenced): 0 when the call above would run this stage as one kernel, else the
@@ -324,9 +309,6 @@ typedef struct {
     int32_t _pad;
     float*  splitk_ws;  /* v2w_convt1d_fwd only: caller-owned split-over-C_in scratch, as in v2w_conv1d_args (NULL: unsplit) */
     int64_t splitk_ws_bytes;
-    int64_t* stats_acc; /* v2w_convt1d_bf16_fwd only (ABI v29; else NULL): [C_out][4] int64 fixed-point accumulator the per-tile (sum, sumsq) are
-                         * ADDED to with integer atomics (order-independent totals; zeroed by the caller) - the statistics a consumer folds
-                         * itself (v2w_stage_split_args::in_stats_acc; csrc/v2w_bnacc.h).  stats_part may then be NULL */
 } v2w_convt1d_args;
 int v2w_convt1d_fwd(const v2w_convt1d_args* a, void* stream);
 long long v2w_convt1d_splitk_ws_bytes(const v2w_convt1d_args* a);   /* as v2w_conv1d_splitk_ws_bytes */

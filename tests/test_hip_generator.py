@@ -9,7 +9,7 @@ import torch
 
 from oracle import vec2wav_oracle as O
 from tests.golden_util import golden_names, load_golden, case_setup, probe_summary, tol_for
-from wavthruvec_pytorch_amd import synthetic, hipops
+from wavthruvec_pytorch_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # |dy| bar of BASELINE.json north_star (fp32)
@@ -223,46 +223,65 @@ def test_generator_resblock1_bf16_storage(dev, B, T, rates, ks, training):
     assert (y2.cpu() - want).abs().max().item() <= 6e-3
 
 
-@pytest.mark.parametrize('B,T', [(3, 64), (2, 128), (5, 16)])
-def test_generator_inline_batchnorm_statistics(dev, B, T):
-    """Statistics without launches (csrc/v2w_bnacc.h; train mode, bf16 storage): the producing kernels add their BatchNorm sums to an int64
-    fixed-point accumulator with integer atomics and every stage kernel folds the statistics of its own input - against the schedule with
-    the reduce / finalize launches between the stage kernels: the same tile sums either way, added exactly instead of in fp64, so outputs and
-    running statistics agree to rounding; num_batches_tracked advances once per forward; two runs are bit-identical (integer atomics are
-    order-independent); and the launches are really gone (no statistics entry points called)."""
+@pytest.mark.parametrize('training,precision', [(True, 'f32'), (False, 'f32'), (True, 'bf16'), (False, 'bf16'), (False, 'f16x3')])
+def test_generator_launch_plan_replays_the_planned_forward(dev, training, precision):
+    """schedule.py: the first no-grad forward of a configuration is planned under a recorder, later ones replay the tape with the three input
+    pointers and the output rebound.  Replays must equal forwards that are planned every time (`use_launch_plan = False`) bit for bit - on
+    NEW inputs, across a parameter update in eval mode (the replayed plan must fold the new weights once and then stop folding), across a
+    shape change (buffers are reallocated: the old plans are dropped) and back."""
     h = synthetic.make_hparams(num_wv_feat=768)
     sd = synthetic.make_state_dict(h, seed=5)
-    inp = to_dev(synthetic.make_inputs(h, B, T, seed=9), dev)
-    res = {}
-    for inline in (True, False):
-        g = build_generator(h, sd, dev, training=True)
-        g.precision = 'bf16'
-        g.inline_stats = inline
-        calls = []
-        keep = {}
-        for nm in ('bn_reduce_partials', 'bn_reduce_finalize_slices', 'bn_finalize', 'bn_stats'):
-            keep[nm] = getattr(hipops, nm)
-            setattr(hipops, nm, (lambda f, n: (lambda *a, **k: (calls.append(n), f(*a, **k))[1]))(keep[nm], nm))
-        try:
-            with torch.no_grad():
-                y1 = g(*inp).clone()
-                y2 = g(*inp).clone()
-        finally:
-            for nm, f in keep.items():
-                setattr(hipops, nm, f)
-        assert g._inline_stats_ok(B, T)
-        assert bool(calls) == (not inline), calls
-        res[inline] = (y1, y2, {k: v.clone() for k, v in g.state_dict().items() if 'batch_nrom' in k})
-        assert torch.isfinite(y1).all()
-    (a1, a2, sa), (b1, b2, sb) = res[True], res[False]
-    # the running statistics move between the two forwards of a generator, the batch statistics do not: y1 == y2 bit for bit
-    assert torch.equal(a1, a2) and torch.equal(b1, b2)
-    assert (a1 - b1).abs().max().item() <= 2e-5, (a1 - b1).abs().max().item()
-    for k in sa:
-        if k.endswith('num_batches_tracked'):
-            assert int(sa[k]) == int(sb[k]) == 2, (k, sa[k], sb[k])
-        else:
-            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-6), (k, (sa[k] - sb[k]).abs().max().item())
+    if not training:
+        O.calibrate_running_stats(sd, h, *synthetic.make_inputs(h, 2, 16, seed=1))
+    ga, gb = build_generator(h, sd, dev, training=training), build_generator(h, sd, dev, training=training)
+    ga.precision = gb.precision = precision
+    gb.use_launch_plan = False
+    inputs = [to_dev(synthetic.make_inputs(h, 2, 16, seed=s), dev) for s in (1, 2, 3)]
+    other = to_dev(synthetic.make_inputs(h, 1, 24, seed=4), dev)
+    with torch.no_grad():
+        for step, inp in enumerate(inputs + [other] + inputs):
+            ya, yb = ga(*inp), gb(*inp)
+            assert torch.equal(ya, yb), (step, (ya - yb).abs().max().item())
+            if step == 1:
+                assert len(ga._tapes) >= 1 and not gb._tapes
+                n_launch = max(t.launches for t in ga._tapes.values())
+                assert 0 < n_launch <= 80
+            if step == 2:          # an optimizer step's worth of change, in place (version counters move)
+                for g in (ga, gb):
+                    g.conv_pre.weight_g.mul_(1.01)
+                    g.resblocks[3].convs[0].weight_v.add_(0.001)
+        for bname in ('running_mean', 'running_var', 'num_batches_tracked'):
+            for ca, cb in zip(ga.cbns, gb.cbns):
+                assert torch.equal(getattr(ca.batch_nrom, bname), getattr(cb.batch_nrom, bname))
+        if not training:           # eval: a parameter update is followed by ONE forward that folds (its own plan), then the plan without folds again
+            for g in (ga, gb):
+                g.conv_post.weight_g.mul_(0.99)
+            for _ in range(2):
+                assert torch.equal(ga(*inputs[0]), gb(*inputs[0]))
+            keys = [k for k in ga._tapes if k[0] == tuple(inputs[0][0].shape)]
+            assert {k[-1] for k in keys} == {'folded', 'refold'}, [k[-1] for k in keys]
+            folded = [ga._tapes[k] for k in keys if k[-1] == 'folded'][0]
+            refold = [ga._tapes[k] for k in keys if k[-1] == 'refold'][0]
+            assert folded.launches < refold.launches
+
+
+def test_backward_is_refused_after_a_refold_from_changed_weights(dev):
+    """backward.py: the folded weights a backward reads live in module-owned buffers.  A later forward that folds CHANGED parameters into them
+    (here: a replayed launch plan after an in-place update) must make the pending backward fail loudly; a later forward of unchanged
+    parameters must not."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = build_generator(h, synthetic.make_state_dict(h, seed=5), dev, training=True)
+    inp = to_dev(synthetic.make_inputs(h, 2, 8, seed=1), dev)
+    y = g(*inp)
+    with torch.no_grad():
+        g(*inp); g(*inp)                       # planned, then replayed: same parameter values, the buffers hold the same folds
+    y.sum().backward()
+    y = g(*inp)
+    with torch.no_grad():
+        g.conv_pre.weight_g.mul_(1.5)
+        g(*inp)                                # replays the plan: folds the CHANGED weights into the buffers the pending backward reads
+    with pytest.raises(RuntimeError, match='re-folded'):
+        y.sum().backward()
 
 
 def test_generator_bf16_storage_falls_back_when_a_layer_has_no_bf16_kernel(dev):

@@ -12,7 +12,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 29
+ABI_VERSION = 28
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -36,7 +36,7 @@ class ConvT1dArgs(C.Structure):
     _fields_ = [('in_', _fp), ('wf', _fp), ('wp', _fp), ('bias', _fp), ('out', _fp), ('stats_part', _fp),
                 ('B', C.c_int32), ('C_in', C.c_int32), ('C_out', C.c_int32), ('L', C.c_int32),
                 ('k', C.c_int32), ('u', C.c_int32), ('slope', C.c_float), ('algo', C.c_int32), ('io_bf16', C.c_int32), ('_pad', C.c_int32),
-                ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64), ('stats_acc', _fp)]
+                ('splitk_ws', _fp), ('splitk_ws_bytes', C.c_int64)]
 
 
 class PairArgs(C.Structure):
@@ -73,10 +73,7 @@ class StageSplitArgs(C.Structure):
                 ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float),
                 ('up_wps', _fp), ('up_bias', _fp), ('up_out', _fp), ('up_stats_part', _fp),
                 ('up_k', C.c_int32), ('up_u', C.c_int32), ('up_slope', C.c_float), ('rb1', C.c_int32),
-                ('in_b', _P4), ('out_b', _P4), ('add0', _fp), ('add1', _fp),
-                ('up_stats_acc', _fp), ('in_stats_acc', _fp), ('in_gb', _fp),
-                ('in_running_mean', _fp), ('in_running_var', _fp), ('in_nbt', _fp),
-                ('in_count', C.c_double), ('in_eps', C.c_float), ('in_momentum', C.c_float)]
+                ('in_b', _P4), ('out_b', _P4), ('add0', _fp), ('add1', _fp)]
 
 
 class BranchConvsArgs(C.Structure):
@@ -186,7 +183,11 @@ SIGNATURES = {
     'v2w_conv_post_tanh': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
 }
 
+# entry points that LAUNCH (their last argument is the stream); the others are host-only queries.  schedule.Recorder tapes the former.
+LAUNCHERS = frozenset(n for n, (_r, a) in SIGNATURES.items() if a and a[-1] is _fp)
+
 _lib = None
+_recorder = None      # schedule.Recorder while a forward is being recorded (one forward at a time per process thread of control)
 
 
 class HipLibraryError(RuntimeError):
@@ -208,6 +209,8 @@ def lib_path() -> str:
 def load():
     """Load (once) and return the library handle; raises HipLibraryError when it is absent or stale."""
     global _lib
+    if _recorder is not None:
+        return _recorder
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
@@ -228,6 +231,13 @@ def load():
         raise HipLibraryError(f'ABI version mismatch: library {lib.v2w_abi_version()}, binding {ABI_VERSION}')
     _lib = lib
     return lib
+
+
+def set_recorder(rec):
+    """Install (or, with None, remove) the recorder `load()` hands out instead of the library; returns the previous one."""
+    global _recorder
+    prev, _recorder = _recorder, rec
+    return prev
 
 
 def check(rc: int, what: str) -> None:

@@ -72,7 +72,9 @@ def generator_backward(gen, sv, dy):
     # the folded weights live in module-owned buffers that the NEXT forward's fold overwrites: harmless while the parameters are unchanged
     # (the same values again); parameters that changed in between - an optimizer step between this graph's forward and its backward -
     # are what autograd itself refuses ("modified by an inplace operation")
-    if sv.get('vers') is not None and gen._fold_key.get('vers') is not None and gen._fold_key['vers'] != sv['vers']:
+    # (`gen`: the fold generation - every fold, a replayed launch plan's included, bumps it.  Unchanged: the buffers are this forward's.  Changed:
+    # they were folded again, from whatever the parameters held then - the same values unless a parameter's version moved since the forward)
+    if sv.get('vers') is not None and gen._fold_key.get('gen') != sv.get('gen') and gen._param_versions() != sv['vers']:
         raise RuntimeError('Generator (HIP) backward: the generator\'s weights were modified and re-folded by a later forward before this '
                            'backward ran (the saved forward used the earlier weights)')
     x, spk, nz, y, training = sv['x'], sv['spk'], sv['nz'], sv['y'], sv['training']

@@ -935,7 +935,6 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
         const int rc = v2w_convt1d_bf16_res(a, g.UP, g.hl, g.KV, stream, ntiles_out, cfg);
         if (rc != V2W_E_SHAPE) return rc;
     }
-    if (a->stats_acc) return V2W_E_SHAPE;     // the statistics accumulator (v2w_bnacc.h) exists in the resident-tile kernels only: queries say so too
     const int rows = p.Cout;
     // the stats tiling (rows of stats_part) depends on the tile width only: every configuration here is 256 or 512 positions wide, the
     // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin
@@ -986,6 +985,9 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t
         if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0) return launch_bf16<1, 2, 2, 2, V2W_BF_CK, false>(ps, n, stream, cfg);
     if (a->C_out % 128 == 0 && tiles >= 2 * 512) return launch_bf16<2, 4, 2, 2>(ps, n, stream, cfg);     // 128 x 256
     if (tiles >= 256 && a->C_in == 64 && a->io_bf16 == 3) return launch_bf16<1, 4, 2, 2, 64>(ps, n, stream, cfg);   // 64 x 256, bf16 tensors: the 64 input channels as ONE chunk
+    // a deep layer (conv_pre: 768 / 1024 input channels x 7 taps) on a grid of one 64 x 256 tile per CU or less walks 24+ chunks behind a
+    // barrier each: 64 x 128 tiles (twice the workgroups) with 64-channel chunks (half the barriers) - 135-143 -> 88-98 us at B = 32 x T = 256
+    if (tiles >= 128 && tiles < 512 && n == 1 && a->C_in >= 512 && a->C_in % 64 == 0 && a->io_bf16 == 2) return launch_bf16<1, 2, 2, 2, 64>(ps, n, stream, cfg);
     if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream, cfg);                                 // 64 x 256
     return launch_bf16<1, 2, 2, 2>(ps, n, stream, cfg);                                                   // 64 x 128: latency sizes
 }

@@ -23,7 +23,6 @@
 //     bias; the epilogue passes 32 positions at a time through a wave-private scratch [32 channels][5 x 32 outputs] (over the dead tile).
 #include <type_traits>
 #include "v2w_tile.h"
-#include "v2w_bnacc.h"
 
 namespace {
 
@@ -35,7 +34,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct CtArgs {
     const unsigned short* in; const unsigned char* wps; const float* bias; unsigned short* out; float* stats_part;
-    long long* stats_acc;      // optional: the per-tile sums are ADDED here ([CoutR][4] int64, v2w_bnacc.h) - instead of / beside stats_part
     int B, Cin, CoutR, L;      // CoutR: real output channels; the kernel's rows are CoutR * UP
     int KV, hl;                // virtual taps and the left halo (input positions)
     int hla, xrows, ntl, ntiles;
@@ -268,7 +266,7 @@ convt_bf16_res_kernel(const CtArgs a) {
     //   UP = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1} each
     constexpr int CPB = 32 / UP;                                                // channels per 32-row block
     const int Lout = L * U;
-    const bool stats = a.stats_part != nullptr || a.stats_acc != nullptr;
+    const bool stats = a.stats_part != nullptr;
     if constexpr (UP == 5) {
         // ---- the exact five phases: block (i, j), register e, lane (lr, hk) = row 32 i + 8 (e / 4) + 4 hk + e % 4 of this wave's 160 =
         // (channel row / 5, phase row % 5) at input position 32 j + lr.  Sixteen channels (rows 0..79 / 80..159: whole register quads) of 32
@@ -323,11 +321,8 @@ convt_bf16_res_kernel(const CtArgs a) {
                 float t1 = s1[h] + __shfl_xor(s1[h], 16, 64), t2 = s2[h] + __shfl_xor(s2[h], 16, 64);
                 t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
                 if (lane < 16) {
-                    if (a.stats_part) {
-                        gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 0] = t1;
-                        gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 1] = t2;
-                    }
-                    if (a.stats_acc) bnacc_add(a.stats_acc, co0 + 16 * h + lane, t1, t2);
+                    gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 0] = t1;
+                    gptr<float>(a.stats_part)[((size_t)tile * CoutR + co0 + 16 * h + lane) * 2 + 1] = t2;
                 }
             }
         }
@@ -458,11 +453,8 @@ convt_bf16_res_kernel(const CtArgs a) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WN; ++w) { t1 += red[(w * (MT / UP) + c) * 2]; t2 += red[(w * (MT / UP) + c) * 2 + 1]; }
-            if (a.stats_part) {
-                gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
-                gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
-            }
-            if (a.stats_acc) bnacc_add(a.stats_acc, m0 / UP + c, t1, t2);
+            gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 0] = t1;
+            gptr<float>(a.stats_part)[((size_t)tile * CoutR + m0 / UP + c) * 2 + 1] = t2;
         }
     }
 }
@@ -510,7 +502,6 @@ int v2w_convt1d_bf16_res(const v2w_convt1d_args* a, int UP, int hl, int KV, hipS
     CtArgs p{};
     p.in = reinterpret_cast<const unsigned short*>(a->in); p.wps = reinterpret_cast<const unsigned char*>(a->wp); p.bias = a->bias;
     p.out = reinterpret_cast<unsigned short*>(a->out); p.stats_part = a->stats_part;
-    p.stats_acc = reinterpret_cast<long long*>(a->stats_acc);
     p.B = a->B; p.Cin = a->C_in; p.CoutR = a->C_out; p.L = a->L; p.KV = KV; p.hl = hl; p.slope = a->slope;
     const int rows = a->C_out * UP;
     if (a->u == 5) {

@@ -471,7 +471,6 @@ int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, 
         if (rc != V2W_E_SHAPE) return rc;
     }
     if (a->post_out) return V2W_E_SHAPE;
-    if (a->in_stats_acc || a->up_stats_acc) return V2W_E_SHAPE;     // the in-kernel BatchNorm fold (v2w_bnacc.h) exists in the resident-tile / n16 kernels only
     if (a->C == 32) return launch_stage_bf16<32>(a, stream);
     if (a->C == 16) return launch_stage_bf16<16>(a, stream);
     return V2W_E_SHAPE;

@@ -18,7 +18,6 @@
 #include <type_traits>
 #include <utility>
 #include "v2w_tile.h"
-#include "v2w_bnacc.h"
 
 namespace {
 
@@ -39,7 +38,6 @@ struct N16Args {
     const float* post_w; const float* post_b; float* post_out;
     float post_slope;
     int nadv, hout;
-    BnFoldArgs fold;          // fold.acc != NULL: the BatchNorm of the stage's input is folded here from the producer's totals (v2w_bnacc.h)
 };
 
 __device__ __forceinline__ unsigned int n16_pack2(float lo, float hi) {
@@ -153,7 +151,6 @@ n16_stage_kernel(const N16Args a) {
     // affine, commit = activation, bf16 rows into LDS.  The loads of tile i + 1 are issued before the stores of tile i and land under them.
     u32x2 pf[NPF][4];
     float av[4], sv[4];
-    float* const mrtab = reinterpret_cast<float*>(smem_n + (2 * XR + W + 16) * RB + 512);     // mean[16] | rstd[16], behind the tail's weights
     const int cq = tid & 3;                                                     // (NTH % 4 == 0: a thread keeps its channel quad)
     auto issue_x = [&](int tile) {
         const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * a.nadv - a.hout;
@@ -169,21 +166,10 @@ n16_stage_kernel(const N16Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[s][i] = *gptr<const u32x2>(inb + (size_t)i * L * 2 + vo);
         }
-        if (a.fold.acc) {           // (mean, rstd) of the 16 channels: in LDS since the kernel's start; gamma | beta of this tile's sample
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fold.gb + (size_t)b * 32 + 4 * cq);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(a.fold.gb + (size_t)b * 32 + 16 + 4 * cq);
-            const f32x4 mn = *reinterpret_cast<const f32x4*>(mrtab + 4 * cq), rs = *reinterpret_cast<const f32x4*>(mrtab + 16 + 4 * cq);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = ga[i] * rs[i];
-                sv[i] = fmaf(-av[i], mn[i], be[i]);
-            }
-        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             av[i] = a.in_a ? a.in_a[b * 16 + 4 * cq + i] : 1.f;
             sv[i] = a.in_a ? a.in_s[b * 16 + 4 * cq + i] : 0.f;
-        }
         }
     };
     // rows of the x tile: lrelu(x) (the conv operand); rows of the r tile: x itself (the residual), both bf16, 0 outside the sequence
@@ -217,14 +203,6 @@ n16_stage_kernel(const N16Args a) {
     float* const wl = reinterpret_cast<float*>(smem_n + (2 * XR + W + 16) * RB);       // (behind the x, t1 and r tiles)
     if constexpr (POST) {
         if (tid < 128) wl[tid] = (tid & 7) < 7 ? a.post_w[(tid & 7) * 16 + (tid >> 3)] : 0.f;
-    }
-    if (a.fold.acc) {
-        if (tid < 16) {
-            float mean, rstd;
-            bnacc_mean_rstd(a.fold, tid, blockIdx.x == 0, mean, rstd);
-            mrtab[tid] = mean; mrtab[16 + tid] = rstd;
-        }
-        __syncthreads();
     }
     issue_x(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -413,13 +391,7 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
     // x, t1 (+ 16 rows of slack behind it: conv2's taps past its end) and r tiles; the store scratch [16][W + 12] floats overlays them
     const size_t tiles = (size_t)(XR + W + 16 + XR) * 32, scratch = (size_t)16 * (W + 12) * sizeof(float) + (post ? (size_t)(NTH / 2) * 16 : 0);
     if (scratch > tiles) return V2W_E_SHAPE;                                    // (the scratch overlays the tiles)
-    const size_t lds = tiles + 512 + 128;                                       // + the tail's weights + (mean, rstd) of the folded BatchNorm
-    if (q->in_stats_acc) {                     // the statistics of the stage's input are folded in the kernel (v2w_bnacc.h)
-        if (!q->in_gb || !(q->in_count >= 1.0) || (reinterpret_cast<uintptr_t>(q->in_gb) & 15)) return V2W_E_ARG;
-        p.fold.acc = reinterpret_cast<const long long*>(q->in_stats_acc); p.fold.gb = q->in_gb;
-        p.fold.running_mean = q->in_running_mean; p.fold.running_var = q->in_running_var; p.fold.nbt = reinterpret_cast<long long*>(q->in_nbt);
-        p.fold.count = q->in_count; p.fold.eps = q->in_eps; p.fold.momentum = q->in_momentum;
-    }
+    const size_t lds = tiles + (post ? 512 : 0);
     if (v2w_dry(stream)) return 0;
     const int ncu = v2w_num_cus();
     // persistent: the registers hold the stage's weights, so a workgroup walks tiles; 8 waves per CU (2 per SIMD: ~230 registers each)

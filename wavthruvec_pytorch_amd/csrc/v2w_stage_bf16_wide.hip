@@ -17,7 +17,6 @@
 //   * weights: the fragments of v2w_pack_bf16 / v2w_split_pack_batch from L2 through a four-slot register ring, three k-steps ahead.
 #include <type_traits>
 #include "v2w_tile.h"
-#include "v2w_bnacc.h"
 
 namespace {
 
@@ -72,10 +71,6 @@ struct WideArgs {
     int rb1, ntiles1;
     const unsigned short* in_b[V2W_WS_MAXB]; unsigned short* out_b[V2W_WS_MAXB];
     const unsigned short* add0; const unsigned short* add1;
-    // statistics without launches (v2w_bnacc.h): fold.acc != NULL - this kernel turns the BatchNorm totals of its input into (a, s) itself
-    // (in_a / in_s unused); up_acc != NULL - the fused upsampler adds its per-tile sums to the next stage's accumulator
-    BnFoldArgs fold;
-    long long* up_acc;
 };
 
 __device__ __forceinline__ unsigned int ws_pack2(float lo, float hi) {
@@ -639,17 +634,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
         float v = 0.f;
         for (int j = rb1 ? prob : 0; j < (rb1 ? prob + 1 : nk); ++j) v += a.bias2[j] ? a.bias2[j][c] : 0.f;
         b2tab[c] = v;
-        if (a.fold.acc) {
-            // the BatchNorm of this stage's input, folded here from the producer's totals (modules.py:23-30): no launch of its own
-            float mean, rstd;
-            bnacc_mean_rstd(a.fold, c, tile == 0, mean, rstd);
-            const float av = a.fold.gb[(size_t)b * 2 * C + c] * rstd;
-            atab[c] = av;
-            atab[C + c] = fmaf(-av, mean, a.fold.gb[(size_t)b * 2 * C + C + c]);
-        } else {
-            atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
-            atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
-        }
+        atab[c] = a.in_a ? a.in_a[b * C + c] : 1.f;
+        atab[C + c] = a.in_a ? a.in_s[b * C + c] : 0.f;
     }
     __syncthreads();
     commit_x();
@@ -747,7 +733,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
         // 32 lanes of a channel meet through a wave-private LDS scratch [channel][32][2] that ONE pass of the wave sums per (channel, stat)
         // in a fixed order - instead of a DPP tree + readlanes per register quad (30 of the ~100 vector instructions of a quad).
         const int Lout = L * UPF;
-        const bool stats = a.up_stats != nullptr || a.up_acc != nullptr;
+        const bool stats = a.up_stats != nullptr;
         unsigned char* const obase = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * CU * Lout * 2;
         const int ncen = nto - 2;                             // input positions this tile is the centre of: window columns h2max + 1 ..
         float* const ssc = ured + WN * CU * 2 + wave * (CHW * 64);       // this wave's scratch (over the dead x tile)
@@ -810,11 +796,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < WN; ++w) { t1 += ured[(w * CU + c) * 2]; t2 += ured[(w * CU + c) * 2 + 1]; }
-                if (a.up_stats) {
-                    gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 0] = t1;
-                    gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 1] = t2;
-                }
-                if (a.up_acc) bnacc_add(a.up_acc, c, t1, t2);
+                gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 0] = t1;
+                gptr<float>(a.up_stats)[((size_t)tile * CU + c) * 2 + 1] = t2;
             }
         }
         V2W_STAMP(23);
@@ -950,7 +933,6 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
         if ((long long)(C / 2) * q->L * UPF * 2 >= (1ll << 31)) return V2W_E_SHAPE;      // 32-bit offsets inside one batch item
         p.up_w = static_cast<const unsigned char*>(q->up_wps); p.up_bias = q->up_bias; p.up_out = reinterpret_cast<unsigned short*>(q->up_out);
         p.up_stats = q->up_stats_part; p.up_slope = q->up_slope;
-        p.up_acc = reinterpret_cast<long long*>(q->up_stats_acc);
         p.hout = 1;
     } else if (q->rb1) {                       // ResBlock1 pair mode: one problem per branch, each with its own input / output tensor
         if (q->up_out || q->post_out || UPF > 0) return V2W_E_ARG;
@@ -963,12 +945,6 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
         if ((reinterpret_cast<uintptr_t>(q->add0) & 15) || (reinterpret_cast<uintptr_t>(q->add1) & 15) || (q->add1 && !q->add0)) return V2W_E_ARG;
         p.rb1 = 1; p.add0 = reinterpret_cast<const unsigned short*>(q->add0); p.add1 = reinterpret_cast<const unsigned short*>(q->add1);
     } else if (!q->out) return V2W_E_ARG;
-    if (q->in_stats_acc) {                     // the statistics of the stage's input are folded in the kernel (v2w_bnacc.h)
-        if (!q->in_gb || !(q->in_count >= 1.0) || q->rb1) return V2W_E_ARG;
-        p.fold.acc = reinterpret_cast<const long long*>(q->in_stats_acc); p.fold.gb = q->in_gb;
-        p.fold.running_mean = q->in_running_mean; p.fold.running_var = q->in_running_var; p.fold.nbt = reinterpret_cast<long long*>(q->in_nbt);
-        p.fold.count = q->in_count; p.fold.eps = q->in_eps; p.fold.momentum = q->in_momentum;
-    }
     p.nto = (W - 2 * p.h2max) & ~3;
     if (p.hout) p.nto = ((W - 2 * p.h2max - 2 * p.hout) & ~3) + 2 * p.hout;     // the tile advances by nto - 2 hout: a multiple of 4
     if (p.nto - 2 * p.hout < W / 2) return V2W_E_SHAPE;

@@ -398,8 +398,6 @@ static int stage_split_dispatch(const v2w_stage_split_args* a, void* stream, int
     }
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
-    if ((a->in_stats_acc || a->up_stats_acc) && !(a->bf16 && a->io_bf16 == 3)) return V2W_E_SHAPE;   // statistics without launches: the bf16-tensor kernels
-    if (a->up_stats_acc && !a->up_out) return V2W_E_ARG;
     for (int j = 0; j < a->nk; ++j) {
         if (!a->wps1[j] || !a->wps2[j] || !a->sc1[j] || !a->sc2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;
@@ -436,7 +434,6 @@ extern "C" int v2w_resblock2_stage_split_config(const v2w_stage_split_args* a) {
         if (!q.sc1[j]) q.sc1[j] = dummy;
         if (!q.sc2[j]) q.sc2[j] = dummy;
     }
-    if (q.in_stats_acc) { if (!q.in_gb) q.in_gb = dummy; if (!(q.in_count >= 1.0)) q.in_count = 1.0; }      // "would the kernel fold the statistics itself?"
     return stage_split_dispatch(&q, V2W_DRY_STREAM, nullptr);
 }
 // Rows of up_stats_part ([rows][C / 2][2]) a fused-upsampler call (up_u != 0) fills; <= 0: the call would not run fused (error code or 0)
@@ -453,7 +450,6 @@ extern "C" int v2w_resblock2_stage_up_tiles(const v2w_stage_split_args* a) {
         if (!q.sc1[j]) q.sc1[j] = dummy;
         if (!q.sc2[j]) q.sc2[j] = dummy;
     }
-    if (q.in_stats_acc) { if (!q.in_gb) q.in_gb = dummy; if (!(q.in_count >= 1.0)) q.in_count = 1.0; }
     int n = 0;
     const int rc = stage_split_dispatch(&q, V2W_DRY_STREAM, &n);
     return rc == 0 ? n : rc;

@@ -186,13 +186,17 @@ class SplitKSlab:
     """Caller-owned scratch of the split over C_in (v2w_conv1d_args::splitk_ws, ABI v28): launches too small to fill the chip - inference at
     B = 1 - store per-slice partial sums here and a second kernel adds them.  The library allocates nothing: the OWNER of a slab (a
     Generator, one slab per stream it launches on) passes it to conv1d / conv1d_multi / convt1d as `splitk_ws=`; launches that share a
-    slab must be ordered on one stream.  Grow-only, so a warmed-up module never allocates inside a HIP graph capture."""
+    slab must be ordered on one stream.  Grow-only, so a warmed-up module never allocates inside a HIP graph capture; a slab that is outgrown is
+    kept (`retired`), never freed under a captured graph that writes its partial sums there."""
 
     def __init__(self):
         self.t = None
+        self.retired = []     # superseded slabs stay alive with their owner: a HIP graph or a launch plan recorded earlier holds their address
 
     def ensure(self, nbytes, device):
         if self.t is None or self.t.device != device or self.t.numel() * 4 < nbytes:
+            if self.t is not None:
+                self.retired.append(self.t)
             self.t = torch.empty(((nbytes + 3) // 4,), device=device, dtype=torch.float32)
         return self.t
 
@@ -260,30 +264,27 @@ def pack_bf16_convt(wf, u, out=None):
     return out
 
 
-def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16=0, stats_acc=None):
+def _convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16=0):
     B, ci, L = x.shape
     a = _hip.ConvT1dArgs()
     a.in_ = x.data_ptr(); a.wf = None; a.wp = _hip.ptr(wps); a.bias = _hip.ptr(bias); a.out = _hip.ptr(out)
     a.stats_part = _hip.ptr(stats_part)
-    a.stats_acc = stats_acc if isinstance(stats_acc, int) else _hip.ptr(stats_acc)
     a.B, a.C_in, a.C_out, a.L, a.k, a.u = B, ci, out.shape[1], L, k, u
     a.slope = slope; a.algo = ALGO_BF16; a.io_bf16 = io_bf16
     return a
 
 
-def convt_bf16_stats_tiles(x, out, k, u, io_bf16=0, acc=False):
+def convt_bf16_stats_tiles(x, out, k, u, io_bf16=0):
     """Rows of `stats_part` the bf16 transposed conv fills for exactly this call (tensors, io_bf16: the kernel and with it the tile
-    width follow them); 0: shape not served.  acc: ask for the kernel that ADDS its sums to a statistics accumulator
-    (v2w_convt1d_args::stats_acc) - 0 when the kernel that would run has no such form."""
-    n = _hip.load().v2w_convt1d_bf16_tiles(C.byref(_convt_bf16_args(x, None, None, out, k, u, 1.0, None, io_bf16, stats_acc=4096 if acc else None)))
+    width follow them); 0: shape not served."""
+    n = _hip.load().v2w_convt1d_bf16_tiles(C.byref(_convt_bf16_args(x, None, None, out, k, u, 1.0, None, io_bf16)))
     return n if n > 0 else 0
 
 
-def convt1d_bf16(x, wps, bias, out, *, k, u, slope=1.0, stats_part=None, io_bf16=0, stats_acc=None):
+def convt1d_bf16(x, wps, bias, out, *, k, u, slope=1.0, stats_part=None, io_bf16=0):
     """Fused leaky_relu -> ConvTranspose1d(k, stride u, padding (k-u)//2) -> +bias on the bf16 matrix pipe (fp32 accumulate).
-    io_bf16 = 3: x and out are bf16 tensors.  stats_acc (int64 [C_out][4], zeroed by the caller): the BatchNorm sums of the output are added
-    to it with integer atomics (csrc/v2w_bnacc.h) - the statistics the next stage kernel folds itself."""
-    _hip.check(_hip.load().v2w_convt1d_bf16_fwd(C.byref(_convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16, stats_acc)), _stream(x)),
+    io_bf16 = 3: x and out are bf16 tensors."""
+    _hip.check(_hip.load().v2w_convt1d_bf16_fwd(C.byref(_convt_bf16_args(x, wps, bias, out, k, u, slope, stats_part, io_bf16)), _stream(x)),
                'v2w_convt1d_bf16_fwd')
     return out
 
@@ -570,34 +571,26 @@ def resblock1_pairs_ok(B, Cc, L, ks, dil1s, dil2s, *, slope) -> bool:
     return _hip.load().v2w_resblock2_stage_split_config(C.byref(a)) == 0
 
 
-def resblock2_stage_split_ok(B, Cc, L, ks, dil1s, dil2s, *, slope, bf16=True, io_bf16=3, fold=False, post_k=0) -> bool:
+def resblock2_stage_split_ok(B, Cc, L, ks, dil1s, dil2s, *, slope, bf16=True, io_bf16=3) -> bool:
     """Shape query: would resblock2_stage_split run this stage (nk branches of kernel sizes `ks`, dilations `dil1s` / `dil2s`) as one
-    kernel on aligned tensors?  Asked of the library (v2w_resblock2_stage_split_config), nothing is launched.
-    fold: ... and fold the BatchNorm statistics of its input itself (in_stats_acc)?  post_k: ... with the generator's tail (post_k taps) behind it?"""
+    kernel on aligned tensors?  Asked of the library (v2w_resblock2_stage_split_config), nothing is launched."""
     a = _hip.StageSplitArgs()
     for j, (k, d1, d2) in enumerate(zip(ks, dil1s, dil2s)):
         a.k[j], a.dil1[j], a.dil2[j] = k, d1, d2
     a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
     a.slope, a.out_div, a.bf16, a.io_bf16 = slope, float(len(ks)), int(bf16), io_bf16
-    if fold:
-        a.in_stats_acc = 4096
-    if post_k:
-        a.post_w, a.post_out, a.post_k, a.post_slope = 4096, 4096, post_k, 0.01
     return _hip.load().v2w_resblock2_stage_split_config(C.byref(a)) == 0
 
 
-def resblock2_stage_up_tiles(B, Cc, L, ks, dil1s, dil2s, *, slope, up_k, up_u, up_slope, fold=False) -> int:
+def resblock2_stage_up_tiles(B, Cc, L, ks, dil1s, dil2s, *, slope, up_k, up_u, up_slope) -> int:
     """Rows of the `stats_part` array the stage kernel WITH the next stage's upsampler fused behind it fills (resblock2_stage_split(up=...)),
-    or 0 when the library does not run this stage fused (shape query, nothing is launched).  fold: as resblock2_stage_split_ok."""
+    or 0 when the library does not run this stage fused (shape query, nothing is launched)."""
     a = _hip.StageSplitArgs()
     for j, (k, d1, d2) in enumerate(zip(ks, dil1s, dil2s)):
         a.k[j], a.dil1[j], a.dil2[j] = k, d1, d2
     a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
     a.slope, a.out_div, a.bf16, a.io_bf16 = slope, float(len(ks)), 1, 3
     a.up_k, a.up_u, a.up_slope = up_k, up_u, up_slope
-    if fold:
-        a.in_stats_acc = 4096
-        a.up_stats_acc = 4096
     n = _hip.load().v2w_resblock2_stage_up_tiles(C.byref(a))
     return n if n > 0 else 0
 
@@ -628,24 +621,16 @@ def resblock1_pairs_bf16(ins, in_affine, branches, outs, *, slope, out_div=0.0, 
     return True
 
 
-def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None, up=None, fold=None, up_acc=None):
+def resblock2_stage_split(x, in_affine, branches, out, *, slope, out_div, bf16=False, io_bf16=0, post=None, up=None):
     """Split-operand (f16x3 / bf16) form of resblock2_stage for C == 32.  `branches`: list of dicts(wps1, b1, wps2, b2, k, dil1, dil2)
     with wps* = (fragments, scale record) of pack_split / SplitPlan.  Returns False when the shape is not taken.
     up = (wps of pack_bf16_convt, bias, out (B, C / 2, u L) bf16, stats_part | None, k, u, slope): the NEXT stage's upsampler run on the
-    stage's output inside the same kernel (`out` may be None: it is not written).
-    Statistics without launches (csrc/v2w_bnacc.h): fold = dict(acc, gb, count, eps, momentum, running_mean, running_var, nbt) - the kernel
-    folds the BatchNorm of ITS input from the accumulator `acc` (in_affine is None then); up_acc: the fused upsampler adds the sums of its
-    output to that accumulator (int64 [C / 2][4], zeroed by the caller)."""
+    stage's output inside the same kernel (`out` may be None: it is not written)."""
     B, Cc, L = x.shape
     a = _hip.StageSplitArgs()
     if up is not None:
         a.up_wps, a.up_bias, a.up_out, a.up_stats_part = up[0].data_ptr(), _hip.ptr(up[1]), up[2].data_ptr(), _hip.ptr(up[3])
         a.up_k, a.up_u, a.up_slope = up[4], up[5], up[6]
-        a.up_stats_acc = _hip.ptr(up_acc)
-    if fold is not None:
-        a.in_stats_acc, a.in_gb = fold['acc'].data_ptr(), fold['gb'].data_ptr()
-        a.in_running_mean, a.in_running_var, a.in_nbt = _hip.ptr(fold.get('running_mean')), _hip.ptr(fold.get('running_var')), _hip.ptr(fold.get('nbt'))
-        a.in_count, a.in_eps, a.in_momentum = float(fold['count']), fold['eps'], fold['momentum']
     a.in_ = x.data_ptr()
     a.in_a, a.in_s = (in_affine[0].data_ptr(), in_affine[1].data_ptr()) if in_affine is not None else (None, None)
     for j, q in enumerate(branches):

@@ -1,0 +1,187 @@
+"""Launch plan of a forward: the ordered C-ABI calls of one `Generator.forward`, recorded once and replayed.
+
+`Generator._forward_hip` decides a forward's schedule - which kernel serves which layer (asked of the library's shape queries), which
+buffers it reads and writes, which launches go to the side stream and where the two streams meet.  None of that depends on the values of
+the inputs: for a given (shape, mode, precision, algorithm, fusion switches, parameter storage) the same calls go out with the same
+argument structs every time; only four pointers change - `x`, `spk_emb`, `noise` and the freshly allocated output.  So the first forward of
+a configuration runs through the planner with a `Recorder` in front of the library: every launching entry point it calls (the ones whose last
+argument is the stream; the host-only shape queries pass through) is appended to a `Tape` with its argument objects, together with the
+stream operations between them.  Every later forward of that configuration is `Tape.replay`: a loop of `fn(*args, stream)` over prebuilt
+ctypes structs - no shape queries, no struct construction, no Python per layer (vec2wav/train.py:246-291 calls the generator once per
+validation utterance; at B = 1 the forward is launch-bound).
+
+A tape owns nothing but references: the structs it replays point into buffers of the module that recorded it (`Generator._ws`, `_wts`,
+fold plans, the split-over-C_in slab), and the module drops its tapes whenever it replaces one of those buffers."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _hip
+
+K_CALL, K_FORK, K_JOIN, K_MARK, K_NEED, K_PY = range(6)
+MAIN, SIDE = 0, 1
+
+
+class Step:
+    __slots__ = ('kind', 'fn', 'args', 'sid', 'tag', 'name')
+
+    def __init__(self, kind, fn=None, args=None, sid=MAIN, tag=None, name=None):
+        self.kind, self.fn, self.args, self.sid, self.tag, self.name = kind, fn, args, sid, tag, name
+
+
+def _struct_slots(obj, out, path=()):
+    """Every pointer-valued slot of a ctypes struct / array (nested ones too) as (container, key) pairs."""
+    if isinstance(obj, C.Array):
+        if issubclass(obj._type_, (C.Structure, C.Array)):
+            for i in range(len(obj)):
+                _struct_slots(obj[i], out)
+        elif obj._type_ is C.c_void_p:
+            for i in range(len(obj)):
+                out.append((obj, i))
+        return
+    if isinstance(obj, C.Structure):
+        for name, typ in obj._fields_:
+            if typ is C.c_void_p:
+                out.append((obj, name))
+            elif isinstance(typ, type) and issubclass(typ, (C.Structure, C.Array)):
+                _struct_slots(getattr(obj, name), out)
+
+
+class Tape:
+    """The recorded schedule.  `binds`: name -> device address at record time of the tensors that differ from call to call."""
+
+    def __init__(self):
+        self.steps: List[Step] = []
+        self.keep: list = []                 # objects the recorded structs point into and nobody else may hold (plans, temporaries)
+        self.patches: Dict[str, list] = {}   # bind name -> [(container, key)] slots holding that address
+        self.events: Dict[str, torch.cuda.Event] = {}
+        self.out = None                      # (shape, dtype) of the output tensor
+        self.launches = 0
+
+    def finalize(self, binds: Dict[str, int]):
+        by_addr = {}
+        for name, addr in binds.items():
+            if addr in by_addr:
+                raise RuntimeError(f'schedule: {name} and {by_addr[addr]} share an address')
+            by_addr[addr] = name
+        self.patches = {name: [] for name in binds}
+        for st in self.steps:
+            if st.kind != K_CALL:
+                continue
+            self.launches += 1
+            for i, a in enumerate(st.args):
+                if isinstance(a, int):
+                    if a in by_addr:
+                        self.patches[by_addr[a]].append((st.args, i))
+                    continue
+                obj = getattr(a, '_obj', a)          # C.byref(struct) keeps its struct in ._obj
+                slots = []
+                _struct_slots(obj, slots)
+                for cont, key in slots:
+                    v = cont[key] if isinstance(key, int) else getattr(cont, key)
+                    if v in by_addr:
+                        self.patches[by_addr[v]].append((cont, key))
+        for name in binds:
+            if name != 'y' and not self.patches[name]:
+                raise RuntimeError(f'schedule: no recorded call reads {name}')
+
+    def replay(self, main, side, binds: Dict[str, int], profile: Optional[list] = None):
+        for name, addr in binds.items():
+            for cont, key in self.patches[name]:
+                if isinstance(key, int):
+                    cont[key] = addr
+                else:
+                    setattr(cont, key, addr)
+        mh, sh = main.cuda_stream, side.cuda_stream
+        open_tag, e0 = None, None
+        for st in self.steps:
+            k = st.kind
+            if profile is not None and st.tag != open_tag:
+                if open_tag is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(main)
+                    profile.append((open_tag, e0, e1))
+                open_tag = st.tag
+                if open_tag is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(main)
+            if k == K_CALL:
+                rc = st.fn(*st.args, mh if st.sid == MAIN else sh)
+                if rc != 0:
+                    _hip.check(rc, st.name)
+            elif k == K_NEED:
+                main.wait_event(self.events[st.name])
+            elif k == K_MARK:
+                self.events[st.name].record(side)
+            elif k == K_FORK:
+                side.wait_stream(main)
+            elif k == K_JOIN:
+                main.wait_stream(side)
+            else:
+                st.fn()
+        if profile is not None and open_tag is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(main)
+            profile.append((open_tag, e0, e1))
+
+
+class Recorder:
+    """Stands in front of the library while a planner runs: launching calls that succeed are taped (and executed), queries pass through."""
+
+    def __init__(self, lib, main, side):
+        self._lib = lib
+        self.tape = Tape()
+        self.main, self.side = main, side
+        self._mh, self._sh = main.cuda_stream, side.cuda_stream
+        self.tag = None
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in _hip.LAUNCHERS:
+            return fn
+
+        def call(*args):
+            rc = fn(*args)
+            if rc == 0:
+                h = args[-1]
+                h = h.value if isinstance(h, C.c_void_p) else h
+                if h == self._mh:
+                    sid = MAIN
+                elif h == self._sh:
+                    sid = SIDE
+                else:
+                    raise RuntimeError(f'schedule: {name} launched on a stream the plan does not know')
+                self.tape.steps.append(Step(K_CALL, fn, list(args[:-1]), sid, self.tag if sid == MAIN else None, name))
+            return rc
+        return call
+
+    # ---- stream operations of the plan (executed now, taped for the replays)
+    def fork(self):
+        self.side.wait_stream(self.main)
+        self.tape.steps.append(Step(K_FORK))
+
+    def join(self):
+        self.main.wait_stream(self.side)
+        self.tape.steps.append(Step(K_JOIN))
+
+    def mark(self, name):
+        ev = self.tape.events.get(name)
+        if ev is None:
+            ev = self.tape.events[name] = torch.cuda.Event()
+        ev.record(self.side)
+        self.tape.steps.append(Step(K_MARK, name=name))
+
+    def need(self, name):
+        self.main.wait_event(self.tape.events[name])
+        self.tape.steps.append(Step(K_NEED, name=name))
+
+    def py(self, fn, tag=None):
+        """A step that is not a C-ABI launch (the statistics all-reduce of a data-parallel run): called now and at every replay."""
+        self.tape.steps.append(Step(K_PY, fn, tag=tag))
+        return fn()
+
+    def keep(self, obj):
+        self.tape.keep.append(obj)
