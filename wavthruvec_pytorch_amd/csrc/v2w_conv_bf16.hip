@@ -271,9 +271,7 @@ conv_bf16_kernel(const MultiArgs m) {
         const unsigned char* Xs = smem_b + (ch & 1) * bufsz;
         unsigned char* Xn = smem_b + ((ch + 1) & 1) * bufsz;
         const bool more = ch + 1 < nch;
-#ifndef V2W_BF_ABL_NOCOMMIT
         if constexpr (VEC) { if (more) prefetch((ch + 1) * CK); }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (ch < 6) V2W_STAMP(2 + 4 * ch);
         const unsigned char* xt = Xs + lbase;
@@ -288,9 +286,7 @@ conv_bf16_kernel(const MultiArgs m) {
 #pragma unroll
                 for (int sq = 0; sq < 4; ++sq) {
                     kstep(ar[sq], sq < 3 ? xt + 32 * (sq + 1) : (last ? xt : xt + step));
-#ifndef V2W_BF_ABL_NOFRAG
                     load_frag(ar[sq], chn, sq, tn);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -298,28 +294,20 @@ conv_bf16_kernel(const MultiArgs m) {
         for (int t = 0; t < K; ++t, xt += step) {
 #pragma unroll
             for (int sp = 0; sp < KS; sp += 2) {             // k-steps sp (ring slot 0) and sp + 1 (slot 1) of the tap
-#ifdef V2W_BF_ABL_NOFRAG
-                if (ch == 0 && t == 0) load_frag(ar[1], ch, sp + 1, t);
-#else
                 load_frag(ar[1], ch, sp + 1, t);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(ar[0], xt + 32 * (sp + 1));
-#ifndef V2W_BF_ABL_NOFRAG
                 if (sp + 2 < KS) load_frag(ar[0], ch, sp + 2, t);
                 else if (t + 1 < K) load_frag(ar[0], ch, 0, t + 1);
                 else load_frag(ar[0], ch + 1, 0, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(ar[1], sp + 2 < KS ? xt + 32 * (sp + 2) : (t + 1 < K ? xt + step : xt));
             }
         }
         if (ch < 6) V2W_STAMP(3 + 4 * ch);
         if (more) {
-#ifndef V2W_BF_ABL_NOCOMMIT
             if constexpr (VEC) commit((ch + 1) * CK, Xn);
             else stage_scalar((ch + 1) * CK, Xn);
-#endif
             if (ch < 6) V2W_STAMP(4 + 4 * ch);
             __syncthreads();
             if (ch < 6) V2W_STAMP(5 + 4 * ch);
@@ -330,9 +318,7 @@ conv_bf16_kernel(const MultiArgs m) {
         int ch = 0, t = 0;                                   // the running tap
         int qc = 0, qt = 2;                                  // the tap two ahead of it (whose fragments the running tap requests)
         while (qt >= K) { qt -= K; ++qc; }
-#ifndef V2W_BF_ABL_NOCOMMIT
         if constexpr (VEC) { if (nch > 1) prefetch(CK); }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         V2W_STAMP(2);
         const unsigned char* xt = smem_b + lbase;
@@ -342,14 +328,10 @@ conv_bf16_kernel(const MultiArgs m) {
             constexpr int S0 = 2 * decltype(par_c)::value;
             const bool last = t + 1 >= K;
             kstep(ar[S0], xt + 32);
-#ifndef V2W_BF_ABL_NOFRAG
             load_frag(ar[S0], qc, 0, qt);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             kstep(ar[S0 + 1], last ? xt : xt + step);
-#ifndef V2W_BF_ABL_NOFRAG
             load_frag(ar[S0 + 1], qc, 1, qt);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if (++qt >= K) { qt = 0; ++qc; }
             if (!last) { ++t; xt += step; return; }
@@ -357,19 +339,15 @@ conv_bf16_kernel(const MultiArgs m) {
             if (ch < 6) V2W_STAMP(3 + 4 * ch);
             const bool more = ch + 1 < nch;
             if (more) {
-#ifndef V2W_BF_ABL_NOCOMMIT
                 if constexpr (VEC) commit((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
                 else stage_scalar((ch + 1) * CK, smem_b + ((ch + 1) & 1) * bufsz);
-#endif
                 if (ch < 6) V2W_STAMP(4 + 4 * ch);
                 __syncthreads();
                 if (ch < 6) V2W_STAMP(5 + 4 * ch);
             }
             ++ch; t = 0;
             if (ch < nch) {
-#ifndef V2W_BF_ABL_NOCOMMIT
                 if constexpr (VEC) { if (ch + 1 < nch) prefetch((ch + 1) * CK); }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (ch < 6) V2W_STAMP(2 + 4 * ch);
                 xt = smem_b + (ch & 1) * bufsz + lbase;
@@ -383,20 +361,6 @@ conv_bf16_kernel(const MultiArgs m) {
         if (g < TT) tap(std::integral_constant<int, 0>{});
     }
     V2W_STAMP(26);
-#ifdef V2W_BF_ABL_NOEPI
-    {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
-        if (sacc == 12345.678f) gptr<float>(p.out)[tid] = sacc;
-        V2W_STAMP(27);
-        return;
-    }
-#endif
 
     if constexpr (EPI == 2) {
         // ---- transposed-conv epilogue: 64 input positions of one 32-row block at a time -> scratch [32 / UP channels][U * 64 output
@@ -905,6 +869,7 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* 
     // will not decline (Generator._bf16_storage_kernels_exist decides on it before the forward starts)
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (p.io_bf16 != 0 && p.io_bf16 != 3) return V2W_E_SHAPE;
+    if (VEC && !p.vec4) return V2W_E_ARG;                     // (the dispatcher sends unaligned inputs to the VEC = false instantiation)
     if (ntiles_out) { *ntiles_out = p.ntiles; return 0; }
     MultiArgs m{};
     m.p[0] = p;
@@ -912,7 +877,6 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* 
     const int grid = ((p.ntiles + 7) / 8) * 8 * (p.Cout / MT);
     m.start[1] = grid;
     for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
-    if (VEC && !p.vec4) return V2W_E_ARG;
     auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true, V2W_BF_CK, VEC> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false, V2W_BF_CK, VEC>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -939,7 +903,7 @@ static int convt_bf16_dispatch(const v2w_convt1d_args* a, hipStream_t stream, in
     // the stats tiling (rows of stats_part) depends on the tile width only: every configuration here is 256 or 512 positions wide, the
     // element-wise-staging fallback (unaligned input or a length that is not a multiple of 4) uses the widths of its aligned twin
     const bool vec = (a->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(a->in) & 15) == 0);
-    if (!vec && !ntiles_out) {
+    if (!vec) {     // (queries too: the answer comes from the instantiation that will launch, with every one of its checks)
         if (rows % 64 == 0 && !(rows % 128 == 0 && (long)a->B * ((a->L + 255) / 256) * (rows / 128) >= 512)) return launch_bf16_convt<1, 4, 2, 2, false>(p, stream, ntiles_out, cfg);
         if (rows % 128 == 0) return launch_bf16_convt<2, 4, 2, 2, false>(p, stream, ntiles_out, cfg);
         if (rows % 32 == 0) return launch_bf16_convt<1, 4, 1, 4, false>(p, stream, ntiles_out, cfg);

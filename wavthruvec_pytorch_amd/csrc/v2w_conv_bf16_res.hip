@@ -224,11 +224,7 @@ conv_bf16_res_kernel(const ResArgs a) {
 
     acc_t acc[MI][NI];
     const unsigned lane16 = (unsigned)lane * 16u;
-#ifdef V2W_RS_BB2
-    u32x4 bb[2][NI];                 // one operand set per k-step of a tap, each refilled for the NEXT tap: an LDS read has a whole k-step to land
-#else
     u32x4 bb[1][NI];
-#endif
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
     };
@@ -318,16 +314,9 @@ conv_bf16_res_kernel(const ResArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             bb[0][j] = *reinterpret_cast<const u32x4*>(smem_r + xt + j * 2048);
-#ifdef V2W_RS_BB2
-            bb[1][j] = *reinterpret_cast<const u32x4*>(smem_r + (xt ^ 32u) + j * 2048);
-#endif
         }
         typedef std::integral_constant<int, 0> set0;
-#ifdef V2W_RS_BB2
-        typedef std::integral_constant<int, 1> set1;
-#else
         typedef std::integral_constant<int, 0> set1;
-#endif
         auto tap = [&](auto par_c) {
             constexpr int S0 = 2 * decltype(par_c)::value;
             // the next tap: same chunk one dilation step on, or tap 0 of the next chunk (past the end: this tap again - unused)
@@ -335,17 +324,10 @@ conv_bf16_res_kernel(const ResArgs a) {
             if (nt_ >= K) { nt_ = 0; ++nch_; }
             if (nch_ >= nch) { nch_ = ch; nt_ = t; }
             const unsigned xn = baddr(nch_, r0 + nt_ * dil);
-#ifdef V2W_RS_BB2
-            kstep(set0{}, ar[S0], xn);                       // k-step 0 of the next tap
-            load_frag(ar[S0], qc, 0, qt);
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(set1{}, ar[S0 + 1], xn ^ 32u);             // k-step 1 of the next tap: slot ^ 2
-#else
             kstep(set0{}, ar[S0], xt ^ 32u);                 // k-step 1 of the tap: slot ^ 2
             load_frag(ar[S0], qc, 0, qt);
             __builtin_amdgcn_sched_barrier(0);
             kstep(set1{}, ar[S0 + 1], xn);
-#endif
             load_frag(ar[S0 + 1], qc, 1, qt);
             __builtin_amdgcn_sched_barrier(0);
             if (++qt >= K) { qt = 0; ++qc; }
@@ -407,11 +389,7 @@ conv_bf16_res_kernel(const ResArgs a) {
             V2W_STAMP(3 + 3 * j);
             conv(rs_uni(a.wps[j]), rs_uni(a.K[j]), rs_uni(a.dil[j]));
             V2W_STAMP(4 + 3 * j);
-#ifndef V2W_RS_ABL_NOEPI
             store_tile(rs_uni(a.out[j]), true, 0.f);
-#else
-            if (acc[0][0][0] == 12345.678f) store_tile(rs_uni(a.out[j]), true, 0.f);
-#endif
             V2W_STAMP(5 + 3 * j);
         }
     } else {
@@ -428,11 +406,7 @@ conv_bf16_res_kernel(const ResArgs a) {
             conv(rs_uni(a.wps[j]), rs_uni(a.K[j]), rs_uni(a.dil[j]));
             V2W_STAMP(5 + 5 * j);
         }
-#ifndef V2W_RS_ABL_NOEPI
         store_tile(rs_uni(a.out[0]), false, a.out_div);
-#else
-        if (acc[0][0][0] == 12345.678f) store_tile(rs_uni(a.out[0]), false, a.out_div);
-#endif
     }
     V2W_STAMP(20);
 }
@@ -478,9 +452,7 @@ int launch_res(const v2w_branch_convs_args* q, hipStream_t stream) {
 V2W_TL_SETTER(v2w_timeline_set_res)
 #endif
 
-#ifndef V2W_RS_C64_CFG
 #define V2W_RS_C64_CFG 0
-#endif
 
 extern "C" int v2w_branch_convs_bf16_fwd(const v2w_branch_convs_args* a, void* stream) {
     if (!a) return V2W_E_ARG;
@@ -498,9 +470,5 @@ extern "C" int v2w_branch_convs_bf16_fwd(const v2w_branch_convs_args* a, void* s
     if ((long long)a->C * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;  // 32-bit lane offsets inside one batch item
     hipStream_t st = (hipStream_t)stream;
     if (a->C % 128 == 0) return launch_res<2, 4, 2, 2>(a, st);          // 128 x 256
-#if V2W_RS_C64_CFG == 1
-    return launch_res<2, 4, 1, 4>(a, st);                               // 64 x 512
-#else
     return launch_res<1, 4, 2, 2>(a, st);                               // 64 x 256
-#endif
 }

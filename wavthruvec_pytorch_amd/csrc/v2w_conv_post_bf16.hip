@@ -28,15 +28,9 @@ struct PostArgs {
     float slope;
 };
 
-#ifndef V2W_PM_NT
 #define V2W_PM_NT 2
-#endif
-#ifndef V2W_PM_DEPTH
 #define V2W_PM_DEPTH 3                            // channels of x in flight ahead of the running one
-#endif
-#ifndef V2W_PM_WGS
 #define V2W_PM_WGS 3                              // resident workgroups per CU the grid is cut for
-#endif
 constexpr int PM_NT = V2W_PM_NT;                  // tiles of 256 outputs per wave and job
 constexpr int PM_JOB = 4 * PM_NT * 256;           // outputs per workgroup job (4 waves)
 

@@ -33,18 +33,10 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4)));   // one 16-byte
 #define V2W_SPLIT_ROWB 80       // bytes per staged position: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad
 #define V2W_SPLIT_UNIT 2048     // bytes of the A fragments of one (32-row block, chunk, tap): [hi, lo][64 lanes][16 B]
 #define V2W_SPLIT_HMAX 32       // largest halo per side
-#ifndef V2W_SPLIT_NAB
 #define V2W_SPLIT_NAB 4         // weight stages resident in LDS: one computing, one published for the next stage, two in flight
-#endif
-#ifndef V2W_SPLIT_WPE
 #define V2W_SPLIT_WPE 2         // waves per SIMD the register allocation targets (= workgroups per CU)
-#endif
-#ifndef V2W_SPLIT_C64
 #define V2W_SPLIT_C64 0
-#endif
-#ifndef V2W_SPLIT_FORCE
 #define V2W_SPLIT_FORCE 0       // experiments: 1 = 64 x 128 tiles, 2 = 128 x 128 tiles for every C_out % 128 == 0 layer
-#endif
 
 #define V2W_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define V2W_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -798,11 +790,7 @@ int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool b
         if (2 * tiles256 >= 384) return launch_split<2, 2, 2, 2>(ps, n, stream, bf);       // 128 x 128
         return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                // 64 x 128
     }
-#if V2W_SPLIT_C64 == 1
-    return launch_split<1, 2, 2, 2>(ps, n, stream, bf);                                    // 64 x 128
-#else
     return launch_split<2, 2, 1, 4>(ps, n, stream, bf);                                    // 64 x 256
-#endif
 }
 
 // Batched form of (v2w_wn_fold_conv + v2w_pack_split) for n Conv1d layers: descs / starts live in DEVICE memory;

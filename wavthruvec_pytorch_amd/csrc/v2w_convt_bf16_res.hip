@@ -250,11 +250,7 @@ convt_bf16_res_kernel(const CtArgs a) {
             if (++qt >= K) { qt = 0; ++qc; }
             ch = nch_; t = nt_; xt = xn;
         };
-#ifdef V2W_CT_EXP_NOMFMA
-        const int TT = UP == 5 ? 0 : nch * K;
-#else
         const int TT = nch * K;
-#endif
         int g = 0;
         for (; g + 1 < TT; g += 2) { tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); }
         if (g < TT) tap(std::integral_constant<int, 0>{});
@@ -278,9 +274,6 @@ convt_bf16_res_kernel(const CtArgs a) {
         unsigned char* const ob0 = reinterpret_cast<unsigned char*>(a.out) + (size_t)b * CoutR * Lout * 2;
         const int cS = lane & 15, qS = lane >> 4;
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#ifdef V2W_CT_EXP_NOEPI
-        if (a.slope > 5.f)
-#endif
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll

@@ -149,25 +149,15 @@ struct FusedConv {
                                         const float* xt, const float* xn, int sw, float slope) {
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
-#ifndef V2W_TL_NOGLOAD    // (diagnostic what-if builds: V2W_TL_NOGLOAD / _NODSREAD / _NOLRELU drop one operand stream; results are wrong)
             if ((q & 3) == 0) ar[(RB + (q >> 2) + RING - 1) % RING] = frag(ap, ap_next, nfrag, g0 + (q >> 2) + RING - 1);
-#endif
             const int qa = q + LOOK;
             const float* src = qa < QT ? xt + qa * KSTEP * sw : xn + (qa - QT) * KSTEP * sw;
-#ifndef V2W_TL_NODSREAD
 #pragma unroll
             for (int j = 0; j < NI; ++j) bq[qa % NB][j] = src[j * MF];
-#else
-            (void)src;
-#endif
             __builtin_amdgcn_sched_barrier(0);      // reads and weight prefetch stay AHEAD of this k-step's MFMAs
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-#ifdef V2W_TL_NOLRELU
-                acc[j] = F::mfma(ar[(RB + (q >> 2)) % RING][q & 3], bq[q % NB][j], acc[j]);
-#else
                 acc[j] = F::mfma(ar[(RB + (q >> 2)) % RING][q & 3], v2w_lrelu(bq[q % NB][j], slope), acc[j]);
-#endif
         }
     }
     // the whole phase; x0 = src + hk*sw + (this lane's column of tap 0).  Zeroes acc first.

@@ -453,19 +453,13 @@ int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, 
         return v2w_resblock2_stage_bf16_wide(a, stream);
     }
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);
-#ifndef V2W_NO_N16
     if (a->C == 16 && a->io_bf16 == 3) {      // the reference's block set on aligned bf16 tensors: weights in registers (+ the 7-tap tail)
         const int rc = v2w_resblock2_stage_bf16_n16(a, stream);
         if (rc != V2W_E_SHAPE) return rc;
     }
-#endif
     // C = 32: the resident-tile family (two-wave workgroups, 729 us against 838 at configs[2]).  C = 16: only for the fused tail - as a plain
     // stage its one-k-step-per-tap form of that kernel measured 912 us against the 791 us of stage_bf16_kernel<16> below
-#ifdef V2W_WS_C16              // (experiments: the 16-channel stage on the wide template without the fused tail)
-    const bool c16_wide = true;
-#else
     const bool c16_wide = a->post_out != nullptr;
-#endif
     if ((a->C == 32 || (a->C == 16 && c16_wide)) && a->io_bf16 == 3) {
         const int rc = v2w_resblock2_stage_bf16_wide(a, stream);
         if (rc != V2W_E_SHAPE) return rc;

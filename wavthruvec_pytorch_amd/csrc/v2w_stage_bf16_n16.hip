@@ -407,9 +407,7 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
 V2W_TL_SETTER(v2w_timeline_set_n16)
 #endif
 
-#ifndef V2W_N16_WN
 #define V2W_N16_WN 4
-#endif
 
 // Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for C = 16 on bf16 tensors.  V2W_E_SHAPE: not the reference's block set / not
 // aligned - the caller runs its own kernels.

@@ -26,23 +26,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define V2W_WS_MAXB 4
 #define V2W_WS_UNIT 2048     // byte pitch of the packed fragments of one (32-row block, 16-channel k-step, tap)
-#ifndef V2W_WS_RING
 #define V2W_WS_RING 2        // taps of weight fragments in flight per wave (2 or 4: measured the same, 1074 vs 1092 us at C = 128)
-#endif
-#ifndef V2W_WS_CFG
-#define V2W_WS_CFG 0
-#endif
-#ifndef V2W_WS_PERSIST
-#define V2W_WS_PERSIST 0     // 1: one residency of workgroups, each walks its tiles with the next tile's x loads in flight under its stores.  Measured
-#endif                       // SLOWER (C = 128 / 64 / 256: 1028-1058 / 1208-1220 / 1103-1133 us against 1003-1022 / 1152-1155 / 1072-1113): the hardware's
-                             // own dispatch of one workgroup per tile keeps the workgroups of a CU out of phase, which is what hides the epilogues
-#ifndef V2W_WS_PRE
-#define V2W_WS_PRE 0         // 1: the first fragments of a conv's weight ring are requested BEFORE the barrier / epilogue that precedes the conv.
-#endif                       // Measured the same within noise (C = 128 / 64 / 256 / 32: 1062-1077 / 1228-1236 / 1122-1124 / 833-839 us against 1052-1078 /
-                             // 1221-1241 / 1111-1114 / 820-826): a wave's cold start is covered by the other wave of its SIMD
-#ifndef V2W_WS_PRIO
-#define V2W_WS_PRIO 0
-#endif
+// Measured inside this kernel in rounds 3-4 and removed again ("measured and rejected"): a persistent tile loop with the next
+// tile's x loads in flight under the stores (0-10 % slower: hardware dispatch of one workgroup per tile keeps the workgroups of a CU out of
+// phase, which is what hides the epilogues); a conv's first fragments requested before the barrier / epilogue in front of it (within noise);
+// s_setprio schemes for the younger half of the workgroup (no gain); 64 x 64 / 64 x 128 outputs per wave (slower).
 
 struct WideArgs {
     const unsigned short* in; const float* in_a; const float* in_s;
@@ -145,7 +133,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
     const float slope = a.slope, inv_slope = a.inv_slope;
 
     const int hout = ws_uni(a.hout);
-    // one tile per workgroup (V2W_WS_PERSIST: a workgroup walks tiles blockIdx.x, + gridDim.x, ... with the x loads of its next tile in flight)
+    // one tile per workgroup
     int b = 0, n0 = 0, pos0 = 0;                                                // batch item, position of the first valid output column, position of x row 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = ws_uni(tid >> 6);
@@ -215,9 +203,6 @@ wide_stage_bf16_kernel(const WideArgs a) {
     };
 
     const bool young = wave >= (WM * WN) / 2;                 // (uniform) the second-dispatched half of the workgroup's waves
-#if V2W_WS_PRIO == 1
-    if (young) __builtin_amdgcn_s_setprio(1);
-#endif
     acc_t acc1[MI][NI], oacc[MI][NI];
     unsigned lane16 = (unsigned)lane * 16u;
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
@@ -373,11 +358,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
             for (int j = 0; j < NI; ++j) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[i][j] = mfma(acc[i][j], av[i], bb[bs][j]);
-#ifndef V2W_WS_ABL_NOB
                 bb[bs][j] = *reinterpret_cast<const u32x4*>(smem_w + nxt + j * CB);
-#else
-                asm volatile("" : "+v"(bb[bs][j]) : "v"(nxt));
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -387,19 +368,13 @@ wide_stage_bf16_kernel(const WideArgs a) {
             advance();
             if constexpr (KS == 2) {
                 kstep(std::integral_constant<int, 0>{}, ar[S0], xn);
-#ifndef V2W_WS_ABL_NOA
                 load_frag(ar[S0], qc, 0, qt);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(std::integral_constant<int, 1>{}, ar[S0 + 1], xn ^ 32u);
-#ifndef V2W_WS_ABL_NOA
                 load_frag(ar[S0 + 1], qc, 1, qt);
-#endif
             } else {
                 kstep(std::integral_constant<int, P & 1>{}, ar[S0], xn);
-#ifndef V2W_WS_ABL_NOA
                 load_frag(ar[S0], qc, 0, qt);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if (++qt >= K) { qt = 0; ++qc; }
@@ -422,32 +397,14 @@ wide_stage_bf16_kernel(const WideArgs a) {
     // every load compiled out - the scalar bookkeeping of a tap (which plane, which tap, wrap-arounds, fragment index multiplies: ~40
     // dependent SALU instructions) stands between the MFMAs of a wave, and two waves that run the same code hit those stretches together.
     // Unrolled over the taps of a plane, every offset is an immediate or one add.
-    // A conv's loop starts cold: its first four fragments (taps 0 and 1) come from L2, ~1.5 k cycles in which the wave issues nothing
-    // (measured per conv: loop time - MFMA issue time, the same for 3, 7 and 11 taps).  conv_pre requests them into `arp` ahead of time -
-    // before the barrier and epilogue in front of conv2_j, before the staging barrier in front of a tile's first conv - and conv_ct
-    // (PRE) starts from those registers.
-    u32x4 arp[4][MI];
-    auto conv_pre = [&](auto k_c, const unsigned char* wps) {
-        constexpr int K = decltype(k_c)::value;
-        unsigned l16 = lane16;
-        asm volatile("" : "+v"(l16));
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const unsigned char* ap = wps + (size_t)(wm0 / 32 + i) * (KS * NCH * K) * V2W_WS_UNIT + l16;
-            arp[0][i] = *gptr<const u32x4>(ap);
-            arp[1][i] = *gptr<const u32x4>(ap + K * V2W_WS_UNIT);
-            arp[2][i] = *gptr<const u32x4>(ap + 1 * V2W_WS_UNIT);
-            arp[3][i] = *gptr<const u32x4>(ap + (K + 1) * V2W_WS_UNIT);
-        }
-    };
+    // (A conv's loop starts cold - its first four fragments come from L2, ~1.5 k cycles in which the wave issues nothing; requesting them ahead of
+    // the barrier / epilogue in front of the conv was measured and changed nothing: the other wave of the SIMD covers the cold start.)
     // (acc: [MIX][NI] blocks, row block i of this wave = block rb0 + i of the weight stream: MIX = MI, rb0 = wm0 / 32 for the stage's own
     // convs; the fused upsampler runs UPF / 2 times as many row blocks per wave)
-    auto conv_ct = [&](auto k_c, auto d_c, auto pre_c, auto& acc, int rb0, unsigned base, int psz, int r0, const unsigned char* wps) {
+    auto conv_ct = [&](auto k_c, auto d_c, auto& acc, int rb0, unsigned base, int psz, int r0, const unsigned char* wps) {
         constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value;
-        constexpr bool PRE = decltype(pre_c)::value;
         constexpr int MIX = (int)std::extent<std::remove_reference_t<decltype(acc)>, 0>::value;
         static_assert(KS == 2 && K >= 2, "64-byte rows");
-        static_assert(!PRE || MIX == MI, "the prefetched fragments are the stage's own");
         const unsigned char* ap[MIX];
 #pragma unroll
         for (int i = 0; i < MIX; ++i) ap[i] = wps + (size_t)(rb0 + i) * (KS * NCH * K) * V2W_WS_UNIT;
@@ -460,17 +417,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
         };
         auto addr = [&](unsigned pbase, int row) { return pbase + (unsigned)(row * RB + ((hk ^ swz(row)) << 4)); };
         // fragment (plane ch, k-step s, tap t) of a row block sits at ((2 ch + s) K + t) units
-        if constexpr (PRE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < MIX; ++i) ar[q][i] = arp[q][i];
-        } else {
-            frag(ar[0], 0);
-            frag(ar[1], K * V2W_WS_UNIT);
-            frag(ar[2], 1 * V2W_WS_UNIT);
-            frag(ar[3], (K + 1) * V2W_WS_UNIT);
-        }
+        frag(ar[0], 0);
+        frag(ar[1], K * V2W_WS_UNIT);
+        frag(ar[2], 1 * V2W_WS_UNIT);
+        frag(ar[3], (K + 1) * V2W_WS_UNIT);
         u32x4 bb[2][NI];
         {
             const unsigned x0 = addr(base, r0);
@@ -488,11 +438,6 @@ wide_stage_bf16_kernel(const WideArgs a) {
             const int fbase = 2 * ch * K * V2W_WS_UNIT;       // (uniform) the plane's k-step 0, tap 0
 #pragma unroll
             for (int t = 0; t < K; ++t) {
-#if V2W_WS_PRIO == 2
-                // the two waves of a SIMD take turns at the higher priority, tap by tap (the older wave wins every arbitration otherwise and the
-                // younger one runs its loop after it: the workgroup then waits for the younger half at every barrier)
-                if (young == (((PAR + t) & 1) != 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
                 const int sl = 2 * ((PAR + t) & 1);
                 // B operands of the next tap: this plane one dilation step on, or tap 0 of the next plane (past the end: this tap again)
                 const bool wrapn = t + 1 >= K;
@@ -539,9 +484,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
 
     bool rb1 = false;
     if constexpr (!STD) rb1 = ws_uni(a.rb1) != 0;
-    auto branch = [&](int jb, auto k_c, auto pre1_c) {
+    auto branch = [&](int jb, auto k_c) {
         constexpr int KC = decltype(k_c)::value;             // > 0: the tap count at compile time (dilations 1 and 3), 0: run-time arguments
-        constexpr bool PRE1 = decltype(pre1_c)::value && V2W_WS_PRE, PRE2 = KC > 0 && V2W_WS_PRE;      // conv1 / conv2 start from `arp`
         const int K = KC ? KC : ws_uni(a.K[jb]), d1 = KC ? 1 : ws_uni(a.d1[jb]), d2 = KC ? 3 : ws_uni(a.d2[jb]);
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col
@@ -557,10 +501,9 @@ wide_stage_bf16_kernel(const WideArgs a) {
                     for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
             }
         V2W_STAMP(3 + 6 * jb);
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, PRE1>{}, acc1, wm0 / 32, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, wm0 / 32, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
         else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
         V2W_STAMP(4 + 6 * jb);
-        if constexpr (PRE2) conv_pre(k_c, ws_uni(a.w2[jb]));          // conv2_j's first fragments: in flight under the barrier and the epilogue
         __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
         V2W_STAMP(5 + 6 * jb);
         // ---- t1 = acc + x (x rebuilt from the activated tile: registers 4g .. 4g+3 of block (i, j) <-> channels 8g + 4hk + {0..3} of plane
@@ -608,19 +551,14 @@ wide_stage_bf16_kernel(const WideArgs a) {
         __syncthreads();
         V2W_STAMP(7 + 6 * jb);
         // ---- conv2_j on the same window, onto the running accumulator
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, std::integral_constant<bool, PRE2>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
         else conv(oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), K, d2);
         V2W_STAMP(8 + 6 * jb);
     };
     issue_x(blockIdx.x);
-#if V2W_WS_PERSIST
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-#else
     {
     const int tile = blockIdx.x;
-#endif
     tile_origin(tile, b, n0, pos0);
-    if constexpr (STD && V2W_WS_PRE) conv_pre(std::integral_constant<int, 3>{}, ws_uni(a.w1[0]));      // the tile's first conv: under the staging
     // every per-lane address term of the unrolled convs derives from these three: opaque per tile, or hipcc hoists ~100 registers of
     // loop-invariant offsets out of the tile loop and spills the accumulators
     asm volatile("" : "+v"(lr), "+v"(hk), "+v"(lane16));
@@ -644,12 +582,12 @@ wide_stage_bf16_kernel(const WideArgs a) {
     V2W_STAMP(2);
     init_oacc();
     if constexpr (STD) {
-        branch(0, std::integral_constant<int, 3>{}, std::true_type{});
-        branch(1, std::integral_constant<int, 7>{}, std::false_type{});
-        branch(2, std::integral_constant<int, 11>{}, std::false_type{});
+        branch(0, std::integral_constant<int, 3>{});
+        branch(1, std::integral_constant<int, 7>{});
+        branch(2, std::integral_constant<int, 11>{});
     } else {
-        if (rb1) branch(prob, std::integral_constant<int, 0>{}, std::false_type{});
-        else for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{}, std::false_type{});
+        if (rb1) branch(prob, std::integral_constant<int, 0>{});
+        else for (int jb = 0; jb < nk; ++jb) branch(jb, std::integral_constant<int, 0>{});
     }
 
     if constexpr (UPF > 0) {
@@ -725,7 +663,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
             }
         // virtual tap tv reads input position q + tv - 1 (2 U taps at stride U: one input position of halo per side)
-        conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::false_type{}, uacc, (wm0 / 32) * (UPF / 2), tbase, tpsz,
+        conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, uacc, (wm0 / 32) * (UPF / 2), tbase, tpsz,
                 wn0 + lr - 1, ws_uni(a.up_w));
         V2W_STAMP(22);
         // ---- epilogue: bf16 stores straight from the accumulators (the phases of a channel are adjacent registers of a lane, consecutive
@@ -835,9 +773,6 @@ wide_stage_bf16_kernel(const WideArgs a) {
         __syncthreads();
         // the next tile's x: in flight under this tile's stores.  Unconditional (past the end: the last tile again, never committed) - under
         // a condition the old values stay live through the whole iteration as the other input of the join: 48 registers, 100 spills
-#if V2W_WS_PERSIST
-        issue_x(min(tile + (int)gridDim.x, a.ntiles - 1));
-#endif
         if (!tail) {
             const int nq = nto >> 2;
             const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
@@ -963,9 +898,6 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     if (!(q->slope > 0.f && q->slope <= 1.f)) return V2W_E_SHAPE;            // lrelu as max(v, slope v), undone as min(a, a / slope)
     bool std_cfg = CH == 32 && !WLDS && q->nk == 3;          // the generator's own blocks: the compile-time form
     for (int j = 0; j < 3 && std_cfg; ++j) std_cfg = q->k[j] == 3 + 4 * j && q->dil1[j] == 1 && q->dil2[j] == 3;
-#ifdef V2W_WS_NOCT
-    std_cfg = false;
-#endif
     if (p.rb1) std_cfg = false;
     if (UPF > 0 && !std_cfg) return V2W_E_SHAPE;             // the fused upsampler exists for the compile-time block set only
     if (up_tiles_out) *up_tiles_out = p.ntiles;              // rows of up_stats_part
@@ -975,10 +907,7 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     if (v2w_dry(stream)) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    // V2W_WS_PERSIST: one residency of the chip (workgroups per CU as the configuration counts on), each workgroup walks its tiles
-    const int ncu = v2w_num_cus();
-    const int slots = V2W_WS_PERSIST ? ncu * ((OCC * 4) / (WM * WN)) : p.ntiles;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 
@@ -1000,7 +929,7 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
     if (a->up_out) {
         // the stage with the next stage's upsampler behind it (stride 4 after the 256- and 128-channel stages, stride 2 after 64 and 32: the
         // generator's (5, 4, 4, 2, 2) and the x640 variant's (8, 5, 4, 2, 2) from the second / third upsampler on)
-        if (a->post_out || V2W_WS_CFG != 0) return V2W_E_SHAPE;
+        if (a->post_out) return V2W_E_SHAPE;
         if (a->C == 256 && a->up_u == 4) return launch_wide<1, 4, 8, 1, 2, 32, false, 4>(a, stream, up_tiles_out);
         if (a->C == 128 && a->up_u == 4) return launch_wide<1, 4, 4, 2, 2, 32, false, 4>(a, stream, up_tiles_out);
         if (a->C == 64 && a->up_u == 2) return launch_wide<2, 2, 1, 4, 2, 32, false, 2>(a, stream, up_tiles_out);
@@ -1010,22 +939,11 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
     // Measured (one MI355X, configs[2] shapes, us per stage): 8 waves of 64 x 64 outputs 1074 / 1225 / 1133 (C = 128 / 64 / 256) against 4 waves of
     // 64 x 128 with the whole register file 1227 / 1467 / 1199: the single wave per SIMD runs its bare MFMA loop at 89 % of the issue rate
     // but nothing covers its epilogues.  C = 64 fits twice per CU as 4-wave workgroups of 256 positions, which run out of phase.
-#if V2W_WS_CFG == 1
-    if (a->C == 128) return launch_wide<2, 4, 2, 2, 1>(a, stream);
-    if (a->C == 64) return launch_wide<2, 4, 1, 4, 1>(a, stream);
-    if (a->C == 256) return launch_wide<2, 4, 4, 1, 1>(a, stream);
-#elif V2W_WS_CFG == 2
-    // 64 x 64 outputs per wave: a weight fragment (global -> register: the CU's vector memory pipe moves 64 B / clk) feeds TWO MFMAs
-    if (a->C == 128) return launch_wide<2, 2, 2, 4>(a, stream);
-    if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);
-    if (a->C == 256) return launch_wide<2, 2, 4, 2>(a, stream);
-#else
     // 32 x 128 outputs per wave: a weight fragment feeds FOUR MFMAs (half the vector-memory traffic of the 64 x 64 form, the operand reads
     // from LDS double: 128 B / clk of its 256)
     if (a->C == 128) return launch_wide<1, 4, 4, 2>(a, stream);                   // 128 channels x 256 positions, 8 waves
     if (a->C == 64) return launch_wide<2, 2, 1, 4>(a, stream);                    // 64 channels x 256 positions, 4 waves of 64 x 64, two workgroups per CU (1135-1145 us; <1, 4, 2, 2>: 1160-1173)
     if (a->C == 256) return launch_wide<1, 4, 8, 1>(a, stream);                   // 256 channels x 128 positions, 8 waves
-#endif
     // 32 channels x 256 positions, TWO waves of 32 x 128 outputs, four workgroups per CU (the workgroups run out of phase: 870 us against the
     // 940 us of stage_bf16_kernel<32>, whose four waves share every barrier)
     if (a->C == 32) return launch_wide<1, 4, 1, 2>(a, stream);
