@@ -182,17 +182,23 @@ def generator_forward_impl(sd: Dict[str, torch.Tensor], h, x, spk_emb, noise, tr
     return torch.tanh(x), new_buffers
 
 
-def generator_gradients(sd, h, x, spk_emb, noise, dy, training: bool = True, dtype=torch.float32):
+def generator_gradients(sd, h, x, spk_emb, noise, dy, training: bool = True, dtype=torch.float32, want_x: bool = False):
     """Reference gradients of sum(y * dy) w.r.t. every floating-point parameter of the state_dict (torch autograd through
-    the restated forward): what `loss_gen_all.backward()` (vec2wav/train.py:214) sends into the generator."""
+    the restated forward): what `loss_gen_all.backward()` (vec2wav/train.py:214) sends into the generator.  want_x: the gradient
+    w.r.t. the latent input as well, under the key '__x__'."""
     leaves = {}
+    if want_x:
+        x = x.detach().clone().to(dtype).requires_grad_(True)
     for k, v in sd.items():
         if v.is_floating_point() and not any(t in k for t in ('running_', 'weight_u', 'layer.weight_v')):
             leaves[k] = v.detach().clone().to(dtype).requires_grad_(True)
     sd2 = {k: leaves.get(k, v) for k, v in sd.items()}
     y, nb = generator_forward_impl(sd2, h, x, spk_emb, noise, training, dtype)
     (y * dy.to(dtype)).sum().backward()
-    return y.detach(), {k: v.grad for k, v in leaves.items()}, nb
+    grads = {k: v.grad for k, v in leaves.items()}
+    if want_x:
+        grads['__x__'] = x.grad
+    return y.detach(), grads, nb
 
 
 def apply_buffers(sd: Dict[str, torch.Tensor], new_buffers: Dict[str, torch.Tensor]) -> None:

@@ -423,8 +423,7 @@ def test_generator_surface_errors(dev):
         g(x.cpu(), spk.cpu(), nz.cpu())        # no CPU fallback
     with pytest.raises(RuntimeError):
         g(x[:, :100].contiguous(), spk, nz)    # wrong feature width
-    with pytest.raises(NotImplementedError):
-        g(x.clone().requires_grad_(True), spk, nz)   # no gradient w.r.t. the latents
+    assert g(x.clone().requires_grad_(True), spk, nz).requires_grad   # the latent is an autograd citizen (test_generator_input_gradient...)
     g1 = Generator(synthetic.make_hparams(num_wv_feat=768, resblock='1')).to(dev)
     assert g1(x, spk, nz).requires_grad        # ResBlock1 generators are differentiable too
     with torch.no_grad():
@@ -659,6 +658,33 @@ def test_generator_backward_matches_oracle_autograd(dev, training, B, T, resbloc
     with torch.no_grad():
         y2 = g2(*to_dev(inp, dev))
     assert (y2 - y.detach()).abs().max().item() <= (1e-6 if precision == 'f32' else 5e-6)
+
+
+@pytest.mark.parametrize('training,resblock', [(True, 1), (False, 1), (True, '1')])
+def test_generator_input_gradient_matches_oracle_autograd(dev, training, resblock):
+    """dL/dx of the latent input (the reference's Generator is an ordinary autograd citizen, models.py:116-123): conv_pre's input-gradient
+    conv, against autograd through the oracle; with the parameters frozen the same value comes out (only x asks)."""
+    B, T = 2, 12
+    h = synthetic.make_hparams(num_wv_feat=768, resblock=resblock)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = synthetic.make_inputs(h, B, T, seed=21)
+    dy = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 1, T * 320)).astype(np.float32))
+    if not training:
+        O.calibrate_running_stats(sd, h, *inp)
+    _y, g_ref, _ = O.generator_gradients(sd, h, *inp, dy, training=training, want_x=True)
+    ref = g_ref['__x__']
+    x, spk, nz = to_dev(inp, dev)
+    got = []
+    for freeze in (False, True):
+        g = build_generator(h, sd, dev, training=training)
+        g.requires_grad_(not freeze)
+        xg = x.clone().requires_grad_(True)
+        (g(xg, spk, nz) * dy.to(dev)).sum().backward()
+        assert xg.grad is not None and xg.grad.shape == x.shape
+        assert (xg.grad.cpu() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item(), (freeze, (xg.grad.cpu() - ref).abs().max().item())
+        assert all((p.grad is None) == freeze for p in g.parameters())
+        got.append(xg.grad)
+    assert torch.equal(got[0], got[1])
 
 
 def test_generator_backward_wide_halo_resblock2(dev):
@@ -1106,8 +1132,24 @@ def test_standalone_resblock_forward_matches_the_oracle(dev, kind):
     with torch.no_grad():
         got = rb(x.to(dev))
     assert (got.cpu() - want).abs().max().item() <= 2e-5
-    with pytest.raises(NotImplementedError):
-        rb(x.to(dev).requires_grad_(True))
+    # ... and differentiable, as the reference's modules are: input and every parameter gradient against autograd through the oracle's block
+    dy = torch.from_numpy(rng.standard_normal((2, C, L)).astype(np.float32))
+    leaves = {n: v.clone().requires_grad_(True) for n, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    (O._resblock({'rb.' + n: v for n, v in leaves.items()}, 'rb', xr, k, (1, 3, 5) if kind == '1' else (1, 3), kind == '1', torch.float32) * dy).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    out = rb(xg)
+    assert out.requires_grad and torch.equal(out.detach(), got)
+    (out * dy.to(dev)).sum().backward()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 2e-3 * xr.grad.abs().max().item()
+    for n, p in rb.named_parameters():
+        assert p.grad is not None, n
+        ref = leaves[n].grad
+        assert (p.grad.cpu() - ref).abs().max().item() <= 4e-3 * max(ref.abs().max().item(), 1e-6), n
+    xg2 = x.to(dev).requires_grad_(True)       # only the input asks
+    rb.requires_grad_(False)
+    rb(xg2).backward(dy.to(dev))
+    assert torch.allclose(xg2.grad, xg.grad, rtol=0, atol=1e-6 * xr.grad.abs().max().item() + 1e-7)
 
 
 def test_backward_uses_the_spectral_norm_state_of_its_own_forward(dev):

@@ -32,15 +32,16 @@ class GeneratorFunction(torch.autograd.Function):
         y = gen._forward_hip(x, spk, nz, save)
         ctx.gen, ctx.names, ctx.saved = gen, names, save
         ctx.needs = [p.requires_grad for p in params]
+        ctx.need_dx = x.requires_grad           # the latent as an autograd citizen (the reference's modules are: models.py:116-123)
         return y
 
     @staticmethod
     @_hip.on_tensor_device
     def backward(ctx, dy):
-        grads = generator_backward(ctx.gen, ctx.saved, dy.contiguous().float())
+        grads = generator_backward(ctx.gen, ctx.saved, dy.contiguous().float(), need_dx=ctx.need_dx)
         ctx.saved = None
         out = [grads.get(n) if need else None for n, need in zip(ctx.names, ctx.needs)]
-        return (None, None, None, None, None, *out)
+        return (None, None, grads.get('__x__'), None, None, *out)
 
 
 def _dconv(gen, x, wT, out, *, k, **kw):
@@ -66,8 +67,9 @@ def _wn_grads(grads, name, m, dwf):
 
 
 @torch.no_grad()
-def generator_backward(gen, sv, dy):
-    """dy (B, 1, L_out) -> {parameter name: gradient}.  `sv` is the dict filled by `Generator._forward_hip(save=...)`."""
+def generator_backward(gen, sv, dy, need_dx=False):
+    """dy (B, 1, L_out) -> {parameter name: gradient}.  `sv` is the dict filled by `Generator._forward_hip(save=...)`.
+    need_dx: also the gradient w.r.t. the latent input x (key '__x__'): conv_pre's input-gradient conv, one more launch."""
     ws, wf = sv['ws'], sv['wf']
     # the folded weights live in module-owned buffers that the NEXT forward's fold overwrites: harmless while the parameters are unchanged
     # (the same values again); parameters that changed in between - an optimizer step between this graph's forward and its backward -
@@ -269,5 +271,74 @@ def generator_backward(gen, sv, dy):
     # ---- conv_pre (models.py:123): no activation in front of it, no input gradient requested
     grads['conv_pre.bias'] = hipops.channel_sum(dxs)
     _wn_grads(grads, 'conv_pre', gen.conv_pre, hipops.wgrad(x, dxs, k=7, dil=1, slope=1.0))
+    if need_dx:     # dL/dx = conv(dxs; W_pre^T, taps reversed) - no activation in front of conv_pre, no mask
+        dxin = torch.empty_like(x)
+        _dconv(gen, dxs, hipops.transpose_flip(wf['conv_pre']), dxin, k=7, dil=1, slope=1.0)
+        grads['__x__'] = dxin
     torch.cuda.current_stream(dev).wait_stream(side)
     return grads
+
+
+class ResBlockFunction(torch.autograd.Function):
+    """A stand-alone `ResBlock1` / `ResBlock2` as an autograd citizen (the reference's are: models.py:37-44, 65-70): the forward of
+    models._resblock_forward with every step's input kept, the backward from the same entry points the generator's backward uses -
+    input-gradient convs with the transposed, tap-reversed weights and the leaky_relu derivative as an epilogue mask, v2w_wgrad, per-channel
+    sums, v2w_wn_bwd.  `pairs`: [(conv_a, conv_b | None)] as in _resblock_forward; params: the parameters of every conv, in `names` order."""
+
+    @staticmethod
+    def forward(ctx, rb, pairs, names, x, *params):
+        from .models import _fold_one
+        cur = x.detach().contiguous().float()
+        steps = []
+        for ca, cb in pairs:
+            wfa, wpa = _fold_one(ca, cur.device)
+            if cb is None:        # ResBlock2: out = cur + conv_a(lrelu(cur))
+                out = torch.empty_like(cur)
+                hipops.conv1d(cur, wfa, ca.bias.detach(), out, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE, res=cur, wp=wpa)
+                steps.append((ca, None, cur, None, wfa, None))
+            else:                 # ResBlock1: out = cur + conv_b(lrelu(conv_a(lrelu(cur))))
+                u = torch.empty_like(cur)
+                hipops.conv1d(cur, wfa, ca.bias.detach(), u, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE, wp=wpa)
+                wfb, wpb = _fold_one(cb, cur.device)
+                out = torch.empty_like(cur)
+                hipops.conv1d(u, wfb, cb.bias.detach(), out, k=cb.kernel_size, dil=cb.dilation, slope=LRELU_SLOPE, res=cur, wp=wpb)
+                steps.append((ca, cb, cur, u, wfa, wfb))
+            cur = out
+        ctx.steps, ctx.names, ctx.prefix = steps, names, {id(m): n for n, m in rb.named_modules()}
+        ctx.needs = [p.requires_grad for p in params]
+        ctx.need_dx = x.requires_grad
+        return cur
+
+    @staticmethod
+    @_hip.on_tensor_device
+    @torch.no_grad()
+    def backward(ctx, dout):
+        dcur = dout.contiguous().float()
+        grads = {}
+
+        def dconv(src, wf, out, m, **kw):
+            wT = hipops.transpose_flip(wf)
+            return hipops.conv1d(src, wT, None, out, k=m.kernel_size, dil=m.dilation, slope=1.0, wp=hipops.pack_mfma(wT), **kw)
+
+        for ca, cb, cur, u, wfa, wfb in reversed(ctx.steps):
+            na = ctx.prefix[id(ca)]
+            if cb is None:
+                # out = cur + conv_a(lrelu cur) + b  ->  dcur' = dout + lrelu'(cur) * conv(dout; Wa^T flipped)
+                _wn_grads(grads, na, ca, hipops.wgrad(cur, dcur, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE))
+                grads[na + '.bias'] = hipops.channel_sum(dcur)
+                dprev = torch.empty_like(dcur)
+                dconv(dcur, wfa, dprev, ca, res=dcur, mask=(cur, None), mask_slope=LRELU_SLOPE)
+            else:
+                nb = ctx.prefix[id(cb)]
+                _wn_grads(grads, nb, cb, hipops.wgrad(u, dcur, k=cb.kernel_size, dil=cb.dilation, slope=LRELU_SLOPE))
+                grads[nb + '.bias'] = hipops.channel_sum(dcur)
+                du = torch.empty_like(dcur)
+                dconv(dcur, wfb, du, cb, mask=(u, None), mask_slope=LRELU_SLOPE)
+                _wn_grads(grads, na, ca, hipops.wgrad(cur, du, k=ca.kernel_size, dil=ca.dilation, slope=LRELU_SLOPE))
+                grads[na + '.bias'] = hipops.channel_sum(du)
+                dprev = torch.empty_like(dcur)
+                dconv(du, wfa, dprev, ca, res=dcur, mask=(cur, None), mask_slope=LRELU_SLOPE)
+            dcur = dprev
+        ctx.steps = None
+        out = [grads.get(n) if need else None for n, need in zip(ctx.names, ctx.needs)]
+        return (None, None, None, dcur if ctx.need_dx else None, *out)

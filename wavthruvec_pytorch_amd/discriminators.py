@@ -25,6 +25,8 @@ import math
 import os
 from typing import List
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -108,7 +110,7 @@ class _DiscConv(nn.Module):
         # can change a parameter between the two calls, and at the reference's batch_size = 2 the ten-odd small launches of this function
         # per layer and call are most of a discriminator forward's wall clock.  (Spectral norm iterates u, v on EVERY call, as the legacy
         # hook does: never shared.)
-        if _PAIR['on'] and not self.spectral and self._pair_rec is not None and self._pair_rec[0] == key:
+        if _PAIR.on and not self.spectral and self._pair_rec is not None and self._pair_rec[0] == key:
             return self._pair_rec[1]
         k, s, P, G = self.k, self.stride, self.padding, self.groups
         cig, cog = self.c_in // G, self.c_out // G
@@ -146,7 +148,7 @@ class _DiscConv(nn.Module):
             rec['ws4'], rec['kps'] = ws, ws.shape[1]
             rec['wps'] = [hipops.pack_split(ws[g]) for g in range(ws.shape[0])]
         self._cache = (key, rec)
-        if _PAIR['on'] and not self.spectral:
+        if _PAIR.on and not self.spectral:
             self._pair_rec = (key, rec)
         return rec
 
@@ -446,12 +448,19 @@ class _DiscFn(torch.autograd.Function):
                     kps = rec['kps']
                     probs = [(dz, rec['wTs4'][gi], None, dxs, dict(k=kps, dil=dil, slope=1.0, pad_left=(kps - 1 - Q) * dil, algo=hipops.ALGO_SPLIT,
                                                                    wps=rec['wTs'][gi], group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
-                    if G == 1:
-                        hipops.conv1d(dz, probs[0][1], None, dxs, **probs[0][4])
-                    else:
-                        for i in range(0, G, 4):
-                            hipops.conv1d_multi(probs[i:i + 4])
-                else:
+                    try:
+                        if G == 1:
+                            hipops.conv1d(dz, probs[0][1], None, dxs, **probs[0][4])
+                        else:
+                            for i in range(0, G, 4):
+                                hipops.conv1d_multi(probs[i:i + 4])
+                    except _hip.HipLibraryError as e:
+                        # the split-f16 kernel took the forward but declines the TRANSPOSED problem (another halo, another channel count per
+                        # group): the exact fp32 input-gradient conv below, for this and every later step
+                        if e.code != _hip.E_SHAPE:
+                            raise
+                        rec.pop('wTs', None); rec.pop('wTs4', None); rec.pop('wps', None)
+                if 'wTs' not in rec:
                     probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
                                                                  group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]
                     for i in range(0, G, 4):
@@ -493,16 +502,26 @@ class DiscriminatorP(_DiscBase):
         return p, H
 
 
-_PAIR = {'on': False}       # True while a multi-discriminator runs its (y, y_hat) pairs: see _DiscConv.kernel_weights
+class _PairState(threading.local):
+    """`on`: this THREAD is inside a multi-discriminator's (y, y_hat) pairs (see _DiscConv.kernel_weights).  Thread-local and counted: replicas
+    driven from several threads (DataParallel) or a nested call do not switch the sharing off under each other."""
+    depth = 0
+
+    @property
+    def on(self):
+        return self.depth > 0
+
+
+_PAIR = _PairState()
 
 
 def _pairwise(discs, inputs):
     """Run every discriminator on its (y, y_hat) pair -> (scores_real, scores_generated, fmaps_real, fmaps_generated)."""
-    _PAIR['on'] = True
+    _PAIR.depth += 1
     try:
         outs = [(d(y), d(y_hat)) for d, (y, y_hat) in zip(discs, inputs)]
     finally:
-        _PAIR['on'] = False
+        _PAIR.depth -= 1
         for d in discs:
             for l in d._layers():
                 l._pair_rec = None

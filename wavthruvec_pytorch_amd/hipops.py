@@ -207,13 +207,27 @@ def _attach_slab(a, slab, nbytes, device):
         a.splitk_ws, a.splitk_ws_bytes = t.data_ptr(), t.numel() * 4
 
 
+_SPLITK_BYTES = {}      # what a launch's split over C_in needs depends on its sizes and switches alone: asked of the library once per combination
+
+
+def _splitk_bytes(a, n):
+    q = a[0] if n > 1 else a
+    key = (n, q.B, q.C_in, q.C_out, q.L, q.k, q.dil, q.algo, q.accumulate, q.in_stride, q.pad_left, q.in_ct, q.out_ct, q.io_bf16,
+           bool(q.res), bool(q.add0), bool(q.add1), bool(q.mask_src), bool(q.in_a), bool(q.rowsum_part), bool(q.wps), bool(q.wp), q.out_div != 0.0,
+           q.out_slope != 0.0)
+    v = _SPLITK_BYTES.get(key)
+    if v is None:
+        v = _SPLITK_BYTES[key] = int(_hip.load().v2w_conv1d_splitk_ws_bytes(a if n > 1 else C.byref(a), n))
+    return v
+
+
 def conv1d(x, wf, bias, out, splitk_ws=None, **kw):
     """Fused [affine] -> leaky_relu -> dilated Conv1d -> +bias [+res] [+= out | + add0 (+ add1)] [/ out_div]; see the header.
     splitk_ws: a SplitKSlab (f32 MFMA path only; without one a small launch simply runs unsplit)."""
     a = _hip.Conv1dArgs()
     _conv1d_args(a, x, wf, bias, out, **kw)
     if splitk_ws is not None:
-        _attach_slab(a, splitk_ws, _hip.load().v2w_conv1d_splitk_ws_bytes(C.byref(a), 1), x.device)
+        _attach_slab(a, splitk_ws, _splitk_bytes(a, 1), x.device)
     _hip.check(_hip.load().v2w_conv1d_fwd(C.byref(a), _stream(x)), 'v2w_conv1d_fwd')
     return out
 
@@ -227,7 +241,7 @@ def conv1d_multi(problems, splitk_ws=None):
         for a, (x, wf, bias, out, kw) in zip(arr, problems):
             _conv1d_args(a, x, wf, bias, out, **kw)
         if splitk_ws is not None:
-            _attach_slab(arr[0], splitk_ws, _hip.load().v2w_conv1d_splitk_ws_bytes(arr, n), problems[0][0].device)
+            _attach_slab(arr[0], splitk_ws, _splitk_bytes(arr, n), problems[0][0].device)
         rc = _hip.load().v2w_conv1d_fwd_multi(arr, n, _stream(problems[0][0]))
         if rc == 0:
             return

@@ -92,7 +92,9 @@ def _resblock_forward(rb, x, pairs):
     if not x.is_cuda:
         raise RuntimeError('ResBlock (HIP): GPU tensors only; there is no CPU fallback')
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rb.parameters())):
-        raise NotImplementedError('ResBlock (HIP): standalone blocks run without autograd; back-propagate through Generator.forward')
+        from .backward import ResBlockFunction
+        names, params = zip(*rb.named_parameters())
+        return ResBlockFunction.apply(rb, pairs, names, x, *params)
     with torch.no_grad():
         cur = x.detach().contiguous().float()
         for ca, cb in pairs:
@@ -237,7 +239,9 @@ class Generator(nn.Module):
         removes the per-launch host cost.  Inputs are copied into static buffers, the returned tensor is the graph's static
         output (clone it to keep it across calls).  Data-parallel statistics exchange cannot be captured.
         Every buffer the captured launches touch - activations, folded weights, the split-over-C_in scratch (`_slab`) - belongs to
-        THIS module, so graphs of different generators may replay concurrently on different streams."""
+        THIS module, so graphs of different generators may replay concurrently on different streams.  One captured configuration per module
+        at a time: a later forward of another shape replaces those buffers, and `run` then refuses to replay (outgrown split-over-C_in slabs
+        are kept alive, hipops.SplitKSlab.retired)."""
         if self.stat_sync is not None:
             raise RuntimeError('capture_graph: the RCCL statistics all-reduce cannot be part of a captured graph')
         sx, ss, sn = x.detach().clone().contiguous(), spk_emb.detach().clone().contiguous(), noise.detach().clone().contiguous()
@@ -256,7 +260,13 @@ class Generator(nn.Module):
             with torch.cuda.graph(graph, stream=side):
                 sy = self.forward(sx, ss, sn)
 
+        epoch = self._ws_epoch
+
         def run(x, spk_emb, noise):
+            if self._ws_epoch != epoch:
+                # the captured launches write into module-owned buffers: a forward of another shape / precision / storage has replaced them
+                raise RuntimeError('capture_graph: the module reallocated its buffers since this graph was captured (a forward of another '
+                                   'configuration ran): capture again - a module serves one captured configuration at a time')
             if x.dtype == sx.dtype and spk_emb.dtype == ss.dtype and noise.dtype == sn.dtype and x.device == sx.device:
                 torch._foreach_copy_([sx, ss, sn], [x, spk_emb, noise])      # the three inputs into the static buffers: ONE launch
             else:
@@ -546,11 +556,9 @@ class Generator(nn.Module):
             raise RuntimeError(f'Generator parameters live on {self.conv_pre.bias.device}, inputs on {dev}')
         if x.dim() != 3 or x.shape[1] != self.h.num_wv_feat:
             raise RuntimeError(f'expected x of shape (B, {self.h.num_wv_feat}, T), got {tuple(x.shape)}')
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError('Generator (HIP): gradients w.r.t. the latent input x are not provided (the reference '
-                                      'training loop never asks for them, vec2wav/train.py:154-167)')
-        x = x.detach().contiguous().float()
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        x_in = x.contiguous().float()         # (keeps x's place in the autograd graph when it asks for a gradient)
+        x = x_in.detach()
         spk = spk_emb.detach().contiguous().float()
         nz = noise.detach().contiguous().float()
         if spk.shape != (x.shape[0], self.h.spk_dim) or nz.shape != (x.shape[0], self.h.noise_dim):
@@ -561,7 +569,7 @@ class Generator(nn.Module):
                                           'back-propagation needs the MFMA schedule (algo = ALGO_AUTO)')
             from .backward import GeneratorFunction
             names, params = zip(*[(n, q) for n, q in self.named_parameters()])
-            return GeneratorFunction.apply(self, names, x, spk, nz, *params)
+            return GeneratorFunction.apply(self, names, x_in if x_in.requires_grad else x, spk, nz, *params)
         return self._forward_hip(x, spk, nz, None)
 
     def _plan_key(self, x):
