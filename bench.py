@@ -250,11 +250,13 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                 upf = 0                                      # the next stage's upsampler fused behind the stage (Generator.fuse_up): its stride
                 if names[-1].startswith('ups.'):
                     upf = layers[names[-1]]['u']
-                wide = {128: f'<1, 4, 4, 2, 2, 32, false, true, {upf}>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}>',
-                        256: f'<1, 4, 8, 1, 2, 32, false, true, {upf}>', 32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}>'}
+                # (the last argument: the half-t1-tile form - 192-position windows - the 256-channel stage runs with a stride-4 upsampler behind it)
+                wide = {128: f'<1, 4, 4, 2, 2, 32, false, true, {upf}, false>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}, false>',
+                        256: '<2, 3, 4, 2, 2, 32, false, true, 4, true>' if upf == 4 else f'<1, 4, 8, 1, 2, 32, false, true, {upf}, false>',
+                        32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}, false>'}
                 tail7 = names[-1] == 'conv_post' and layers['conv_post']['k'] == 7
                 if names[-1] == 'conv_post' and not tail7:
-                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false, 0>'
+                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false, 0, false>'
                 if ls[0]['cout'] == 16 and 16 not in wide and ls[0]['L'] % 4 == 0:
                     wide[16] = None                          # the reference's block set on 16 channels: v2w_stage_bf16_n16.hip (+ the 7-tap tail)
                 kname = ((('n16_stage_kernel<4, true>' if tail7 else 'n16_stage_kernel<4, false>') if wide[ls[0]['cout']] is None
@@ -262,9 +264,9 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                          if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         if rb1:
-            kname = 'wide_stage_bf16_kernel' + {256: '<1, 4, 8, 1, 2, 32, false, false, 0>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0>',
-                                                64: '<2, 2, 1, 4, 2, 32, false, false, 0>', 32: '<1, 4, 1, 2, 2, 32, false, false, 0>',
-                                                16: '<1, 4, 1, 2, 2, 16, false, false, 0>'}[ls[0]['cout']]
+            kname = 'wide_stage_bf16_kernel' + {256: '<1, 4, 8, 1, 2, 32, false, false, 0, false>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0, false>',
+                                                64: '<2, 2, 1, 4, 2, 32, false, false, 0, false>', 32: '<1, 4, 1, 2, 2, 32, false, false, 0, false>',
+                                                16: '<1, 4, 1, 2, 2, 16, false, false, 0, false>'}[ls[0]['cout']]
         nbytes = sum(l['bytes'] for l in ls)
         if fused:                              # the intermediate is neither written nor re-read
             nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])

@@ -101,14 +101,24 @@ template <typename T> __device__ __forceinline__ T* ws_uni(T* v) { pin_s(v); ret
 // the second (hparams.py:42-43 with ResBlock2) - with every tap count and dilation a compile-time constant (conv_ct below); the launcher
 // checks the arguments against it.  !STD: any branch count / kernel size / dilation at run time.
 // UPF: 0, or the stride (2 / 4) of the NEXT stage's transposed conv, run here on the stage's output while it is still on chip (STD only)
-template <int MI, int NI, int WM, int WN, int OCC, int CH, bool WLDS, bool STD, int UPF = 0>
+// TSP (round 5; MI = 2, fused upsampler only): the t1 tile holds HALF the channels.  At C = 256 the x and t1 tiles of all channels bound the
+// window to 128 positions - 96 valid outputs per tile, a third of the MFMA work spent on halo columns, 1.75 residencies of the chip at
+// B = 32 x T = 256.  Here every branch runs in two passes: pass h computes the conv1 rows of the waves' row blocks 2 wm + h (t1 planes
+// h, h + 2, ..: half a tile), conv2 accumulates that half of its reduction; the t1 of a pass is the wave's own accumulator block h, so the
+// fp32 residual into the running output needs no exchange.  The window grows to 192 positions (160 valid: a fifth of halo work, ONE
+// residency at B = 32 x T = 256); the fused upsampler runs its virtual rows in two halves (its accumulators would not fit otherwise), its
+// operand tile z over the dead x tile, its scratch over the t1 half tile.
+template <int MI, int NI, int WM, int WN, int OCC, int CH, bool WLDS, bool STD, int UPF = 0, bool TSP = false>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 wide_stage_bf16_kernel(const WideArgs a) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     static_assert(CH == 32 || (CH == 16 && MI == 1 && WM == 1), "16 channels: one row block");
     static_assert(UPF == 0 || ((UPF == 2 || UPF == 4) && STD && CH == 32), "fused upsampler: the compile-time block set, strides 2 and 4");
+    static_assert(!TSP || (MI == 2 && UPF > 0 && STD && CH == 32 && !WLDS), "half t1 tile: two row blocks per wave, the fused upsampler");
     constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32;
+    constexpr int MI1 = TSP ? 1 : MI;                                           // conv1 row blocks per pass
+    constexpr int NCHT = TSP ? NCH / 2 : NCH;                                   // planes of the t1 tile
     constexpr int RB = 2 * CH;                                                  // bytes of a tile row (one position of one plane)
     constexpr int KS = CH / 16;                                                 // k-steps per (plane, tap)
     constexpr int NG = CH / 8;                                                  // accumulator register quads that hold real channels
@@ -126,10 +136,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
     const int h1max = ws_uni(a.h1max), h2max = ws_uni(a.h2max), nto = ws_uni(a.nto);
     const int xpsz = xrows * RB, tpsz = trows * RB;                             // bytes per plane
     const unsigned xbase = 0, tbase = (unsigned)(NCH * xpsz);                   // LDS byte offsets of the two tiles
-    float* const btab = reinterpret_cast<float*>(smem_w + tbase + NCH * tpsz); // bias1[nk][C], then sum_j bias2_j [C], then a[C], s[C]
+    float* const btab = reinterpret_cast<float*>(smem_w + tbase + NCHT * tpsz); // bias1[nk][C], then sum_j bias2_j [C], then a[C], s[C]
     float* const b2tab = btab + V2W_WS_MAXB * C;
     float* const atab = b2tab + C;
-    const unsigned wring = tbase + (unsigned)(NCH * tpsz) + (unsigned)((V2W_WS_MAXB + 3) * C * sizeof(float));     // WLDS: the fragment ring
+    const unsigned wring = tbase + (unsigned)(NCHT * tpsz) + (unsigned)((V2W_WS_MAXB + 3) * C * sizeof(float));     // WLDS: the fragment ring
     const float slope = a.slope, inv_slope = a.inv_slope;
 
     const int hout = ws_uni(a.hout);
@@ -203,7 +213,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
     };
 
     const bool young = wave >= (WM * WN) / 2;                 // (uniform) the second-dispatched half of the workgroup's waves
-    acc_t acc1[MI][NI], oacc[MI][NI];
+    acc_t acc1[MI1][NI], oacc[MI][NI];
     unsigned lane16 = (unsigned)lane * 16u;
     auto mfma = [&](acc_t c, u32x4 av, u32x4 bv) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
@@ -401,8 +411,12 @@ wide_stage_bf16_kernel(const WideArgs a) {
     // the barrier / epilogue in front of the conv was measured and changed nothing: the other wave of the SIMD covers the cold start.)
     // (acc: [MIX][NI] blocks, row block i of this wave = block rb0 + i of the weight stream: MIX = MI, rb0 = wm0 / 32 for the stage's own
     // convs; the fused upsampler runs UPF / 2 times as many row blocks per wave)
-    auto conv_ct = [&](auto k_c, auto d_c, auto& acc, int rb0, unsigned base, int psz, int r0, const unsigned char* wps) {
+    // nchp_c planes of the tile are walked; plane ch of the tile is reduction plane PMUL ch + padd of the weights (all of them: PMUL = 1,
+    // padd = 0; the half t1 tile of a TSP pass: PMUL = 2, padd = the pass)
+    auto conv_ct = [&](auto k_c, auto d_c, auto& acc, int rb0, unsigned base, int psz, int r0, const unsigned char* wps, auto nchp_c, int padd)
+        __attribute__((always_inline)) {
         constexpr int K = decltype(k_c)::value, DIL = decltype(d_c)::value;
+        constexpr int NCHP = decltype(nchp_c)::value, PMUL = NCH / NCHP;
         constexpr int MIX = (int)std::extent<std::remove_reference_t<decltype(acc)>, 0>::value;
         static_assert(KS == 2 && K >= 2, "64-byte rows");
         const unsigned char* ap[MIX];
@@ -417,10 +431,11 @@ wide_stage_bf16_kernel(const WideArgs a) {
         };
         auto addr = [&](unsigned pbase, int row) { return pbase + (unsigned)(row * RB + ((hk ^ swz(row)) << 4)); };
         // fragment (plane ch, k-step s, tap t) of a row block sits at ((2 ch + s) K + t) units
-        frag(ar[0], 0);
-        frag(ar[1], K * V2W_WS_UNIT);
-        frag(ar[2], 1 * V2W_WS_UNIT);
-        frag(ar[3], (K + 1) * V2W_WS_UNIT);
+        const int f0 = 2 * padd * K * V2W_WS_UNIT;
+        frag(ar[0], f0);
+        frag(ar[1], f0 + K * V2W_WS_UNIT);
+        frag(ar[2], f0 + 1 * V2W_WS_UNIT);
+        frag(ar[3], f0 + (K + 1) * V2W_WS_UNIT);
         u32x4 bb[2][NI];
         {
             const unsigned x0 = addr(base, r0);
@@ -434,8 +449,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
         auto plane = [&](auto par_c, int ch) {
             constexpr int PAR = decltype(par_c)::value;       // parity of the plane's first tap in the global tap order (K is odd)
             const unsigned pbase = base + (unsigned)(ch * psz);
-            const bool lastp = ch + 1 >= NCH;
-            const int fbase = 2 * ch * K * V2W_WS_UNIT;       // (uniform) the plane's k-step 0, tap 0
+            const bool lastp = ch + 1 >= NCHP;
+            const int fbase = 2 * (PMUL * ch + padd) * K * V2W_WS_UNIT;       // (uniform) the plane's k-step 0, tap 0
 #pragma unroll
             for (int t = 0; t < K; ++t) {
                 const int sl = 2 * ((PAR + t) & 1);
@@ -444,7 +459,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 const unsigned xn = wrapn ? (lastp ? addr(pbase, r0 + t * DIL) : addr(pbase + (unsigned)psz, r0)) : addr(pbase, r0 + (t + 1) * DIL);
                 // fragments two taps on: this plane, or the next one (its blocks lie 2 K units further; past the end: this plane's again)
                 const int t2 = (t + 2) % K;
-                const int f2 = fbase + ((t + 2 >= K && !lastp) ? 2 * K * V2W_WS_UNIT : 0) + t2 * V2W_WS_UNIT;
+                const int f2 = fbase + ((t + 2 >= K && !lastp) ? 2 * PMUL * K * V2W_WS_UNIT : 0) + t2 * V2W_WS_UNIT;
 #pragma unroll
                 for (int sq = 0; sq < 2; ++sq) {
 #pragma unroll
@@ -458,15 +473,17 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
             }
         };
-        if constexpr (NCH == 1) {
+        if constexpr (NCHP == 1) {
             plane(std::integral_constant<int, 0>{}, 0);
         } else {
-            for (int ch = 0; ch < NCH; ch += 2) {
+#pragma nounroll
+            for (int ch = 0; ch < NCHP; ch += 2) {
                 plane(std::integral_constant<int, 0>{}, ch);
                 plane(std::integral_constant<int, 1>{}, ch + 1);
             }
         }
     };
+    constexpr std::integral_constant<int, NCH> all_planes{};
     // ---- the running output accumulator starts at sum_j b2_j
     auto init_oacc = [&]() {
 #pragma unroll
@@ -484,32 +501,27 @@ wide_stage_bf16_kernel(const WideArgs a) {
 
     bool rb1 = false;
     if constexpr (!STD) rb1 = ws_uni(a.rb1) != 0;
-    auto branch = [&](int jb, auto k_c) {
+    auto branch = [&](int jb, auto k_c) __attribute__((always_inline)) {
         constexpr int KC = decltype(k_c)::value;             // > 0: the tap count at compile time (dilations 1 and 3), 0: run-time arguments
         const int K = KC ? KC : ws_uni(a.K[jb]), d1 = KC ? 1 : ws_uni(a.d1[jb]), d2 = KC ? 3 : ws_uni(a.d2[jb]);
         const int h1 = d1 * (K - 1) / 2, h2 = d2 * (K - 1) / 2;
-        // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+        // ---- conv1_j on the window: column col <-> position n0 - h2max + col <-> x row xc0 + col.  (ab: one row block of conv1's accumulators,
+        // rowblk: its index among the C / 32 row blocks)
+        auto init_acc1 = [&](acc_t (&ab)[NI], int rowblk) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (g < NG) bv = *reinterpret_cast<const f32x4*>(btab + jb * C + wm0 + 32 * i + 8 * g + 4 * hk);
+                if (g < NG) bv = *reinterpret_cast<const f32x4*>(btab + jb * C + 32 * rowblk + 8 * g + 4 * hk);
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) acc1[i][j][4 * g + x] = bv[x];
+                    for (int j = 0; j < NI; ++j) ab[j][4 * g + x] = bv[x];
             }
-        V2W_STAMP(3 + 6 * jb);
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, wm0 / 32, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]));
-        else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
-        V2W_STAMP(4 + 6 * jb);
-        __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
-        V2W_STAMP(5 + 6 * jb);
-        // ---- t1 = acc + x (x rebuilt from the activated tile: registers 4g .. 4g+3 of block (i, j) <-> channels 8g + 4hk + {0..3} of plane
-        // wm0 / 32 + i at this lane's position = 8 contiguous bytes); the running output takes t1 in fp32, the tile lrelu(t1) as bf16
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+        };
+        // ---- t1 = acc + x (x rebuilt from the activated tile: registers 4g .. 4g+3 of block j <-> channels 8g + 4hk + {0..3} of plane xplane
+        // at this lane's position = 8 contiguous bytes); the running output block ob takes t1 in fp32, plane tplane of the t1 tile lrelu(t1)
+        // as bf16
+        auto t1_epi = [&](acc_t (&ab)[NI], acc_t (&ob)[NI], int xplane, int tplane) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 int col = wn0 + lr;
@@ -518,8 +530,8 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 const int pos = n0 - h2max + col;
                 const bool in_seq = pos >= 0 && pos < L;    // conv2 zero-pads t1 outside the sequence
                 const int xrow = xc0 + col, trow = col;
-                const unsigned xq = xbase + (unsigned)((wm0 / 32 + i) * xpsz + xrow * RB + 8 * hk);
-                const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + trow * RB + 8 * hk);
+                const unsigned xq = xbase + (unsigned)(xplane * xpsz + xrow * RB + 8 * hk);
+                const unsigned tq = tbase + (unsigned)(tplane * tpsz + trow * RB + 8 * hk);
                 const int xsw = swz(xrow), tsw = swz(trow);
                 // (two elements per vector instruction where the ISA has a packed form - multiply, add; the position mask is a factor 0 / 1:
                 // every value here is finite, x is exactly 0 outside the sequence.  6 vector instructions per element instead of 11.)
@@ -534,12 +546,12 @@ wide_stage_bf16_kernel(const WideArgs a) {
                         const f32x2 xa = {ws_lo(w[h]), ws_hi(w[h])};
                         const f32x2 xi = xa * isl2;
                         const f32x2 xr = {ws_min(xa[0], xi[0]), ws_min(xa[1], xi[1])};       // lrelu undone (slope < 1)
-                        f32x2 t = f32x2{acc1[i][j][4 * g + 2 * h], acc1[i][j][4 * g + 2 * h + 1]};
+                        f32x2 t = f32x2{ab[j][4 * g + 2 * h], ab[j][4 * g + 2 * h + 1]};
                         if (!rb1) t = t + xr;                // ResBlock2: t1 = x + conv1(..); ResBlock1: the intermediate carries no residual
                         t = t * msk;
                         const f32x2 radd = rb1 ? xr : t;     // ... its residual x (0 outside the sequence) joins the OUTPUT instead
-                        oacc[i][j][4 * g + 2 * h] += radd[0];
-                        oacc[i][j][4 * g + 2 * h + 1] += radd[1];
+                        ob[j][4 * g + 2 * h] += radd[0];
+                        ob[j][4 * g + 2 * h + 1] += radd[1];
                         const f32x2 ts = t * sl2;
                         packed[h] = ws_pack2(fmaxf(t[0], ts[0]), fmaxf(t[1], ts[1]));
                     }
@@ -547,12 +559,39 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (TSP) {
+            // ---- two passes: conv1 rows of row block 2 wm + h -> the t1 half tile (plane wm of it) -> that half of conv2's reduction
+            auto pass = [&](auto h_c) __attribute__((always_inline)) {
+                constexpr int H = decltype(h_c)::value;
+                init_acc1(acc1[0], wm0 / 32 + H);
+                conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, wm0 / 32 + H, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), all_planes, 0);
+                __syncthreads();          // the previous pass's conv2 has finished reading the t1 half tile
+                t1_epi(acc1[0], oacc[H], wm0 / 32 + H, wave / WN);
+                __syncthreads();
+                conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]),
+                        std::integral_constant<int, NCHT>{}, H);
+            };
+            pass(std::integral_constant<int, 0>{});
+            pass(std::integral_constant<int, 1>{});
+        } else {
+#pragma unroll
+        for (int i = 0; i < MI1; ++i) init_acc1(acc1[i], wm0 / 32 + i);
+        V2W_STAMP(3 + 6 * jb);
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 1>{}, acc1, wm0 / 32, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), all_planes, 0);
+        else conv(acc1, xbase, xpsz, xc0 - h1 + wn0 + lr, ws_uni(a.w1[jb]), K, d1);
+        V2W_STAMP(4 + 6 * jb);
+        __syncthreads();          // conv2 of the previous branch has finished reading the t1 tile
+        V2W_STAMP(5 + 6 * jb);
+#pragma unroll
+        for (int i = 0; i < MI1; ++i) t1_epi(acc1[i], oacc[i], wm0 / 32 + i, wm0 / 32 + i);
         V2W_STAMP(6 + 6 * jb);
         __syncthreads();
         V2W_STAMP(7 + 6 * jb);
         // ---- conv2_j on the same window, onto the running accumulator
-        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]));
+        if constexpr (KC > 0) conv_ct(k_c, std::integral_constant<int, 3>{}, oacc, wm0 / 32, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), all_planes, 0);
         else conv(oacc, tbase, tpsz, wn0 + lr - h2, ws_uni(a.w2[jb]), K, d2);
+        }
         V2W_STAMP(8 + 6 * jb);
     };
     issue_x(blockIdx.x);
@@ -598,10 +637,14 @@ wide_stage_bf16_kernel(const WideArgs a) {
         // the BatchNorm partial sums of the fp32 values.  The stage's own output never exists in memory: one tensor written and one tensor
         // read less per stage, one launch less, no staging of the upsampler's input.
         constexpr int MIU = MI * UPF / 2;                     // 32-row blocks of virtual rows per wave
+        constexpr int UH = TSP ? 2 : 1, MIUH = MIU / UH;      // ... run in UH passes of MIUH blocks (TSP: 192 accumulator registers would not fit)
         constexpr int CPB = 32 / UPF, CU = C / 2;             // channels per 32-row block; real output channels
         __syncthreads();                                      // conv2 of the last branch has read the t1 tile
         V2W_STAMP(27);
-        float* const ubias = reinterpret_cast<float*>(smem_w + xbase);           // over the dead x tile: bias [C / 2], partial sums [WN][C / 2][2]
+        // the operand tile z: the dead t1 tile - or (TSP: the t1 tile holds half the planes) the dead x tile, a slack of 256 bytes in front of
+        // it for tap -1 of plane 0; the scratch (bias [C / 2], partial sums [WN][C / 2][2], the waves' strips): the other dead tile
+        const unsigned zbase = TSP ? xbase + 256u : tbase;
+        float* const ubias = reinterpret_cast<float*>(smem_w + (TSP ? tbase : xbase));
         float* const ured = ubias + CU;
         for (int c = tid; c < CU; c += NTH) ubias[c] = a.up_bias ? a.up_bias[c] : 0.f;
         {
@@ -616,7 +659,7 @@ wide_stage_bf16_kernel(const WideArgs a) {
                     col += 32 * j;
                     const int pos = n0 - h2max + col;
                     const bool in_seq = pos >= 0 && pos < L;  // the transposed conv sees the L positions of the sequence only
-                    const unsigned tq = tbase + (unsigned)((wm0 / 32 + i) * tpsz + col * RB + 8 * hk);
+                    const unsigned tq = zbase + (unsigned)((wm0 / 32 + i) * tpsz + col * RB + 8 * hk);
                     const int tsw = swz(col);
                     // (packed forms; the mask as a factor: the out-of-sequence columns a stored output can read - position -1, position L -
                     // lie inside the tile's valid window and are finite)
@@ -647,11 +690,27 @@ wide_stage_bf16_kernel(const WideArgs a) {
         //   UPF = 4: channel 8 i + 2 g + hk, outputs 4 q + {0..3};   UPF = 2: channels 16 i + 4 g + 2 hk + {0, 1}, outputs 2 q + {0, 1}
         // The accumulators start at the bias of their channel (no add in the epilogue).
         constexpr int NC = UPF == 2 ? 2 : 1;                  // channels of a register quad
-        constexpr int CHW = MIU * CPB;                        // channels of this wave
-        const int cw0 = (wm0 / 32) * (UPF / 2) * CPB;         // its first channel
-        acc_t uacc[MIU][NI];
+        constexpr int CHW = MIUH * CPB;                       // channels of this wave per pass
+        const int Lout = L * UPF;
+        const bool stats = a.up_stats != nullptr;
+        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * CU * Lout * 2;
+        const int ncen = nto - 2;                             // input positions this tile is the centre of: window columns h2max + 1 ..
+        float* const ssc = ured + WN * CU * 2 + wave * (CHW * 64);       // this wave's scratch, reused by its passes
+        unsigned qo[NI];                                      // byte offset of output position U q inside a channel row; 0xffffffff: not stored
 #pragma unroll
-        for (int i = 0; i < MIU; ++i)
+        for (int jj = 0; jj < NI; ++jj) {
+            const int col = wn0 + 32 * jj + lr;
+            const int cc = col - h2max - 1;                   // index among the tile's centres
+            const int q = n0 + 1 + cc;
+            const bool ok = cc >= 0 && cc < ncen && q < L;
+            qo[jj] = ok ? (unsigned)(UPF * q) * 2u : 0xffffffffu;
+        }
+#pragma unroll 1
+        for (int uh = 0; uh < UH; ++uh) {
+        const int cw0 = ((wm0 / 32) * (UPF / 2) + MIUH * uh) * CPB;       // the first channel of this wave's pass
+        acc_t uacc[MIUH][NI];
+#pragma unroll
+        for (int i = 0; i < MIUH; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = CPB * i + (UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk);
@@ -663,32 +722,18 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 }
             }
         // virtual tap tv reads input position q + tv - 1 (2 U taps at stride U: one input position of halo per side)
-        conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, uacc, (wm0 / 32) * (UPF / 2), tbase, tpsz,
-                wn0 + lr - 1, ws_uni(a.up_w));
+        conv_ct(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, uacc, (wm0 / 32) * (UPF / 2) + MIUH * uh, zbase, tpsz,
+                wn0 + lr - 1, ws_uni(a.up_w), all_planes, 0);
         V2W_STAMP(22);
         // ---- epilogue: bf16 stores straight from the accumulators (the phases of a channel are adjacent registers of a lane, consecutive
         // lanes = consecutive output positions).  BatchNorm partial sums of the fp32 values: a lane adds up its columns of a channel, the
         // 32 lanes of a channel meet through a wave-private LDS scratch [channel][32][2] that ONE pass of the wave sums per (channel, stat)
         // in a fixed order - instead of a DPP tree + readlanes per register quad (30 of the ~100 vector instructions of a quad).
-        const int Lout = L * UPF;
-        const bool stats = a.up_stats != nullptr;
-        unsigned char* const obase = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * CU * Lout * 2;
-        const int ncen = nto - 2;                             // input positions this tile is the centre of: window columns h2max + 1 ..
-        float* const ssc = ured + WN * CU * 2 + wave * (CHW * 64);       // this wave's scratch (over the dead x tile)
-        unsigned qo[NI];                                      // byte offset of output position U q inside a channel row; 0xffffffff: not stored
 #pragma unroll
-        for (int jj = 0; jj < NI; ++jj) {
-            const int col = wn0 + 32 * jj + lr;
-            const int cc = col - h2max - 1;                   // index among the tile's centres
-            const int q = n0 + 1 + cc;
-            const bool ok = cc >= 0 && cc < ncen && q < L;
-            qo[jj] = ok ? (unsigned)(UPF * q) * 2u : 0xffffffffu;
-        }
-#pragma unroll
-        for (int i = 0; i < MIU; ++i)
+        for (int i = 0; i < MIUH; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cl = CPB * i + (UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk);       // channel inside the wave (+ 1: the second of UPF = 2)
+                const int cl = CPB * i + (UPF == 4 ? 2 * g + hk : 4 * g + 2 * hk);       // channel inside the wave's pass (+ 1: the second of UPF = 2)
                 float s1[NC], s2[NC];
 #pragma unroll
                 for (int n = 0; n < NC; ++n) s1[n] = s2[n] = 0.f;
@@ -729,6 +774,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
                 for (int k = 0; k < 32; ++k) t += ssc[(chl * 32 + ((k + lane) & 31)) * 2 + st];
                 ured[((wave % WN) * CU + cw0 + chl) * 2 + st] = t;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the strip is read before the next pass rewrites it)
+        }
+        }     // (uh)
+        if (stats) {
             __syncthreads();
             for (int c = tid; c < CU; c += NTH) {
                 float t1 = 0.f, t2 = 0.f;
@@ -840,9 +889,10 @@ wide_stage_bf16_kernel(const WideArgs a) {
     }
 }
 
-template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32, bool WLDS = false, int UPF = 0>
+template <int MI, int NI, int WM, int WN, int OCC = 2, int CH = 32, bool WLDS = false, int UPF = 0, bool TSP = false>
 int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles_out = nullptr) {
     constexpr int NTH = 64 * WM * WN, C = CH == 16 ? 16 : 32 * MI * WM, W = 32 * NI * WN, NCH = CH == 16 ? 1 : C / 32, RB = 2 * CH;
+    constexpr int NCHT = TSP ? NCH / 2 : NCH;                // planes of the t1 tile (TSP: half of them, see the kernel)
     WideArgs p{};
     p.in = reinterpret_cast<const unsigned short*>(q->in); p.in_a = q->in_a; p.in_s = q->in_s;
     p.out = reinterpret_cast<unsigned short*>(q->out);
@@ -890,11 +940,19 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     p.ntl = (q->L + (p.nto - 2 * p.hout) - 1) / (p.nto - 2 * p.hout);
     p.ntiles = q->B * p.ntl;
     if (p.rb1) { p.ntiles1 = p.ntiles; p.ntiles = q->nk * p.ntiles1; }
-    const size_t tiles = (size_t)NCH * (p.xrows + p.trows) * RB;
-    // (+ 32 rows of slack: conv2's taps past the last plane of the t1 tile stay inside the allocation)
-    const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float) + (WLDS ? (size_t)3 * (C / 32) * (CH / 16) * 1024 : 0) + 32 * RB;
+    const size_t tiles = ((size_t)NCH * p.xrows + (size_t)NCHT * p.trows) * RB;
+    // (+ 32 rows of slack: conv2's taps past the last plane of the t1 tile stay inside the allocation; TSP: the tables behind the tile - 7 KB
+    // at C = 256 - are that slack, the budget has no room for another)
+    const size_t lds = tiles + (size_t)(V2W_WS_MAXB + 3) * C * sizeof(float) + (WLDS ? (size_t)3 * (C / 32) * (CH / 16) * 1024 : 0) + (TSP ? 0 : 32 * RB);
     if (lds * ((OCC * 4) / (WM * WN)) > 160 * 1024) return V2W_E_SHAPE;       // (as many workgroups per CU as the configuration counts on)
-    if (lds < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;       // the store scratch [C][W + 8] overlays the tiles (and the dead tables / ring)
+    if (UPF == 0 && lds < (size_t)C * (W + 8) * sizeof(float)) return V2W_E_SHAPE;   // the store scratch [C][W + 8] overlays the tiles (and the dead tables / ring)
+    if (TSP) {
+        // z (all planes, W rows, 256 bytes of slack in front) over the x tile; the upsampler's scratch over the t1 half tile
+        constexpr int CUc = C / 2, CHWc = (MI * UPF / 2 / 2) * (32 / (UPF ? UPF : 1));
+        if ((size_t)NCH * W * RB + 256 + RB > (size_t)NCH * p.xrows * RB) return V2W_E_SHAPE;
+        if ((size_t)(CUc + WN * CUc * 2 + WM * WN * CHWc * 64) * sizeof(float) > (size_t)NCHT * p.trows * RB) return V2W_E_SHAPE;
+        if (p.h2max * RB > (int)((V2W_WS_MAXB + 3) * C * sizeof(float))) return V2W_E_SHAPE;
+    }
     if (!(q->slope > 0.f && q->slope <= 1.f)) return V2W_E_SHAPE;            // lrelu as max(v, slope v), undone as min(a, a / slope)
     bool std_cfg = CH == 32 && !WLDS && q->nk == 3;          // the generator's own blocks: the compile-time form
     for (int j = 0; j < 3 && std_cfg; ++j) std_cfg = q->k[j] == 3 + 4 * j && q->dil1[j] == 1 && q->dil2[j] == 3;
@@ -902,7 +960,7 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     if (UPF > 0 && !std_cfg) return V2W_E_SHAPE;             // the fused upsampler exists for the compile-time block set only
     if (up_tiles_out) *up_tiles_out = p.ntiles;              // rows of up_stats_part
     constexpr bool STDK = CH == 32 && !WLDS;
-    auto kern = (std_cfg && STDK) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, STDK, (STDK ? UPF : 0)>
+    auto kern = (std_cfg && STDK) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, STDK, (STDK ? UPF : 0), (STDK && UPF > 0 ? TSP : false)>
                                   : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false, 0>;
     if (v2w_dry(stream)) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -930,7 +988,13 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
         // the stage with the next stage's upsampler behind it (stride 4 after the 256- and 128-channel stages, stride 2 after 64 and 32: the
         // generator's (5, 4, 4, 2, 2) and the x640 variant's (8, 5, 4, 2, 2) from the second / third upsampler on)
         if (a->post_out) return V2W_E_SHAPE;
-        if (a->C == 256 && a->up_u == 4) return launch_wide<1, 4, 8, 1, 2, 32, false, 4>(a, stream, up_tiles_out);
+        if (a->C == 256 && a->up_u == 4) {
+            // 192-position windows (160 valid outputs) on a half t1 tile, 64 x 96 outputs per wave - 256 tiles = ONE residency of the chip at
+            // B = 32 x T = 256 (96-output windows: 448 tiles, 1.75) and a fifth of the MFMA work on halo columns instead of a third
+            const int rc = launch_wide<2, 3, 4, 2, 2, 32, false, 4, true>(a, stream, up_tiles_out);
+            if (rc != V2W_E_SHAPE) return rc;
+            return launch_wide<1, 4, 8, 1, 2, 32, false, 4>(a, stream, up_tiles_out);
+        }
         if (a->C == 128 && a->up_u == 4) return launch_wide<1, 4, 4, 2, 2, 32, false, 4>(a, stream, up_tiles_out);
         if (a->C == 64 && a->up_u == 2) return launch_wide<2, 2, 1, 4, 2, 32, false, 2>(a, stream, up_tiles_out);
         if (a->C == 32 && a->up_u == 2) return launch_wide<1, 4, 1, 2, 2, 32, false, 2>(a, stream, up_tiles_out);
