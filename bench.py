@@ -251,7 +251,7 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                 if names[-1].startswith('ups.'):
                     upf = layers[names[-1]]['u']
                 # (the last argument: the half-t1-tile form - 192-position windows - the 256-channel stage runs with a stride-4 upsampler behind it)
-                wide = {128: f'<1, 4, 4, 2, 2, 32, false, true, {upf}, false>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}, false>',
+                wide = {128: '<2, 3, 2, 4, 2, 32, false, true, 4, true>' if upf == 4 else f'<1, 4, 4, 2, 2, 32, false, true, {upf}, false>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}, false>',
                         256: '<2, 3, 4, 2, 2, 32, false, true, 4, true>' if upf == 4 else f'<1, 4, 8, 1, 2, 32, false, true, {upf}, false>',
                         32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}, false>'}
                 tail7 = names[-1] == 'conv_post' and layers['conv_post']['k'] == 7
