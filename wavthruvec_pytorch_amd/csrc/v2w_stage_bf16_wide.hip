@@ -996,12 +996,13 @@ int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t str
             return launch_wide<1, 4, 8, 1, 2, 32, false, 4>(a, stream, up_tiles_out);
         }
         if (a->C == 128 && a->up_u == 4) {
-            // the same form at 128 channels: 384-position windows (352 valid) - measured 1.4 % of a configs[2] forward; at 64 channels
-            // (<2, 3, 1, 4, .., 2, true>: two workgroups of 384 positions per CU) it measured 0.3 %: not taken
+            // the same form at 128 channels: 384-position windows (352 valid) - measured 1.4 % of a configs[2] forward
             const int rc = launch_wide<2, 3, 2, 4, 2, 32, false, 4, true>(a, stream, up_tiles_out);
             if (rc != V2W_E_SHAPE) return rc;
             return launch_wide<1, 4, 4, 2, 2, 32, false, 4>(a, stream, up_tiles_out);
         }
+        // (64 channels on that form - <2, 3, 1, 4, .., 2, true>: two workgroups of 384 positions per CU, or <2, 3, 1, 8, .., 2, true>: one of 768 -
+        // measured within +-0.5 % of this configuration at configs[2] and 0.7 % slower at B = 32 x T = 256: not taken)
         if (a->C == 64 && a->up_u == 2) return launch_wide<2, 2, 1, 4, 2, 32, false, 2>(a, stream, up_tiles_out);
         if (a->C == 32 && a->up_u == 2) return launch_wide<1, 4, 1, 2, 2, 32, false, 2>(a, stream, up_tiles_out);
         return V2W_E_SHAPE;
