@@ -5,6 +5,9 @@ T=${1:?round tag}; O=gpurun_out/profiles_new; P=profiles
 cp $O/all_configs.txt $P/${T}_all_configs.txt
 cp $O/cfg1_latency_timeline.txt $P/${T}_cfg1_latency_timeline.txt
 cp $O/bench.json $P/${T}_cfg2_bench.json
+cp $O/bench_detail.json $P/${T}_cfg2_bench_detail.json
+cp $O/cfg2_bf16_hbm_traffic.json $P/${T}_cfg2_bf16_hbm_traffic.json
+cp $O/cfg2_bf16_per_layer.txt $P/${T}_cfg2_bf16_per_layer.txt
 cp $O/ks/ks_kernel_stats.csv $P/${T}_cfg2_kernel_stats.csv
 cp $O/ks_bf16/ks_kernel_stats.csv $P/${T}_cfg2_bf16_kernel_stats.csv
 cp $O/ks_f16x3/ks_kernel_stats.csv $P/${T}_cfg2_f16x3_kernel_stats.csv

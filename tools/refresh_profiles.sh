@@ -20,6 +20,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_cfg3 -
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ks_lat -o ks -- python3 $R/tools/latency_bench.py 1 50 > $O/ks_lat.log 2>&1
 # one train.py GAN iteration (generator, mel, D step, G step) at the cfg2 shape: kernel stats of 1 + 2 warm-up iterations
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_gan -o ks -- python3 $R/tools/gan_step_bench.py 32 256 1 > $O/ks_gan.log 2>&1
+# the north-star shape B = 32 x T = 256 in the bf16 arithmetic: fabric traffic per kernel (bench.py reads cfg2_bf16's `traffic` from it)
+B3B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --precision bf16"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/c2b_fetch -o pf -- $B3B > $O/c2bpf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c2b_write -o pw -- $B3B > $O/c2bpw.log 2>&1
 B3C="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --precision bf16 --batch 64 --frames 512"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -o pf -- $B3C > $O/c3pf.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c3_write -o pw -- $B3C > $O/c3pw.log 2>&1
@@ -34,10 +38,14 @@ python3 tools/train_step_bench.py 32 256 5 > $O/train_step.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/hbm_traffic.json 2> $O/pmc.err
 python3 tools/pmc_sq.py $O/sq_a $O/sq_b > $O/sq_counters.json 2> $O/sq.err
 python3 tools/pmc_traffic.py $O/c3_fetch $O/c3_write > $O/cfg3_bf16_hbm_traffic.json 2> $O/c3pmc.err
+python3 tools/pmc_traffic.py $O/c2b_fetch $O/c2b_write > $O/cfg2_bf16_hbm_traffic.json 2> $O/c2bpmc.err
+python3 tools/trace_layers.py $O/ks_bf16 32 256 -2 2 > $O/cfg2_bf16_per_layer.txt 2>&1
 python3 tools/pmc_sq.py $O/c3_sq_a $O/c3_sq_b > $O/cfg3_bf16_sq_counters.json 2> $O/c3sq.err
 cp $O/hbm_traffic.json profiles/${TAG}_cfg2_hbm_traffic.json    # bench.py reads the traffic of its dominant kernel from here
 cp $O/cfg3_bf16_hbm_traffic.json profiles/${TAG}_cfg3_bf16_hbm_traffic.json
-timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err
+cp $O/cfg2_bf16_hbm_traffic.json profiles/${TAG}_cfg2_bf16_hbm_traffic.json
+timeout 900 python3 bench.py > $O/bench.json 2> $O/bench.err            # the driver's line (compact: ends in `summary`)
+cp gpurun_out/bench_detail.json $O/bench_detail.json                   # ... and the full-precision line with every per-kernel table
 # the RCCL branch on a one-rank communicator: the per-step cost of the five statistics all-reduces (bench.py `stat_sync`)
 python3 - "$O" > $O/sync_overhead.txt <<'PYEOF'
 import json, sys

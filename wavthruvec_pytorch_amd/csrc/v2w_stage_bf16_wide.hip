@@ -960,8 +960,15 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
     if (UPF > 0 && !std_cfg) return V2W_E_SHAPE;             // the fused upsampler exists for the compile-time block set only
     if (up_tiles_out) *up_tiles_out = p.ntiles;              // rows of up_stats_part
     constexpr bool STDK = CH == 32 && !WLDS;
-    auto kern = (std_cfg && STDK) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, STDK, (STDK ? UPF : 0), (STDK && UPF > 0 ? TSP : false)>
-                                  : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false, 0>;
+    // (a TSP configuration exists in its compile-time form only: the run-time form of that tiling would need the full t1 tile)
+    void (*kern)(const WideArgs) = nullptr;
+    if constexpr (TSP) {
+        if (!(std_cfg && STDK)) return V2W_E_SHAPE;
+        kern = wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, true, UPF, true>;
+    } else {
+        kern = (std_cfg && STDK) ? wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, STDK, (STDK ? UPF : 0), false>
+                                 : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false, 0>;
+    }
     if (v2w_dry(stream)) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
