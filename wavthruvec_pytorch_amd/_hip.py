@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 from . import build as _build
 
@@ -187,7 +188,8 @@ SIGNATURES = {
 LAUNCHERS = frozenset(n for n, (_r, a) in SIGNATURES.items() if a and a[-1] is _fp)
 
 _lib = None
-_recorder = None      # schedule.Recorder while a forward is being recorded (one forward at a time per process thread of control)
+_tls = threading.local()      # .recorder: the schedule.Recorder of THIS thread while it records a forward (replicas driven from several threads
+                              # - nn.DataParallel - record independently)
 
 
 class HipLibraryError(RuntimeError):
@@ -209,8 +211,9 @@ def lib_path() -> str:
 def load():
     """Load (once) and return the library handle; raises HipLibraryError when it is absent or stale."""
     global _lib
-    if _recorder is not None:
-        return _recorder
+    rec = getattr(_tls, 'recorder', None)
+    if rec is not None:
+        return rec
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
@@ -235,8 +238,8 @@ def load():
 
 def set_recorder(rec):
     """Install (or, with None, remove) the recorder `load()` hands out instead of the library; returns the previous one."""
-    global _recorder
-    prev, _recorder = _recorder, rec
+    prev = getattr(_tls, 'recorder', None)
+    _tls.recorder = rec
     return prev
 
 
