@@ -243,7 +243,8 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
         rb1 = tag.startswith('rb1:')              # ResBlock1 pairs on bf16 tensors: the run-time form of the resident-tile kernel, one launch per pair position
         if fused:
             kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
-                    ('<32, 2, 4>' if ls[0]['cout'] == 32 else '<16, 4, 4>')
+                    ('<32, 2, 4' if ls[0]['cout'] == 32 else '<16, 4, 4') + \
+                    ((', true>' if names[-1] == 'conv_post' else ', false>') if staged else '>')
             if staged and precision != 'f32':
                 # launch_wide configurations (v2w_stage_bf16_wide.hip; the trailing 'false, true': fragments through registers, the generator's
                 # own (k, dilation) set at compile time); C = 16 runs there only with the fused tail (fuse_post)

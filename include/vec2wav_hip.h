@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 28
+#define V2W_ABI_VERSION 29
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -217,6 +217,13 @@ typedef struct {
     float* out;
     int32_t nk, B, C, L;
     float slope, out_div;
+    /* optional fused tail of the generator (ABI v29; v2w_resblock2_stage_fwd with C == 16 only; models.py:143-145): when post_out != NULL the
+     * kernel does not write `out` (it may be NULL) but  post_out (B, 1, L) fp32 = tanh(conv_post(leaky_relu(stage output, post_slope)))  with
+     * post_w = the folded conv_post weight [post_k][C][1] (v2w_wn_fold_conv), post_b its bias (1 value or NULL), post_k odd <= 9.  The
+     * stage's output - 168 MB at BASELINE configs[1] - is neither written nor read back, one launch less. */
+    const float* post_w; const float* post_b; float* post_out;
+    int32_t post_k;
+    float post_slope;
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
 /* The same section for an 8-channel stage (the sixth stage of a x640 generator, upsample_rates (5,4,4,2,2,2); ABI v27), fp32 on the

@@ -1207,6 +1207,49 @@ def test_resblock2_stage_fused_equals_branchwise(dev, C, L):
     assert (got.cpu() - want / 3.0).abs().max().item() <= 3e-5
 
 
+@pytest.mark.parametrize('L,kp', [(3000, 7), (218, 7), (5, 7), (1001, 7), (437, 3), (2048, 9), (64, 1)])
+def test_resblock2_stage_f32_with_the_fused_tail(dev, L, kp):
+    """v2w_resblock2_stage_fwd with post_out (ABI v29): the residual section of the last (16-channel) stage AND the generator's tail
+    leaky_relu(0.01) -> conv_post (16 -> 1, kp taps) -> tanh (models.py:143-145) in one exact-fp32 kernel; the stage's output is not written.
+    Against the two-kernel path (the same stage kernel without the tail + v2w_conv_post_tanh) and stock torch; lengths that are not
+    multiples of 4 (scalar stores), shorter than a window, several windows with the 3-position tap halo across their seams."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(40 + L + kp)
+    B, C = 2, 16
+    x = _t(r.standard_normal((B, C, L), dtype=np.float32), dev)
+    aff = (_t((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32), dev), _t((0.3 * r.standard_normal((B, C))).astype(np.float32), dev))
+    branches = []
+    for k in (3, 7, 11):
+        w1 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        w2 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        branches.append(dict(wp1=hipops.pack_mfma(_t(_relayout(w1).numpy(), dev)), b1=_t(r.standard_normal(C).astype(np.float32), dev),
+                             wp2=hipops.pack_mfma(_t(_relayout(w2).numpy(), dev)), b2=_t(r.standard_normal(C).astype(np.float32), dev),
+                             k=k, dil1=1, dil2=3, w1=w1, w2=w2))
+    wpost = torch.from_numpy((r.standard_normal((1, C, kp)) / np.sqrt(C * kp)).astype(np.float32))
+    bpost = _t(r.standard_normal(1).astype(np.float32), dev)
+    wf_post = _t(_relayout(wpost).numpy(), dev)               # [kp][C][1]
+    stage = torch.full((B, C, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage(x, aff, branches, stage, slope=0.1, out_div=3.0)
+    y2 = torch.full((B, 1, L), float('nan'), device=dev)
+    hipops.conv_post_tanh(stage, wf_post, bpost, y2, k=kp, slope=0.01)
+    y = torch.full((B, 1, L), float('nan'), device=dev)
+    assert hipops.resblock2_stage(x, aff, branches, None, slope=0.1, out_div=3.0, post=(wf_post, bpost, y, kp, 0.01))
+    assert torch.isfinite(y).all(), 'positions left unwritten'
+    assert (y - y2).abs().max().item() <= 2e-6
+    xin = (aff[0][:, :, None] * x + aff[1][:, :, None]).cpu()
+    tot = None
+    for br in branches:
+        t1 = xin + F.conv1d(F.leaky_relu(xin, 0.1), br['w1'], br['b1'].cpu(), padding=(br['k'] - 1) // 2)
+        rj = t1 + F.conv1d(F.leaky_relu(t1, 0.1), br['w2'], br['b2'].cpu(), padding=3 * (br['k'] - 1) // 2, dilation=3)
+        tot = rj if tot is None else tot + rj
+    want = torch.tanh(F.conv1d(F.leaky_relu(tot / 3.0, 0.01), wpost, bpost.cpu(), padding=(kp - 1) // 2))
+    assert (y.cpu() - want).abs().max().item() <= 3e-5
+    # the 32-channel stage has no tail form: declined, nothing launched
+    x32 = torch.zeros((1, 32, 64), device=dev)
+    br32 = [dict(wp1=branches[0]['wp1'], b1=None, wp2=branches[0]['wp2'], b2=None, k=3, dil1=1, dil2=3)]
+    assert hipops.resblock2_stage(x32, None, br32, None, slope=0.1, out_div=1.0, post=(wf_post, bpost, torch.empty((1, 1, 64), device=dev), kp, 0.01)) is False
+
+
 @pytest.mark.parametrize('B,C,L,k,dil', [(2, 256, 300, 11, 3), (2, 64, 700, 7, 1), (3, 32, 1000, 3, 3), (2, 16, 3000, 11, 1)])
 def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
     """Backward through one ResBlock2 step  y = x + conv_{k,d}(lrelu(x)),  x = a*in + s  (first piece):

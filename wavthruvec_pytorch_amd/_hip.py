@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -52,7 +52,8 @@ class StageArgs(C.Structure):
                 ('wp1', _fp * 4), ('bias1', _fp * 4), ('wp2', _fp * 4), ('bias2', _fp * 4),
                 ('k', C.c_int32 * 4), ('dil1', C.c_int32 * 4), ('dil2', C.c_int32 * 4),
                 ('out', _fp), ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
-                ('slope', C.c_float), ('out_div', C.c_float)]
+                ('slope', C.c_float), ('out_div', C.c_float),
+                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float)]
 
 
 class FoldDesc(C.Structure):

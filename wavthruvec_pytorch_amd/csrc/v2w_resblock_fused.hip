@@ -367,6 +367,12 @@ struct StageArgs {
     int nto, ntl;      // valid outputs per tile, tiles per batch item
     int vec4;
     float slope, out_div;
+    // fused tail (POST instantiations; models.py:143-145): y = tanh(conv_post(leaky_relu(stage output, post_slope))), post_k <= 9 taps, written as
+    // (B, 1, L); `out` is not written.  A tile then advances by nadv = (nto - 2 hout) & ~3 positions and starts hout = (post_k - 1) / 2 positions
+    // early (they feed the taps only); without the tail nadv = nto, hout = 0.
+    const float* post_w; const float* post_b; float* post_out;
+    int post_k, nadv, hout;
+    float post_slope;
 };
 
 template <int MF> struct StageGeom {
@@ -450,7 +456,7 @@ struct StageConv {
     }
 };
 
-template <int MF, int NI, int WN>
+template <int MF, int NI, int WN, bool POST = false>
 __global__ void __launch_bounds__(64 * WN)
 resblock2_stage_kernel(const StageArgs p) {
     typedef Frag<MF> F;
@@ -465,7 +471,7 @@ resblock2_stage_kernel(const StageArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tile = blockIdx.x;
     const int b = tile / p.ntl;
-    const int n0 = (tile % p.ntl) * p.nto;  // first valid output position of the tile (multiple of 4)
+    const int n0 = (tile % p.ntl) * p.nadv - p.hout;  // first valid output position of the tile (multiple of 4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & (MF - 1), hk = lane / MF;
@@ -483,6 +489,13 @@ resblock2_stage_kernel(const StageArgs p) {
         const int j = i / C, c = i - j * C;
         etab[i] = p.bias1[j] ? p.bias1[j][c] : 0.f;
         etab[V2W_STAGE_MAXB * C + i] = p.bias2[j] ? p.bias2[j][c] : 0.f;
+    }
+    if constexpr (POST) {         // the tail's weights as wl[c][12] (see the store phase), behind the tables: never overlaid
+        float* const wl0 = etab + 2 * V2W_STAGE_MAXB * C;
+        for (int i = tid; i < C * 12; i += NTHREADS) {
+            const int c = i / 12, t = i - 12 * c;
+            wl0[i] = t < p.post_k ? p.post_w[t * C + c] : 0.f;
+        }
     }
 
     // ---- stage x = a*in + s: lrelu(x) into Xa (all rows), raw x of the window into Ta (the residual of every branch).
@@ -657,14 +670,78 @@ resblock2_stage_kernel(const StageArgs p) {
         constexpr int SRS = W + 4;
         float* const scr = Ta;
         const int soff = (p.h2max + 3) & ~3;          // scratch column of window column h2max: 16-byte aligned
+        const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int sc = wn0 + j * MF + lr - p.h2max + soff;      // scratch column of this lane's window column
+            if constexpr (POST) {
+                // the tail's operand z = leaky_relu(out / nk, post_slope), exactly 0 outside the sequence (conv_post zero-pads)
+                const int pos = n0 - p.h2max + wn0 + j * MF + lr;
+                const bool in_seq = pos >= 0 && pos < L;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    float v = oacc[j][e];
+                    if (p.out_div != 0.f) v = v2w_div_by(v, p.out_div, dinv);
+                    scr[F::row(e, hk) * SRS + sc] = in_seq ? v2w_lrelu(v, p.post_slope) : 0.f;
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < NR; ++e) scr[F::row(e, hk) * SRS + sc] = oacc[j][e];
+            }
         }
         __syncthreads();
-        const float dinv = p.out_div != 0.f ? 1.f / p.out_div : 1.f;
+        if constexpr (POST) {
+            // y[p] = tanh(b + sum_c sum_t w[t][c] z[c][p + t - hout]) (hout = (post_k - 1) / 2) for the nadv positions p = n0 + hout + m: scratch
+            // column of z[c][p + t - hout] is soff + m + t.  Thread (output quad q, channel group cg) adds the taps of 4 channels for 4
+            // consecutive outputs - per channel the three aligned float4s from scratch column soff + 4 q hold the <= 12 values it needs, the
+            // weights come from the table wl[c][12] the kernel's first instructions put behind the bias tables - the four groups meet through LDS
+            // and the quad's first thread finishes: bias, tanh, one float4 store.  (One thread per quad walking all 16 channels with the
+            // weights as scalar loads: 12 k cycles per tile, 100 us of a 585 us kernel.)
+            const int PK = p.post_k, nq = p.nadv >> 2;
+            float* const part = scr + C * SRS;                       // [4][nq] float4
+            const float* const wl = etab + 2 * V2W_STAGE_MAXB * C;   // [C][12]: taps 0 .. post_k - 1, zeros behind them (filled at the kernel's start)
+            const int qd = tid % nq, cg = tid / nq;
+            const int p0 = n0 + p.hout + 4 * qd;
+            if (cg < 4 && p0 < L) {
+                f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cc = 0; cc < C / 4; ++cc) {
+                    const int c = (C / 4) * cg + cc;
+                    const float* zr = scr + c * SRS + soff + 4 * qd;
+                    float z[12], wv[12];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const f32x4 zz = *reinterpret_cast<const f32x4*>(zr + 4 * u);
+                        const f32x4 ww = *reinterpret_cast<const f32x4*>(wl + 12 * c + 4 * u);
+                        z[4 * u] = zz[0]; z[4 * u + 1] = zz[1]; z[4 * u + 2] = zz[2]; z[4 * u + 3] = zz[3];
+                        wv[4 * u] = ww[0]; wv[4 * u + 1] = ww[1]; wv[4 * u + 2] = ww[2]; wv[4 * u + 3] = ww[3];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) y[x] = fmaf(wv[t], z[t + x], y[x]);     // (taps past post_k: zero weights)
+                }
+                *reinterpret_cast<f32x4*>(part + (cg * nq + qd) * 4) = y;
+            }
+            __syncthreads();
+            if (cg == 0 && p0 < L) {
+                const float pb = p.post_b ? p.post_b[0] : 0.f;
+                f32x4 y = *reinterpret_cast<const f32x4*>(part + qd * 4);
+#pragma unroll
+                for (int g2 = 1; g2 < 4; ++g2) y += *reinterpret_cast<const f32x4*>(part + (g2 * nq + qd) * 4);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) y[x] = tanhf(y[x] + pb);
+                float* dst = p.post_out + (size_t)b * L + p0;
+                if (p.vec4) {
+                    *reinterpret_cast<f32x4*>(dst) = y;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (p0 + x < L) dst[x] = y[x];
+                }
+            }
+            return;
+        }
         const int nq = p.nto >> 2;
         const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
         for (int idx = tid; idx < C * nq; idx += NTHREADS) {
@@ -691,6 +768,7 @@ resblock2_stage_kernel(const StageArgs p) {
 
 template <int MF, int NI, int WN>
 int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
+    const bool post = q->post_out != nullptr;
     typedef StageGeom<MF> G;
     constexpr int W = MF * NI * WN;
     StageArgs p{};
@@ -706,20 +784,30 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     }
     p.nto = (W - 2 * p.h2max) & ~3;
     if (p.nto < W / 2 || p.h1max > G::HMAX) return V2W_E_SHAPE;
-    const int hsum = p.h1max + p.h2max;
+    p.nadv = p.nto; p.hout = 0;
+    if (post) {                     // the generator's tail behind the stage: C -> 1 channels, an odd tap count <= 9, fp32 (B, 1, L) output
+        if (!q->post_w || q->post_k < 1 || q->post_k > 9 || !(q->post_k & 1) || MF != 16) return V2W_E_SHAPE;
+        p.post_w = q->post_w; p.post_b = q->post_b; p.post_out = q->post_out; p.post_k = q->post_k; p.post_slope = q->post_slope;
+        p.hout = (q->post_k - 1) / 2; p.nadv = (p.nto - 2 * p.hout) & ~3;
+        if (p.nadv < W / 4) return V2W_E_SHAPE;
+    }
+    const int hsum = p.h1max + p.h2max + p.hout;       // (X row 0 sits at a position that is a multiple of 4: n0 + hout is one)
     p.xoff = ((hsum + 3) & ~3) - hsum;
     p.xrows = (p.xoff + W + 2 * p.h1max + 3) & ~3;
     if (p.xrows < p.h2max) return V2W_E_SHAPE;
     if (MF * (W + 4) > (W + p.h2max) * G::RS) return V2W_E_SHAPE;    // the store scratch [C][W + 4] overlays the T1 tile
-    p.ntl = (q->L + p.nto - 1) / p.nto;
+    p.ntl = (q->L + p.nadv - 1) / p.nadv;
     p.vec4 = (q->L % 4 == 0) && ((reinterpret_cast<uintptr_t>(q->in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(q->out) & 15) == 0) &&
+             ((reinterpret_cast<uintptr_t>(q->post_out) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(q->in_a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(q->in_s) & 15) == 0);
-    size_t lds = ((size_t)(p.xrows + W + p.h2max) * G::RS + 2 * V2W_STAGE_MAXB * MF) * sizeof(float);
+    size_t lds = ((size_t)(p.xrows + W + p.h2max) * G::RS + 2 * V2W_STAGE_MAXB * MF + (post ? MF * 12 : 0)) * sizeof(float);
+    if (post && (size_t)MF * (W + 4) + 4 * (p.nadv >> 2) * 4 > (size_t)(W + p.h2max) * G::RS) return V2W_E_SHAPE;     // the partial sums sit behind the scratch, inside the T1 tile
+    if (post && 4 * (p.nadv >> 2) > 64 * WN) return V2W_E_SHAPE;                                                       // one thread per (output quad, channel group)
 #ifdef V2W_TIMELINE
     if (const char* e = getenv("V2W_TL_LDSPAD")) lds += (size_t)atoi(e);      // fewer workgroups per CU: what does ONE wave per SIMD reach?
 #endif
     if (lds > 160 * 1024) return V2W_E_SHAPE;
-    auto kern = resblock2_stage_kernel<MF, NI, WN>;
+    auto kern = post ? resblock2_stage_kernel<MF, NI, WN, (MF == 16)> : resblock2_stage_kernel<MF, NI, WN, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -749,9 +837,10 @@ extern "C" int v2w_resblock_pair_fwd(const v2w_pair_args* a, int n, void* stream
 }
 
 extern "C" int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream) {
-    if (!a || !a->in || !a->out || a->nk < 1 || a->nk > V2W_STAGE_MAXB) return V2W_E_ARG;
+    if (!a || !a->in || (!a->out && !a->post_out) || a->nk < 1 || a->nk > V2W_STAGE_MAXB) return V2W_E_ARG;
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
     if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
+    if (a->post_out && a->C != 16) return V2W_E_SHAPE;           // the fused tail: the last (16-channel) stage
     for (int j = 0; j < a->nk; ++j) {
         if (!a->wp1[j] || !a->wp2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;
         if ((a->k[j] & 1) == 0) return V2W_E_SHAPE;

@@ -394,11 +394,20 @@ class ForwardPlanner:
                      k=rb.kernel_size, dil1=rb.convs[0].dilation, dil2=rb.convs[1].dilation) for nm, rb in zip(self.names, self.rbs)]
 
     def rb2_stage_f32(self, i):
-        """The whole residual section of a narrow stage in ONE f32-MFMA kernel: x read once, t1_j in LDS, sum in registers."""
+        """The whole residual section of a narrow stage in ONE f32-MFMA kernel: x read once, t1_j in LDS, sum in registers - the last
+        (16-channel) stage with the generator's tail behind it (models.py:143-145; round 5): its output is neither written nor read back."""
+        g = self.g
         if self.st or not (self.C in self.fuse_stage and self.all_wp):
             return False
-        return self.timed(self.stage_tag(), hipops.resblock2_stage, self.xr, self.aff, self._f32_branches(self.wp, 'wp1', 'wp2'), self.xs,
-                          slope=LRELU_SLOPE, out_div=float(self.nk))
+        branches = self._f32_branches(self.wp, 'wp1', 'wp2')
+        kp = g.conv_post.kernel_size
+        if g.fuse_post and i == self.ns - 1 and self.C == 16 and kp <= 9 and kp % 2 == 1 and g.conv_post.in_channels == 16:
+            y = torch.empty((self.B, 1, self.Lo), device=self.dev, dtype=torch.float32)
+            if self.timed(self.stage_tag('+conv_post'), hipops.resblock2_stage, self.xr, self.aff, branches, None, slope=LRELU_SLOPE,
+                          out_div=float(self.nk), post=(self.wf['conv_post'], g.conv_post.bias.detach(), y, kp, 0.01)):
+                self.y = y
+                return True
+        return self.timed(self.stage_tag(), hipops.resblock2_stage, self.xr, self.aff, branches, self.xs, slope=LRELU_SLOPE, out_div=float(self.nk))
 
     def rb2_stage_small(self, i):
         """8 channels (the sixth stage of a x640 generator): below every MFMA tile - the whole section as one FMA kernel."""

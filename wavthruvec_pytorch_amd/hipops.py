@@ -691,9 +691,10 @@ def branch_convs_bf16(mode, ins, in_affine, wps, biases, outs, ks, dils, *, slop
     return True
 
 
-def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
+def resblock2_stage(x, in_affine, branches, out, *, slope, out_div, post=None):
     """Whole ResBlock2 residual section of a narrow stage in one kernel.  `branches`: list of dicts(wp1, b1, wp2, b2, k, dil1, dil2).
-    Returns False (nothing launched) when the shape is not taken."""
+    post = (wf [k][C][1], bias | None, y (B, 1, L) fp32, k, slope): the generator's tail fused behind the 16-channel stage - `out` may be None,
+    it is not written.  Returns False (nothing launched) when the shape is not taken."""
     B, Cc, L = x.shape
     a = _hip.StageArgs()
     a.in_ = x.data_ptr()
@@ -702,9 +703,12 @@ def resblock2_stage(x, in_affine, branches, out, *, slope, out_div):
         a.wp1[j] = br['wp1'].data_ptr(); a.bias1[j] = _hip.ptr(br['b1'])
         a.wp2[j] = br['wp2'].data_ptr(); a.bias2[j] = _hip.ptr(br['b2'])
         a.k[j], a.dil1[j], a.dil2[j] = br['k'], br['dil1'], br['dil2']
-    a.out = out.data_ptr()
+    a.out = _hip.ptr(out)
     a.nk, a.B, a.C, a.L = len(branches), B, Cc, L
     a.slope = slope; a.out_div = out_div
+    if post is not None:
+        a.post_w, a.post_b, a.post_out = post[0].data_ptr(), _hip.ptr(post[1]), post[2].data_ptr()
+        a.post_k, a.post_slope = post[3], post[4]
     rc = _hip.load().v2w_resblock2_stage_fwd(C.byref(a), _stream(x))
     if rc == -2:
         return False

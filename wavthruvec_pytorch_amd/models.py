@@ -212,7 +212,7 @@ class Generator(nn.Module):
         self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
         self.fuse_up = True                   # bf16 storage: the NEXT stage's transposed conv (stride 2 / 4) inside the kernel of a stage (C = 32 .. 256):
                                               # the stage's output never leaves the chip, one launch less per stage
-        self.fuse_post = True                 # bf16 storage: leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage: the stage's
+        self.fuse_post = True                 # leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage (bf16 storage, and - round 5 - the fp32 stage kernel): the stage's
                                               # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
