@@ -442,8 +442,11 @@ def train_step_block(dev, B, T, steps, precision='f32'):
     del g, opt
     torch.cuda.empty_cache()
     return dict(workload=f'generator training step (vec2wav/train.py:204-215 without the discriminators): forward + backward + AdamW, B={B} x T={T}, '
-                         '768-d, x320, ResBlock2, ' + ('exact fp32' if precision == 'f32' else 'forward and input-gradient convs as f16 hi+lo '
-                                                        '(3 MFMA per product, fp32 accumulate), weight gradients exact fp32'),
+                         '768-d, x320, ResBlock2, ' + {'f32': 'exact fp32', 'f16x3': 'forward and input-gradient convs as f16 hi+lo (3 MFMA per product, fp32 '
+                                                      'accumulate), weight gradients exact fp32',
+                                                      'bf16': 'the reference autocast arithmetic on fp32 tensors: forward, input- and weight-gradient '
+                                                      'convs from bf16 operands with fp32 accumulation (v2w_wgrad_bf16) wherever the layer has '
+                                                      'that kernel'}[precision],
                 dtype=precision, steps=steps, ms_per_step=st * 1e3,
                 ms_per_step_event_median=median(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)),
                 value=B * T * up / st, unit='trained samples/s', flops=3.0 * fl, tflops=3.0 * fl / st / 1e12,
@@ -531,9 +534,10 @@ def compact_block(b):
         if b.get('dtype') == 'bf16' and 'resblock' not in str(b.get('workload', '')).lower()[:40] and isinstance(r.get('per_kernel'), dict):
             # the bf16 pipeline's launches, largest first: [kernel, ms per step, TFLOP/s]
             out['kernels'] = [[k.replace(' ', ''), _r(v['ms']), _r(v['tflops'])] for k, v in list(r['per_kernel'].items())[:7]]
-    alt = b.get('alt_precision_f16x3')
-    if isinstance(alt, dict):
-        out['alt_precision_f16x3'] = {k: _r(alt[k]) for k in ('ms_per_step', 'value', 'tflops', 'error') if k in alt}
+    for key in ('alt_precision_f16x3', 'alt_precision_bf16'):
+        alt = b.get(key)
+        if isinstance(alt, dict):
+            out[key] = {k: _r(alt[k]) for k in ('ms_per_step', 'value', 'tflops', 'error') if k in alt}
     return out
 
 
@@ -566,9 +570,10 @@ def summary_of(out, blocks):
             sm[name] = [_r(b.get('stat_sync_ms_per_step')), _r(b.get('allreduce_us_event_mean')), None]
         else:
             sm[name] = [_r(b.get('ms_per_step')), _r(b.get('hbm_frac')), _r(b.get('mfma_frac'))]
-            alt = b.get('alt_precision_f16x3')
-            if isinstance(alt, dict) and 'ms_per_step' in alt:
-                sm[name + '.f16x3'] = [_r(alt['ms_per_step']), None, None]
+            for prec in ('f16x3', 'bf16'):
+                alt = b.get('alt_precision_' + prec)
+                if isinstance(alt, dict) and 'ms_per_step' in alt:
+                    sm[name + '.' + prec] = [_r(alt['ms_per_step']), None, None]
     return sm
 
 
@@ -764,8 +769,9 @@ def main():
                        'tests/test_hip_generator.py::test_generator_resblock1_bf16_full_size_vs_oracle_train (the reference autocast bar)')
         train = guarded(train_step_block, dev, B, T, max(4, args.steps // 4))
         if isinstance(train, dict) and 'error' not in train:
-            alt_t = guarded(train_step_block, dev, B, T, max(4, args.steps // 4), 'f16x3')
-            train['alt_precision_f16x3'] = {k: alt_t.get(k) for k in ('ms_per_step', 'value', 'tflops', 'workload', 'error') if k in alt_t}
+            for prec in ('f16x3', 'bf16'):
+                alt_t = guarded(train_step_block, dev, B, T, max(4, args.steps // 4), prec)
+                train['alt_precision_' + prec] = {k: alt_t.get(k) for k in ('ms_per_step', 'value', 'tflops', 'workload', 'error') if k in alt_t}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 29
+#define V2W_ABI_VERSION 30
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -421,6 +421,15 @@ int v2w_affine_apply(const float* x, const float* a, const float* s, float* out,
 int v2w_wgrad_slabs(int B, int c_in, int c_out, int Lq);
 int v2w_wgrad(const float* x, const float* x_a, const float* x_s, const float* dy, float* dwf, float* slab_ws,
               int B, int c_in, int c_out, int Lq, int k, int dil, int u, float slope, void* stream);
+
+/* v2w_wgrad_bf16 (ABI v30): the same Conv1d weight gradient from bf16 OPERANDS, fp32 accumulation - what the reference's autocast backward
+ * computes (vec2wav/train.py:167,214: `loss_gen_all.backward()` of a forward run under torch.autocast).  act(x) = lrelu(x_a*x + x_s) is
+ * evaluated in fp32 and rounded once.  io_bf16 = 0: x and dy are fp32 tensors (rounded while staged); 3: both are bf16 tensors.
+ *   slab_ws: v2w_wgrad_bf16_slabs(...) * k*C_in*C_out floats.  V2W_E_SHAPE (and 0 slabs) unless C_in == C_out in {16, 32} or a multiple of 64,
+ *   k odd <= 11, Lq % 8 == 0 and the halo (k-1)/2*dil fits the staged tile: the caller runs v2w_wgrad then. */
+int v2w_wgrad_bf16_slabs(int B, int c_in, int c_out, int Lq, int k);
+int v2w_wgrad_bf16(const void* x, const float* x_a, const float* x_s, const void* dy, float* dwf, float* slab_ws,
+                   int B, int c_in, int c_out, int Lq, int k, int dil, float slope, int io_bf16, void* stream);
 
 /* Conditional BatchNorm backward (modules.py:20-30).  Given dx = dL/d(gamma*xhat+beta) and xr (the BN input):
  *   v2w_cbn_bwd_sums : dgb (B, 2C) = [dgamma | dbeta] and csum[2C] fp64 = [sum_b gamma*dbeta | sum_b gamma*dgamma]

@@ -1309,6 +1309,52 @@ def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
     assert (got - want).abs().max().item() <= 2e-5 * max(1.0, scale) * 10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('stored', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,C,L,k,dil', [(2, 16, 1024, 3, 1), (3, 16, 520, 7, 3), (2, 16, 2048, 11, 3), (2, 32, 1000, 3, 3), (3, 32, 648, 7, 1),
+                                         (2, 32, 1024, 11, 3), (2, 64, 512, 3, 1), (2, 64, 328, 7, 3), (1, 64, 640, 11, 1), (2, 128, 264, 11, 3),
+                                         (1, 256, 136, 7, 5), (2, 64, 512, 5, 1), (2, 32, 512, 9, 1), (2, 64, 256, 9, 2)])
+def test_wgrad_bf16_matches_the_products_of_rounded_operands(dev, B, C, L, k, dil, stored):
+    """v2w_wgrad_bf16: dW of [affine] -> lrelu -> Conv1d from bf16 operands with fp32 accumulation.  The reference value is torch autograd (fp64)
+    on the operands rounded the way the kernel rounds them - act(x) computed in fp32 and rounded once, dy rounded - so only the fp32 summation
+    order differs.  `stored`: the tensors handed over are fp32 (rounded while staged) or already bf16."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(31)
+    x = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    dy = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    a = torch.from_numpy((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32))
+    s = torch.from_numpy((0.3 * r.standard_normal((B, C))).astype(np.float32))
+    if stored == 'bf16':
+        x, dy = x.bfloat16(), dy.bfloat16()
+    act = F.leaky_relu(torch.addcmul(s[:, :, None], a[:, :, None], x.float()), 0.1).bfloat16().double()     # fma, like the kernel
+    w = torch.zeros((C, C, k), dtype=torch.float64, requires_grad=True)
+    F.conv1d(act, w, None, padding=dil * (k - 1) // 2, dilation=dil).backward(dy.bfloat16().double())
+    want = w.grad.permute(2, 1, 0)
+    got = hipops.wgrad_bf16(x.to(dev), dy.to(dev), k=k, dil=dil, slope=0.1, x_affine=(a.to(dev), s.to(dev)))
+    assert got is not None
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    # no affine: the plain activated signal
+    w2 = torch.zeros((C, C, k), dtype=torch.float64, requires_grad=True)
+    F.conv1d(F.leaky_relu(x.float(), 0.1).bfloat16().double(), w2, None, padding=dil * (k - 1) // 2, dilation=dil).backward(dy.bfloat16().double())
+    got2 = hipops.wgrad_bf16(x.to(dev), dy.to(dev), k=k, dil=dil, slope=0.1)
+    assert (got2.cpu().double() - w2.grad.permute(2, 1, 0)).abs().max().item() <= 2e-5 * max(1.0, w2.grad.abs().max().item())
+    # deterministic
+    assert torch.equal(got2, hipops.wgrad_bf16(x.to(dev), dy.to(dev), k=k, dil=dil, slope=0.1))
+
+
+@pytest.mark.gpu
+def test_wgrad_bf16_declines_shapes_it_has_no_kernel_for(dev):
+    from wavthruvec_pytorch_amd import hipops
+    x = torch.randn(2, 48, 256, device=dev)
+    assert hipops.wgrad_bf16(x, x, k=3) is None                    # 48 channels
+    x = torch.randn(2, 32, 252, device=dev)
+    assert hipops.wgrad_bf16(x, x, k=3) is None                    # rows not 16-byte aligned in bf16
+    x = torch.randn(2, 32, 256, device=dev)
+    assert hipops.wgrad_bf16(x, x, k=11, dil=7) is None            # halo beyond the staged tile
+    assert hipops.wgrad_bf16(x, x, k=4) is None
+
+
 @pytest.mark.parametrize('B,cin,cout,L,k,u', [(2, 512, 256, 50, 11, 5), (2, 128, 64, 333, 8, 4), (2, 64, 32, 500, 4, 2),
                                              (2, 32, 16, 1000, 4, 2), (1, 512, 256, 17, 16, 8)])
 def test_convt1d_dgrad_matches_autograd(dev, B, cin, cout, L, k, u):

@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -176,6 +176,8 @@ SIGNATURES = {
     'v2w_wgrad_slabs': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'v2w_wgrad': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_float, _fp]),
+    'v2w_wgrad_bf16_slabs': (C.c_int, [C.c_int] * 5),
+    'v2w_wgrad_bf16': (C.c_int, [_fp] * 6 + [C.c_int] * 6 + [C.c_float, C.c_int, _fp]),
     'v2w_cbn_bwd_sums': (C.c_int, [_fp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     'v2w_cbn_bwd_apply': (C.c_int, [_fp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     'v2w_tail_bwd': (C.c_int, [_fp] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),

@@ -56,6 +56,16 @@ def _dconv(gen, x, wT, out, *, k, **kw):
     return hipops.conv1d(x, wT, None, out, k=k, wp=hipops.pack_mfma(wT), **kw)
 
 
+def _wgrad(gen, x, dy, *, k, dil, slope, x_affine=None):
+    """Conv1d weight gradient in the generator's arithmetic: bf16 operands with fp32 accumulation when the generator computes in bf16 (what
+    the reference's autocast backward does, train.py:167,214) and the layer shape has that kernel, the exact fp32 kernel otherwise."""
+    if gen.precision == 'bf16':
+        dwf = hipops.wgrad_bf16(x, dy, k=k, dil=dil, slope=slope, x_affine=x_affine)
+        if dwf is not None:
+            return dwf
+    return hipops.wgrad(x, dy, k=k, dil=dil, slope=slope, x_affine=x_affine)
+
+
 def _wn_grads(grads, name, m, dwf):
     """dW in the [k][C_in][C_out] layout -> gradients of the layer's weight_v / weight_g (or plain weight)."""
     if m.weight_normed:
@@ -206,7 +216,7 @@ def generator_backward(gen, sv, dy, need_dx=False):
                     du = torch.empty_like(dr)
                     _dconv(gen, dcur, w2T, du, k=k, dil=1, slope=1.0,
                                   mask=(u, None), mask_slope=LRELU_SLOPE)
-                    _wn_grads(grads, f'{name}.convs2.{n}', c2, hipops.wgrad(u, dcur, k=k, dil=1, slope=LRELU_SLOPE))
+                    _wn_grads(grads, f'{name}.convs2.{n}', c2, _wgrad(gen, u, dcur, k=k, dil=1, slope=LRELU_SLOPE))
                     grads[f'{name}.convs2.{n}.bias'] = hipops.channel_sum(dcur) if n < 2 else db2
                     w1T = hipops.transpose_flip(wf[f'{name}.convs1.{n}'])
                     if n > 0:
@@ -218,7 +228,7 @@ def generator_backward(gen, sv, dy, need_dx=False):
                                       mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
                         dprev = None
                     _wn_grads(grads, f'{name}.convs1.{n}', c1,
-                              hipops.wgrad(xin[n], du, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=x_aff))
+                              _wgrad(gen, xin[n], du, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=x_aff))
                     grads[f'{name}.convs1.{n}.bias'] = hipops.channel_sum(du)
                     dcur = dprev
                 continue
@@ -229,14 +239,14 @@ def generator_backward(gen, sv, dy, need_dx=False):
             dt1 = torch.empty_like(dr)
             _dconv(gen, dr, w2T, dt1, k=k, dil=c2.dilation, slope=1.0, res=dr,
                           mask=(t1, None), mask_slope=LRELU_SLOPE)
-            _wn_grads(grads, name + '.convs.1', c2, hipops.wgrad(t1, dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
+            _wn_grads(grads, name + '.convs.1', c2, _wgrad(gen, t1, dr, k=k, dil=c2.dilation, slope=LRELU_SLOPE))
             grads[name + '.convs.1.bias'] = db2
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx += dt1 + lrelu'(x) * conv(dt1; W1^T flipped)
             w1T = hipops.transpose_flip(wf[name + '.convs.0'])
             _dconv(gen, dt1, w1T, dx, k=k, dil=c1.dilation, slope=1.0, res=dt1,
                           mask=(xr, aff), mask_slope=LRELU_SLOPE, accumulate=(j > 0))
             _wn_grads(grads, name + '.convs.0', c1,
-                      hipops.wgrad(xr, dt1, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+                      _wgrad(gen, xr, dt1, k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
             grads[name + '.convs.0.bias'] = hipops.channel_sum(dt1)
 
         # ---- Conditional BatchNorm (modules.py:20-30): through the affine, the batch statistics and into gamma / beta

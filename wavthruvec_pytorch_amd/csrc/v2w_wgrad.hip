@@ -363,6 +363,37 @@ wgrad_reduce_kernel(const float* slab, float* dwf, size_t n, int nslab) {
     if (g == 0 && i < n) *reinterpret_cast<f32x4*>(dwf + i) = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
 
+// The same sum for many slabs and few outputs (the narrow layers: 2048 slabs of 3072 .. 11264 weights - the 4-lane form walks them in 3 - 11
+// workgroups, 80 - 150 us of load latency): 16 slab lanes per block of 64 float4 outputs, combined in fixed order.
+__global__ void __launch_bounds__(1024)
+wgrad_reduce16_kernel(const float* slab, float* dwf, size_t n, int nslab) {
+    __shared__ f32x4 part[16][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + o) * 4;
+    slab += (size_t)blockIdx.y * nslab * n; dwf += (size_t)blockIdx.y * n;   // grid.y = group
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int s = g;
+        f32x4 v1 = v, v2 = v, v3 = v;
+        for (; s + 48 < nslab; s += 64) {
+            v  += *reinterpret_cast<const f32x4*>(slab + (size_t)s * n + i);
+            v1 += *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 16) * n + i);
+            v2 += *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 32) * n + i);
+            v3 += *reinterpret_cast<const f32x4*>(slab + (size_t)(s + 48) * n + i);
+        }
+        for (; s < nslab; s += 16) v += *reinterpret_cast<const f32x4*>(slab + (size_t)s * n + i);
+        v = (v + v1) + (v2 + v3);
+    }
+    part[g][o] = v;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        f32x4 r = part[0][o];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) r += part[j][o];
+        *reinterpret_cast<f32x4*>(dwf + i) = r;
+    }
+}
+
 }  // namespace
 
 // Wave arrangement of a workgroup's 4 waves over (C_out, C_in, positions) and the number of partial slabs.  Conv1d (u = 1):
@@ -532,6 +563,7 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
         }
     }
     const size_t nw = (size_t)k * c_in * c_out;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
+    if (nslab >= 128) hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(1024), 0, st, slab_ws, dwf, nw, nslab);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
     return v2w_launch_status();
 }

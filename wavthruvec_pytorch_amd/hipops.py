@@ -755,6 +755,29 @@ def wgrad(x, dy, *, k, dil=1, u=1, slope=1.0, x_affine=None, out=None):
     return out
 
 
+def wgrad_bf16(x, dy, *, k, dil=1, slope=1.0, x_affine=None, out=None):
+    """Conv1d weight gradient dwf [k][C_in][C_out] from bf16 operands with fp32 accumulation (v2w_wgrad_bf16): x and dy both fp32 (rounded
+    on the way in) or both bf16 tensors.  Returns None when the layer shape has no bf16 instantiation (the caller runs `wgrad`)."""
+    B, ci, Lq = x.shape
+    co = dy.shape[1]
+    if x.dtype != dy.dtype or x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('v2w_wgrad_bf16: x and dy must both be float32 or both bfloat16')
+    lib = _hip.load()
+    ns = lib.v2w_wgrad_bf16_slabs(B, ci, co, Lq, k)
+    if ns == 0:
+        return None
+    if out is None:
+        out = torch.empty((k, ci, co), device=x.device, dtype=torch.float32)
+    slab = torch.empty((ns * k * ci * co,), device=x.device, dtype=torch.float32)
+    xa, xs = (x_affine[0].data_ptr(), x_affine[1].data_ptr()) if x_affine is not None else (None, None)
+    rc = lib.v2w_wgrad_bf16(x.data_ptr(), xa, xs, dy.data_ptr(), out.data_ptr(), slab.data_ptr(), B, ci, co, Lq, k, dil, slope,
+                            3 if x.dtype == torch.bfloat16 else 0, _stream(x))
+    if rc == _hip.E_SHAPE:
+        return None
+    _hip.check(rc, 'v2w_wgrad_bf16')
+    return out
+
+
 def convt1d_dgrad(dy, wf, out, *, k, u, mask=None, mask_slope=1.0, algo=ALGO_AUTO):
     """Input gradient of the fused lrelu -> ConvTranspose1d(k, stride u, pad (k-u)/2): dx = lrelu'(x) * sum over the u
     output phases of a small Conv1d on that phase of dy.  dy (B, C_out, u*L), wf [k][C_in][C_out], out (B, C_in, L)."""
