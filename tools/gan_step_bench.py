@@ -118,6 +118,9 @@ def main():
         if it == 2:
             times.clear()
             torch.cuda.synchronize(); t_all = time.perf_counter()
+            if os.environ.get('V2W_CPROFILE'):      # diagnostic: host profile of the timed iterations only
+                import cProfile
+                prof = cProfile.Profile(); prof.enable()
         t0 = time.perf_counter()
         y_g_hat = g(*inp)
         y_g_hat_mel = mel_spectrogram(y_g_hat.squeeze(1), *margs)
@@ -143,6 +146,10 @@ def main():
         optim_g.step()
         t0 = tick('G step: backward (D, mel, G) + AdamW', t0)
     torch.cuda.synchronize()
+    if os.environ.get('V2W_CPROFILE'):
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats(os.environ['V2W_CPROFILE'] if os.environ['V2W_CPROFILE'] in ('tottime', 'cumtime') else 'tottime').print_stats(45)
     if os.environ.get('V2W_LIVE_TENSORS'):      # diagnostic: what is still allocated after an iteration (storages, largest first)
         import gc
         seen, rows = set(), []
