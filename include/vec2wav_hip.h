@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 30
+#define V2W_ABI_VERSION 31
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -224,8 +224,21 @@ typedef struct {
     const float* post_w; const float* post_b; float* post_out;
     int32_t post_k;
     float post_slope;
+    /* optional INPUT-GRADIENT form (ABI v31; v2w_resblock2_stage_fwd only; the backward of models.py:135-141 for a narrow stage, train.py:214):
+     * when bwd_mask2 != NULL the kernel computes, with dr = in_a * in + in_s (the caller passes in = dL/d(out), in_a = 1 / nk, in_s = 0),
+     *     bwd_mid[j] (B, C, L) = dt1_j = dr + lrelu'(bwd_mask1[j]) * conv(dr; wp1[j])                  bwd_mask1[j] = the forward's t1_j
+     *     out (B, C, L)        = sum_j dt1_j + lrelu'(bwd_mask2_a * bwd_mask2 + bwd_mask2_s) * sum_j conv(dt1_j; wp2[j])      bwd_mask2 = the forward's xr
+     * where wp1[j] / wp2[j] are the fragment streams of the TRANSPOSED, tap-reversed weights of conv2_j / conv1_j (v2w_pack_mfma_dgrad),
+     * dil1[j] / dil2[j] their dilations (conv2_j's first), lrelu'(v) = v > 0 ? 1 : bwd_slope.  slope must be 1, the biases NULL, out_div 0. */
+    const float* bwd_mask1[4]; float* bwd_mid[4];
+    const float* bwd_mask2; const float* bwd_mask2_a; const float* bwd_mask2_s;
+    float bwd_slope;
+    /* bwd_rowsum[j] (optional): v2w_resblock2_stage_bwd_rows(a) rows of [C][2] floats - per (tile, wave) the channel sums of dt1_j over the
+     * positions the tile owns (second value 0): the bias gradient of conv1_j after v2w_bn_reduce_partials adds the rows up. */
+    float* bwd_rowsum[4];
 } v2w_stage_args;
 int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream);
+int v2w_resblock2_stage_bwd_rows(const v2w_stage_args* a);
 /* The same section for an 8-channel stage (the sixth stage of a x640 generator, upsample_rates (5,4,4,2,2,2); ABI v27), fp32 on the
  * vector ALU: C == 8, odd kernel sizes, halos <= 32, nk <= 4.  HERE wp1[j] / wp2[j] are the FOLDED weights [k][C][C] of
  * v2w_wn_fold_conv (there is no fragment stream for 8 channels).  V2W_E_SHAPE otherwise. */

@@ -660,6 +660,31 @@ def test_generator_backward_matches_oracle_autograd(dev, training, B, T, resbloc
     assert (y2 - y.detach()).abs().max().item() <= (1e-6 if precision == 'f32' else 5e-6)
 
 
+def test_generator_backward_with_the_one_kernel_narrow_stages(dev):
+    """`fuse_stage_backward` (opt-in): the input gradients of the 32- and 16-channel stages from v2w_resblock2_stage_fwd's backward form - every
+    parameter gradient against the oracle's autograd at the bar of test_generator_backward_matches_oracle_autograd, and equal (to rounding) to
+    the default schedule's."""
+    B, T = 2, 20
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = synthetic.make_inputs(h, B, T, seed=21)
+    dy = torch.from_numpy(np.random.default_rng(5).standard_normal((B, 1, T * 320)).astype(np.float32))
+    _, g_ref, _ = O.generator_gradients(sd, h, *inp, dy, training=True)
+    got = {}
+    for on in (True, False):
+        g = build_generator(h, sd, dev, training=True)
+        g.fuse_stage_backward = on
+        (g(*to_dev(inp, dev)) * dy.to(dev)).sum().backward()
+        got[on] = {n: p.grad.cpu() for n, p in g.named_parameters()}
+    bad = {}
+    for n, ref in g_ref.items():
+        floor = 0.25 if (n.startswith('ups.') and n.endswith('.bias')) else 1e-6
+        sc = max(ref.abs().max().item(), floor)
+        if (got[True][n] - ref).abs().max().item() / sc > 4e-3 or (got[True][n] - got[False][n]).abs().max().item() / sc > 1e-3:
+            bad[n] = ((got[True][n] - ref).abs().max().item() / sc, (got[True][n] - got[False][n]).abs().max().item() / sc)
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+
+
 @pytest.mark.parametrize('resblock', [1, '1'])
 def test_generator_bf16_training_gradients_vs_reference_autocast(dev, resblock):
     """A training step in the bf16 arithmetic (`precision = 'bf16'`: forward, input-gradient and - v2w_wgrad_bf16 - weight-gradient convs

@@ -1250,6 +1250,52 @@ def test_resblock2_stage_f32_with_the_fused_tail(dev, L, kp):
     assert hipops.resblock2_stage(x32, None, br32, None, slope=0.1, out_div=1.0, post=(wf_post, bpost, torch.empty((1, 1, 64), device=dev), kp, 0.01)) is False
 
 
+@pytest.mark.parametrize('C,L,ks,d1,d2', [(32, 1000, (3, 7, 11), 1, 3), (16, 3000, (3, 7, 11), 1, 3), (32, 200, (3, 7, 11), 1, 3), (16, 37, (3, 5), 2, 1),
+                                         (32, 517, (11, 7, 3), 3, 1), (16, 2048, (3, 7, 11), 1, 3)])
+def test_resblock2_stage_input_gradient_in_one_kernel(dev, C, L, ks, d1, d2):
+    """v2w_resblock2_stage_fwd in its input-gradient form (ABI v31: v2w_stage_args::bwd_*): the backward of a narrow stage's residual section
+    (models.py:135-141) - dt1_j of every branch and the stage's dx - from ONE kernel, against torch autograd through the section.  Lengths
+    that are not multiples of 4, shorter than a window, several windows (the dt1_j of a position is written by the tile that owns it)."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(50 + L + C)
+    B, nk = 2, len(ks)
+    xr = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    a = torch.from_numpy((1 + 0.2 * r.standard_normal((B, C))).astype(np.float32))
+    s = torch.from_numpy((0.3 * r.standard_normal((B, C))).astype(np.float32))
+    dout = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32))
+    x = (a[:, :, None] * xr + s[:, :, None]).requires_grad_(True)
+    ws, t1s, tot = [], [], None
+    for k in ks:
+        w1 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        w2 = torch.from_numpy((r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+        t1 = x + F.conv1d(F.leaky_relu(x, 0.1), w1, None, padding=d1 * (k - 1) // 2, dilation=d1)
+        t1.retain_grad()
+        rj = t1 + F.conv1d(F.leaky_relu(t1, 0.1), w2, None, padding=d2 * (k - 1) // 2, dilation=d2)
+        tot = rj if tot is None else tot + rj
+        ws.append((w1, w2)); t1s.append(t1)
+    (tot / nk).backward(dout)
+    branches = [dict(wp1=hipops.pack_mfma_dgrad(_t(_relayout(w2).numpy(), dev)), b1=None, wp2=hipops.pack_mfma_dgrad(_t(_relayout(w1).numpy(), dev)), b2=None,
+                     k=k, dil1=d2, dil2=d1) for k, (w1, w2) in zip(ks, ws)]
+    inv, zero = torch.full((B, C), 1.0 / nk, device=dev), torch.zeros((B, C), device=dev)
+    dt1 = [torch.full((B, C, L), float('nan'), device=dev) for _ in ks]
+    dx = torch.full((B, C, L), float('nan'), device=dev)
+    rows = hipops.resblock2_stage_bwd_rows(B, C, L, list(ks), [d2] * nk, [d1] * nk)
+    assert rows > 0
+    rsum = [torch.full((rows * C * 2,), float('nan'), device=dev) for _ in ks]
+    assert hipops.resblock2_stage(dout.to(dev), (inv, zero), branches, dx, slope=1.0, out_div=0.0,
+                                  bwd=([t.detach().to(dev) for t in t1s], dt1, xr.to(dev), (a.to(dev), s.to(dev)), 0.1, rsum))
+    for j in range(nk):
+        assert torch.isfinite(dt1[j]).all(), 'positions left unwritten'
+        assert (dt1[j].cpu() - t1s[j].grad).abs().max().item() <= 3e-5 * max(1.0, t1s[j].grad.abs().max().item()), j
+        # the (tile, wave) partial sums add up to the bias gradient of conv1_j
+        st = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        hipops.bn_reduce_partials(rsum[j], rows, C, B * L, st)
+        want_b = t1s[j].grad.double().sum(dim=(0, 2))
+        assert (st[:C].cpu() - want_b).abs().max().item() <= 1e-4 * max(1.0, want_b.abs().max().item()), j
+    assert torch.isfinite(dx).all()
+    assert (dx.cpu() - x.grad).abs().max().item() <= 5e-5 * max(1.0, x.grad.abs().max().item())
+
+
 @pytest.mark.parametrize('B,C,L,k,dil', [(2, 256, 300, 11, 3), (2, 64, 700, 7, 1), (3, 32, 1000, 3, 3), (2, 16, 3000, 11, 1)])
 def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
     """Backward through one ResBlock2 step  y = x + conv_{k,d}(lrelu(x)),  x = a*in + s  (first piece):

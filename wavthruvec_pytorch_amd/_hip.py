@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -53,7 +53,9 @@ class StageArgs(C.Structure):
                 ('k', C.c_int32 * 4), ('dil1', C.c_int32 * 4), ('dil2', C.c_int32 * 4),
                 ('out', _fp), ('nk', C.c_int32), ('B', C.c_int32), ('C', C.c_int32), ('L', C.c_int32),
                 ('slope', C.c_float), ('out_div', C.c_float),
-                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float)]
+                ('post_w', _fp), ('post_b', _fp), ('post_out', _fp), ('post_k', C.c_int32), ('post_slope', C.c_float),
+                ('bwd_mask1', _fp * 4), ('bwd_mid', _fp * 4), ('bwd_mask2', _fp), ('bwd_mask2_a', _fp), ('bwd_mask2_s', _fp),
+                ('bwd_slope', C.c_float), ('bwd_rowsum', _fp * 4)]
 
 
 class FoldDesc(C.Structure):
@@ -151,6 +153,7 @@ SIGNATURES = {
     'v2w_conv1d_splitk_ws_bytes': (C.c_longlong, [C.POINTER(Conv1dArgs), C.c_int]),
     'v2w_convt1d_splitk_ws_bytes': (C.c_longlong, [C.POINTER(ConvT1dArgs)]),
     'v2w_resblock_pair_fwd': (C.c_int, [C.POINTER(PairArgs), C.c_int, _fp]),
+    'v2w_resblock2_stage_bwd_rows': (C.c_int, [C.POINTER(StageArgs)]),
     'v2w_resblock2_stage_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_resblock2_stage_small_fwd': (C.c_int, [C.POINTER(StageArgs), _fp]),
     'v2w_branch_convs_bf16_fwd': (C.c_int, [C.POINTER(BranchConvsArgs), _fp]),

@@ -149,22 +149,35 @@ def generator_backward(gen, sv, dy, need_dx=False):
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
             # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
             # (the launch's tile shape follows its WIDEST halo - the wide-halo tile variants are other shapes: probe with that branch)
-            kw, dw = max(((rb.kernel_size, rb.convs[1].dilation) for rb in rbs), key=lambda kd: kd[1] * (kd[0] - 1))
-            ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, kw, dw) if Lo % 4 == 0 else 0
-            rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
-            hipops.conv1d_multi([(dxs, None, None, dt1s[j],
-                                  dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, in_affine=(inv, zero), res=dxs,
-                                       res_affine=(inv, zero), mask=(t1s[j], None), mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA,
-                                       rowsum=rsp[j])) for j in order])
+            # narrow stages (C = 32 / 16): both input-gradient convs of all branches in ONE kernel (v2w_stage_args::bwd_*) - dxs read once,
+            # every dt1_j written once and not read back, the branch sum in registers: 9 tensor passes instead of 18
+            fused, ntile, rsp = False, 0, None
+            if C in gen.fuse_stage and C in (16, 32) and gen.fuse_stage_backward and all(q is not None for q in p1 + p2):
+                ks_, dd2, dd1 = [rb.kernel_size for rb in rbs], [rb.convs[1].dilation for rb in rbs], [rb.convs[0].dilation for rb in rbs]
+                ntile = hipops.resblock2_stage_bwd_rows(B, C, Lo, ks_, dd2, dd1)
+                if ntile:
+                    rsp = [torch.empty((ntile * C * 2,), device=dev) for _ in range(nk)]       # (tile, wave) channel sums of dt1_j: conv1_j's bias gradient
+                    fused = hipops.resblock2_stage(
+                        dxs, (inv, zero), [dict(wp1=p2[j], b1=None, wp2=p1[j], b2=None, k=ks_[j], dil1=dd2[j], dil2=dd1[j]) for j in range(nk)],
+                        dx, slope=1.0, out_div=0.0, bwd=(t1s, dt1s, xr, aff, LRELU_SLOPE, rsp))
+            if not fused:
+                kw, dw = max(((rb.kernel_size, rb.convs[1].dilation) for rb in rbs), key=lambda kd: kd[1] * (kd[0] - 1))
+                ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, kw, dw) if Lo % 4 == 0 else 0
+                rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
+            if not fused:
+                hipops.conv1d_multi([(dxs, None, None, dt1s[j],
+                                      dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, in_affine=(inv, zero), res=dxs,
+                                           res_affine=(inv, zero), mask=(t1s[j], None), mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA,
+                                           rowsum=rsp[j])) for j in order])
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx = sum_j dt1_j + lrelu'(x) * conv(dt1_j; W1^T flipped)
-            parts = [torch.empty_like(dxs) for _ in range(nk - 1)]
-
             def dconv1(j, out, **extra):
                 return (dt1s[j], None, None, out,
                         dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=1.0, res=dt1s[j], mask=(xr, aff), mask_slope=LRELU_SLOPE,
                              wp=p1[j], algo=hipops.ALGO_MFMA, **extra))
-            hipops.conv1d_multi([dconv1(j, parts[j]) for j in order if j < nk - 1])
-            hipops.conv1d_multi([dconv1(nk - 1, dx, add=parts)])
+            if not fused:
+                parts = [torch.empty_like(dxs) for _ in range(nk - 1)]
+                hipops.conv1d_multi([dconv1(j, parts[j]) for j in order if j < nk - 1])
+                hipops.conv1d_multi([dconv1(nk - 1, dx, add=parts)])
             # weight / bias gradients: nothing downstream waits for them - side stream, beside the next stage's gradient convs
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)

@@ -373,6 +373,11 @@ struct StageArgs {
     const float* post_w; const float* post_b; float* post_out;
     int post_k, nadv, hout;
     float post_slope;
+    // input-gradient form (BWD instantiations; the backward of the section): see v2w_stage_args::bwd_*
+    const float* mask1[V2W_STAGE_MAXB]; float* mid_out[V2W_STAGE_MAXB];
+    float* rowsum[V2W_STAGE_MAXB];   // optional [tiles * WN][C][2]: per (tile, wave) channel sums of dt1_j over the positions the tile owns (, 0)
+    const float* mask2; const float* mask2_a; const float* mask2_s;
+    float mask_slope;
 };
 
 template <int MF> struct StageGeom {
@@ -456,7 +461,14 @@ struct StageConv {
     }
 };
 
-template <int MF, int NI, int WN, bool POST = false>
+// BWD: the section's INPUT GRADIENT on the same tiles (backward.py; the backward of models.py:135-141).  With dr = in_a * in (= dxs / nk):
+//   dt1_j = dr + lrelu'(t1_j) * conv(dr; W2_j^T, taps reversed)   ->  mid_out[j] (the weight and bias gradients of conv1_j read it),
+//   dx    = sum_j dt1_j + lrelu'(x) * sum_j conv(dt1_j; W1_j^T, taps reversed)   ->  out,        x = mask2_a * mask2 + mask2_s.
+// The caller hands the transposed fragment streams as wp1 (conv2's) / wp2 (conv1's) with the dilations swapped, slope = 1 (the operands are
+// gradients: no activation), no biases; mask1[j] = the forward's t1_j, mask2 = the forward's xr.  dr is read ONCE for the three branches, every
+// dt1_j is written once and never read back by this kernel, the branch sum stays in registers: 9 tensor passes instead of the 18 of the
+// three merged launches.
+template <int MF, int NI, int WN, bool POST = false, bool BWD = false>
 __global__ void __launch_bounds__(64 * WN)
 resblock2_stage_kernel(const StageArgs p) {
     typedef Frag<MF> F;
@@ -614,6 +626,23 @@ resblock2_stage_kernel(const StageArgs p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) row_get(Ta + (wn0 + j * MF + lr) * RS, xres[j]);
 
+    // BWD: the sign of x = a * xr + s at this lane's outputs, one bit per accumulator register (lrelu'(x) of the final sum)
+    unsigned m2bits = 0u;
+    if constexpr (BWD) {
+        static_assert(NI * NR <= 32, "one mask bit per accumulator register");
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int pos = n0 - p.h2max + wn0 + j * MF + lr;
+            if (pos >= 0 && pos < L) {
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    const int ch = b * C + F::row(e, hk);
+                    const float xv = fmaf(p.mask2_a ? p.mask2_a[ch] : 1.f, p.mask2[(size_t)ch * L + pos], p.mask2_a ? p.mask2_s[ch] : 0.f);
+                    m2bits |= (xv > 0.f ? 1u : 0u) << (j * NR + e);
+                }
+            }
+        }
+    }
     acc_t acc[NI];
     float t1r[NI][NR], oacc[NI][NR];
     const float* const xl = Xa + (wn0 + lr) * RS + 4 * hk;     // this lane's float4 in X / T1 row (window column) 0
@@ -628,14 +657,61 @@ resblock2_stage_kernel(const StageArgs p) {
         // ---- conv1_j on the window: column col <-> position n0 - h2max + col
         float brow[NR];
         bias_rows(etab + jb * C, brow);
+        if constexpr (BWD) {
+            // the forward's t1_j at this lane's accumulator elements (the mask of the first epilogue): issued here, into the registers of
+            // t1r - dead until that epilogue - so that the 2 x NR loads land under the conv's MFMA loop
+            const float* const mk = p.mask1[jb] + (size_t)b * C * L;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int pos = n0 - p.h2max + wn0 + j * MF + lr;
+                const bool in_seq = pos >= 0 && pos < L;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) t1r[j][e] = in_seq ? mk[(size_t)F::row(e, hk) * L + pos] : 1.f;
+            }
+        }
         sc.run(acc, brow, w1, w2, K, lane, xl + (xc0 - h1) * RS, d1, jb == 0 ? 16 : (jb == 2 ? 19 : -1));
         V2W_STAMP(3 + 4 * jb);
+        if constexpr (BWD) {
+            // dt1_j = dr + lrelu'(t1_j) * acc: the forward's t1_j comes from global memory at the accumulator's own (channel, position) - 128
+            // contiguous bytes per register and lane half - and dt1_j goes back the same way, each position from the tile that owns it
+            float* const mo = p.mid_out[jb] + (size_t)b * C * L;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = wn0 + j * MF + lr, pos = n0 - p.h2max + col;
+                const bool in_seq = pos >= 0 && pos < L;
+                const bool own = in_seq && col >= p.h2max && col < p.h2max + p.nto;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    const float v = in_seq ? xres[j][e] + (t1r[j][e] > 0.f ? acc[j][e] : acc[j][e] * p.mask_slope) : 0.f;
+                    t1r[j][e] = v;
+                    if (own) mo[(size_t)F::row(e, hk) * L + pos] = v;
+                }
+            }
+            if (p.rowsum[jb]) {
+                // the bias gradient of conv1_j = the channel sums of dt1_j: this wave's share, one row per (tile, wave), reduced by the caller
+                // (v2w_bn_reduce_partials) in a fixed order
+                float* const rs = p.rowsum[jb] + ((size_t)(tile * WN + wave) * C) * 2;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int col = wn0 + j * MF + lr, pos = n0 - p.h2max + col;
+                        if (pos >= 0 && pos < L && col >= p.h2max && col < p.h2max + p.nto) sum += t1r[j][e];
+                    }
+#pragma unroll
+                    for (int off = MF / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);      // over the MF lanes that share (e, hk)
+                    if (lr == 0) *reinterpret_cast<f32x2*>(rs + 2 * F::row(e, hk)) = f32x2{sum, 0.f};
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int pos = n0 - p.h2max + wn0 + j * MF + lr;
             const bool in_seq = pos >= 0 && pos < L;            // conv2 zero-pads t1 outside the sequence
 #pragma unroll
             for (int e = 0; e < NR; ++e) t1r[j][e] = in_seq ? acc[j][e] + xres[j][e] : 0.f;
+        }
         }
         __syncthreads();                      // everyone is done reading Ta (raw x at jb == 0, the previous branch's t1 after)
 #pragma unroll
@@ -656,7 +732,9 @@ resblock2_stage_kernel(const StageArgs p) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < NR; ++e) {
-                const float r = acc[j][e] + t1r[j][e];
+                float r = acc[j][e];
+                if constexpr (BWD) r = (m2bits >> (j * NR + e)) & 1u ? r : r * p.mask_slope;     // lrelu'(x): the same mask for every branch
+                r += t1r[j][e];
                 oacc[j][e] = jb == 0 ? r : oacc[j][e] + r;
             }
         V2W_STAMP(6 + 4 * jb);
@@ -807,7 +885,17 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     if (const char* e = getenv("V2W_TL_LDSPAD")) lds += (size_t)atoi(e);      // fewer workgroups per CU: what does ONE wave per SIMD reach?
 #endif
     if (lds > 160 * 1024) return V2W_E_SHAPE;
-    auto kern = post ? resblock2_stage_kernel<MF, NI, WN, (MF == 16)> : resblock2_stage_kernel<MF, NI, WN, false>;
+    const bool bwd = q->bwd_mask2 != nullptr;
+    if (bwd) {
+        if (post || q->slope != 1.f) return V2W_E_ARG;
+        for (int j = 0; j < q->nk; ++j) {
+            if (!q->bwd_mask1[j] || !q->bwd_mid[j] || q->bias1[j] || q->bias2[j]) return V2W_E_ARG;
+            p.mask1[j] = q->bwd_mask1[j]; p.mid_out[j] = q->bwd_mid[j]; p.rowsum[j] = q->bwd_rowsum[j];
+        }
+        p.mask2 = q->bwd_mask2; p.mask2_a = q->bwd_mask2_a; p.mask2_s = q->bwd_mask2_s; p.mask_slope = q->bwd_slope;
+    }
+    auto kern = bwd ? resblock2_stage_kernel<MF, NI, WN, false, true>
+                    : (post ? resblock2_stage_kernel<MF, NI, WN, (MF == 16)> : resblock2_stage_kernel<MF, NI, WN, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -836,10 +924,24 @@ extern "C" int v2w_resblock_pair_fwd(const v2w_pair_args* a, int n, void* stream
     return V2W_E_SHAPE;
 }
 
+// Rows of v2w_stage_args::bwd_rowsum the input-gradient form writes for this problem (one per (tile, wave)): the launcher's own geometry.
+extern "C" int v2w_resblock2_stage_bwd_rows(const v2w_stage_args* a) {
+    if (!a || a->nk < 1 || a->nk > V2W_STAGE_MAXB || a->B <= 0 || a->L <= 0 || (a->C != 16 && a->C != 32)) return 0;
+    int h2max = 0;
+    for (int j = 0; j < a->nk; ++j) { const int h2 = a->dil2[j] * (a->k[j] - 1) / 2; if (h2 > h2max) h2max = h2; }
+    const int nto256 = (256 - 2 * h2max) & ~3;
+    const bool small = nto256 > 0 && (long long)a->B * ((a->L + nto256 - 1) / nto256) < 224 && 128 - 2 * h2max >= 64;
+    const int nto = ((small ? 128 : 256) - 2 * h2max) & ~3;
+    if (nto <= 0) return 0;
+    const long long rows = (long long)a->B * ((a->L + nto - 1) / nto) * 4;
+    return rows > 0x7fffffffll ? 0 : (int)rows;
+}
+
 extern "C" int v2w_resblock2_stage_fwd(const v2w_stage_args* a, void* stream) {
     if (!a || !a->in || (!a->out && !a->post_out) || a->nk < 1 || a->nk > V2W_STAGE_MAXB) return V2W_E_ARG;
     if (a->B <= 0 || a->C <= 0 || a->L <= 0) return V2W_E_ARG;
-    if ((a->in_a == nullptr) != (a->in_s == nullptr)) return V2W_E_ARG;
+    if ((a->in_a == nullptr) != (a->in_s == nullptr) || (a->bwd_mask2_a == nullptr) != (a->bwd_mask2_s == nullptr)) return V2W_E_ARG;
+    if (a->bwd_mask2 && (!a->out || a->post_out)) return V2W_E_ARG;
     if (a->post_out && a->C != 16) return V2W_E_SHAPE;           // the fused tail: the last (16-channel) stage
     for (int j = 0; j < a->nk; ++j) {
         if (!a->wp1[j] || !a->wp2[j] || a->k[j] <= 0 || a->dil1[j] <= 0 || a->dil2[j] <= 0) return V2W_E_ARG;

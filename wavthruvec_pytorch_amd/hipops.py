@@ -691,10 +691,12 @@ def branch_convs_bf16(mode, ins, in_affine, wps, biases, outs, ks, dils, *, slop
     return True
 
 
-def resblock2_stage(x, in_affine, branches, out, *, slope, out_div, post=None):
+def resblock2_stage(x, in_affine, branches, out, *, slope, out_div, post=None, bwd=None):
     """Whole ResBlock2 residual section of a narrow stage in one kernel.  `branches`: list of dicts(wp1, b1, wp2, b2, k, dil1, dil2).
     post = (wf [k][C][1], bias | None, y (B, 1, L) fp32, k, slope): the generator's tail fused behind the 16-channel stage - `out` may be None,
-    it is not written.  Returns False (nothing launched) when the shape is not taken."""
+    it is not written.  bwd = (t1s [nk], dt1s [nk], xr, (a, s) | None, mask_slope[, rowsums [nk]]): the section's input gradient instead (v2w_stage_args::bwd_*:
+    x = dL/d(out), in_affine = (1 / nk, 0), wp1 / wp2 the transposed streams of conv2 / conv1, slope 1).
+    Returns False (nothing launched) when the shape is not taken."""
     B, Cc, L = x.shape
     a = _hip.StageArgs()
     a.in_ = x.data_ptr()
@@ -709,11 +711,30 @@ def resblock2_stage(x, in_affine, branches, out, *, slope, out_div, post=None):
     if post is not None:
         a.post_w, a.post_b, a.post_out = post[0].data_ptr(), _hip.ptr(post[1]), post[2].data_ptr()
         a.post_k, a.post_slope = post[3], post[4]
+    if bwd is not None:
+        t1s, dt1s, xr, xaff, mslope = bwd[:5]
+        rowsums = bwd[5] if len(bwd) > 5 else None
+        for j in range(len(branches)):
+            a.bwd_mask1[j] = t1s[j].data_ptr(); a.bwd_mid[j] = dt1s[j].data_ptr()
+            a.bwd_rowsum[j] = _hip.ptr(rowsums[j]) if rowsums is not None else None
+        a.bwd_mask2 = xr.data_ptr()
+        a.bwd_mask2_a, a.bwd_mask2_s = (xaff[0].data_ptr(), xaff[1].data_ptr()) if xaff is not None else (None, None)
+        a.bwd_slope = mslope
     rc = _hip.load().v2w_resblock2_stage_fwd(C.byref(a), _stream(x))
     if rc == -2:
         return False
     _hip.check(rc, 'v2w_resblock2_stage_fwd')
     return True
+
+
+def resblock2_stage_bwd_rows(B, Cc, L, ks, dil1s, dil2s) -> int:
+    """Rows of [C][2] floats per branch the input-gradient form of `resblock2_stage` writes into its `rowsums` buffers (0: shape not taken).
+    dil1s / dil2s as handed to the kernel (conv2's dilations first)."""
+    a = _hip.StageArgs()
+    a.nk, a.B, a.C, a.L = len(ks), B, Cc, L
+    for j in range(len(ks)):
+        a.k[j], a.dil1[j], a.dil2[j] = ks[j], dil1s[j], dil2s[j]
+    return _hip.load().v2w_resblock2_stage_bwd_rows(C.byref(a))
 
 
 def resblock2_stage_small(x, in_affine, branches, out, *, slope, out_div):

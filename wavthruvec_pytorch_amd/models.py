@@ -214,6 +214,9 @@ class Generator(nn.Module):
                                               # the stage's output never leaves the chip, one launch less per stage
         self.fuse_post = True                 # leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage (bf16 storage, and - round 5 - the fp32 stage kernel): the stage's
                                               # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
+        self.fuse_stage_backward = False      # exact fp32 backward of a narrow stage (C in fuse_stage): both input-gradient convs of all branches in
+                                              # ONE kernel (v2w_stage_args::bwd_*, round 5) instead of three merged launches.  Off: measured - the two
+                                              # kernels take 0.2 ms less than the six launches they replace, the step 0.35 ms MORE
         self._split_wide = set()
         self._ws: Dict[str, torch.Tensor] = {}
         self._slabs: Dict[tuple, 'hipops.SplitKSlab'] = {}
