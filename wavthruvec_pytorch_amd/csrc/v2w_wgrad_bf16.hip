@@ -14,8 +14,9 @@
 // Two arrangements of the workgroup's 4 waves:
 //   64 x 64 tile, 2 x 2 waves (C_in, C_out multiples of 64): every wave owns a 32 x 32 block for ALL taps of the launch (<= 7: 112
 //       accumulator registers; k = 9 / 11 take two launches);
-//   MF x MF tile, MF = 32 / 16 (the narrow stages): the waves share the TAPS (wave w: taps w*NT .. w*NT+NT-1, NT = ceil(k / 4)) and every
-//       wave reduces over all positions of the item - one launch per layer whatever k, a quarter of the partial slabs of a position split.
+//   MF x MF tile, MF = 32 / 16 (the narrow stages): the waves share the TAPS (wave w: taps w*NT .. w*NT+NT-1) and every
+//       wave reduces over all positions of the item - one launch per layer whatever k, a quarter of the partial slabs of a position split
+//       (k <= 4: one tap per wave; above: three - two per wave measured slower).
 // These layers are bound by the read of x and dy (C <= 64: one pass over both per launch), not by the matrix pipe; inputs are fp32
 // tensors (converted while staging) or bf16 tensors (io_bf16 = 3).  Partials go to per-split slabs, summed in fixed order: deterministic.
 #include <type_traits>
@@ -335,7 +336,7 @@ extern "C" int v2w_wgrad_bf16(const void* x, const float* x_a, const float* x_s,
     const bool bf = io_bf16 == 3;
     bool ok = true;
     if (ts) {
-        const int nt = (k + 3) / 4;
+        const int nt = k <= 4 ? 1 : 3;                                // (two taps per wave - k = 5 .. 8 - measured slower than three: 110 against 75 us at C = 32, k = 7)
         p.tap0 = 0; p.ntap = k;
         if (mf == 32) ok = bf ? wgb_launch_nt<32, 1, 1, true>(nt, p, tiles, lds, st) : wgb_launch_nt<32, 1, 1, false>(nt, p, tiles, lds, st);
         else ok = bf ? wgb_launch_nt<16, 1, 1, true>(nt, p, tiles, lds, st) : wgb_launch_nt<16, 1, 1, false>(nt, p, tiles, lds, st);
