@@ -117,7 +117,7 @@ def generator_backward(gen, sv, dy, need_dx=False):
         from .models import ResBlock1, ResBlock2
         # the merged launches run on ALGO_MFMA, which has no direct-kernel fallback: every gradient conv of every branch must have a
         # tile configuration at ITS kernel size and dilation (a wide halo, e.g. k = 11 with dilation 7, has none: per-branch path)
-        merged = gen.precision == 'f32' and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 \
+        merged = gen.precision in ('f32', 'bf16') and gen.algo == hipops.ALGO_AUTO and 1 < nk <= 3 \
             and all(isinstance(gen.resblocks[i * nk + j], ResBlock2) for j in range(nk)) \
             and all(hipops.conv_tile_config(B * nk, C, C, Lo, gen.resblocks[i * nk + j].kernel_size, c.dilation) is not None
                     for j in range(nk) for c in gen.resblocks[i * nk + j].convs)
@@ -142,10 +142,18 @@ def generator_backward(gen, sv, dy, need_dx=False):
             # fragment streams of the gradient convs straight from the forward-layout weights (no transposed copies: C -> C layers)
             # (built by the forward's batched weight fold, beside the forward streams, when the layer is one of its C -> C residual convs)
             wpd = sv.get('wpd', {})
-            p2 = [wpd.get(names[j] + '.convs.1') if wpd.get(names[j] + '.convs.1') is not None else hipops.pack_mfma_dgrad(wf[names[j] + '.convs.1'])
-                  for j in range(nk)]
-            p1 = [wpd.get(names[j] + '.convs.0') if wpd.get(names[j] + '.convs.0') is not None else hipops.pack_mfma_dgrad(wf[names[j] + '.convs.0'])
-                  for j in range(nk)]
+            # the generator's bf16 arithmetic (precision = 'bf16': the reference under torch.autocast): the wide stages' gradient convs on the bf16
+            # kernel the forward used - transposed, tap-reversed fragments packed here - the narrow stages' on the exact fp32 tile kernel
+            use_bf = gen.precision == 'bf16' and C >= gen.split_min_channels and hipops.split_supported(C, C) \
+                and all(rb.kernel_size >= 3 and (rb.kernel_size & 1) for rb in rbs)
+
+            def wsel(nm):
+                """Kernel and weights of the input-gradient conv of layer `nm`."""
+                if use_bf:
+                    return dict(algo=hipops.ALGO_BF16, wps=hipops.pack_split(hipops.transpose_flip(wf[nm]), bf16=True))
+                return dict(algo=hipops.ALGO_MFMA, wp=wpd.get(nm) if wpd.get(nm) is not None else hipops.pack_mfma_dgrad(wf[nm]))
+            w2s, w1s = [wsel(names[j] + '.convs.1') for j in range(nk)], [wsel(names[j] + '.convs.0') for j in range(nk)]
+            p2, p1 = [q.get('wp') for q in w2s], [q.get('wp') for q in w1s]
             # r_j = t1 + conv2(lrelu(t1)) + b2   ->   dt1 = dr + lrelu'(t1) * conv(dr; W2^T flipped)
             # ... and, from the same launch's epilogue, the per-tile channel sums of dt1_j = the bias gradient of conv1_j
             # (the launch's tile shape follows its WIDEST halo - the wide-halo tile variants are other shapes: probe with that branch)
@@ -162,18 +170,18 @@ def generator_backward(gen, sv, dy, need_dx=False):
                         dx, slope=1.0, out_div=0.0, bwd=(t1s, dt1s, xr, aff, LRELU_SLOPE, rsp))
             if not fused:
                 kw, dw = max(((rb.kernel_size, rb.convs[1].dilation) for rb in rbs), key=lambda kd: kd[1] * (kd[0] - 1))
-                ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, kw, dw) if Lo % 4 == 0 else 0
+                ntile = hipops.conv_rowsum_tiles(B, nk, C, C, Lo, kw, dw) if Lo % 4 == 0 and not use_bf else 0      # (an epilogue of the f32 tile kernel)
                 rsp = [torch.empty((ntile * C * 2,), device=dev) if ntile else None for _ in range(nk)]
             if not fused:
                 hipops.conv1d_multi([(dxs, None, None, dt1s[j],
                                       dict(k=rbs[j].kernel_size, dil=rbs[j].convs[1].dilation, slope=1.0, in_affine=(inv, zero), res=dxs,
-                                           res_affine=(inv, zero), mask=(t1s[j], None), mask_slope=LRELU_SLOPE, wp=p2[j], algo=hipops.ALGO_MFMA,
-                                           rowsum=rsp[j])) for j in order])
+                                           res_affine=(inv, zero), mask=(t1s[j], None), mask_slope=LRELU_SLOPE, rowsum=rsp[j], **w2s[j]))
+                                     for j in order])
             # t1 = x + conv1(lrelu(x)) + b1, x = a*xr + s   ->   dx = sum_j dt1_j + lrelu'(x) * conv(dt1_j; W1^T flipped)
             def dconv1(j, out, **extra):
                 return (dt1s[j], None, None, out,
                         dict(k=rbs[j].kernel_size, dil=rbs[j].convs[0].dilation, slope=1.0, res=dt1s[j], mask=(xr, aff), mask_slope=LRELU_SLOPE,
-                             wp=p1[j], algo=hipops.ALGO_MFMA, **extra))
+                             **w1s[j], **extra))
             if not fused:
                 parts = [torch.empty_like(dxs) for _ in range(nk - 1)]
                 hipops.conv1d_multi([dconv1(j, parts[j]) for j in order if j < nk - 1])
@@ -184,9 +192,9 @@ def generator_backward(gen, sv, dy, need_dx=False):
             def branch_grads(j, db2):
                 c1, c2 = rbs[j].convs[0], rbs[j].convs[1]
                 k = rbs[j].kernel_size
-                _wn_grads(grads, names[j] + '.convs.1', c2, hipops.wgrad(t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
+                _wn_grads(grads, names[j] + '.convs.1', c2, _wgrad(gen, t1s[j], dxs, k=k, dil=c2.dilation, slope=LRELU_SLOPE).mul_(1.0 / nk))
                 grads[names[j] + '.convs.1.bias'] = db2
-                _wn_grads(grads, names[j] + '.convs.0', c1, hipops.wgrad(xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
+                _wn_grads(grads, names[j] + '.convs.0', c1, _wgrad(gen, xr, dt1s[j], k=k, dil=c1.dilation, slope=LRELU_SLOPE, x_affine=aff))
                 if ntile:
                     st = torch.empty((2 * C + 1,), device=dev, dtype=torch.float64)
                     hipops.bn_reduce_partials(rsp[j], ntile, C, B * Lo, st)
