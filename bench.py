@@ -756,7 +756,8 @@ def main():
         cfg3 = guarded(config_block, dict(num_wv_feat=768), 64, 512, 'bf16', max(5, 5 * args.steps), max(8, args.warmup), dev,
                        'BASELINE configs[2]: Generator.forward, B=64 x T=512, 768-d latents, x320, train mode, bf16 compute / fp32 accumulate, '
                        'bf16 activation storage', bf16_parity, '_cfg3_bf16_hbm_traffic.json')
-        cfg2b = guarded(config_block, dict(num_wv_feat=768), 32, 256, 'bf16', max(5, args.steps), max(3, args.warmup), dev,
+        cfg2b = guarded(config_block, dict(num_wv_feat=768), 32, 256, 'bf16', max(5, 5 * args.steps), max(8, args.warmup), dev,      # (1.4 ms steps: 100 of them,
+                        # like cfg3 - over 20 the start / drain of the timed loop is 1-3 % of the reading)
                         'the north_star shape B=32 x T=256 (BASELINE configs[1]) in the configs[2] arithmetic: bf16 compute / fp32 accumulate, '
                         'bf16 activation storage, train mode', bf16_parity, '_cfg2_bf16_hbm_traffic.json')
         cfg5 = guarded(config_block, dict(num_wv_feat=1024, upsample_rates=[8, 5, 4, 2, 2], upsample_kernel_sizes=[16, 11, 8, 4, 4]), 16, 256, 'f32',
