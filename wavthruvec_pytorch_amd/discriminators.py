@@ -515,11 +515,35 @@ class _PairState(threading.local):
 _PAIR = _PairState()
 
 
+# (y, y_hat) of a weight-normed discriminator as ONE call on the batch [y; y_hat] (the stacks hold no batch statistics: every sample's
+# result is what the two calls give; the spectral-normed discriminator iterates u, v once per call and keeps its two calls).  Half the
+# launches of a discriminator step's forwards and backwards, and no gradient accumulation over the two calls: train.py's own batch_size = 2 is
+# launch-bound.  Only when the parameters ask for gradients - with frozen parameters the real half of two calls needs no backward at all.
+# 'auto': up to _BATCH_PAIRS_MAX_SAMPLES input samples per half (above, the autograd slices of the split feature maps cost more than the launches).
+BATCH_PAIRS = 'auto'
+_BATCH_PAIRS_MAX_SAMPLES = 1 << 20
+
+
+def _batch_pair(d, y, y_hat):
+    if BATCH_PAIRS is False or y.shape != y_hat.shape or any(l.spectral for l in d._layers()):
+        return False
+    if not (torch.is_grad_enabled() and any(p.requires_grad for p in d.parameters())):
+        return False
+    return BATCH_PAIRS is True or y.numel() <= _BATCH_PAIRS_MAX_SAMPLES
+
+
 def _pairwise(discs, inputs):
     """Run every discriminator on its (y, y_hat) pair -> (scores_real, scores_generated, fmaps_real, fmaps_generated)."""
     _PAIR.depth += 1
     try:
-        outs = [(d(y), d(y_hat)) for d, (y, y_hat) in zip(discs, inputs)]
+        outs = []
+        for d, (y, y_hat) in zip(discs, inputs):
+            if _batch_pair(d, y, y_hat):
+                nb = y.shape[0]
+                score, fmap = d(torch.cat([y, y_hat], 0))
+                outs.append(((score[:nb], [f[:nb] for f in fmap]), (score[nb:], [f[nb:] for f in fmap])))
+            else:
+                outs.append((d(y), d(y_hat)))
     finally:
         _PAIR.depth -= 1
         for d in discs:
