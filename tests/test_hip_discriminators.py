@@ -223,6 +223,39 @@ def test_frozen_discriminators_give_the_same_input_gradient(dev, kind):
     assert torch.equal(yh.grad, gy)
 
 
+@pytest.mark.parametrize('kind', ['mpd', 'msd'])
+def test_pair_as_one_batched_call_equals_two_calls(dev, kind, monkeypatch):
+    """`BATCH_PAIRS`: (y, y_hat) of a weight-normed discriminator as ONE call on the batch [y; y_hat] - scores, every feature map, every
+    parameter gradient and dL/dy_hat against the two calls of models.py:208-214 / 266-273 (a sample's result does not depend on its batch;
+    only the tile choice of a launch, hence the order of its fp32 additions, may).  The spectral-normed scale discriminator keeps its two calls."""
+    from wavthruvec_pytorch_amd import discriminators as HD
+    spec = synthetic.mpd_state_dict_spec() if kind == 'mpd' else synthetic.msd_state_dict_spec()
+    sd = synthetic.make_disc_state_dict(spec, seed=23)
+    y, y_hat = synthetic.make_audio_pair(2, 2300, seed=14)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(HD, 'BATCH_PAIRS', mode)
+        calls = []
+        orig = HD._DiscBase.forward
+        monkeypatch.setattr(HD._DiscBase, 'forward', lambda self, x, _o=orig, _c=calls: (_c.append(x.shape[0]), _o(self, x))[1])
+        m = build(kind, sd, dev)
+        yh = y_hat.to(dev).requires_grad_(True)
+        outs = m(y.to(dev), yh)
+        D.smooth_loss(outs).backward()
+        monkeypatch.setattr(HD._DiscBase, 'forward', orig)
+        res[mode] = (outs, {k: p.grad.clone() for k, p in m.named_parameters()}, yh.grad.clone(), calls)
+    n = len(res[True][0][0])
+    nsn = 0 if kind == 'mpd' else 1
+    assert sorted(res[True][3]) == sorted([4] * (n - nsn) + [2] * (2 * nsn)) and res[False][3] == [2] * (2 * n)
+    (sr, sg, fr, fg), (sr2, sg2, fr2, fg2) = res[True][0], res[False][0]
+    for a, b in zip(sr + sg + [f for fm in fr + fg for f in fm], sr2 + sg2 + [f for fm in fr2 + fg2 for f in fm]):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    for k, g in res[True][1].items():
+        g2 = res[False][1][k]
+        assert (g - g2).abs().max().item() <= 2e-4 * max(g2.abs().max().item(), 1e-6), k
+    assert (res[True][2] - res[False][2]).abs().max().item() <= 2e-4 * res[False][2].abs().max().item()
+
+
 def _disc_ddp_worker(rank, world, port, out_dir):
     import os
     import torch.distributed as dist
