@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 31
+#define V2W_ABI_VERSION 32
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -456,7 +456,8 @@ int v2w_cbn_bwd_apply(const float* dx, const float* xr, const float* gb, const d
                       const float* running_mean, const float* running_var, float* tab_ws, float* dxr,
                       int B, int C, int L, int training, float eps, void* stream);
 /* tanh + conv_post backward (models.py:143-145): dp = dy*(1-y^2) (dp_ws: B*L floats; its sum is d conv_post.bias),
- * dx = lrelu'(x) * conv_post^T(dp), dwf [k][C_in][1]; part_ws: C_in*k*64 doubles. */
+ * dx = lrelu'(x) * conv_post^T(dp), dwf [k][C_in][1]; part_ws: C_in*k*512 doubles (ABI v32: the one-pass kernel for C_in = 16, k = 7 writes one
+ * row of partial weight gradients per persistent workgroup; 64 rows before). */
 int v2w_tail_bwd(const float* dy, const float* y, const float* x, const float* wf, float* dp_ws, double* part_ws,
                  float* dx, float* dwf, int B, int C_in, int L, int k, float slope, void* stream);
 /* weight-norm backward: (dwf [k][C_in][C_out], v, g) -> dv (v's layout), dg; g == NULL: dv = dw relayouted, dg untouched. */

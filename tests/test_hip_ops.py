@@ -1296,6 +1296,27 @@ def test_resblock2_stage_input_gradient_in_one_kernel(dev, C, L, ks, d1, d2):
     assert (dx.cpu() - x.grad).abs().max().item() <= 5e-5 * max(1.0, x.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('B,C,L,k', [(2, 16, 4100, 7), (3, 16, 1024, 7), (1, 16, 8, 7), (2, 16, 1030, 7), (2, 16, 2052, 5), (2, 32, 1000, 7), (2, 8, 640, 7)])
+def test_tail_backward_matches_autograd(dev, B, C, L, k):
+    """v2w_tail_bwd: the backward of leaky_relu(0.01) -> conv_post -> tanh (models.py:143-145) - dx, the weight gradient and dp (whose sum is the
+    bias gradient) against torch autograd.  C = 16, k = 7 at L % 4 == 0 runs the one-pass kernel (ABI v32: x read once for both gradients,
+    several 1 024-position tiles with their seams, a length below one tile); everything else the per-tap kernels."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(60 + L + C + k)
+    x = torch.from_numpy(r.standard_normal((B, C, L), dtype=np.float32)).requires_grad_(True)
+    w = torch.from_numpy((r.standard_normal((1, C, k)) / np.sqrt(C * k)).astype(np.float32)).requires_grad_(True)
+    bias = torch.zeros(1, requires_grad=True)
+    y = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, bias, padding=(k - 1) // 2))
+    dy = torch.from_numpy(r.standard_normal((B, 1, L), dtype=np.float32))
+    y.backward(dy)
+    dx, dwf, dp = hipops.tail_backward(_t(dy.numpy(), dev), _t(y.detach().numpy(), dev), _t(x.detach().numpy(), dev), _t(_relayout(w.detach()).numpy(), dev),
+                                       k=k, slope=0.01)
+    assert torch.isfinite(dx).all() and (dx.cpu() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+    want_w = w.grad.permute(2, 1, 0)                                   # [k][C][1]
+    assert (dwf.cpu() - want_w).abs().max().item() <= 1e-4 * max(1.0, want_w.abs().max().item())
+    assert abs(dp.sum().item() - bias.grad.item()) <= 1e-3 * max(1.0, abs(bias.grad.item()))
+
+
 @pytest.mark.parametrize('B,C,L,k,dil', [(2, 256, 300, 11, 3), (2, 64, 700, 7, 1), (3, 32, 1000, 3, 3), (2, 16, 3000, 11, 1)])
 def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
     """Backward through one ResBlock2 step  y = x + conv_{k,d}(lrelu(x)),  x = a*in + s  (first piece):

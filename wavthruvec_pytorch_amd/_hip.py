@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4

@@ -854,7 +854,7 @@ def tail_backward(dy, y, x, wf, *, k, slope):
     B, ci, L = x.shape
     dev = x.device
     dp = torch.empty((B, 1, L), device=dev)
-    part = torch.empty((ci * k * 64,), device=dev, dtype=torch.float64)
+    part = torch.empty((ci * k * 512,), device=dev, dtype=torch.float64)
     dx = torch.empty_like(x)
     dwf = torch.empty((k, ci, 1), device=dev)
     _hip.check(_hip.load().v2w_tail_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), wf.data_ptr(), dp.data_ptr(), part.data_ptr(),
