@@ -11,7 +11,7 @@ dy = torch.randn(B, 1, T * 320, device=dev)
 gs = {}
 for on in (True, False):
     g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train()
-    g.fuse_stage_backward = on
+    setattr(g, os.environ.get("V2W_AB_ATTR", "fuse_stage_backward"), on)
     gs[on] = (g, torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99)))
 for rep in range(3):
     for on in (True, False):
@@ -23,4 +23,4 @@ for rep in range(3):
             (g(*inp) * dy).sum().backward()
             opt.step()
         torch.cuda.synchronize()
-        print(f'fuse_stage_backward={on}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms/step')
+        print(f'{os.environ.get("V2W_AB_ATTR", "fuse_stage_backward")}={on}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms/step')
