@@ -265,9 +265,11 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                          if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
                     if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
         if rb1:
-            kname = 'wide_stage_bf16_kernel' + {256: '<1, 4, 8, 1, 2, 32, false, false, 0, false>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0, false>',
+            kname = 'wide_stage_bf16_kernel' + ({256: '<1, 4, 8, 1, 2, 32, false, false, 0, false>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0, false>',
                                                 64: '<2, 2, 1, 4, 2, 32, false, false, 0, false>', 32: '<1, 4, 1, 2, 2, 32, false, false, 0, false>',
-                                                16: '<1, 4, 1, 2, 2, 16, false, false, 0, false>'}[ls[0]['cout']]
+                                                16: None}[ls[0]['cout']] or '')
+            if ls[0]['cout'] == 16:                # 16 channels: one launch per branch of the weights-in-registers pair kernel (v2w_stage_bf16_n16.hip)
+                kname = 'n16_pair_kernel<4, K, D> (one launch per branch)' if ls[0]['L'] % 4 == 0 else 'wide_stage_bf16_kernel<1, 4, 1, 2, 2, 16, false, false, 0, false>'
         nbytes = sum(l['bytes'] for l in ls)
         if fused:                              # the intermediate is neither written nor re-read
             nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])

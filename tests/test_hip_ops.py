@@ -613,7 +613,8 @@ def test_resblock2_wide_stage_other_block_sets(dev, B, C, L, ks, d1, d2):
 @pytest.mark.parametrize('dil', [1, 3, 5])
 def test_resblock1_pairs_bf16(dev, B, C, L, dil):
     """resblock1_pairs_bf16 (v2w_stage_split_args::rb1): three independent ResBlock1 pairs - kernel sizes 3 / 7 / 11, first conv at dilation
-    `dil`, second at 1, each on its OWN input tensor - in one launch, then the summing form (the last problem adds the others' results and
+    `dil`, second at 1, each on its OWN input tensor - in one call (one launch on the resident-tile template; at 16 channels one launch per
+    branch of the weights-in-registers pair kernel, round 5), then the summing form (the last problem adds the others' results and
     divides): against fp64 math on the same bf16 operands (models.py:37-44: xt = c2(lrelu(c1(lrelu x))); x = xt + x)."""
     from wavthruvec_pytorch_amd import hipops
     g = torch.Generator().manual_seed(500 + C + L + dil)
@@ -629,7 +630,8 @@ def test_resblock1_pairs_bf16(dev, B, C, L, dil):
     def ref(x, j, affine):
         xa = (a[:, :, None] * x.float() + s_[:, :, None]) if affine else x.float()
         xact = F.leaky_relu(xa, 0.1).bfloat16().double()
-        xres = torch.where(xact > 0, xact, xact / 0.1)            # the kernel rebuilds the residual from the activated operand
+        # the resident-tile kernel rebuilds the residual from the activated operand; the 16-channel kernel keeps x itself (rounded once) beside it
+        xres = xa.bfloat16().double() if C == 16 else torch.where(xact > 0, xact, xact / 0.1)
         u = F.conv1d(xact, w1[j].bfloat16().double(), b1[j].double(), dilation=dil, padding=dil * (ks[j] - 1) // 2)
         uact = F.leaky_relu(u.float(), 0.1).bfloat16().double()
         return xres + F.conv1d(uact, w2[j].bfloat16().double(), b2[j].double(), padding=(ks[j] - 1) // 2)

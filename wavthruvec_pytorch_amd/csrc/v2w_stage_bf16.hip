@@ -441,6 +441,7 @@ V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
 
 int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out = nullptr);   // v2w_stage_bf16_wide.hip
 int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
+int v2w_resblock1_pairs_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
 
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out) {
@@ -448,8 +449,12 @@ int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, 
         if (a->io_bf16 != 3 || a->C < 32) return V2W_E_SHAPE;
         return v2w_resblock2_stage_bf16_wide(a, stream, up_tiles_out);
     }
-    if (a->rb1) {           // ResBlock1 pair mode: the resident-tile template's run-time form (bf16 tensors, C = 16 .. 256)
+    if (a->rb1) {           // ResBlock1 pair mode: 16 channels on the weights-in-registers kernel, else the resident-tile template's run-time form
         if (a->io_bf16 != 3) return V2W_E_SHAPE;
+        if (a->C == 16) {
+            const int rc = v2w_resblock1_pairs_bf16_n16(a, stream);
+            if (rc != V2W_E_SHAPE) return rc;
+        }
         return v2w_resblock2_stage_bf16_wide(a, stream);
     }
     if (a->C >= 64) return v2w_resblock2_stage_bf16_wide(a, stream);

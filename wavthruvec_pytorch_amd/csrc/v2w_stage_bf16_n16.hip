@@ -401,6 +401,281 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
     return v2w_launch_status();
 }
 
+
+// ---- ResBlock1 on 16 channels (models.py:37-44 with h.resblock == '1'; v2w_stage_split_args::rb1): ONE (dilated conv, conv) pair of one branch,
+//   out = ( x + conv_{K,1}(lrelu(u)) + b2 [ + add0 + add1 ] ) [ / out_div ],   u = conv_{K,D1}(lrelu(x)) + b1,   x = a * in + s,
+// with the machinery of the stage kernel above: v_mfma_f32_16x16x32_bf16 on two taps x 16 channels per k-step, the pair's 2 x ceil(K / 2)
+// weight operands in registers for the whole persistent kernel, conv loops of nothing but ds_read_b128 + MFMA.  (The resident-tile template's
+// run-time form served these pairs at 0.06 of the bf16 MFMA peak: 275 us per three-branch launch at B = 32 x 81 920 positions against the ~100 us
+// its 0.5 GB take.)  One launch per branch - K and D1 are template parameters; x tile rows = positions n0 - H2 - H1 - XOFF .., u tile rows = window
+// columns (position n0 - H2 + column), valid outputs = columns H2 .. H2 + nto.
+struct N16PairArgs {
+    const unsigned short* in; const float* in_a; const float* in_s;
+    const unsigned char* w1; const float* bias1;
+    const unsigned char* w2; const float* bias2;
+    unsigned short* out;
+    const unsigned short* add0; const unsigned short* add1;
+    int B, L, nto, ntl, ntiles;
+    float slope, out_div;
+};
+
+template <int WN, int K, int D1>
+__global__ void __launch_bounds__(64 * WN, 2)
+n16_pair_kernel(const N16PairArgs a) {
+    constexpr int H1 = D1 * (K - 1) / 2, H2 = (K - 1) / 2, XOFF = (4 - (H1 + H2) % 4) % 4;
+    constexpr int NTH = 64 * WN, W = 128 * WN, XR = (W + 2 * H1 + XOFF + 3) & ~3, RB = 32, NB = N16_NB;
+    constexpr int SRS = W + 12, SOFF = (4 - H2 % 4) % 4;                        // scratch row stride (floats); scratch column = window column + SOFF
+    constexpr unsigned XB = 0, TB = XR * RB, RT = (XR + W + 16) * RB;           // x tile, u tile (+ 16 rows of slack), r tile (x itself)
+    constexpr int NIT = 4 * (XR / 4), NPF = (NIT + NTH - 1) / NTH;
+    constexpr int NP = (K + 1) / 2;
+    static_assert(H2 <= 16 && 16 * SRS * 4 <= (2 * XR + W + 16) * RB, "conv2 may reach 16 rows past the u tile; the store scratch overlays the (dead) tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_n[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kg = lane >> 4;
+    const int L = __builtin_amdgcn_readfirstlane(a.L), nto = __builtin_amdgcn_readfirstlane(a.nto);
+    const float slope = a.slope;
+
+    u32x4 wa[2][NP];
+    {
+        const unsigned lo16 = (unsigned)(j + 32 * (kg & 1)) * 16u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned char* w = s ? a.w2 : a.w1;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int t = 2 * p + (kg >> 1);
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (t < K) v = *reinterpret_cast<const u32x4*>(w + (size_t)t * 2048 + lo16);
+                wa[s][p] = v;
+            }
+        }
+    }
+    float b1[4], b2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b1[r] = a.bias1 ? a.bias1[4 * kg + r] : 0.f;
+        b2[r] = a.bias2 ? a.bias2[4 * kg + r] : 0.f;
+    }
+    auto mfma = [&](f32x4 c, u32x4 av, u32x4 bv) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, av), __builtin_bit_cast(b8, bv), c, 0, 0, 0);
+    };
+    const int col0 = 128 * wave + j;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_n);
+    // (the conv loop of n16_stage_kernel: a ring of 8 operands in flight, every offset an immediate)
+    auto conv = [&](auto d_c, auto s_c, f32x4 (&acc)[NB], unsigned base, int r0) {
+        constexpr int DIL = decltype(d_c)::value, S = decltype(s_c)::value;
+        constexpr int N = NP * NB, RING = 8;
+        unsigned ab = lds0 + base + (unsigned)(r0 * RB + (kg & 1) * 16);
+        asm volatile("" : "+v"(ab));
+        const unsigned ab2 = ab + (unsigned)((kg >> 1) * DIL * RB);
+        u32x4 ring[RING];
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        n16_for(std::make_integer_sequence<int, RING>{}, [&ring, &ab, &ab2](auto n_c) {
+            constexpr int n = decltype(n_c)::value, p = n / NB, cb = n % NB;
+            if constexpr (2 * p + 1 >= K) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n]) : "v"(ab), "n"((2 * p * DIL + 16 * cb) * RB));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n]) : "v"(ab2), "n"((2 * p * DIL + 16 * cb) * RB));
+        });
+        n16_for(std::make_integer_sequence<int, N>{}, [&ring, &ab, &ab2, &acc, &wa, &mfma](auto n_c) {
+            constexpr int n = decltype(n_c)::value;
+            constexpr int left = (N - 1 - n) < (RING - 1) ? (N - 1 - n) : (RING - 1);
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[n % RING]) : "n"(left));
+            acc[n % NB] = mfma(acc[n % NB], wa[S][n / NB], ring[n % RING]);
+            if constexpr (n + RING < N) {
+                constexpr int m = n + RING, p = m / NB, cb = m % NB;
+                if constexpr (2 * p + 1 >= K) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(ab), "n"((2 * p * DIL + 16 * cb) * RB));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(ab2), "n"((2 * p * DIL + 16 * cb) * RB));
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    u32x2 pf[NPF][4];
+    float av[4], sv[4];
+    const int cq = tid & 3;
+    auto issue_x = [&](int tile) {
+        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * nto;
+        const int pos0 = n0 - H1 - H2 - XOFF;
+        const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * 16 * L * 2;
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTH, pq = idx >> 2;
+            const int pos = pos0 + 4 * pq;
+            const bool ok = idx < NIT && pos >= 0 && pos < L;
+            unsigned vo = (unsigned)(4 * cq * L + (ok ? pos : 0)) * 2u;
+            asm volatile("" : "+v"(vo));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[s][i] = *gptr<const u32x2>(inb + (size_t)i * L * 2 + vo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = a.in_a ? a.in_a[b * 16 + 4 * cq + i] : 1.f;
+            sv[i] = a.in_a ? a.in_s[b * 16 + 4 * cq + i] : 0.f;
+        }
+    };
+    auto commit_x = [&](int pos0) {
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) {
+            const int idx = tid + s * NTH, pq = idx >> 2;
+            if (idx >= NIT) continue;
+            const int pos = pos0 + 4 * pq;
+            const bool ok = pos >= 0 && pos < L;
+            unsigned char* dst = smem_n + XB + (4 * pq) * RB + cq * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y[4], v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xv = (e & 1) ? n16_hi(pf[s][i][e >> 1]) : n16_lo(pf[s][i][e >> 1]);
+                    y[i] = fmaf(av[i], xv, sv[i]);
+                    v[i] = fmaxf(y[i], y[i] * slope);
+                }
+                u32x2 w = {n16_pack2(v[0], v[1]), n16_pack2(v[2], v[3])};
+                u32x2 r = {n16_pack2(y[0], y[1]), n16_pack2(y[2], y[3])};
+                if (!ok) { w = u32x2{0u, 0u}; r = w; }
+                *reinterpret_cast<u32x2*>(dst + e * RB) = w;
+                *reinterpret_cast<u32x2*>(dst + e * RB + RT) = r;
+            }
+        }
+    };
+
+    issue_x(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int b = tile / a.ntl, n0 = (tile - b * a.ntl) * nto;
+        const bool edge = n0 - H2 < 0 || n0 - H2 + W > L;
+        n16_lds_barrier();                                                        // the previous tile's stores have read the scratch
+        commit_x(n0 - H1 - H2 - XOFF);
+        n16_lds_barrier();
+
+        f32x4 acc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{b1[0], b1[1], b1[2], b1[3]};
+        // conv_a: window column col <-> x row col + H1 + XOFF; tap t reads row col + XOFF + t * D1
+        conv(std::integral_constant<int, D1>{}, std::integral_constant<int, 0>{}, acc, XB, col0 + XOFF);
+        // u (0 outside the sequence: conv_b zero-pads lrelu(u)) -> the u tile as bf16 lrelu(u); no residual on the intermediate
+        {
+            int colv = col0;
+            asm volatile("" : "+v"(colv));
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                const int col = colv + 16 * cb;
+                f32x4 u = acc[cb];
+                if (edge) {
+                    const int pos = n0 - H2 + col;
+                    if (pos < 0 || pos >= L) u = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const f32x4 us = u * slope;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = fmaxf(u[r], us[r]);
+                *reinterpret_cast<u32x2*>(smem_n + TB + col * RB + 8 * kg) = u32x2{n16_pack2(u[0], u[1]), n16_pack2(u[2], u[3])};
+            }
+        }
+        n16_lds_barrier();
+        // conv_b (dilation 1) on the same window + the pair's residual x (the r tile) + b2
+        {
+            u32x2 rw[NB];
+            int colv = col0;
+            asm volatile("" : "+v"(colv));
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) rw[cb] = *reinterpret_cast<const u32x2*>(smem_n + RT + (colv + 16 * cb + H1 + XOFF) * RB + 8 * kg);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+                acc[cb] = f32x4{b2[0], b2[1], b2[2], b2[3]} + f32x4{n16_lo(rw[cb][0]), n16_hi(rw[cb][0]), n16_lo(rw[cb][1]), n16_hi(rw[cb][1])};
+        }
+        conv(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, acc, TB, col0 - H2);
+
+        // ---- the nto valid columns (window columns H2 .. H2 + nto) through the fp32 scratch [16][SRS] over the dead tiles, then 8-byte bf16 stores
+        n16_lds_barrier();
+        {
+            float* const scr = reinterpret_cast<float*>(smem_n);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                int col = col0;
+                asm volatile("" : "+v"(col));
+                col += 16 * cb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(4 * kg + r) * SRS + col + SOFF] = acc[cb][r];
+            }
+            n16_lds_barrier();
+            issue_x(min(tile + (int)gridDim.x, a.ntiles - 1));                    // the next tile's x: in flight under this tile's stores
+            const int nq = nto >> 2;
+            const unsigned magic = (unsigned)(((1ull << 32) + nq - 1) / nq);
+            const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f;
+            const size_t boff = (size_t)b * 16 * L * 2;
+            unsigned char* const obase = reinterpret_cast<unsigned char*>(a.out) + boff;
+            for (int idx = tid; idx < 16 * nq; idx += NTH) {
+                const int row = (int)__umulhi((unsigned)idx, magic), q = idx - row * nq;
+                const int pos = n0 + 4 * q;
+                if (pos >= L) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * SRS + H2 + SOFF + 4 * q);
+                const unsigned eo = (unsigned)(row * L + pos) * 2u;
+                if (a.add0) {                                                     // ((add0 + add1) + value): the reference's order over the branches
+                    const u32x2 p0 = *gptr<const u32x2>(reinterpret_cast<const unsigned char*>(a.add0) + boff + eo);
+                    f32x4 s = {n16_lo(p0[0]), n16_hi(p0[0]), n16_lo(p0[1]), n16_hi(p0[1])};
+                    if (a.add1) {
+                        const u32x2 p1 = *gptr<const u32x2>(reinterpret_cast<const unsigned char*>(a.add1) + boff + eo);
+                        s += f32x4{n16_lo(p1[0]), n16_hi(p1[0]), n16_lo(p1[1]), n16_hi(p1[1])};
+                    }
+                    v = s + v;
+                }
+                if (a.out_div != 0.f) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) v[x] = v2w_div_by(v[x], a.out_div, dinv);
+                }
+                *gptr<u32x2>(obase + eo) = u32x2{n16_pack2(v[0], v[1]), n16_pack2(v[2], v[3])};
+            }
+        }
+    }
+}
+
+template <int WN, int K, int D1>
+int launch_n16_pair(const v2w_stage_split_args* q, int pr, bool last, hipStream_t stream) {
+    constexpr int H1 = D1 * (K - 1) / 2, H2 = (K - 1) / 2, XOFF = (4 - (H1 + H2) % 4) % 4;
+    constexpr int NTH = 64 * WN, W = 128 * WN, XR = (W + 2 * H1 + XOFF + 3) & ~3;
+    N16PairArgs p{};
+    p.in = reinterpret_cast<const unsigned short*>(q->in_b[pr] ? q->in_b[pr] : q->in);
+    p.in_a = q->in_a; p.in_s = q->in_s;
+    p.w1 = static_cast<const unsigned char*>(q->wps1[pr]); p.bias1 = q->bias1[pr];
+    p.w2 = static_cast<const unsigned char*>(q->wps2[pr]); p.bias2 = q->bias2[pr];
+    p.out = reinterpret_cast<unsigned short*>(q->out_b[pr]);
+    if (last) { p.add0 = reinterpret_cast<const unsigned short*>(q->add0); p.add1 = reinterpret_cast<const unsigned short*>(q->add1); p.out_div = q->out_div; }
+    p.B = q->B; p.L = q->L; p.slope = q->slope;
+    p.nto = (W - 2 * H2) & ~3;
+    p.ntl = (q->L + p.nto - 1) / p.nto;
+    if ((long long)q->B * p.ntl > 0x7fffffffll) return V2W_E_SHAPE;
+    p.ntiles = q->B * p.ntl;
+    const size_t lds = (size_t)(XR + W + 16 + XR) * 32;
+    if (lds > 80 * 1024) return V2W_E_SHAPE;                                     // two workgroups per CU
+    if (v2w_dry(stream)) return 0;
+    const int slots = v2w_num_cus() * (8 / WN);
+    auto kern = n16_pair_kernel<WN, K, D1>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    return v2w_launch_status();
+}
+
+template <int WN>
+int launch_n16_pair_kd(const v2w_stage_split_args* q, int pr, bool last, hipStream_t stream) {
+    const int key = q->k[pr] * 10 + q->dil1[pr];
+    switch (key) {
+        case 31:  return launch_n16_pair<WN, 3, 1>(q, pr, last, stream);
+        case 33:  return launch_n16_pair<WN, 3, 3>(q, pr, last, stream);
+        case 35:  return launch_n16_pair<WN, 3, 5>(q, pr, last, stream);
+        case 71:  return launch_n16_pair<WN, 7, 1>(q, pr, last, stream);
+        case 73:  return launch_n16_pair<WN, 7, 3>(q, pr, last, stream);
+        case 75:  return launch_n16_pair<WN, 7, 5>(q, pr, last, stream);
+        case 111: return launch_n16_pair<WN, 11, 1>(q, pr, last, stream);
+        case 113: return launch_n16_pair<WN, 11, 3>(q, pr, last, stream);
+        case 115: return launch_n16_pair<WN, 11, 5>(q, pr, last, stream);
+        default:  return V2W_E_SHAPE;
+    }
+}
+
 }  // namespace
 
 #ifdef V2W_TIMELINE
@@ -421,4 +696,26 @@ int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stre
     if ((long long)16 * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;            // 32-bit offsets inside one batch item
     if (!(a->slope > 0.f && a->slope < 1.f)) return V2W_E_SHAPE;                // lrelu as max(v, slope v), undone as min(a, a / slope)
     return launch_n16<V2W_N16_WN>(a, stream);
+}
+
+// Called by v2w_resblock2_stage_bf16 (v2w_stage_bf16.hip) for the ResBlock1 pair mode (rb1) at C = 16: one launch per problem (branch).
+// V2W_E_SHAPE - nothing launched - unless EVERY problem has a kernel (k in {3, 7, 11}, first dilation in {1, 3, 5}, second 1, aligned bf16 tensors).
+int v2w_resblock1_pairs_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream) {
+    if (!a->rb1 || a->C != 16 || a->io_bf16 != 3 || !a->bf16 || a->nk < 1 || a->nk > 4) return V2W_E_SHAPE;
+    auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+    if (a->L % 4 != 0 || (long long)16 * a->L * 2 >= (1ll << 31) || !(a->slope > 0.f && a->slope < 1.f)) return V2W_E_SHAPE;
+    if (!al16(a->add0) || !al16(a->add1) || (a->add1 && !a->add0)) return V2W_E_SHAPE;
+    for (int p = 0; p < a->nk; ++p) {
+        const void* src = a->in_b[p] ? a->in_b[p] : static_cast<const void*>(a->in);
+        if (!al16(src) || !al16(a->out_b[p]) || a->dil2[p] != 1) return V2W_E_SHAPE;
+        if (!v2w_dry(stream) && (!src || !a->out_b[p] || !a->wps1[p] || !a->wps2[p])) return V2W_E_ARG;
+        const int rc = launch_n16_pair_kd<V2W_N16_WN>(a, p, false, V2W_DRY_STREAM);          // every problem first: all or nothing
+        if (rc != 0) return rc;
+    }
+    if (v2w_dry(stream)) return 0;
+    for (int p = 0; p < a->nk; ++p) {
+        const int rc = launch_n16_pair_kd<V2W_N16_WN>(a, p, p == a->nk - 1, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
