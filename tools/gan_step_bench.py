@@ -76,6 +76,10 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     stock = len(sys.argv) > 4 and sys.argv[4] == 'stock'
     freeze = 'frozen' in sys.argv[4:]      # discriminator parameters do not require grad during the G step (their grads are discarded anyway)
+    if 'pairs' in sys.argv[4:]:            # (y, y_hat) of the weight-normed discriminators as one batched call at any size ('auto': small batches only)
+        HD.BATCH_PAIRS = True
+    if 'nopairs' in sys.argv[4:]:
+        HD.BATCH_PAIRS = False
     f16x3 = 'f16x3' in sys.argv[4:]        # the dense five-tap 1024 -> 1024 discriminator convs (forward + input gradient) and the generator's
     #                                        forward / input-gradient convs as f16 hi + lo operands; every weight gradient exact
     dev = torch.device('cuda:0')
