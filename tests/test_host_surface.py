@@ -223,3 +223,50 @@ def test_bench_line_is_compact_and_ends_in_the_summary():
     for n in ('cfg2_f32', 'cfg3_bf16', 'cfg2_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync'):
         assert n in out['summary'], n
     assert len(line[-2048:].split('"summary"')) == 2       # the summary sits inside the last 2 KB
+
+
+def test_launch_plan_tape_patches_bound_pointers_and_keeps_order():
+    """schedule.Tape (the recorded launch plan of a forward, host logic only): a recorded call's pointer slots that held the address of a bound
+    tensor - a plain integer argument, a c_void_p field of a struct passed by reference, an element of a pointer array inside it - are rewritten
+    at every replay, everything else is left alone; calls go out in recorded order on the stream they were recorded on; a bound input nobody
+    reads is an error (the plan would silently ignore it)."""
+    import ctypes as C
+    from wavthruvec_pytorch_amd import schedule
+
+    class Args(C.Structure):
+        _fields_ = [('in_', C.c_void_p), ('w', C.c_void_p), ('outs', C.c_void_p * 3), ('n', C.c_int32)]
+
+    class FakeStream:
+        def __init__(self, h):
+            self.cuda_stream = h
+
+    calls = []
+
+    def fake(name):
+        def fn(*a):
+            calls.append((name,) + tuple(getattr(x, '_obj', x) for x in a))
+            return 0
+        return fn
+
+    X, W, Y, NZ = 0x1000, 0x2000, 0x3000, 0x4000
+    a1 = Args(); a1.in_, a1.w, a1.n = X, W, 7
+    a1.outs[0], a1.outs[1], a1.outs[2] = 0x5000, Y, 0x6000
+    a2 = Args(); a2.in_, a2.w, a2.n = NZ, W, 9
+    tape = schedule.Tape()
+    tape.steps.append(schedule.Step(schedule.K_CALL, fake('first'), [C.byref(a1)], schedule.MAIN, 'conv_pre', 'first'))
+    tape.steps.append(schedule.Step(schedule.K_CALL, fake('second'), [C.byref(a2), X], schedule.SIDE, None, 'second'))
+    tape.finalize({'x': X, 'nz': NZ, 'y': Y})
+    assert tape.launches == 2 and len(tape.patches['x']) == 2 and len(tape.patches['nz']) == 1 and len(tape.patches['y']) == 1
+    main, side = FakeStream(11), FakeStream(22)
+    tape.replay(main, side, {'x': 0xA000, 'nz': 0xB000, 'y': 0xC000})
+    assert [c[0] for c in calls] == ['first', 'second'] and calls[0][-1] == 11 and calls[1][-1] == 22
+    assert (a1.in_, a1.w, a1.n, a1.outs[0], a1.outs[1], a1.outs[2]) == (0xA000, W, 7, 0x5000, 0xC000, 0x6000)
+    assert (a2.in_, a2.w, a2.n) == (0xB000, W, 9) and calls[1][2] == 0xA000
+    tape.replay(main, side, {'x': 0xD000, 'nz': 0xE000, 'y': 0xF000})          # a second replay rebinds the same slots
+    assert (a1.in_, a1.outs[1], a2.in_) == (0xD000, 0xF000, 0xE000) and calls[3][2] == 0xD000
+    bad = schedule.Tape()
+    bad.steps.append(schedule.Step(schedule.K_CALL, fake('only'), [C.byref(a2)], schedule.MAIN, None, 'only'))
+    with pytest.raises(RuntimeError, match='no recorded call reads x'):
+        bad.finalize({'x': 0x7777, 'y': Y})
+    with pytest.raises(RuntimeError, match='share an address'):
+        schedule.Tape().finalize({'x': 0x1, 'nz': 0x1})
