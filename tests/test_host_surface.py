@@ -81,7 +81,7 @@ def _header_struct_fields(header, name):
 
 
 @pytest.mark.parametrize('cname,mirror', [('v2w_conv1d_args', 'Conv1dArgs'), ('v2w_convt1d_args', 'ConvT1dArgs'),
-                                          ('v2w_stage_split_args', 'StageSplitArgs')])
+                                          ('v2w_stage_split_args', 'StageSplitArgs'), ('v2w_stage_args', 'StageArgs')])
 def test_struct_layouts_match_header_field_order(cname, mirror):
     """The ctypes mirrors list the header's fields in the header's order (ABI v28 added splitk_ws / splitk_ws_bytes to both conv structs)."""
     header = open(os.path.join(ROOT, 'include', 'vec2wav_hip.h')).read()
@@ -270,3 +270,27 @@ def test_launch_plan_tape_patches_bound_pointers_and_keeps_order():
         bad.finalize({'x': 0x7777, 'y': Y})
     with pytest.raises(RuntimeError, match='share an address'):
         schedule.Tape().finalize({'x': 0x1, 'nz': 0x1})
+
+
+def test_round5_host_only_queries_answer_without_a_gpu():
+    """The shape queries added in round 5 are host-only (no stream, nothing dereferenced): the bf16 weight gradient's slab count and the row count
+    of the backward stage kernel's bias-gradient partials - which shapes they take and which they decline."""
+    lib = _hip.load()
+    # v2w_wgrad_bf16_slabs(B, c_in, c_out, Lq, k): C_in == C_out in {16, 32} or a multiple of 64, k odd <= 11, Lq % 8 == 0
+    for C_, L in ((16, 81920), (32, 40960), (64, 20480), (128, 5120), (256, 1280)):
+        for k in (3, 7, 11):
+            assert lib.v2w_wgrad_bf16_slabs(32, C_, C_, L, k) > 0, (C_, k)
+    assert lib.v2w_wgrad_bf16_slabs(32, 48, 48, 1024, 3) == 0          # 48 channels
+    assert lib.v2w_wgrad_bf16_slabs(32, 64, 32, 1024, 3) == 0          # C_in != C_out
+    assert lib.v2w_wgrad_bf16_slabs(32, 32, 32, 1028, 3) == 0          # rows not 16-byte aligned in bf16
+    assert lib.v2w_wgrad_bf16_slabs(32, 32, 32, 1024, 4) == 0 and lib.v2w_wgrad_bf16_slabs(32, 32, 32, 1024, 13) == 0
+    assert lib.v2w_wgrad_bf16_slabs(2, 16, 16, 64, 3) <= 2             # never more splits than staged items
+    # v2w_resblock2_stage_bwd_rows: one row per (tile, wave) of the launcher's own geometry (conv2's dilations first)
+    a = _hip.StageArgs()
+    a.nk, a.B, a.C, a.L = 3, 32, 32, 40960
+    for j, k in enumerate((3, 7, 11)):
+        a.k[j], a.dil1[j], a.dil2[j] = k, 3, 1
+    nto = (256 - 2 * 5) & ~3
+    assert lib.v2w_resblock2_stage_bwd_rows(ctypes.byref(a)) == 32 * ((40960 + nto - 1) // nto) * 4
+    a.C = 64
+    assert lib.v2w_resblock2_stage_bwd_rows(ctypes.byref(a)) == 0      # wide stages have no one-kernel backward
