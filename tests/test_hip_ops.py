@@ -609,7 +609,8 @@ def test_resblock2_wide_stage_other_block_sets(dev, B, C, L, ks, d1, d2):
     assert err.mean().item() <= 4e-3
 
 
-@pytest.mark.parametrize('B,C,L', [(2, 128, 512), (3, 64, 1000), (2, 256, 260), (2, 32, 2000), (3, 16, 4100), (1, 32, 24), (1, 128, 8)])
+@pytest.mark.parametrize('B,C,L', [(2, 128, 512), (3, 64, 1000), (2, 256, 260), (2, 32, 2000), (3, 16, 4100), (1, 32, 24), (1, 128, 8),
+                                   (1, 16, 24), (2, 16, 504), (2, 16, 1012)])       # (16 channels: below one window, one window exactly, a seam)
 @pytest.mark.parametrize('dil', [1, 3, 5])
 def test_resblock1_pairs_bf16(dev, B, C, L, dil):
     """resblock1_pairs_bf16 (v2w_stage_split_args::rb1): three independent ResBlock1 pairs - kernel sizes 3 / 7 / 11, first conv at dilation
@@ -1381,6 +1382,8 @@ def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
 @pytest.mark.gpu
 @pytest.mark.parametrize('stored', ['f32', 'bf16'])
 @pytest.mark.parametrize('B,C,L,k,dil', [(2, 16, 1024, 3, 1), (3, 16, 520, 7, 3), (2, 16, 2048, 11, 3), (2, 32, 1000, 3, 3), (3, 32, 648, 7, 1),
+                                         (1, 16, 8, 3, 1), (1, 32, 16, 11, 3), (1, 64, 136, 7, 1), (5, 128, 8, 3, 1),      # below one staged item, one item + 8, B > splits
+
                                          (2, 32, 1024, 11, 3), (2, 64, 512, 3, 1), (2, 64, 328, 7, 3), (1, 64, 640, 11, 1), (2, 128, 264, 11, 3),
                                          (1, 256, 136, 7, 5), (2, 64, 512, 5, 1), (2, 32, 512, 9, 1), (2, 64, 256, 9, 2)])
 def test_wgrad_bf16_matches_the_products_of_rounded_operands(dev, B, C, L, k, dil, stored):
