@@ -165,7 +165,8 @@ def test_conv1d_split_f16(dev, B, cin, cout, L, k, dil):
     assert e_split <= 2 * e_f32 + 1e-6, f'split max err {e_split} vs f32 kernel {e_f32}'
 
 
-@pytest.mark.parametrize('B,cin,cout,L,k,dil', [SPLIT_CASES[0], SPLIT_CASES[2], SPLIT_CASES[5], SPLIT_CASES[6]])
+@pytest.mark.parametrize('B,cin,cout,L,k,dil', [SPLIT_CASES[0], SPLIT_CASES[2], SPLIT_CASES[5], SPLIT_CASES[6],
+                                                (2, 32, 32, 2000, 11, 3), (3, 32, 32, 520, 3, 1), (1, 64, 32, 260, 7, 1)])      # 32 output channels (round 5)
 def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     """V2W_ALGO_BF16 (BASELINE configs[2]: bf16 compute / fp32 accumulate) == an fp64 convolution of the bf16-rounded
     operands to fp32-accumulation accuracy; the rounding itself is the configuration's stated precision."""

@@ -144,7 +144,7 @@ def generator_backward(gen, sv, dy, need_dx=False):
             wpd = sv.get('wpd', {})
             # the generator's bf16 arithmetic (precision = 'bf16': the reference under torch.autocast): the wide stages' gradient convs on the bf16
             # kernel the forward used - transposed, tap-reversed fragments packed here - the narrow stages' on the exact fp32 tile kernel
-            use_bf = gen.precision == 'bf16' and C >= gen.split_min_channels and hipops.split_supported(C, C) \
+            use_bf = gen.precision == 'bf16' and ((C >= gen.split_min_channels and hipops.split_supported(C, C)) or (C == 32 and Lo % 4 == 0)) \
                 and all(rb.kernel_size >= 3 and (rb.kernel_size & 1) for rb in rbs)
 
             def wsel(nm):

@@ -924,7 +924,8 @@ V2W_TL_SETTER(v2w_timeline_set_bf16)
 // Called by v2w_conv1d_split for V2W_ALGO_BF16.  V2W_E_SHAPE: the caller falls back to the split kernel's bf16 form.
 int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t* cfg) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
-    if (a->C_in % V2W_BF_CK != 0 || a->C_out % 64 != 0 || a->k < 1) return V2W_E_SHAPE;
+    const bool c32 = a->C_out == 32;            // 32 output channels (the narrow stage of a generator trained in the bf16 arithmetic: input gradients on fp32 tensors)
+    if (a->C_in % V2W_BF_CK != 0 || (a->C_out % 64 != 0 && !c32) || a->k < 1) return V2W_E_SHAPE;
     TileArgs ps[V2W_MAX_MULTI];
     long tiles = 0;
     for (int i = 0; i < n; ++i) {
@@ -944,6 +945,11 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t
         p.io_bf16 = q->io_bf16;
         ps[i] = p;
         tiles += (long)p.B * ((p.L + 255) / 256) * (p.Cout / 64);
+    }
+    if (c32) {                           // one 32-row block x 256 positions per workgroup, aligned fp32 tensors only
+        for (int i = 0; i < n; ++i)
+            if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0 || a[i].io_bf16 != 0) return V2W_E_SHAPE;
+        return launch_bf16<1, 2, 1, 4>(ps, n, stream, cfg);
     }
     for (int i = 0; i < n; ++i)          // unaligned input or L % 4 != 0: element-wise staging, one small-tile instantiation serves every shape
         if (a[i].L % 4 != 0 || (reinterpret_cast<uintptr_t>(a[i].in) & 15) != 0) return launch_bf16<1, 2, 2, 2, V2W_BF_CK, false>(ps, n, stream, cfg);

@@ -748,10 +748,10 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t
 // Called by v2w_api.hip for algo == V2W_ALGO_SPLIT (bf = false) and V2W_ALGO_BF16 (bf = true).  n problems sharing B, C_in, C_out, L in one launch.
 int v2w_conv1d_split(const v2w_conv1d_args* a, int n, hipStream_t stream, bool bf) {
     if (n < 1 || n > V2W_MAX_MULTI) return V2W_E_ARG;
-    if (!v2w_split_supported(a->C_in, a->C_out, 1)) return V2W_E_SHAPE;
+    if (!v2w_split_supported(a->C_in, a->C_out, 1) && !(bf && a->C_out == 32 && a->C_in % 32 == 0)) return V2W_E_SHAPE;
     if (bf) {      // bf16 operands: the chunk-per-barrier kernel of v2w_conv_bf16.hip; shapes it does not take fall through to this file's
         const int rc = v2w_conv1d_bf16(a, n, stream, nullptr);
-        if (rc != V2W_E_SHAPE) return rc;
+        if (rc != V2W_E_SHAPE || a->C_out % 64 != 0) return rc;             // (32 output channels: the bf16 kernel or nothing)
         for (int i = 0; i < n; ++i) if (a[i].io_bf16) return V2W_E_SHAPE;      // this file's kernels read and write fp32 only
     }
     TileArgs ps[V2W_MAX_MULTI];

@@ -146,6 +146,7 @@ class ForwardPlanner:
         self.S.fork()
         self.slab = g._slab(self.dev)
         self.y = None
+        self.wps32 = {}
         self.up_done = None        # rows of bn.part{i} when the kernel of stage i - 1 already ran ups[i] (fuse_up)
 
     def buf(self, name, shape, dtype=torch.float32):
@@ -206,6 +207,8 @@ class ForwardPlanner:
     def ck(self, nm, io=3):
         """Kernel choice of one Conv1d layer: bf16 / split-f16 fragments when prepared, else the f32 MFMA stream."""
         g = self.g
+        if nm in self.wps32:
+            return dict(algo=hipops.ALGO_BF16, wps=self.wps32[nm])
         if nm in self.wps and nm in g._split_wide:
             if self.st:       # bf16 storage: io bit 0 = the input tensor is bf16, bit 1 = out / res / addends are bf16
                 return dict(algo=hipops.ALGO_BF16, wps=self.wps[nm], io_bf16=io)
@@ -303,6 +306,14 @@ class ForwardPlanner:
         g, nk = self.g, self.nk
         self.rbs = [g.resblocks[i * nk + j] for j in range(nk)]
         self.names = [f'resblocks.{i * nk + j}' for j in range(nk)]
+        # a back-propagated forward in the bf16 arithmetic (fp32 tensors): the 32-channel stage's convs layer by layer on the bf16 kernel too
+        # (32 x 256 tiles; fragments packed here from the folded weights - the arena holds this stage's in the fused kernel's unit order)
+        self.wps32 = {}
+        if (self.save is not None and g.precision == 'bf16' and not self.st and self.C == 32 and self.Lo % 4 == 0 and self.algo == hipops.ALGO_AUTO
+                and all(isinstance(rb, ResBlock2) and rb.kernel_size >= 3 and rb.kernel_size % 2 == 1 for rb in self.rbs)):
+            for nm in self.names:
+                for c in (0, 1):
+                    self.wps32[f'{nm}.convs.{c}'] = hipops.pack_split(self.wf[f'{nm}.convs.{c}'], bf16=True)
         if not (self.algo != hipops.ALGO_DIRECT and nk <= 3):
             return self.residual_serial(i)
         B, C, Lo = self.B, self.C, self.Lo
