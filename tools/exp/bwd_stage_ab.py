@@ -10,7 +10,7 @@ inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
 dy = torch.randn(B, 1, T * 320, device=dev)
 gs = {}
 for on in (True, False):
-    g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train()
+    g = Generator(h); g.load_state_dict(synthetic.make_state_dict(h, seed=0)); g = g.to(dev).train(); g.precision = os.environ.get('V2W_AB_PREC', 'f32')
     setattr(g, os.environ.get("V2W_AB_ATTR", "fuse_stage_backward"), on)
     gs[on] = (g, torch.optim.AdamW(g.parameters(), 2e-4, betas=(0.8, 0.99)))
 for rep in range(3):
