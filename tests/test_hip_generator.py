@@ -259,10 +259,58 @@ def test_generator_launch_plan_replays_the_planned_forward(dev, training, precis
             for _ in range(2):
                 assert torch.equal(ga(*inputs[0]), gb(*inputs[0]))
             keys = [k for k in ga._tapes if k[0] == tuple(inputs[0][0].shape)]
-            assert {k[-1] for k in keys} == {'folded', 'refold'}, [k[-1] for k in keys]
+            # 'ws': the first forward (weights and sigma stale), 'w': the forwards behind the conv updates, 'folded': everything cached
+            assert {k[-1] for k in keys} >= {'folded', 'w'}, [k[-1] for k in keys]
             folded = [ga._tapes[k] for k in keys if k[-1] == 'folded'][0]
-            refold = [ga._tapes[k] for k in keys if k[-1] == 'refold'][0]
+            refold = [ga._tapes[k] for k in keys if k[-1] == 'w'][0]
             assert folded.launches < refold.launches
+
+
+def test_launch_plan_key_separates_weight_folds_from_sigma(dev):
+    """what is stale when a plan is recorded is part of its key, separately for the conv weight folds ('w') and for sigma of the
+    spectral norm ('s').  A train-mode no-grad forward leaves the folds cached and sigma_ws holding its own values: the next eval forward
+    records a plan with cond_sigma and NO weight fold - that plan must not serve the eval forward behind an in-place conv update (it would
+    run on the old folded weights, silently), nor may a weights-only plan serve a forward whose sigma is stale."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=5)
+    O.calibrate_running_stats(sd, h, *synthetic.make_inputs(h, 2, 16, seed=1))
+    ga, gb = build_generator(h, sd, dev, training=False), build_generator(h, sd, dev, training=False)
+    for g in (ga, gb):
+        g.always_refold = False
+    gb.use_launch_plan = False
+    inp = to_dev(synthetic.make_inputs(h, 2, 16, seed=2), dev)
+
+    def both(check=True):
+        ya, yb = ga(*inp), gb(*inp)
+        if check:
+            assert torch.equal(ya, yb), (ya - yb).abs().max().item()
+
+    with torch.no_grad():
+        both()                                                   # eval, everything stale: 'ws'
+        for g in (ga, gb):
+            g.train()
+        both(); both()                                           # train mode: sigma_ws takes the power iteration's values, the folds stay cached
+        for g in (ga, gb):
+            g.eval()
+        both()                                                   # eval, only sigma stale: recorded under 's' (no weight fold on this tape)
+        tags = {k[-1] for k in ga._tapes if k[3] is False}
+        assert 's' in tags, tags
+        for g in (ga, gb):
+            g.conv_pre.weight_g.mul_(1.25)
+            g.resblocks[7].convs[1].weight_v.add_(0.01)
+        both()                                                   # eval, only the weights stale: must fold - 'w', not the 's' tape
+        both()
+        for g in (ga, gb):
+            g.train()
+        both()
+        for g in (ga, gb):
+            g.eval()
+            g.ups[1].weight_g.mul_(0.9)
+            g.cbns[2].layer.weight_orig.mul_(1.05)
+        both()                                                   # both stale again
+        both()
+        tags = {k[-1] for k in ga._tapes if k[3] is False}
+        assert tags >= {'ws', 'w', 's', 'folded'}, tags
 
 
 def test_backward_is_refused_after_a_refold_from_changed_weights(dev):

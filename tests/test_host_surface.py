@@ -294,3 +294,37 @@ def test_round5_host_only_queries_answer_without_a_gpu():
     assert lib.v2w_resblock2_stage_bwd_rows(ctypes.byref(a)) == 32 * ((40960 + nto - 1) // nto) * 4
     a.C = 64
     assert lib.v2w_resblock2_stage_bwd_rows(ctypes.byref(a)) == 0      # wide stages have no one-kernel backward
+
+
+def test_generator_copies_and_pickles_without_its_launch_plans():
+    """Generator._tapes holds ctypes function pointers, byref objects and pointer-bearing structs (schedule.Tape); workspaces and
+    fold caches hold device tensors and descriptor tables of THIS module.  copy.deepcopy / pickle (the EMA or snapshot pattern) must not
+    raise on them and must not hand them to the copy - which would replay into the original's buffers."""
+    import copy
+    import ctypes
+    import pickle
+    from wavthruvec_pytorch_amd import Generator, synthetic
+
+    h = synthetic.make_hparams(num_wv_feat=768)
+    g = Generator(h)
+    g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+
+    class Args(ctypes.Structure):
+        _fields_ = [('p', ctypes.c_void_p), ('n', ctypes.c_int)]
+
+    arg = Args(12345, 3)
+    fake_tape = dict(fn=ctypes.CFUNCTYPE(ctypes.c_int)(lambda: 0), args=(ctypes.byref(arg), arg, ctypes.pointer(arg)))
+    with pytest.raises((ValueError, TypeError)):
+        copy.deepcopy(fake_tape)                                 # what a tape is made of does not copy
+    g._tapes[('key',)] = fake_tape
+    g._ws['act.pre'] = torch.zeros(4)
+    g._fold_key.update(state=('x',), plan=fake_tape, gen=3)
+    g._ws_epoch = 7
+    g.precision = 'bf16'
+    for clone in (copy.deepcopy(g), pickle.loads(pickle.dumps(g))):
+        assert clone._tapes == {} and clone._ws == {} and clone._fold_key == {} and clone._slabs == {} and clone._ws_epoch == 0
+        assert clone.precision == 'bf16' and clone.use_launch_plan
+        for (ka, va), (kb, vb) in zip(g.state_dict().items(), clone.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb)
+        assert clone.conv_pre.weight_v.data_ptr() != g.conv_pre.weight_v.data_ptr()
+    assert g._tapes and g._ws and g._ws_epoch == 7               # the original keeps its own

@@ -228,6 +228,14 @@ class Generator(nn.Module):
         self._ws_epoch = 0                    # bumped whenever a workspace / weight buffer is (re)allocated: recorded tapes point into them
 
     # -------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save of the module (the EMA or snapshot pattern): parameters, buffers and switches travel; recorded
+        launch plans (ctypes structs and function pointers into THIS module's buffers), workspaces, folded weights, split-over-C_in slabs
+        and the profile list do not - the copy plans, allocates and folds for itself at its first forward."""
+        st = self.__dict__.copy()
+        st.update(_tapes={}, _ws={}, _slabs={}, _wts={}, _fold_key={}, _profile=None, _ws_epoch=0)
+        return st
+
     def enable_sync_batchnorm(self, group=None, single_rank_collective=None):
         """Data-parallel CondBN: all-reduce the per-stage batch statistics over `group` (RCCL on GPUs).  A one-rank group exchanges
         nothing unless `single_rank_collective=True` (bench.py --force-pg and the -m gpu tests: the RCCL code path on a one-GPU box)."""
@@ -592,17 +600,21 @@ class Generator(nn.Module):
         main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
         if save is not None or not self.use_launch_plan or self.stat_sync is not None:
             return ForwardPlanner(self, x, spk, nz, save, DirectStreams(main, side)).run()
-        key, refold_vers = self._tape_key(x)
+        key, refold = self._tape_key(x)
         tape = self._tapes.get(key)
         if tape is not None:
             y = torch.empty(tape.out[0], device=dev, dtype=tape.out[1])
             tape.replay(main, side, dict(x=x.data_ptr(), spk=spk.data_ptr(), nz=nz.data_ptr(), y=y.data_ptr()), self._profile)
-            if refold_vers is not None:                 # the replay folded the weights as they are now: what the fold cache must say
-                self._fold_key['gen'] = self._fold_key.get('gen', 0) + 1
-                if refold_vers:
-                    self._fold_key.update(vers=refold_vers, state=(refold_vers,) + tape.fold_state_tail)
-                    if not self.training:
-                        self._fold_key['sigma'] = self._sigma_key(dev)
+            if refold is not None:                      # the replay folded what was stale: what the fold cache must say now
+                wvers, sigma = refold
+                if wvers is not None:                   # it held the weight folds
+                    self._fold_key['gen'] = self._fold_key.get('gen', 0) + 1
+                    if wvers:
+                        self._fold_key.update(vers=wvers, state=(wvers,) + tape.fold_state_tail)
+                if sigma:                               # ... cond_sigma (eval mode)
+                    self._fold_key['sigma'] = self._sigma_key(dev)
+            if self.training:
+                self._fold_key.pop('sigma', None)       # (sigma_ws now holds this forward's own power-iteration values, as the planned forward notes)
             return y
         if self._profile is not None:                   # (a profiled forward of a configuration without a plan yet: planned, timed, not recorded)
             return ForwardPlanner(self, x, spk, nz, None, DirectStreams(main, side)).run()
@@ -629,16 +641,20 @@ class Generator(nn.Module):
         return (tuple((q.data_ptr(), q._version) for q in sn_p), str(dev))
 
     def _tape_key(self, x):
-        """(key of the launch plan this forward needs; None when that plan contains no weight fold, else the parameter versions the fold
-        cache holds after it ran - () in train mode with always_refold, where the cache is not consulted)."""
+        """(key of the launch plan this forward needs, what that plan refreshes).  A recorded tape holds exactly the launches that were due
+        when it was recorded, so the two things that can be stale are SEPARATE parts of the key: 'w' - the weight folds (a conv parameter
+        changed), 's' - sigma of the spectral norm (eval mode: a cbns parameter changed, or a train-mode forward left its own values in
+        sigma_ws).  Second value: None when the plan refreshes nothing, else (parameter versions the fold cache holds after the folds ran |
+        None when the plan has no weight fold - () in train mode with always_refold, where the cache is not consulted -, sigma refreshed)."""
         base = self._plan_key(x)
         if self.training and self.always_refold:
-            return base + ('refold',), ()
+            return base + ('refold',), ((), False)
         vers = self._param_versions()
-        folded = self._fold_key.get('vers') == vers and self._fold_key.get('state') is not None
-        if not self.training:
-            folded = folded and self._fold_key.get('sigma') == self._sigma_key(x.device)
-        return base + ('folded' if folded else 'refold',), (None if folded else vers)
+        wstale = not (self._fold_key.get('vers') == vers and self._fold_key.get('state') is not None)
+        sstale = (not self.training) and self._fold_key.get('sigma') != self._sigma_key(x.device)
+        if not (wstale or sstale):
+            return base + ('folded',), None
+        return base + (('w' if wstale else '') + ('s' if sstale else ''),), (vers if wstale else None, sstale)
 
     def _param_versions(self):
         vers = []
