@@ -196,30 +196,16 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                 for tag, e0, e1 in g._profile:
                     (sync_t if tag.startswith('stat_sync.') else per.setdefault(tag, [])).append(e0.elapsed_time(e1) * 1e-3)
         g._profile = None
+    # which kernel(s) ran each tagged launch: asked of the LIBRARY (v2w_name_sink, ABI v33: every launching entry point reports the kernels it
+    # selects, as rocprofv3 prints them) - this file holds no kernel name and no tile table.  One more forward, on every rank (a data-parallel
+    # forward contains the statistics all-reduce).
+    tag_kernels = g.profile_kernel_names(*inp)
     if not record:
         return None
     bf16_run = precision == 'bf16'
     act_bytes = 2 if (bf16_run and g.bf16_storage) else 4      # bytes of an activation element between layers in this mode
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16_run else PEAK_FP32_MFMA_TFLOPS
     layers = {l['name']: l for l in workmodel.conv_layers(h, B, T, act_bytes)}
-
-    def kernel_of(l, nprob=1):
-        if l['name'] == 'conv_post':
-            if bf16_run and act_bytes == 2 and l['cin'] in (8, 16) and l['k'] <= 9 and l['L'] % 8 == 0 and l['L'] >= 8:   # (the kernel's own condition)
-                return 'conv_post_tanh_mfma_kernel<%d>' % l['cin']            # v2w_conv_post_bf16.hip
-            return 'conv_post_tanh_vec4_kernel'
-        direct = 'conv1d_direct_kernel' if l['kind'] == 'conv' else 'convt1d_direct_kernel'
-        if algo == 'direct':
-            return direct
-        if bf16_run and (l['kind'] == 'conv' or act_bytes == 2) and l['cin'] % 32 == 0 and (l['cout'] % 64 == 0 or l['kind'] == 'convt'):
-            name = hipops.conv_bf16_config(B, nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1), io_bf16=3 if act_bytes == 2 and l['name'] != 'conv_pre' else (2 if act_bytes == 2 else 0))
-            if name:
-                return name
-        if precision != 'f32' and l['kind'] == 'conv' and l['cout'] >= g.split_min_channels and l['cout'] % 64 == 0:
-            return 'conv_split_kernel (%s)' % precision
-        # a merged launch of nprob branches picks its tile shape from the summed tile count (= nprob x the batch)
-        return hipops.conv_tile_config(B * nprob, l['cin'], l['cout'], l['L'], l['k'], l.get('d', 1), l.get('u', 1)) or direct
-
     launches = {}      # tag -> dict(kernel, flops, bytes, t)
     for tag, ts in per.items():
         names, fused = [], False
@@ -237,39 +223,10 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
             tag_names = tag.split(':', 1)[1]
             names = tag_names.split('+')
             ls = [layers[n] for n in names]
-        kname = kernel_of(ls[0], len(tag.split('+')))
-        if bconv:
-            kname = 'conv_bf16_res_kernel<%s, %d>' % ('2, 4, 2, 2' if ls[0]['cout'] % 128 == 0 else '1, 4, 2, 2', int(tag[5]))
-        rb1 = tag.startswith('rb1:')              # ResBlock1 pairs on bf16 tensors: the run-time form of the resident-tile kernel, one launch per pair position
-        if fused:
-            kname = ('resblock2_stage_kernel' if staged else 'resblock_pair_kernel') + \
-                    ('<32, 2, 4' if ls[0]['cout'] == 32 else '<16, 4, 4') + \
-                    ((', true>' if names[-1] == 'conv_post' else ', false>') if staged else '>')
-            if staged and precision != 'f32':
-                # launch_wide configurations (v2w_stage_bf16_wide.hip; the trailing 'false, true': fragments through registers, the generator's
-                # own (k, dilation) set at compile time); C = 16 runs there only with the fused tail (fuse_post)
-                upf = 0                                      # the next stage's upsampler fused behind the stage (Generator.fuse_up): its stride
-                if names[-1].startswith('ups.'):
-                    upf = layers[names[-1]]['u']
-                # (the last argument: the half-t1-tile form - 192-position windows - the 256-channel stage runs with a stride-4 upsampler behind it)
-                wide = {128: '<2, 3, 2, 4, 2, 32, false, true, 4, true>' if upf == 4 else f'<1, 4, 4, 2, 2, 32, false, true, {upf}, false>', 64: f'<2, 2, 1, 4, 2, 32, false, true, {upf}, false>',
-                        256: '<2, 3, 4, 2, 2, 32, false, true, 4, true>' if upf == 4 else f'<1, 4, 8, 1, 2, 32, false, true, {upf}, false>',
-                        32: f'<1, 4, 1, 2, 2, 32, false, true, {upf}, false>'}
-                tail7 = names[-1] == 'conv_post' and layers['conv_post']['k'] == 7
-                if names[-1] == 'conv_post' and not tail7:
-                    wide[16] = '<1, 4, 1, 2, 2, 16, false, false, 0, false>'
-                if ls[0]['cout'] == 16 and 16 not in wide and ls[0]['L'] % 4 == 0:
-                    wide[16] = None                          # the reference's block set on 16 channels: v2w_stage_bf16_n16.hip (+ the 7-tap tail)
-                kname = ((('n16_stage_kernel<4, true>' if tail7 else 'n16_stage_kernel<4, false>') if wide[ls[0]['cout']] is None
-                          else 'wide_stage_bf16_kernel' + wide[ls[0]['cout']])
-                         if ls[0]['cout'] in wide else ('stage_bf16_kernel<%d' % ls[0]['cout'])) \
-                    if bf16_run else 'stage_split_kernel<%d, 2, 4, false>' % (ls[0]['cout'] // 16)
-        if rb1:
-            kname = 'wide_stage_bf16_kernel' + ({256: '<1, 4, 8, 1, 2, 32, false, false, 0, false>', 128: '<1, 4, 4, 2, 2, 32, false, false, 0, false>',
-                                                64: '<2, 2, 1, 4, 2, 32, false, false, 0, false>', 32: '<1, 4, 1, 2, 2, 32, false, false, 0, false>',
-                                                16: None}[ls[0]['cout']] or '')
-            if ls[0]['cout'] == 16:                # 16 channels: one launch per branch of the weights-in-registers pair kernel (v2w_stage_bf16_n16.hip)
-                kname = 'n16_pair_kernel<4, K, D> (one launch per branch)' if ls[0]['L'] % 4 == 0 else 'wide_stage_bf16_kernel<1, 4, 1, 2, 2, 16, false, false, 0, false>'
+        ran = list(dict.fromkeys(tag_kernels.get(tag, [])))      # distinct kernels behind this tag, in launch order
+        if not ran:
+            raise RuntimeError(f'bench: the library reported no kernel for the launch tagged {tag!r}')
+        kname = ran[0] if len(ran) == 1 else ' + '.join(ran)
         nbytes = sum(l['bytes'] for l in ls)
         if fused:                              # the intermediate is neither written nor re-read
             nbytes -= sum(2 * B * l['cout'] * l['L'] * act_bytes for l in ls[::2])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 32
+#define V2W_ABI_VERSION 33
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -47,6 +47,18 @@ extern "C" {
 
 int         v2w_abi_version(void);
 const char* v2w_build_arch(void);       /* "gfx950" */
+
+/* ---- Which kernels would this call launch?  (ABI v33; host-only.)  Every launching entry point - the ones whose last argument is the stream -
+ * accepts a NAME SINK in place of the stream: the call runs every shape check and every kernel selection it would make, launches nothing, sets
+ * no attribute, dereferences no tensor pointer, and appends the demangled name of each kernel it would have launched, one per line and in launch
+ * order, to the caller's buffer (exactly the string `rocprofv3 --kernel-trace` prints for that kernel: "void (anonymous namespace)::
+ * wide_stage_bf16_kernel<1, 4, 1, 2, 2, 32, false, true, 2, false>((anonymous namespace)::WideArgs)").  The return value is the one the real call
+ * would give up to the launch (0, or V2W_E_*).  bench.py labels its per-kernel rooflines and looks up the counter profiles with these names
+ * instead of a table of template arguments kept by hand.  The sink is the caller's: { V2W_NAME_SINK_MAGIC, buf, cap, 0 }; `len` counts
+ * the bytes written (names that do not fit are dropped, `len` stays below cap, the buffer is always NUL-terminated). */
+typedef struct { uint64_t magic; char* buf; int32_t cap; int32_t len; } v2w_name_sink;
+#define V2W_NAME_SINK_MAGIC 0x5632574e414d4531ull
+#define V2W_NAME_SINK_STREAM(sink) ((void*)((uintptr_t)(sink) | (uintptr_t)1))   /* pass as `stream`: real stream handles are aligned pointers */
 
 /* ---- K0: weight-norm fold (torch.nn.utils.weight_norm pre-forward hook, dim=0; triggered by
  * models.py:18-33,58-61,83,90-92,100).  w = g * v / ||v||, norm over all dims but 0.

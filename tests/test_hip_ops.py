@@ -669,8 +669,9 @@ def test_resblock1_pairs_bf16(dev, B, C, L, dil):
 @pytest.mark.parametrize('B,L', [(2, 1000), (3, 4100), (1, 24), (2, 216), (2, 220), (2, 224), (2, 468), (2, 472), (2, 476), (1, 948)])
 def test_resblock2_stage16_with_the_fused_tail(dev, B, L, kp):
     """The last (C = 16) stage with leaky_relu(0.01) -> conv_post -> tanh (models.py:143-145) inside the same kernel: the stage's output is
-    not written, the fp32 audio is - against fp64 math on the same bf16 operands.  kp = 7 (the reference's conv_post): the weights-in-
-    registers kernel (v2w_stage_bf16_n16.hip, tiles advance by 472 outputs); kp = 9: the resident-tile template (220 outputs per tile)."""
+    not written, the fp32 audio is - against fp64 math on the same bf16 operands.  kp = 7 (the reference's conv_post): the streaming kernel
+    (v2w_stage_bf16_n16s.hip: one wave per workgroup walks runs of the sequence, run seams at multiples of 64 positions); kp = 9: the
+    resident-tile template (220 outputs per tile)."""
     from wavthruvec_pytorch_amd import hipops
     C = 16
     g = torch.Generator().manual_seed(300 + L)
@@ -695,7 +696,12 @@ def test_resblock2_stage16_with_the_fused_tail(dev, B, L, kp):
     assert ok, 'the fused tail was declined'
     assert torch.isfinite(y).all()
     err = (y.cpu().double() - y_want).abs()
-    assert err.max().item() <= 5e-3, f'max err {err.max().item()} at {tuple(int(v) for v in torch.nonzero(err == err.max())[0])}'
+    # kp = 7 (round 6: the streaming kernel, v2w_stage_bf16_n16s.hip): conv_post runs on the matrix pipe, its operand lrelu(stage output) is rounded
+    # to bf16 ONCE - the arithmetic of every other conv of this mode and of the reference under autocast - against weights kept to 16 mantissa
+    # bits (hi + lo rows): with these unit-scale random tail weights that is ~7e-4 mean, < 1e-2 max (the two-kernel form below differs as much)
+    bound, mean_bound = (1e-2, 1.5e-3) if kp == 7 else (5e-3, 5e-4)
+    assert err.max().item() <= bound, f'max err {err.max().item()} at {tuple(int(v) for v in torch.nonzero(err == err.max())[0])}'
+    assert err.mean().item() <= mean_bound, err.mean().item()
     # == the two-kernel form (stage output rounded to bf16, then v2w_conv_post_tanh_bf16in) to the rounding of that tensor
     out = torch.empty((B, C, L), device=dev, dtype=torch.bfloat16)
     assert hipops.resblock2_stage_split(x.to(dev), (a.to(dev), s.to(dev)), br, out, slope=0.1, out_div=3.0, bf16=True, io_bf16=3)

@@ -328,3 +328,74 @@ def test_generator_copies_and_pickles_without_its_launch_plans():
             assert ka == kb and torch.equal(va, vb)
         assert clone.conv_pre.weight_v.data_ptr() != g.conv_pre.weight_v.data_ptr()
     assert g._tapes and g._ws and g._ws_epoch == 7               # the original keeps its own
+
+
+def test_kernel_name_sink_reports_what_a_call_would_launch():
+    """ABI v33: a launching entry point handed a v2w_name_sink in place of the stream runs its checks and kernel selection, launches nothing and
+    appends the demangled kernel names.  Host-only (no GPU here): the residual stages on bf16 tensors, with and without the fused tail / the
+    fused upsampler, and a conv.  bench.py labels its rooflines with these names - it holds no kernel-name table of its own."""
+    import ctypes as C
+    import re
+    lib = _hip.load()
+
+    def stage(Cc, L, post=False, up=0):
+        a = _hip.StageSplitArgs()
+        for j, k in enumerate((3, 7, 11)):
+            a.k[j], a.dil1[j], a.dil2[j] = k, 1, 3
+            a.wps1[j], a.wps2[j], a.sc1[j], a.sc2[j] = 0x10000, 0x20000, 0x30000, 0x30000      # (aligned, never dereferenced)
+        a.in_, a.nk, a.B, a.C, a.L = 0x100000, 3, 2, Cc, L
+        a.slope, a.out_div, a.bf16, a.io_bf16 = 0.1, 3.0, 1, 3
+        if post:
+            a.post_w, a.post_out, a.post_k, a.post_slope = 0x5000, 0x600000, 7, 0.01
+        elif up:
+            a.up_wps, a.up_out, a.up_k, a.up_u, a.up_slope = 0x8000, 0x900000, 2 * up, up, 0.1
+        else:
+            a.out = 0x700000
+        return a
+
+    got = {}
+    for key, a in dict(c16_tail=stage(16, 4096, post=True), c16=stage(16, 4096), c32=stage(32, 4096), c128_up4=stage(128, 4096, up=4),
+                       c256=stage(256, 1024)).items():
+        rc, names = _hip.kernel_names(lib.v2w_resblock2_stage_split_fwd, C.byref(a))
+        assert rc in (0, 100), (key, rc)            # (100 = hipErrorNoDevice from hipGetLastError in a GPU-less process: nothing was launched)
+        assert len(names) == 1, (key, names)
+        got[key] = names[0]
+    assert got['c16_tail'] == 'n16s_stage_kernel' and got['c16'].startswith('n16_stage_kernel<')
+    assert all(got[k].startswith('wide_stage_bf16_kernel<') for k in ('c32', 'c128_up4', 'c256')) and len(set(got.values())) == 5
+    c = _hip.Conv1dArgs()
+    c.in_, c.out, c.wp = 0x1000, 0x2000, 0x3000
+    c.B, c.C_in, c.C_out, c.L, c.k, c.dil, c.slope = 32, 768, 512, 256, 7, 1, 1.0
+    rc, names = _hip.kernel_names(lib.v2w_conv1d_fwd, C.byref(c), short=False)
+    assert rc in (0, 100) and len(names) == 1
+    assert re.fullmatch(r'void \(anonymous namespace\)::conv_tile_kernel<[^()]*>\(\(anonymous namespace\)::MultiArgs\)', names[0]), names
+    assert _hip.kernel_name_short(names[0]).startswith('conv_tile_kernel<32, 1,')
+    # a sink too small for a name drops it and stays terminated
+    buf = C.create_string_buffer(16)
+    sink = _hip.NameSink(_hip.NAME_SINK_MAGIC, C.addressof(buf), len(buf), 0)
+    lib.v2w_conv1d_fwd(C.byref(c), C.c_void_p(C.addressof(sink) | 1))
+    assert sink.len == 0 and buf.value == b''
+    # bench.py asks the library: no kernel-name literal, no template-argument table
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert not re.search(r"_kernel\s*<|[a-z0-9]_kernel\b(?!s)", src.replace('per_kernel', '').replace('sum_conv_kernel_ms', '').replace('profile_kernel_names', ''))
+
+
+def test_integration_md_stub_runs_against_the_library():
+    """the ctypes stub INTEGRATION.md documents must work as written - it is executed here (up to the first device tensor), its
+    ABI check against the header's constant, its struct against the binding the package uses."""
+    import ctypes as C
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = text[text.index('```python', text.index('## 2. C-ABI level')) + len('```python'):]
+    block = block[:block.index('```')]
+    host_part = block[:block.index('# x + conv')]
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(host_part, 'INTEGRATION.md', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    assert ns['abi'] == _hip.ABI_VERSION
+    stub, mirror = ns['Conv1dArgs'], _hip.Conv1dArgs
+    assert C.sizeof(stub) == C.sizeof(mirror)
+    assert [(n, getattr(stub, n).offset, getattr(stub, n).size) for n, _t in stub._fields_] == \
+           [(n, getattr(mirror, n).offset, getattr(mirror, n).size) for n, _t in mirror._fields_]

@@ -78,6 +78,7 @@ def parity():
 
 
 def timing():
+    variants = [('new', {}), ('old', {'V2W_N16S_OFF': '1'})] + [(f'stg{n}', {'V2W_N16S_STAGGER': str(n)}) for n in (4, 8, 12, 16)]
     for B, T in [(64, 512), (32, 256)]:
         L = T * 320
         args = make(B, L, 7)
@@ -85,11 +86,10 @@ def timing():
         call = run(*args, y)
         res = {}
         for rnd in range(3):
-            for off in ('', '1'):
-                if off:
-                    os.environ['V2W_N16S_OFF'] = '1'
-                else:
-                    os.environ.pop('V2W_N16S_OFF', None)
+            for name, env in variants:
+                for k in ('V2W_N16S_OFF', 'V2W_N16S_STAGGER'):
+                    os.environ.pop(k, None)
+                os.environ.update(env)
                 for _ in range(3):
                     call()
                 torch.cuda.synchronize()
@@ -99,9 +99,10 @@ def timing():
                     call()
                 e1.record()
                 torch.cuda.synchronize()
-                res.setdefault('old' if off else 'new', []).append(e0.elapsed_time(e1) / 20 * 1e3)
-        print(f'B={B} T={T}: ' + '  '.join(f'{k} {min(v):.1f} us (median {sorted(v)[1]:.1f})' for k, v in res.items()), flush=True)
-    os.environ.pop('V2W_N16S_OFF', None)
+                res.setdefault(name, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+        print(f'B={B} T={T}: ' + '  '.join(f'{k} {min(v):.1f}' for k, v in res.items()), flush=True)
+    for k in ('V2W_N16S_OFF', 'V2W_N16S_STAGGER'):
+        os.environ.pop(k, None)
 
 
 if __name__ == '__main__':

@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -247,6 +247,43 @@ def set_recorder(rec):
     prev = getattr(_tls, 'recorder', None)
     _tls.recorder = rec
     return prev
+
+
+class NameSink(C.Structure):
+    """include/vec2wav_hip.h `v2w_name_sink` (ABI v33): handed to a launching entry point in place of the stream, it collects the names of
+    the kernels that call would launch."""
+    _fields_ = [('magic', C.c_uint64), ('buf', C.c_void_p), ('cap', C.c_int32), ('len', C.c_int32)]
+
+
+NAME_SINK_MAGIC = 0x5632574e414d4531
+
+
+def kernel_name_short(full: str) -> str:
+    """'void (anonymous namespace)::conv_bf16_kernel<2, 4, ...>((anonymous namespace)::MultiArgs)' -> 'conv_bf16_kernel<2, 4, ...>': the key
+    the profile summaries (tools/pmc_traffic.py, tools/pmc_sq.py) and bench.py's tables use."""
+    s = full.strip()
+    if s.startswith('void '):
+        s = s[5:]
+    s = s.replace('(anonymous namespace)::', '')
+    depth = 0
+    for i, ch in enumerate(s):          # cut the parameter list: the first '(' outside the template argument list
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            return s[:i]
+    return s
+
+
+def kernel_names(fn, *args, short=True):
+    """(return code, names of the kernels `fn(*args, stream)` would launch, in order) - `fn` a launching entry point of the library, `args` its
+    arguments WITHOUT the stream.  Host-only: nothing is launched, no tensor pointer is dereferenced (v2w_name_sink)."""
+    buf = C.create_string_buffer(8192)
+    sink = NameSink(NAME_SINK_MAGIC, C.addressof(buf), len(buf), 0)
+    rc = fn(*args, C.c_void_p(C.addressof(sink) | 1))
+    names = [n for n in buf.value.decode().split('\n') if n]
+    return rc, ([kernel_name_short(n) for n in names] if short else names)
 
 
 def check(rc: int, what: str) -> None:

@@ -307,8 +307,8 @@ extern "C" int v2w_cbn_bwd_sums(const float* dx, const float* xr, const float* g
     if (!dx || !xr || !gb || !s12_ws || !dgb || !csum || B <= 0 || C <= 0 || L <= 0) return V2W_E_ARG;
     if (training ? !stats : (!running_mean || !running_var)) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cbn_bwd_rowsums_kernel, dim3(B * C), dim3(256), 0, st, dx, xr, s12_ws, L);
-    hipLaunchKernelGGL(cbn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s12_ws, gb, stats, running_mean, running_var, dgb, csum,
+    V2W_LAUNCH(cbn_bwd_rowsums_kernel, dim3(B * C), dim3(256), 0, st, dx, xr, s12_ws, L);
+    V2W_LAUNCH(cbn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s12_ws, gb, stats, running_mean, running_var, dgb, csum,
                        B, C, training, eps);
     return v2w_launch_status();
 }
@@ -319,10 +319,10 @@ extern "C" int v2w_cbn_bwd_apply(const float* dx, const float* xr, const float* 
     if (!dx || !xr || !gb || !csum || !tab_ws || !dxr || B <= 0 || C <= 0 || L <= 0) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     float* A = tab_ws; float* Bc = tab_ws + (size_t)B * C; float* Cc = Bc + C;
-    hipLaunchKernelGGL(cbn_bwd_tables_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, gb, stats, csum, running_mean, running_var,
+    V2W_LAUNCH(cbn_bwd_tables_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, gb, stats, csum, running_mean, running_var,
                        A, Bc, Cc, B, C, training, eps);
     int gx = (L + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(affine3_kernel, dim3(gx, B * C), dim3(256), 0, st, dx, xr, A, Bc, Cc, dxr, C, L);
+    V2W_LAUNCH(affine3_kernel, dim3(gx, B * C), dim3(256), 0, st, dx, xr, A, Bc, Cc, dxr, C, L);
     return v2w_launch_status();
 }
 
@@ -332,7 +332,7 @@ extern "C" int v2w_tail_bwd(const float* dy, const float* y, const float* x, con
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)B * L;
     int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(g), dim3(256), 0, st, dy, y, dp_ws, n);
+    V2W_LAUNCH(tanh_bwd_kernel, dim3(g), dim3(256), 0, st, dy, y, dp_ws, n);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (C_in == 16 && k == 7 && L % 4 == 0 && al16(x) && al16(dx) && al16(dp_ws)) {       // the generator's tail: one pass over x for both gradients
         constexpr int TP = 1024;
@@ -342,24 +342,24 @@ extern "C" int v2w_tail_bwd(const float* dy, const float* y, const float* x, con
             const int nwg = ntiles < V2W_TAIL_PARTS ? (int)ntiles : V2W_TAIL_PARTS;
             const size_t lds = ((size_t)17 * (TP + 8) + 7 * 16 + 4 * 16 * 7) * sizeof(float);
             auto kern = tail_bwd_fused_kernel<16, 7>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, st);
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, dp_ws, wf, x, dx, part_ws, L, slope, ntl, (int)ntiles);
-            hipLaunchKernelGGL(conv_post_wgrad_reduce_kernel, dim3((C_in * k + 63) / 64), dim3(64), 0, st, part_ws, dwf, C_in, k, nwg);
+            V2W_LAUNCH(kern, dim3(nwg), dim3(256), lds, st, dp_ws, wf, x, dx, part_ws, L, slope, ntl, (int)ntiles);
+            V2W_LAUNCH(conv_post_wgrad_reduce_kernel, dim3((C_in * k + 63) / 64), dim3(64), 0, st, part_ws, dwf, C_in, k, nwg);
             return v2w_launch_status();
         }
     }
-    hipLaunchKernelGGL(conv_post_dgrad_kernel, dim3((L + 255) / 256, C_in, B), dim3(256), 0, st, dp_ws, wf, x, dx, C_in, L, k, slope);
+    V2W_LAUNCH(conv_post_dgrad_kernel, dim3((L + 255) / 256, C_in, B), dim3(256), 0, st, dp_ws, wf, x, dx, C_in, L, k, slope);
     const int nsplit = 64;
-    hipLaunchKernelGGL(conv_post_wgrad_kernel, dim3(nsplit, C_in), dim3(256), 0, st, x, dp_ws, part_ws, B, C_in, L, k, slope, nsplit);
-    hipLaunchKernelGGL(conv_post_wgrad_reduce_kernel, dim3((C_in * k + 63) / 64), dim3(64), 0, st, part_ws, dwf, C_in, k, nsplit);
+    V2W_LAUNCH(conv_post_wgrad_kernel, dim3(nsplit, C_in), dim3(256), 0, st, x, dp_ws, part_ws, B, C_in, L, k, slope, nsplit);
+    V2W_LAUNCH(conv_post_wgrad_reduce_kernel, dim3((C_in * k + 63) / 64), dim3(64), 0, st, part_ws, dwf, C_in, k, nsplit);
     return v2w_launch_status();
 }
 
 extern "C" int v2w_wn_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg,
                           int c_in, int c_out, int k, int transposed, void* stream) {
     if (!dwf || !v || !dv || (g && !dg) || c_in <= 0 || c_out <= 0 || k <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(wn_bwd_kernel, dim3(transposed ? c_in : c_out), dim3(256), 0, (hipStream_t)stream, dwf, v, g, dv, dg,
+    V2W_LAUNCH(wn_bwd_kernel, dim3(transposed ? c_in : c_out), dim3(256), 0, (hipStream_t)stream, dwf, v, g, dv, dg,
                        c_in, c_out, k, transposed);
     return v2w_launch_status();
 }
@@ -373,7 +373,7 @@ extern "C" int v2w_cond_bwd(const float* dgb, const float* z, const float* sn_w,
     const int R = 2 * C;
     for (int phase = 0; phase < 5; ++phase) {
         const int grid = phase == 0 || phase == 3 ? R : (phase == 1 ? B : (phase == 2 ? 1 : 128));
-        hipLaunchKernelGGL(cond_bwd_kernel, dim3(grid), dim3(128), 0, st, dgb, z, sn_w, sn_u, sn_v, sigma, spk, noise,
+        V2W_LAUNCH(cond_bwd_kernel, dim3(grid), dim3(128), 0, st, dgb, z, sn_w, sn_u, sn_v, sigma, spk, noise,
                            d_sn_w, d_sn_b, d_fc_w, d_fc_b, dz_ws, B, R, spk_dim, noise_dim, phase);
     }
     return v2w_launch_status();

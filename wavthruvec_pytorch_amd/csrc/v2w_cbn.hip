@@ -363,7 +363,7 @@ affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ a, co
 extern "C" int v2w_affine_apply(const float* x, const float* a, const float* s, float* out, int B, int C, int L, void* stream) {
     if (!x || !a || !s || !out || B <= 0 || C <= 0 || L <= 0) return V2W_E_ARG;
     int gx = (L + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, a, s, out, L);
+    V2W_LAUNCH(affine_apply_kernel, dim3(gx, B * C), dim3(256), 0, (hipStream_t)stream, x, a, s, out, L);
     return v2w_launch_status();
 }
 
@@ -381,9 +381,9 @@ extern "C" int v2w_cond_gamma_beta(const v2w_cond_args* a, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_fc = (size_t)(a->spk_dim + a->noise_dim) * sizeof(float);
-    hipLaunchKernelGGL(cond_fc_kernel, dim3(a->B, a->n_stages), dim3(128), lds_fc, st, *a);
-    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), st, *a);
-    hipLaunchKernelGGL(cond_linear_kernel, dim3(a->B, a->n_stages, (maxR + 63) / 64), dim3(256), 0, st, *a);
+    V2W_LAUNCH(cond_fc_kernel, dim3(a->B, a->n_stages), dim3(128), lds_fc, st, *a);
+    V2W_LAUNCH(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), st, *a);
+    V2W_LAUNCH(cond_linear_kernel, dim3(a->B, a->n_stages, (maxR + 63) / 64), dim3(256), 0, st, *a);
     return v2w_launch_status();
 }
 
@@ -396,7 +396,7 @@ extern "C" int v2w_cond_sigma(const v2w_cond_args* a, void* stream) {
         if (!a->sn_w[s] || !a->sn_u[s] || !a->sn_v[s] || a->C[s] <= 0) return V2W_E_ARG;
         if (2 * a->C[s] > maxR) maxR = 2 * a->C[s];
     }
-    hipLaunchKernelGGL(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), (hipStream_t)stream, *a);
+    V2W_LAUNCH(cond_sn_kernel, dim3(a->n_stages), dim3(1024), (size_t)2 * maxR * sizeof(float), (hipStream_t)stream, *a);
     return v2w_launch_status();
 }
 
@@ -415,7 +415,7 @@ extern "C" int v2w_cond_affine_eval(const v2w_cond_eval_args* e, void* stream) {
     }
     const size_t lds = (size_t)(a->spk_dim + a->noise_dim) * sizeof(float);
     if (lds > 48 * 1024) return V2W_E_SHAPE;
-    hipLaunchKernelGGL(cond_affine_eval_kernel, dim3(a->B, a->n_stages, (maxC + 31) / 32), dim3(256), lds, (hipStream_t)stream, *e);
+    V2W_LAUNCH(cond_affine_eval_kernel, dim3(a->B, a->n_stages, (maxC + 31) / 32), dim3(256), lds, (hipStream_t)stream, *e);
     return v2w_launch_status();
 }
 
@@ -424,14 +424,14 @@ extern "C" int v2w_bn_stats(const float* x, double* stats, double* partial_ws, i
     hipStream_t st = (hipStream_t)stream;
     int slice = (L + V2W_BN_SPLITS - 1) / V2W_BN_SPLITS;
     slice = (slice + 63) & ~63;   // keep wave-wide row reads aligned
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(V2W_BN_SPLITS, C), dim3(256), 0, st, x, partial_ws, B, C, L, slice);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial_ws, stats, C, (double)B * (double)L);
+    V2W_LAUNCH(bn_stats_kernel, dim3(V2W_BN_SPLITS, C), dim3(256), 0, st, x, partial_ws, B, C, L, slice);
+    V2W_LAUNCH(bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial_ws, stats, C, (double)B * (double)L);
     return v2w_launch_status();
 }
 
 extern "C" int v2w_bn_reduce_partials(const float* part, int ntiles, int C, double count, double* stats, void* stream) {
     if (!part || !stats || ntiles <= 0 || C <= 0 || count <= 0.0) return V2W_E_ARG;
-    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, stats, ntiles, C, count);
+    V2W_LAUNCH(bn_reduce_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, stats, ntiles, C, count);
     return v2w_launch_status();
 }
 
@@ -442,7 +442,7 @@ extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
     if (!gb || !a_out || !s_out || !running_mean || !running_var || B <= 0 || C <= 0) return V2W_E_ARG;
     if (training && !stats) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
+    V2W_LAUNCH(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
                        running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps);
     return v2w_launch_status();
 }
@@ -453,14 +453,14 @@ extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
 // order of the fp64 additions; a data-parallel run, which all-reduces the array, keeps the one-level form.
 extern "C" int v2w_bn_reduce_slices(const float* part, int ntiles, int C, double* slices, int nslices, void* stream) {
     if (!part || !slices || ntiles <= 0 || C <= 0 || nslices <= 0 || nslices > 1024) return V2W_E_ARG;
-    hipLaunchKernelGGL(bn_reduce_slices_kernel, dim3(nslices), dim3(256), 0, (hipStream_t)stream, part, slices, ntiles, C);
+    V2W_LAUNCH(bn_reduce_slices_kernel, dim3(nslices), dim3(256), 0, (hipStream_t)stream, part, slices, ntiles, C);
     return v2w_launch_status();
 }
 extern "C" int v2w_bn_finalize_slices(const double* slices, int nslices, double count, const float* gb,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream) {
     if (!slices || nslices <= 0 || !(count > 0.0) || !gb || !a_out || !s_out || !running_mean || !running_var || B <= 0 || C <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(bn_finalize_slices_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, slices, nslices, count, gb,
+    V2W_LAUNCH(bn_finalize_slices_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, slices, nslices, count, gb,
                        running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, momentum, eps);
     return v2w_launch_status();
 }

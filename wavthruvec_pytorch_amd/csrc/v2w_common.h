@@ -1,7 +1,10 @@
 // Shared device helpers for the Vec2Wav gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cxxabi.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/vec2wav_hip.h"
 
 #define V2W_WAVE 64  // CDNA wavefront width (hard-coded: warpSize folds to 64 on gfx950)
@@ -19,6 +22,41 @@ static inline int v2w_launch_status() {
 // check the real call makes is made, nothing is launched, no attribute is set, no pointer is dereferenced.
 #define V2W_DRY_STREAM (reinterpret_cast<hipStream_t>(static_cast<intptr_t>(-1)))
 static inline bool v2w_dry(hipStream_t s) { return s == V2W_DRY_STREAM; }
+
+// Name sink (include/vec2wav_hip.h, ABI v33): a "stream" with bit 0 set that is not the dry-run sentinel points at the caller's v2w_name_sink.
+// A call made with it goes as far as a real call - every launch site is V2W_LAUNCH, every attribute change V2W_MAX_LDS - and appends the
+// demangled name of each kernel it reaches instead of launching it.  The runtime maps the host stub to the kernel's symbol
+// (hipKernelNameRefByPtr: a table lookup, no device needed), so no launch site spells a name.
+static inline v2w_name_sink* v2w_sink(hipStream_t s) {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(s);
+    if (!(u & 1) || s == V2W_DRY_STREAM) return nullptr;
+    v2w_name_sink* k = reinterpret_cast<v2w_name_sink*>(u & ~static_cast<uintptr_t>(1));
+    return k->magic == V2W_NAME_SINK_MAGIC ? k : nullptr;
+}
+static inline void v2w_sink_add(v2w_name_sink* k, const void* host_fn) {
+    const char* m = hipKernelNameRefByPtr(host_fn, nullptr);
+    int st = 0;
+    char* d = m ? abi::__cxa_demangle(m, nullptr, nullptr, &st) : nullptr;
+    const char* nm = d ? d : (m ? m : "?");
+    const int n = (int)strlen(nm);
+    if (k->buf && k->cap > 0 && k->len + n + 2 <= k->cap) {
+        memcpy(k->buf + k->len, nm, n);
+        k->buf[k->len + n] = '\n';
+        k->len += n + 1;
+        k->buf[k->len] = 0;
+    }
+    free(d);
+}
+#define V2W_LAUNCH(kern, grid, block, lds, stream, ...)                                                          \
+    do {                                                                                                         \
+        if (v2w_name_sink* v2w_ns_ = v2w_sink(stream)) v2w_sink_add(v2w_ns_, reinterpret_cast<const void*>(kern)); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                    \
+    } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize for a launch that needs more than 64 KB of LDS (set at every such launch: the library keeps no
+// per-device state to remember it in); nothing to set for a name sink
+static inline hipError_t v2w_max_lds(const void* host_fn, int lds, hipStream_t s) {
+    return v2w_sink(s) ? hipSuccess : hipFuncSetAttribute(host_fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
 
 // Compute units of the CURRENT device (the device the caller's stream belongs to: every entry point runs with it made current).
 // Asked of the runtime at every launch of a persistent kernel - no process-wide cache: a value remembered from the first caller's

@@ -792,10 +792,10 @@ int launch_bf16(const TileArgs* ps, int nprob, hipStream_t stream, int32_t* cfg 
               : io == 2 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, false, true, CK, VEC>
                         : conv_bf16_kernel<MI, NI, WM, WN, NPF, 0, true, true, CK, VEC>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
     return v2w_launch_status();
 }
 
@@ -879,10 +879,10 @@ int launch_bf16_convt(TileArgs p, hipStream_t stream, int* ntiles_out, int32_t* 
     for (int i = 2; i <= V2W_MAX_MULTI; ++i) m.start[i] = 0x7fffffff;
     auto kern = p.io_bf16 ? conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, true, true, V2W_BF_CK, VEC> : conv_bf16_kernel<MI, NI, WM, WN, NPF, 2, false, false, V2W_BF_CK, VEC>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
     return v2w_launch_status();
 }
 
@@ -970,14 +970,14 @@ extern "C" int v2w_pack_bf16_convt(const float* wf, void* wps, int k, int c_in, 
     if ((c_out * g.UP) % 32 != 0) return V2W_E_SHAPE;
     const size_t total = (size_t)(c_out * g.UP / 32) * (c_in / 16) * g.KV * 64;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_bf16_convt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), k, c_in, c_out, u,
+    V2W_LAUNCH(pack_bf16_convt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), k, c_in, c_out, u,
                        g.UP, g.hl, g.KV);
     if (convt_exact_region(c_out, u, g.UP)) {
         // a stride that is no power of two (5): the same taps again over the EXACT phases, rows co * u + phase, behind the padded rows - the
         // resident kernel of v2w_convt_bf16_res.hip then spends no MFMA on the dead phases
         const size_t total2 = (size_t)(c_out * u / 32) * (c_in / 16) * g.KV * 64;
         int grid2 = (int)((total2 + 255) / 256); if (grid2 > 4096) grid2 = 4096;
-        hipLaunchKernelGGL(pack_bf16_convt_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, wf,
+        V2W_LAUNCH(pack_bf16_convt_kernel, dim3(grid2), dim3(256), 0, (hipStream_t)stream, wf,
                            reinterpret_cast<b8*>(reinterpret_cast<unsigned char*>(wps) + total / 64 * V2W_BF_UNIT), k, c_in, c_out, u, u, g.hl, g.KV);
     }
     return v2w_launch_status();

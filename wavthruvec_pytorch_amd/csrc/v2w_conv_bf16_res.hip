@@ -439,10 +439,10 @@ int launch_res(const v2w_branch_convs_args* q, hipStream_t stream) {
     const int grid = ((p.ntiles + 7) / 8) * 8 * (q->C / MT);
     auto kern = q->mode == 0 ? conv_bf16_res_kernel<MI, NI, WM, WN, 0> : conv_bf16_res_kernel<MI, NI, WM, WN, 1>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 

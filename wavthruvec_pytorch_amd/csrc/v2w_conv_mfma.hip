@@ -760,17 +760,17 @@ int launch_tile(const TileArgs* ps, int nprob, hipStream_t stream) {
                        : (epi == 2 ? conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 2, false> : conv_tile_kernel<MF, U, MI, NI, WM, WN, CK, NPF, RING, 0, false>));
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
     if (S > 1) {
         const int rc = v2w_launch_status();
         if (rc != 0) return rc;
         long long blocks = (red.start[nprob] + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        if (red_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, red);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, red);
+        if (red_vec) V2W_LAUNCH(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, red);
+        else V2W_LAUNCH(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, red);
     }
     return v2w_launch_status();
 }
@@ -931,7 +931,7 @@ extern "C" int v2w_pack_mfma(const float* wf, float* wp, int k, int c_in, int c_
     if (!cfg.mf) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
+    V2W_LAUNCH(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
     return v2w_launch_status();
 }
 
@@ -944,7 +944,7 @@ extern "C" int v2w_pack_mfma_dgrad(const float* wf, float* wp, int k, int c_in, 
     if (!cfg.mf) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, 1, 1);
+    V2W_LAUNCH(pack_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, 1, 1);
     return v2w_launch_status();
 }
 
@@ -956,7 +956,7 @@ extern "C" int v2w_pack_mfma_batch(const float* wf, float* wp, int k, int c_in, 
     if (!cfg.mf) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * c_out;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_mfma_kernel, dim3(grid, n), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
+    V2W_LAUNCH(pack_mfma_kernel, dim3(grid, n), dim3(256), 0, (hipStream_t)stream, wf, wp, k, c_in, c_out, cfg.mf, cfg.ck, u);
     return v2w_launch_status();
 }
 
@@ -1070,11 +1070,10 @@ extern "C" int v2w_fold_pack_batch(const v2w_fold_desc* descs_dev, const int32_t
     if (!descs_dev || !starts_dev || n <= 0 || nblk_scale <= 0 || nblk_pack <= 0 || lds_bytes <= 0) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_pack_batch_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(fold_pack_batch_kernel), lds_bytes, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(fold_scale_batch_kernel, dim3(nblk_scale), dim3(256), 0, st, descs_dev, starts_dev, n);
-    hipLaunchKernelGGL(fold_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds_bytes, st, descs_dev, starts_dev + n + 1, n);
+    V2W_LAUNCH(fold_scale_batch_kernel, dim3(nblk_scale), dim3(256), 0, st, descs_dev, starts_dev, n);
+    V2W_LAUNCH(fold_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds_bytes, st, descs_dev, starts_dev + n + 1, n);
     return v2w_launch_status();
 }

@@ -136,7 +136,7 @@ int launch_post(const PostArgs& p, hipStream_t stream) {
     const int ncu = v2w_num_cus();
     // two resident workgroups per CU, each builds the operand image once and walks its jobs
     const int grid = p.njobs < V2W_PM_WGS * ncu ? p.njobs : V2W_PM_WGS * ncu;
-    hipLaunchKernelGGL(conv_post_tanh_mfma_kernel<C>, dim3(grid), dim3(256), (size_t)C * 3 * 64 * sizeof(u32x4), stream, p);
+    V2W_LAUNCH(conv_post_tanh_mfma_kernel<C>, dim3(grid), dim3(256), (size_t)C * 3 * 64 * sizeof(u32x4), stream, p);
     return v2w_launch_status();
 }
 

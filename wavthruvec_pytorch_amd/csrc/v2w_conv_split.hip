@@ -519,10 +519,10 @@ int launch_split(const TileArgs* ps, int nprob, hipStream_t stream, bool bf) {
                    : (vec ? conv_split_kernel<MI, NI, WM, WN, true, false, HM> : conv_split_kernel<MI, NI, WM, WN, false, false, HM>);
     if (lds > 160 * 1024) return V2W_E_SHAPE;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTHREADS), lds, stream, m);
     return v2w_launch_status();
 }
 
@@ -723,14 +723,14 @@ extern "C" int v2w_pack_split(const float* wf, void* wps, float* sc, int k, int 
     if (!v2w_split_packable(c_in, c_out)) return V2W_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     unsigned int* amax = reinterpret_cast<unsigned int*>(sc + 2);
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned int), st);
+    hipError_t e = v2w_sink(st) ? hipSuccess : hipMemsetAsync(amax, 0, sizeof(unsigned int), st);
     if (e != hipSuccess) return (int)e;
     const size_t n = (size_t)k * c_in * c_out;
     int g1 = (int)((n + 255) / 256); if (g1 > 256) g1 = 256;
-    hipLaunchKernelGGL(split_absmax_kernel, dim3(g1), dim3(256), 0, st, wf, n, amax);
+    V2W_LAUNCH(split_absmax_kernel, dim3(g1), dim3(256), 0, st, wf, n, amax);
     const size_t total = (size_t)k * c_in * ((c_out + 31) / 32 * 32) / 8;   // one thread per 8 (padded) weights
     int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL(pack_split_kernel, dim3(g2), dim3(256), 0, st, wf, reinterpret_cast<h8*>(wps), amax, sc, k, c_in, c_out);
+    V2W_LAUNCH(pack_split_kernel, dim3(g2), dim3(256), 0, st, wf, reinterpret_cast<h8*>(wps), amax, sc, k, c_in, c_out);
     return v2w_launch_status();
 }
 
@@ -739,7 +739,7 @@ extern "C" int v2w_pack_bf16(const float* wf, void* wps, float* sc, int k, int c
     if (!v2w_split_packable(c_in, c_out)) return V2W_E_SHAPE;
     const size_t total = (size_t)k * c_in * ((c_out + 31) / 32 * 32) / 8;
     int g2 = (int)((total + 255) / 256); if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), sc, k, c_in, c_out);
+    V2W_LAUNCH(pack_bf16_kernel, dim3(g2), dim3(256), 0, (hipStream_t)stream, wf, reinterpret_cast<b8*>(wps), sc, k, c_in, c_out);
     return v2w_launch_status();
 }
 
@@ -802,8 +802,8 @@ extern "C" int v2w_split_pack_batch(const v2w_split_desc* descs_dev, const int32
     hipStream_t st = (hipStream_t)stream;
     const int lds = 32 * (V2W_SPLIT_CK * k_max + 1) * (int)sizeof(float);
     if (lds > 64 * 1024) return V2W_E_SHAPE;
-    if (!all_bf16) hipLaunchKernelGGL(split_zero_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, st, descs_dev, n);
-    hipLaunchKernelGGL(split_rowscale_batch_kernel, dim3(nblk_rows), dim3(256), 0, st, descs_dev, starts_dev, n);
-    hipLaunchKernelGGL(split_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds, st, descs_dev, starts_dev + n + 1, n);
+    if (!all_bf16) V2W_LAUNCH(split_zero_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, st, descs_dev, n);
+    V2W_LAUNCH(split_rowscale_batch_kernel, dim3(nblk_rows), dim3(256), 0, st, descs_dev, starts_dev, n);
+    V2W_LAUNCH(split_pack_batch_kernel, dim3(nblk_pack), dim3(256), lds, st, descs_dev, starts_dev + n + 1, n);
     return v2w_launch_status();
 }

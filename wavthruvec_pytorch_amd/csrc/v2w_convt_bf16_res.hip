@@ -476,10 +476,10 @@ int launch_ct(CtArgs p, hipStream_t stream, int* ntiles_out, int32_t* cfg) {
     const int grid = ((p.ntiles + 7) / 8) * 8 * ((p.CoutR * UP) / MT);
     auto kern = convt_bf16_res_kernel<MI, NI, WM, WN, UP, U>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(grid), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 

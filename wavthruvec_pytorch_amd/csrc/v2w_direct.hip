@@ -300,16 +300,16 @@ conv_post_tanh_vec4_kernel(const typename IN::elem_t* __restrict__ in, const flo
 int v2w_conv1d_direct(const v2w_conv1d_args* a, hipStream_t stream) {
     const int istr = a->in_stride > 0 ? a->in_stride : 1;
     if (a->C_out == 1 && istr == 1 && !a->in_a && !a->res && !a->add0 && !a->mask_src && !a->accumulate && a->out_div == 0.f) {
-        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((a->L + 31) / 32, a->B), dim3(256), 0, stream, *a);
+        V2W_LAUNCH(conv1d_cout1_kernel, dim3((a->L + 31) / 32, a->B), dim3(256), 0, stream, *a);
         return v2w_launch_status();
     }
     if (a->C_out >= 2 && a->C_out <= 8 && a->B <= 65535) {
-        if (a->C_out == 8) hipLaunchKernelGGL((conv1d_small_kernel<8, true>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
-        else hipLaunchKernelGGL((conv1d_small_kernel<8, false>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
+        if (a->C_out == 8) V2W_LAUNCH((conv1d_small_kernel<8, true>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
+        else V2W_LAUNCH((conv1d_small_kernel<8, false>), dim3((a->L + 255) / 256, a->B), dim3(256), 0, stream, *a);
         return v2w_launch_status();
     }
     dim3 grid((a->L + 255) / 256, a->C_out, a->B);
-    hipLaunchKernelGGL(conv1d_direct_kernel, grid, dim3(256), 0, stream, *a);
+    V2W_LAUNCH(conv1d_direct_kernel, grid, dim3(256), 0, stream, *a);
     return v2w_launch_status();
 }
 
@@ -317,14 +317,14 @@ int v2w_convt1d_direct(const v2w_convt1d_args* a, hipStream_t stream) {
     if (a->C_out >= 2 && a->C_out <= 8 && a->B <= 65535 && (a->u == 2 || a->u == 4) && a->k >= a->u && ((a->k - a->u) & 1) == 0 &&
         (reinterpret_cast<uintptr_t>(a->out) & 15) == 0) {
         const dim3 grid((a->L + 255) / 256, a->B);
-        if (a->u == 2 && a->C_out == 8) hipLaunchKernelGGL((convt1d_small_kernel<8, 2, true>), grid, dim3(256), 0, stream, *a);
-        else if (a->u == 2) hipLaunchKernelGGL((convt1d_small_kernel<8, 2, false>), grid, dim3(256), 0, stream, *a);
-        else if (a->C_out == 8) hipLaunchKernelGGL((convt1d_small_kernel<8, 4, true>), grid, dim3(256), 0, stream, *a);
-        else hipLaunchKernelGGL((convt1d_small_kernel<8, 4, false>), grid, dim3(256), 0, stream, *a);
+        if (a->u == 2 && a->C_out == 8) V2W_LAUNCH((convt1d_small_kernel<8, 2, true>), grid, dim3(256), 0, stream, *a);
+        else if (a->u == 2) V2W_LAUNCH((convt1d_small_kernel<8, 2, false>), grid, dim3(256), 0, stream, *a);
+        else if (a->C_out == 8) V2W_LAUNCH((convt1d_small_kernel<8, 4, true>), grid, dim3(256), 0, stream, *a);
+        else V2W_LAUNCH((convt1d_small_kernel<8, 4, false>), grid, dim3(256), 0, stream, *a);
         return v2w_launch_status();
     }
     dim3 grid((a->L * a->u + 255) / 256, a->C_out, a->B);
-    hipLaunchKernelGGL(convt1d_direct_kernel, grid, dim3(256), 0, stream, *a);
+    V2W_LAUNCH(convt1d_direct_kernel, grid, dim3(256), 0, stream, *a);
     return v2w_launch_status();
 }
 
@@ -338,11 +338,11 @@ static int conv_post_tanh_impl(const typename IN::elem_t* in, const float* wf, c
     hipStream_t s = (hipStream_t)stream;
     const bool aligned = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (aligned && k <= 9) {
-        hipLaunchKernelGGL(conv_post_tanh_vec4_kernel<IN>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+        V2W_LAUNCH(conv_post_tanh_vec4_kernel<IN>, grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
         return v2w_launch_status();
     }
-    if (k <= 7) hipLaunchKernelGGL((conv_post_tanh_kernel<7, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
-    else hipLaunchKernelGGL((conv_post_tanh_kernel<15, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    if (k <= 7) V2W_LAUNCH((conv_post_tanh_kernel<7, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
+    else V2W_LAUNCH((conv_post_tanh_kernel<15, IN>), grid, dim3(256), lds, s, in, wf, bias, out, B, C_in, L, k, slope);
     return v2w_launch_status();
 }
 

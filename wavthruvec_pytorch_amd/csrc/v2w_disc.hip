@@ -161,21 +161,21 @@ extern "C" int v2w_phase_split(const float* x, float* out, int B, int C, int Cg,
         const dim3 grid(gx, B * C);
         hipStream_t st = (hipStream_t)stream;
         switch (s) {
-            case 2: hipLaunchKernelGGL(phase_split_vec_kernel<2>, grid, dim3(256), 0, st, x, out, C, U); break;
-            case 4: hipLaunchKernelGGL(phase_split_vec_kernel<4>, grid, dim3(256), 0, st, x, out, C, U); break;
-            case 5: hipLaunchKernelGGL(phase_split_vec_kernel<5>, grid, dim3(256), 0, st, x, out, C, U); break;
-            default: hipLaunchKernelGGL(phase_split_vec_kernel<8>, grid, dim3(256), 0, st, x, out, C, U); break;
+            case 2: V2W_LAUNCH(phase_split_vec_kernel<2>, grid, dim3(256), 0, st, x, out, C, U); break;
+            case 4: V2W_LAUNCH(phase_split_vec_kernel<4>, grid, dim3(256), 0, st, x, out, C, U); break;
+            case 5: V2W_LAUNCH(phase_split_vec_kernel<5>, grid, dim3(256), 0, st, x, out, C, U); break;
+            default: V2W_LAUNCH(phase_split_vec_kernel<8>, grid, dim3(256), 0, st, x, out, C, U); break;
         }
         return v2w_launch_status();
     }
     if (opitch % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (long long)B * s * C < (1ll << 31) && opitch < (1 << 22)) {
         int gy = (opitch / 4 + 255) / 256; if (gy > 64) gy = 64;
-        hipLaunchKernelGGL(phase_split_rows_kernel, dim3(B * s * C, gy), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U,
+        V2W_LAUNCH(phase_split_rows_kernel, dim3(B * s * C, gy), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U,
                            ipitch, opitch, 1.f / (float)inner);
         return v2w_launch_status();
     }
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U, ipitch, opitch);
+    V2W_LAUNCH(phase_split_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, Cg, L, inner, s, U, ipitch, opitch);
     return v2w_launch_status();
 }
 
@@ -193,7 +193,7 @@ extern "C" int v2w_zero_tail(float* x, long long rows, int pitch, int valid, voi
     if (valid == pitch) return 0;
     const long total = rows * (pitch - valid);
     int gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-    hipLaunchKernelGGL(zero_tail_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, (long)rows, pitch, valid);
+    V2W_LAUNCH(zero_tail_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, (long)rows, pitch, valid);
     return v2w_launch_status();
 }
 
@@ -207,7 +207,7 @@ extern "C" int v2w_unfold1(const float* x, float* out, int B, int T, int H, int 
     if (opitch < U * inner) return V2W_E_ARG;
     const size_t total = (size_t)rows * opitch;
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(unfold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, T, H, inner, s, k, pad, rows, U, opitch);
+    V2W_LAUNCH(unfold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, T, H, inner, s, k, pad, rows, U, opitch);
     return v2w_launch_status();
 }
 
@@ -215,7 +215,7 @@ extern "C" int v2w_avgpool4(const float* x, float* out, int B, int L, void* stre
     if (!x || !out || B <= 0 || L <= 0) return V2W_E_ARG;
     const int Lo = L / 2 + 1;
     int gx = (Lo + 255) / 256; if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(avgpool4_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, L, Lo);
+    V2W_LAUNCH(avgpool4_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, L, Lo);
     return v2w_launch_status();
 }
 
@@ -230,7 +230,7 @@ extern "C" int v2w_unfold_taps(const float* x, float* out, int B, int C, int L, 
     if (ipitch < L * inner || opitch < U * inner) return V2W_E_ARG;
     const size_t total = (size_t)k * C * opitch;
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(unfold_taps_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, L, inner, s, k, pad, U, ipitch, opitch);
+    V2W_LAUNCH(unfold_taps_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, out, C, L, inner, s, k, pad, U, ipitch, opitch);
     return v2w_launch_status();
 }
 
@@ -391,10 +391,10 @@ static int disc_dz_launch(bool merge, const float* f, const float* g, const floa
     const long blocks = (rows + rpb - 1) / rpb;
     if (blocks > 0x7fffffffL) return V2W_E_SHAPE;
     if (merge)
-        hipLaunchKernelGGL(disc_dz_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
+        V2W_LAUNCH(disc_dz_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
                            dpitch, pitch, valid, slope, rpb);
     else
-        hipLaunchKernelGGL(disc_dz_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
+        V2W_LAUNCH(disc_dz_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, f, g, d, dz, rowsum, rows, C, Cg, inner, s,
                            dpitch, pitch, valid, slope, rpb);
     return v2w_launch_status();
 }
@@ -415,7 +415,7 @@ extern "C" int v2w_phase_merge(const float* dxs, float* out, int B, int C, int C
     if (ipitch < U * inner || opitch < L * inner) return V2W_E_ARG;
     const size_t total = (size_t)C * L * inner;
     int gx = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(phase_merge_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxs, out, C, Cg, L, inner, s, ipitch, opitch);
+    V2W_LAUNCH(phase_merge_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxs, out, C, Cg, L, inner, s, ipitch, opitch);
     return v2w_launch_status();
 }
 
@@ -427,20 +427,20 @@ extern "C" int v2w_fold1(const float* dxu, float* dx, int B, int T, int H, int i
     if (ipitch <= 0) ipitch = U * inner;
     if (ipitch < U * inner) return V2W_E_ARG;
     int gx = (T + 255) / 256; if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(fold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxu, dx, T, H, inner, s, k, pad, rows, U, ipitch);
+    V2W_LAUNCH(fold1_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxu, dx, T, H, inner, s, k, pad, rows, U, ipitch);
     return v2w_launch_status();
 }
 
 extern "C" int v2w_avgpool4_bwd(const float* dout, float* dx, int B, int L, void* stream) {
     if (!dout || !dx || B <= 0 || L <= 0) return V2W_E_ARG;
     int gx = (L + 255) / 256; if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(avgpool4_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dout, dx, L, L / 2 + 1);
+    V2W_LAUNCH(avgpool4_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dout, dx, L, L / 2 + 1);
     return v2w_launch_status();
 }
 
 extern "C" int v2w_cout1_wgrad(const float* x, const float* dz, float* dwf, int B, int C, int L, int k, int dil, int tap0, void* stream) {
     if (!x || !dz || !dwf || B <= 0 || C <= 0 || L <= 0 || k <= 0 || dil <= 0 || tap0 < 0 || tap0 >= k) return V2W_E_ARG;
-    hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dz, dwf, B, C, L, k, dil, tap0);
+    V2W_LAUNCH(cout1_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dz, dwf, B, C, L, k, dil, tap0);
     return v2w_launch_status();
 }
 
@@ -458,6 +458,6 @@ extern "C" int v2w_disc_dz_merge(const float* f, const float* g, const float* dx
 // db[c] = sum over the B batch items of rowsum[b][c] (fp64, fixed order): the bias gradient from v2w_disc_dz's row sums
 extern "C" int v2w_rowsum_reduce(const float* rowsum, float* db, int B, int C, void* stream) {
     if (!rowsum || !db || B <= 0 || C <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(rowsum_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, rowsum, db, B, C);
+    V2W_LAUNCH(rowsum_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, rowsum, db, B, C);
     return v2w_launch_status();
 }

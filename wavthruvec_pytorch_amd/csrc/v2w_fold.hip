@@ -84,7 +84,7 @@ transpose_flip_kernel(const float* __restrict__ wf, float* __restrict__ out, int
 
 extern "C" int v2w_wf_transpose_flip(const float* wf, float* out, int k, int c_in, int c_out, void* stream) {
     if (!wf || !out || k <= 0 || c_in <= 0 || c_out <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, k), dim3(256), 0, (hipStream_t)stream,
+    V2W_LAUNCH(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, k), dim3(256), 0, (hipStream_t)stream,
                        wf, out, k - 1, -1, c_in, c_out);
     return v2w_launch_status();
 }
@@ -93,7 +93,7 @@ extern "C" int v2w_wf_gather_transpose(const float* wf, float* out, int k, int c
                                        void* stream) {
     if (!wf || !out || k <= 0 || c_in <= 0 || c_out <= 0 || n <= 0) return V2W_E_ARG;
     if (t_start < 0 || t_start >= k || t_start + (n - 1) * t_step < 0 || t_start + (n - 1) * t_step >= k) return V2W_E_ARG;
-    hipLaunchKernelGGL(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, n), dim3(256), 0, (hipStream_t)stream,
+    V2W_LAUNCH(transpose_flip_kernel, dim3((c_out + 31) / 32, (c_in + 31) / 32, n), dim3(256), 0, (hipStream_t)stream,
                        wf, out, t_start, t_step, c_in, c_out);
     return v2w_launch_status();
 }
@@ -103,8 +103,8 @@ extern "C" int v2w_wn_fold_conv(const float* v, const float* g, float* wf, float
     if (!v || !wf || !scratch || c_out <= 0 || c_in <= 0 || k <= 0) return V2W_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int inner = c_in * k;
-    hipLaunchKernelGGL(wn_scale_kernel, dim3(c_out), dim3(256), 0, st, v, g, scratch, inner);
-    hipLaunchKernelGGL(relayout_conv_kernel, dim3((inner + 31) / 32, (c_out + 31) / 32), dim3(256), 0, st,
+    V2W_LAUNCH(wn_scale_kernel, dim3(c_out), dim3(256), 0, st, v, g, scratch, inner);
+    V2W_LAUNCH(relayout_conv_kernel, dim3((inner + 31) / 32, (c_out + 31) / 32), dim3(256), 0, st,
                        v, scratch, wf, c_out, c_in, k);
     return v2w_launch_status();
 }
@@ -113,6 +113,6 @@ extern "C" int v2w_wn_fold_convt(const float* v, const float* g, float* wf, floa
                                  int c_in, int c_out, int k, void* stream) {
     (void)scratch;
     if (!v || !wf || c_out <= 0 || c_in <= 0 || k <= 0) return V2W_E_ARG;
-    hipLaunchKernelGGL(fold_convt_kernel, dim3(c_in), dim3(256), 0, (hipStream_t)stream, v, g, wf, c_in, c_out, k);
+    V2W_LAUNCH(fold_convt_kernel, dim3(c_in), dim3(256), 0, (hipStream_t)stream, v, g, wf, c_in, c_out, k);
     return v2w_launch_status();
 }

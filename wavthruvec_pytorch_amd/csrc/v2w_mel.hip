@@ -128,7 +128,7 @@ mel_phase_bwd_kernel(const float* __restrict__ dxp, float* __restrict__ dy, int 
 extern "C" int v2w_mel_phases(const float* y, float* xp, int B, int L, int hop, int pad, int FP, void* stream) {
     if (!y || !xp || B <= 0 || L <= 1 || hop <= 0 || pad < 0 || pad >= L || FP <= 0) return V2W_E_ARG;
     int gx = (hop * FP + 255) / 256; if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(mel_phase_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, y, xp, L, hop, pad, FP);
+    V2W_LAUNCH(mel_phase_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, y, xp, L, hop, pad, FP);
     return v2w_launch_status();
 }
 
@@ -138,7 +138,7 @@ extern "C" int v2w_mel_finish(const float* spec, const float* basis, float* out,
     if (!spec || !basis || !out || B <= 0 || F <= 0 || FP < F || nb <= 0 || Cs < 2 * nb || n_mels <= 0) return V2W_E_ARG;
     const size_t lds = (size_t)nb * V2W_MEL_FT * sizeof(float);
     if (lds > 64 * 1024) return V2W_E_SHAPE;
-    hipLaunchKernelGGL(mel_finish_kernel, dim3((F + V2W_MEL_FT - 1) / V2W_MEL_FT, B), dim3(256), lds, (hipStream_t)stream,
+    V2W_LAUNCH(mel_finish_kernel, dim3((F + V2W_MEL_FT - 1) / V2W_MEL_FT, B), dim3(256), lds, (hipStream_t)stream,
                        spec, basis, out, Cs, FP, F, nb, n_mels);
     return v2w_launch_status();
 }
@@ -152,7 +152,7 @@ extern "C" int v2w_mel_finish_bwd(const float* spec, const float* basis, const f
         return V2W_E_ARG;
     const size_t lds = (size_t)(nb + n_mels) * V2W_MEL_FT * sizeof(float);
     if (lds > 64 * 1024) return V2W_E_SHAPE;
-    hipLaunchKernelGGL(mel_finish_bwd_kernel, dim3((F + V2W_MEL_FT - 1) / V2W_MEL_FT, B), dim3(256), lds, (hipStream_t)stream,
+    V2W_LAUNCH(mel_finish_bwd_kernel, dim3((F + V2W_MEL_FT - 1) / V2W_MEL_FT, B), dim3(256), lds, (hipStream_t)stream,
                        spec, basis, basisT, gout, dspec, Cs, FP, F, nb, n_mels);
     return v2w_launch_status();
 }
@@ -161,6 +161,6 @@ extern "C" int v2w_mel_finish_bwd(const float* spec, const float* basis, const f
 extern "C" int v2w_mel_phases_bwd(const float* dxp, float* dy, int B, int L, int hop, int pad, int FP, void* stream) {
     if (!dxp || !dy || B <= 0 || L <= 1 || hop <= 0 || pad < 0 || pad >= L || FP <= 0) return V2W_E_ARG;
     int gx = (L + 255) / 256; if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(mel_phase_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxp, dy, L, hop, pad, FP);
+    V2W_LAUNCH(mel_phase_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dxp, dy, L, hop, pad, FP);
     return v2w_launch_status();
 }

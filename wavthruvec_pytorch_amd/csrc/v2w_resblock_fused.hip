@@ -328,10 +328,10 @@ int launch_pair(const v2w_pair_args* a, int n, hipStream_t stream) {
     auto kern = resblock_pair_kernel<MF, NI, WN>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return V2W_E_SHAPE;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, stream, m);
+    V2W_LAUNCH(kern, dim3(grid), dim3(64 * WN), lds, stream, m);
     return v2w_launch_status();
 }
 
@@ -897,10 +897,10 @@ int launch_stage(const v2w_stage_args* q, hipStream_t stream) {
     auto kern = bwd ? resblock2_stage_kernel<MF, NI, WN, false, true>
                     : (post ? resblock2_stage_kernel<MF, NI, WN, (MF == 16)> : resblock2_stage_kernel<MF, NI, WN, false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(q->B * p.ntl), dim3(64 * WN), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(q->B * p.ntl), dim3(64 * WN), lds, stream, p);
     return v2w_launch_status();
 }
 

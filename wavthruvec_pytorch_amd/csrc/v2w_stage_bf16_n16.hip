@@ -397,8 +397,8 @@ int launch_n16(const v2w_stage_split_args* q, hipStream_t stream) {
     const int ncu = v2w_num_cus();
     // persistent: the registers hold the stage's weights, so a workgroup walks tiles; 8 waves per CU (2 per SIMD: ~230 registers each)
     const int slots = ncu * (8 / WN);
-    if (post) hipLaunchKernelGGL((n16_stage_kernel<WN, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
-    else hipLaunchKernelGGL((n16_stage_kernel<WN, false>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    if (post) V2W_LAUNCH((n16_stage_kernel<WN, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    else V2W_LAUNCH((n16_stage_kernel<WN, false>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 
@@ -653,10 +653,10 @@ int launch_n16_pair(const v2w_stage_split_args* q, int pr, bool last, hipStream_
     const int slots = v2w_num_cus() * (8 / WN);
     auto kern = n16_pair_kernel<WN, K, D1>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(p.ntiles < slots ? p.ntiles : slots), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 

@@ -55,6 +55,9 @@ __device__ __forceinline__ unsigned int s_pack2(float lo, float hi) {
 __device__ __forceinline__ float s_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float s_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
+// max(v, w) as ONE instruction: fmaxf(v, w) costs two here - hipcc first canonicalises an operand that comes out of an MFMA with v_max_f32(v, v)
+__device__ __forceinline__ float s_max(float v, float w) { float t; asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
+
 template <int... I, class F> __device__ __forceinline__ void s_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 // ---- the operand reads and MFMAs of one step, as tables (I = step number mod 4: every ring slot of the step is a compile-time constant)
@@ -176,6 +179,7 @@ n16s_stage_kernel(const N16SArgs a) {
     rbase[2] = rb_t + (unsigned)(sl * 48);
     rbase[3] = rb_t;
     rbase[4] = rb_t + (unsigned)(sl * 16);
+    asm volatile("" : "+v"(rbase[2]), "+v"(rbase[3]), "+v"(rbase[4]));            // (opaque: one register each, never re-derived per read)
     // epilogue writes: this lane's 4 channels (4 kg ..) of position j = 8 bytes at plane sl, row j, half h
     unsigned char* const wbase = smem_s + sl * S_TP + j * 16 + h * 8;
     // staging: thread (channel quad cq, position quad c) of a 64-position burst; plane cq >> 1, half cq & 1
@@ -238,11 +242,10 @@ n16s_stage_kernel(const N16SArgs a) {
         };
 
         // ---- one step: conv1 of block s (x ring slot 4 (g & 1) + I), conv2 of block s - 2, the tail of block s - 4
-        auto step = [&](auto i_c, int s, unsigned xtog) __attribute__((always_inline)) {
+        auto step = [&](auto i_c, int s, unsigned bx0, unsigned bx1) __attribute__((always_inline)) {
             constexpr int I = decltype(i_c)::value;
             constexpr int RING = 8;
-            unsigned bx0 = rbase[0] + xtog, bx1 = rbase[1] + xtog, bt2 = rbase[2], bt3 = rbase[3], bt4 = rbase[4];
-            asm volatile("" : "+v"(bx0), "+v"(bx1), "+v"(bt2), "+v"(bt3), "+v"(bt4));
+            const unsigned bt2 = rbase[2], bt3 = rbase[3], bt4 = rbase[4];
             f32x4 acc[5];
             const f32x4 init[5] = {b1v[0], b1v[1], b1v[2], ts[I & 1], f32x4{0.f, 0.f, 0.f, 0.f}};
             su32x4 ring[RING];
@@ -281,11 +284,14 @@ n16s_stage_kernel(const N16SArgs a) {
 #pragma unroll
             for (int jb = 0; jb < 3; ++jb) {
                 f32x4 t1v = acc[jb];
-                if (edge1) { if (pos1 < 0 || pos1 >= L) t1v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (edge1) {                                                    // (a uniform branch: the empty asm keeps hipcc from turning it into 4 selects per branch)
+                    asm volatile("" ::: "memory");
+                    if (pos1 < 0 || pos1 >= L) t1v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 tsum += t1v;
                 const f32x4 tsl = t1v * slope;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[r] = fmaxf(t1v[r], tsl[r]);
+                for (int r = 0; r < 4; ++r) t1v[r] = s_max(t1v[r], tsl[r]);
                 const su32x2 w = {s_pack2(t1v[0], t1v[1]), s_pack2(t1v[2], t1v[3])};
                 unsigned char* const d = wbase + S_TOFF + jb * 2 * S_TP;
                 *reinterpret_cast<su32x2*>(d + (I + 1) * S_BLK) = w;
@@ -300,8 +306,11 @@ n16s_stage_kernel(const N16SArgs a) {
                 f32x4 z = acc[3];
                 const f32x4 zs = z * pslope;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[r] = fmaxf(z[r], zs[r]);
-                if (edge2) { if (pos2 < 0 || pos2 >= L) z = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int r = 0; r < 4; ++r) z[r] = s_max(z[r], zs[r]);
+                if (edge2) {
+                    asm volatile("" ::: "memory");
+                    if (pos2 < 0 || pos2 >= L) z = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 const su32x2 w = {s_pack2(z[0], z[1]), s_pack2(z[2], z[3])};
                 constexpr int ZS = (I + 2) & 3;
                 unsigned char* const d = wbase + S_ZOFF;
@@ -316,7 +325,7 @@ n16s_stage_kernel(const N16SArgs a) {
                 // tanh(v) = 1 - 2 / (1 + e^(2 v)): e^(2 v) = inf -> 1, = 0 -> -1
                 const float t = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);
                 const float y = fmaf(-2.f, __builtin_amdgcn_rcpf(t + 1.f), 1.f);
-                if (kg == 0 && s >= 4 && s - 4 < nblk && pos4 < L) *gptr<float>(yb + pos4) = y;
+                if (kg == 0 && s >= 4 && s - 4 < nblk && pos4 < L) *gptr<float>(reinterpret_cast<unsigned char*>(yb) + (unsigned)pos4 * 4u) = y;
             }
         };
 
@@ -325,16 +334,21 @@ n16s_stage_kernel(const N16SArgs a) {
         issue_x(-1);
         commit_x(-1);
         issue_x(0);
-        step(std::integral_constant<int, 2>{}, -2, 4u * S_BLK);
-        step(std::integral_constant<int, 3>{}, -1, 4u * S_BLK);
+        {
+            unsigned bx0 = rbase[0] + 4u * S_BLK, bx1 = rbase[1] + 4u * S_BLK;
+            asm volatile("" : "+v"(bx0), "+v"(bx1));
+            step(std::integral_constant<int, 2>{}, -2, bx0, bx1);
+            step(std::integral_constant<int, 3>{}, -1, bx0, bx1);
+        }
         for (int g = 0; g < ngrp; ++g) {
             commit_x(g);
             issue_x(g + 1);
-            const unsigned xtog = (g & 1) ? 4u * S_BLK : 0u;
-            step(std::integral_constant<int, 0>{}, 4 * g, xtog);
-            step(std::integral_constant<int, 1>{}, 4 * g + 1, xtog);
-            step(std::integral_constant<int, 2>{}, 4 * g + 2, xtog);
-            step(std::integral_constant<int, 3>{}, 4 * g + 3, xtog);
+            unsigned bx0 = rbase[0] + ((g & 1) ? 4u * S_BLK : 0u), bx1 = rbase[1] + ((g & 1) ? 4u * S_BLK : 0u);
+            asm volatile("" : "+v"(bx0), "+v"(bx1));
+            step(std::integral_constant<int, 0>{}, 4 * g, bx0, bx1);
+            step(std::integral_constant<int, 1>{}, 4 * g + 1, bx0, bx1);
+            step(std::integral_constant<int, 2>{}, 4 * g + 2, bx0, bx1);
+            step(std::integral_constant<int, 3>{}, 4 * g + 3, bx0, bx1);
         }
     }
 }
@@ -355,7 +369,7 @@ int v2w_resblock2_stage_bf16_n16s(const v2w_stage_split_args* q, hipStream_t str
     }
     p.post_w = q->post_w; p.post_b = q->post_b; p.post_out = q->post_out;
     p.B = q->B; p.L = q->L; p.slope = q->slope; p.out_div = q->out_div; p.post_slope = q->post_slope;
-    const int ncu = v2w_dry(stream) ? 256 : v2w_num_cus();
+    const int ncu = v2w_num_cus();
     const int nwaves = ncu * 7;
     // run length: the multiple of 64 positions that minimises (runs per wave) x (steps per run); a run costs its blocks + 6 steps of lead-in / drain
     long long best = -1; int bestR = 64;
@@ -369,6 +383,6 @@ int v2w_resblock2_stage_bf16_n16s(const v2w_stage_split_args* q, hipStream_t str
     if ((long long)q->B * p.rpr > 0x7fffffffll) return V2W_E_SHAPE;
     p.nruns = q->B * p.rpr;
     if (v2w_dry(stream)) return 0;
-    hipLaunchKernelGGL(n16s_stage_kernel, dim3(p.nruns < nwaves ? p.nruns : nwaves), dim3(64), S_LDS, stream, p);
+    V2W_LAUNCH(n16s_stage_kernel, dim3(p.nruns < nwaves ? p.nruns : nwaves), dim3(64), S_LDS, stream, p);
     return v2w_launch_status();
 }

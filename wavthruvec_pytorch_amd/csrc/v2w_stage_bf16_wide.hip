@@ -970,9 +970,9 @@ int launch_wide(const v2w_stage_split_args* q, hipStream_t stream, int* up_tiles
                                  : wide_stage_bf16_kernel<MI, NI, WM, WN, OCC, CH, WLDS, false, 0>;
     }
     if (v2w_dry(stream)) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(p.ntiles), dim3(NTH), lds, stream, p);
     return v2w_launch_status();
 }
 

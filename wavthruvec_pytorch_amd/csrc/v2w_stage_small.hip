@@ -144,6 +144,6 @@ extern "C" int v2w_resblock2_stage_small_fwd(const v2w_stage_args* q, void* stre
     p.ntl = (q->L + p.nto - 1) / p.nto;
     if ((long long)q->B * p.ntl > 0x7fffffffll) return V2W_E_SHAPE;
     const size_t lds = (size_t)SS_C * (SS_W + 2 * p.h1max + 2 * SS_W) * sizeof(float);
-    hipLaunchKernelGGL(small_stage_kernel, dim3(q->B * p.ntl), dim3(SS_NTH), lds, (hipStream_t)stream, p);
+    V2W_LAUNCH(small_stage_kernel, dim3(q->B * p.ntl), dim3(SS_NTH), lds, (hipStream_t)stream, p);
     return v2w_launch_status();
 }

@@ -374,10 +374,10 @@ int launch_stage_split(const v2w_stage_split_args* q, hipStream_t stream) {
     if (v2w_dry(stream)) return 0;
     auto kern = q->bf16 ? stage_split_kernel<NCH, NI, WN, true> : stage_split_kernel<NCH, NI, WN, false>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, stream);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(q->B * p.ntl), dim3(64 * WN), lds, stream, p);
+    V2W_LAUNCH(kern, dim3(q->B * p.ntl), dim3(64 * WN), lds, stream, p);
     return v2w_launch_status();
 }
 

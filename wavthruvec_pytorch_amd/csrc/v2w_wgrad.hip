@@ -297,8 +297,8 @@ static bool launch_pipe(const WgradArgs& p, int tiles, size_t lds, hipStream_t s
     if (!tiles) return true;                                       // dry run: "is this shape instantiated?"
     auto kern = wgrad_pipe_kernel<MF, WCO, WCI, NT, U, WIDE>;
     // the > 64 KiB LDS opt-in is per device: set on the current device at every launch (idempotent, host-side only; the library keeps no state)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
+    (void)v2w_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024, st);
+    V2W_LAUNCH(kern, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
     return true;
 }
 
@@ -553,17 +553,17 @@ static int wgrad_impl(const float* x, const float* x_a, const float* x_s, const 
                 const size_t lds = set_strides(128);
                 if (lds > 160 * 1024) return V2W_E_SHAPE;
                 if (mf == 32) {
-                    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
+                    if (lds > 64 * 1024) (void)v2w_max_lds(reinterpret_cast<const void*>(wgrad_kernel<32>), (int)lds, st);
+                    V2W_LAUNCH(wgrad_kernel<32>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 } else {
-                    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
+                    if (lds > 64 * 1024) (void)v2w_max_lds(reinterpret_cast<const void*>(wgrad_kernel<16>), (int)lds, st);
+                    V2W_LAUNCH(wgrad_kernel<16>, dim3(tiles, p.S, p.ngroups), dim3(256), lds, st, p);
                 }
             }
         }
     }
     const size_t nw = (size_t)k * c_in * c_out;
-    if (nslab >= 128) hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(1024), 0, st, slab_ws, dwf, nw, nslab);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
+    if (nslab >= 128) V2W_LAUNCH(wgrad_reduce16_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(1024), 0, st, slab_ws, dwf, nw, nslab);
+    else V2W_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256), ngroups), dim3(256), 0, st, slab_ws, dwf, nw, nslab);
     return v2w_launch_status();
 }

@@ -281,8 +281,8 @@ static int wgb_plan(int B, int c_in, int c_out, int Lq, int k, int* mf_o, int* t
 template <int MF, int WCO, int WCI, int NT, bool BF>
 static void wgb_launch(const WgBfArgs& p, int tiles, size_t lds, hipStream_t st) {
     auto kern = wgrad_bf16_kernel<MF, WCO, WCI, NT, BF>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.S), dim3(256), lds, st, p);
+    if (lds > 64 * 1024) (void)v2w_max_lds(reinterpret_cast<const void*>(kern), (int)lds, st);
+    V2W_LAUNCH(kern, dim3(tiles, p.S), dim3(256), lds, st, p);
 }
 
 template <int MF, int WCO, int WCI, bool BF>
@@ -349,6 +349,6 @@ extern "C" int v2w_wgrad_bf16(const void* x, const float* x_a, const float* x_s,
     }
     if (!ok) return V2W_E_SHAPE;
     const size_t nw = (size_t)k * c_in * c_out;
-    hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(1024), 0, st, slab_ws, dwf, nw, S);
+    V2W_LAUNCH(wgrad_bf16_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(1024), 0, st, slab_ws, dwf, nw, S);
     return v2w_launch_status();
 }

@@ -97,8 +97,17 @@ class ForwardPlanner:
             if g._profile is None or not isinstance(self.S, DirectStreams):
                 return fn(*args, **kw)          # (a recorded plan is profiled at replay)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pn = g._profile_names                # Generator.profile_kernel_names: also ask every launch of the tag for its kernel names
             e0.record()
-            r = fn(*args, **kw)
+            if pn is not None:
+                from . import _hip, schedule
+                prev = _hip.set_recorder(schedule.NameProbe(_hip.load(), pn.setdefault(tag, [])))
+                try:
+                    r = fn(*args, **kw)
+                finally:
+                    _hip.set_recorder(prev)
+            else:
+                r = fn(*args, **kw)
             e1.record()
             g._profile.append((tag, e0, e1))
             return r

@@ -223,6 +223,7 @@ class Generator(nn.Module):
         self._wts: Dict[str, torch.Tensor] = {}
         self._fold_key: Dict[str, tuple] = {}
         self._profile = None                  # list -> (tag, start_event, end_event) per conv launch (bench.py roofline)
+        self._profile_names = None            # dict -> tag: kernel names, filled beside `_profile` by profile_kernel_names
         self.use_launch_plan = True           # no-grad forwards: planned once per configuration, replayed from the recorded tape (schedule.py)
         self._tapes: Dict[tuple, object] = {}
         self._ws_epoch = 0                    # bumped whenever a workspace / weight buffer is (re)allocated: recorded tapes point into them
@@ -233,7 +234,7 @@ class Generator(nn.Module):
         launch plans (ctypes structs and function pointers into THIS module's buffers), workspaces, folded weights, split-over-C_in slabs
         and the profile list do not - the copy plans, allocates and folds for itself at its first forward."""
         st = self.__dict__.copy()
-        st.update(_tapes={}, _ws={}, _slabs={}, _wts={}, _fold_key={}, _profile=None, _ws_epoch=0)
+        st.update(_tapes={}, _ws={}, _slabs={}, _wts={}, _fold_key={}, _profile=None, _profile_names=None, _ws_epoch=0)
         return st
 
     def enable_sync_batchnorm(self, group=None, single_rank_collective=None):
@@ -242,6 +243,20 @@ class Generator(nn.Module):
         from .distributed import BNStatSync
         self.stat_sync = BNStatSync(group, single_rank_collective=single_rank_collective)
         return self
+
+    def profile_kernel_names(self, x, spk_emb, noise):
+        """tag -> names of the kernels behind each tagged launch of ONE no-grad forward of these inputs (the tags of `_profile`), as
+        `rocprofv3 --kernel-trace` prints them minus namespace and parameter list.  Asked of the library (v2w_name_sink: every launching entry
+        point reports the kernels it selects), never reconstructed from tile tables on this side.  The forward runs; its timing is not meant
+        to be used (the name queries sit between its launches)."""
+        keep = self._profile
+        self._profile, self._profile_names = [], {}
+        try:
+            with torch.no_grad():
+                self.forward(x, spk_emb, noise)
+            return dict(self._profile_names)
+        finally:
+            self._profile, self._profile_names = keep, None
 
     def capture_graph(self, x, spk_emb, noise, warmup: int = 2):
         """Capture one forward (current train/eval mode, these shapes) into a HIP graph and return `run(x, spk_emb, noise)`.
@@ -605,6 +620,8 @@ class Generator(nn.Module):
         if tape is not None:
             y = torch.empty(tape.out[0], device=dev, dtype=tape.out[1])
             tape.replay(main, side, dict(x=x.data_ptr(), spk=spk.data_ptr(), nz=nz.data_ptr(), y=y.data_ptr()), self._profile)
+            if self._profile_names is not None:
+                self._profile_names.update(tape.kernel_names())
             if refold is not None:                      # the replay folded what was stale: what the fold cache must say now
                 wvers, sigma = refold
                 if wvers is not None:                   # it held the weight folds

@@ -88,6 +88,16 @@ class Tape:
             if name != 'y' and not self.patches[name]:
                 raise RuntimeError(f'schedule: no recorded call reads {name}')
 
+    def kernel_names(self) -> Dict[str, list]:
+        """tag -> names of the kernels the tagged main-stream calls of this plan launch, in order (asked of the library call by call through
+        a v2w_name_sink: host-only, nothing runs).  bench.py labels its per-launch timings with these."""
+        out: Dict[str, list] = {}
+        for st in self.steps:
+            if st.kind == K_CALL and st.tag is not None:
+                _rc, names = _hip.kernel_names(st.fn, *st.args)
+                out.setdefault(st.tag, []).extend(names)
+        return out
+
     def replay(self, main, side, binds: Dict[str, int], profile: Optional[list] = None):
         for name, addr in binds.items():
             for cont, key in self.patches[name]:
@@ -126,6 +136,26 @@ class Tape:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(main)
             profile.append((open_tag, e0, e1))
+
+
+class NameProbe:
+    """Stands in front of the library while ONE tagged step of a profiled, planned forward runs (forward_plan.ForwardPlanner.timed): every
+    launching call is made, and asked for its kernel names through a v2w_name_sink."""
+
+    def __init__(self, lib, names: list):
+        self._lib, self._names = lib, names
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in _hip.LAUNCHERS:
+            return fn
+
+        def call(*args):
+            rc = fn(*args)
+            if rc == 0:
+                self._names.extend(_hip.kernel_names(fn, *args[:-1])[1])
+            return rc
+        return call
 
 
 class Recorder:
