@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(PKG_DIR, 'libvec2wav_hip.so')
-SOURCES = ['v2w_api.hip', 'v2w_conv_mfma.hip', 'v2w_conv_split.hip', 'v2w_conv_bf16.hip', 'v2w_conv_bf16_res.hip', 'v2w_convt_bf16_res.hip', 'v2w_stage_split.hip', 'v2w_stage_bf16.hip', 'v2w_stage_bf16_wide.hip', 'v2w_stage_bf16_n16.hip', 'v2w_stage_bf16_n16s.hip', 'v2w_resblock_fused.hip', 'v2w_stage_small.hip',
+SOURCES = ['v2w_api.hip', 'v2w_conv_mfma.hip', 'v2w_conv_split.hip', 'v2w_conv_bf16.hip', 'v2w_conv_bf16_res.hip', 'v2w_convt_bf16_res.hip', 'v2w_stage_split.hip', 'v2w_stage_bf16.hip', 'v2w_stage_bf16_wide.hip', 'v2w_stage_bf16_n16.hip', 'v2w_stage_bf16_n16s.hip', 'v2w_stage_bf16_n32s.hip', 'v2w_resblock_fused.hip', 'v2w_stage_small.hip',
            'v2w_wgrad.hip', 'v2w_wgrad_bf16.hip', 'v2w_backward.hip', 'v2w_direct.hip', 'v2w_conv_post_bf16.hip', 'v2w_cbn.hip', 'v2w_fold.hip', 'v2w_mel.hip', 'v2w_disc.hip']
 HEADERS = ['v2w_common.h', 'v2w_tile.h', os.path.join('..', '..', 'include', 'vec2wav_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']

@@ -442,11 +442,16 @@ V2W_TL_SETTER(v2w_timeline_set_stage_bf16)
 int v2w_resblock2_stage_bf16_wide(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out = nullptr);   // v2w_stage_bf16_wide.hip
 int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
 int v2w_resblock1_pairs_bf16_n16(const v2w_stage_split_args* a, hipStream_t stream);    // v2w_stage_bf16_n16.hip
+int v2w_resblock2_stage_bf16_n32s(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out);   // v2w_stage_bf16_n32s.hip
 
 // Called by v2w_resblock2_stage_split_fwd when a->bf16 is set.  V2W_E_SHAPE: the caller falls back to the split stage kernel.
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out) {
     if (a->up_out) {        // the stage + the next upsampler in one kernel: the resident-tile template only (C = 32 .. 256 on bf16 tensors)
         if (a->io_bf16 != 3 || a->C < 32) return V2W_E_SHAPE;
+        if (a->C == 32 && !getenv("V2W_N32S_OFF")) {      // 32 channels + the stride-2 upsampler: the streaming kernel of four-wave teams
+            const int rc = v2w_resblock2_stage_bf16_n32s(a, stream, up_tiles_out);
+            if (rc != V2W_E_SHAPE) return rc;
+        }
         return v2w_resblock2_stage_bf16_wide(a, stream, up_tiles_out);
     }
     if (a->rb1) {           // ResBlock1 pair mode: 16 channels on the weights-in-registers kernel, else the resident-tile template's run-time form

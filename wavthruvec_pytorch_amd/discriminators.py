@@ -440,7 +440,7 @@ class _DiscFn(torch.autograd.Function):
                     wT4 = rec['w4'].flip(1).transpose(2, 3).contiguous()        # [G][kp][cog][cigp], taps reversed
                     rec['wT'] = list(wT4.unbind(0))
                     rec['wTp'] = list(hipops.pack_mfma_batch(wT4).unbind(0)) if packable else [None] * G
-                if 'wps' in rec and 'wTs' not in rec and hipops.split_supported(cog, cigp):
+                if 'wps' in rec and 'wTs' not in rec and hipops.split_supported(cog, cigp) and getattr(layer, '_no_split_dgrad', None) != (cog, cigp, P):
                     # the same layer's input-gradient conv in split-f16 form: transposed, tap-reversed (the zero pad tap comes first)
                     wTs4 = rec['ws4'].flip(1).transpose(2, 3).contiguous()       # [G][kps][cog][cigp]
                     rec['wTs4'], rec['wTs'] = wTs4, [hipops.pack_split(wTs4[gi]) for gi in range(G)]
@@ -456,10 +456,14 @@ class _DiscFn(torch.autograd.Function):
                                 hipops.conv1d_multi(probs[i:i + 4])
                     except _hip.HipLibraryError as e:
                         # the split-f16 kernel took the forward but declines the TRANSPOSED problem (another halo, another channel count per
-                        # group): the exact fp32 input-gradient conv below, for this and every later step
+                        # group): the exact fp32 input-gradient conv below - for this step and, remembered ON THE LAYER (`rec` is rebuilt whenever
+                        # a parameter version moves, i.e. after every optimizer step), for every later one: no re-pack, no retry.  The exact conv
+                        # overwrites whatever groups the declined launches wrote.
                         if e.code != _hip.E_SHAPE:
                             raise
-                        rec.pop('wTs', None); rec.pop('wTs4', None); rec.pop('wps', None)
+                        layer._no_split_dgrad = (cog, cigp, P)
+                        for key in ('wTs', 'wTs4'):
+                            rec.pop(key, None)
                 if 'wTs' not in rec:
                     probs = [(dz, rec['wT'][gi], None, dxs, dict(k=kp, dil=dil, slope=1.0, pad_left=(kp - 1 - Q) * dil, wp=rec['wTp'][gi],
                                                                  group=(gi, cog, cigp) if G > 1 else None)) for gi in range(G)]

@@ -211,10 +211,13 @@ _SPLITK_BYTES = {}      # what a launch's split over C_in needs depends on its s
 
 
 def _splitk_bytes(a, n):
-    q = a[0] if n > 1 else a
-    key = (n, q.B, q.C_in, q.C_out, q.L, q.k, q.dil, q.algo, q.accumulate, q.in_stride, q.pad_left, q.in_ct, q.out_ct, q.io_bf16,
-           bool(q.res), bool(q.add0), bool(q.add1), bool(q.mask_src), bool(q.in_a), bool(q.rowsum_part), bool(q.wps), bool(q.wp), q.out_div != 0.0,
-           q.out_slope != 0.0)
+    """Bytes of split-over-C_in scratch the launch of these n problems would use (0: unsplit).  The library's answer depends on EVERY problem of
+    a multi-problem launch - tap count and dilation (the widest halo picks the tile variant and the grid), the epilogue kind of each - so the key
+    holds them all (keyed by problem 0 alone, two launches that differ in problems 1.. could share a stale byte count)."""
+    qs = [a[i] for i in range(n)] if n > 1 else [a]
+    key = (n,) + tuple((q.B, q.C_in, q.C_out, q.L, q.k, q.dil, q.algo, q.accumulate, q.in_stride, q.pad_left, q.in_ct, q.out_ct, q.io_bf16,
+                        bool(q.res), bool(q.add0), bool(q.add1), bool(q.mask_src), bool(q.in_a), bool(q.rowsum_part), bool(q.wps), bool(q.wp),
+                        q.out_div != 0.0, q.out_slope != 0.0) for q in qs)
     v = _SPLITK_BYTES.get(key)
     if v is None:
         v = _SPLITK_BYTES[key] = int(_hip.load().v2w_conv1d_splitk_ws_bytes(a if n > 1 else C.byref(a), n))
