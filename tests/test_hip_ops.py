@@ -507,8 +507,15 @@ def test_resblock2_wide_stage_with_the_next_upsampler_fused(dev, B, C, L, u, wit
         assert torch.isfinite(part).all()
         sums = part.view(nt, cu, 2).double().sum(0).cpu()
         n = B * L * u
-        assert (sums[:, 0] - want.sum((0, 2))).abs().max().item() <= 5e-3 * n ** 0.5 + 1e-3 * want.sum((0, 2)).abs().max().item()
-        assert (sums[:, 1] - (want * want).sum((0, 2))).abs().max().item() <= 2e-3 * (want * want).sum((0, 2)).max().item()
+        # the partial rows add up to the sums of the fp32 values behind the STORED tensor (one bf16 rounding per element: 2^-9 relative, random
+        # sign) - a tighter statement than a comparison with the reference's sums, which also carries the kernels' legitimate rounding choices
+        # (round 6: the 32-channel streaming kernel adds t1 back as a bf16 tensor, as the reference under autocast does)
+        own = out.cpu().double()
+        rms = (own * own).mean().sqrt().item()
+        assert (sums[:, 0] - own.sum((0, 2))).abs().max().item() <= 2.0 ** -9 * rms * (6 * n ** 0.5 + 8) + 1e-6 * n
+        assert (sums[:, 1] - (own * own).sum((0, 2))).abs().max().item() <= 2e-3 * (own * own).sum((0, 2)).max().item()
+        assert (sums[:, 0] - want.sum((0, 2))).abs().max().item() <= 1.5e-2 * n ** 0.5 + 1e-3 * want.sum((0, 2)).abs().max().item()
+        assert (sums[:, 1] - (want * want).sum((0, 2))).abs().max().item() <= 4e-3 * (want * want).sum((0, 2)).max().item()
     # shapes the fused form does not exist for are declined by the query (the caller then runs the two kernels)
     assert hipops.resblock2_stage_up_tiles(B, C, L, ks, d1, d2, slope=0.1, up_k=11, up_u=5, up_slope=0.1) == 0
     assert hipops.resblock2_stage_up_tiles(B, C, L, [3, 5, 7], d1, d2, slope=0.1, up_k=ku, up_u=u, up_slope=0.1) == 0

@@ -17,12 +17,21 @@ for B, T in ((32, 256), (64, 512), (16, 256)):
     name = hipops.conv_bf16_config(B, 1, cin, 512, T, 7, 1, 1, io_bf16=2)
     def run():
         hipops.conv1d(x, None, bias, out, k=7, dil=1, slope=1.0, algo=hipops.ALGO_BF16, wps=wps, io_bf16=2)
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(20):
-        run()
-    e1.record(); torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / 20 * 1e-3
-    print(f'B={B} T={T} cin={cin}: {name}  {t * 1e6:.1f} us  {2 * cin * 512 * 7 * B * T / t / 1e12:.0f} TF')
+    ref = None
+    for var in ('', '1', '', '1'):                  # V2W_PRE_TILE=1: the 128 x 128 tile (round-6 experiment switch in v2w_conv1d_bf16)
+        os.environ.pop('V2W_PRE_TILE', None)
+        if var:
+            os.environ['V2W_PRE_TILE'] = var
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 20 * 1e-3
+        o = out.float().clone()
+        if ref is None:
+            ref = o
+        print(f'B={B} T={T} cin={cin} tile-switch={var or 0}: {t * 1e6:.1f} us  {2 * cin * 512 * 7 * B * T / t / 1e12:.0f} TF  max diff vs first {(o - ref).abs().max().item():.2e}')
+    os.environ.pop('V2W_PRE_TILE', None)

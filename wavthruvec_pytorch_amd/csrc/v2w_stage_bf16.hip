@@ -448,7 +448,7 @@ int v2w_resblock2_stage_bf16_n32s(const v2w_stage_split_args* a, hipStream_t str
 int v2w_resblock2_stage_bf16(const v2w_stage_split_args* a, hipStream_t stream, int* up_tiles_out) {
     if (a->up_out) {        // the stage + the next upsampler in one kernel: the resident-tile template only (C = 32 .. 256 on bf16 tensors)
         if (a->io_bf16 != 3 || a->C < 32) return V2W_E_SHAPE;
-        if (a->C == 32 && !getenv("V2W_N32S_OFF")) {      // 32 channels + the stride-2 upsampler: the streaming kernel of four-wave teams
+        if (a->C == 32) {      // 32 channels + the stride-2 upsampler: the streaming kernel of four-wave teams
             const int rc = v2w_resblock2_stage_bf16_n32s(a, stream, up_tiles_out);
             if (rc != V2W_E_SHAPE) return rc;
         }

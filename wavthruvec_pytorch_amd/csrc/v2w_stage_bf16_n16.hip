@@ -15,7 +15,6 @@
 //   * the accumulator of a 16 x 16 block holds, per lane, 4 consecutive CHANNELS of one position = 8 contiguous bytes of a tile row: the
 //     residual read and the t1 write of the epilogue are single 8-byte LDS accesses.
 // One operand read per MFMA is exactly the LDS's 256 B / clk / CU: the conv loops are LDS-bound (~0.13 ms at configs[2]), not weight-bound.
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include "v2w_tile.h"
@@ -698,7 +697,7 @@ int v2w_resblock2_stage_bf16_n16(const v2w_stage_split_args* a, hipStream_t stre
     if (a->L % 4 != 0 || !al16(a->in) || !al16(a->out) || (!a->out && !a->post_out)) return V2W_E_SHAPE;
     if ((long long)16 * a->L * 2 >= (1ll << 31)) return V2W_E_SHAPE;            // 32-bit offsets inside one batch item
     if (!(a->slope > 0.f && a->slope < 1.f)) return V2W_E_SHAPE;                // lrelu as max(v, slope v), undone as min(a, a / slope)
-    if (a->post_out && !getenv("V2W_N16S_OFF")) {                               // stage + tail: the streaming kernel (one wave per workgroup, no barriers)
+    if (a->post_out) {                               // stage + tail: the streaming kernel (one wave per workgroup, no barriers)
         const int rc = v2w_resblock2_stage_bf16_n16s(a, stream);
         if (rc != V2W_E_SHAPE) return rc;
     }

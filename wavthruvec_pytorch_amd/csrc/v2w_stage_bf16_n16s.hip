@@ -57,6 +57,11 @@ __device__ __forceinline__ float s_hi(unsigned int w) { return __builtin_bit_cas
 
 // max(v, w) as ONE instruction: fmaxf(v, w) costs two here - hipcc first canonicalises an operand that comes out of an MFMA with v_max_f32(v, v)
 __device__ __forceinline__ float s_max(float v, float w) { float t; asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
+// scalar-form multiplies and adds beside MFMAs: left to -O3 these are SLP-packed into v_pk_mul_f32 / v_pk_add_f32, which issue at well under half the
+// rate of two plain instructions next to matrix work (MI355X guide, 'price of one filler beside MFMAs')
+__device__ __forceinline__ float s_mul(float v, float w) { float t; asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float t; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c)); return t; }
+__device__ __forceinline__ float s_add(float v, float w) { float t; asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
 
 template <int... I, class F> __device__ __forceinline__ void s_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -229,8 +234,8 @@ n16s_stage_kernel(const N16SArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float xv = (e & 1) ? s_hi(pf[i][e >> 1]) : s_lo(pf[i][e >> 1]);
-                    y[i] = fmaf(av[i], xv, sv[i]);
-                    v[i] = fmaxf(y[i], y[i] * slope);
+                    y[i] = s_fma(av[i], xv, sv[i]);
+                    v[i] = s_max(y[i], s_mul(y[i], slope));
                 }
                 su32x2 w = {s_pack2(v[0], v[1]), s_pack2(v[2], v[3])};
                 su32x2 r = {s_pack2(y[0], y[1]), s_pack2(y[2], y[3])};
@@ -246,6 +251,13 @@ n16s_stage_kernel(const N16SArgs a) {
             constexpr int I = decltype(i_c)::value;
             constexpr int RING = 8;
             const unsigned bt2 = rbase[2], bt3 = rbase[3], bt4 = rbase[4];
+#ifdef V2W_TIMELINE
+            const bool tl = s == 9 && run == (int)blockIdx.x;                  // one steady-state step of the wave's first run
+#define S_STAMP(k) do { if (tl) V2W_STAMP(k); } while (0)
+#else
+#define S_STAMP(k) ((void)0)
+#endif
+            S_STAMP(0);
             f32x4 acc[5];
             const f32x4 init[5] = {b1v[0], b1v[1], b1v[2], ts[I & 1], f32x4{0.f, 0.f, 0.f, 0.f}};
             su32x4 ring[RING];
@@ -261,6 +273,7 @@ n16s_stage_kernel(const N16SArgs a) {
                 else if constexpr (bs == 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(bt3), "n"(imm));
                 else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % RING]) : "v"(bt4), "n"(imm));
             };
+            S_STAMP(1);
             s_for(std::make_integer_sequence<int, RING>{}, rd);
             s_for(std::make_integer_sequence<int, S_NM>{}, [&ring, &acc, &init, &W, &rd, &mfma](auto m_c) __attribute__((always_inline)) {
                 constexpr int m = decltype(m_c)::value;
@@ -275,6 +288,7 @@ n16s_stage_kernel(const N16SArgs a) {
                 if constexpr (kStepProg<I>.last_use(q.rd) == m && q.rd + RING < S_NR) rd(std::integral_constant<int, q.rd + RING>{});
             });
             __builtin_amdgcn_sched_barrier(0);
+            S_STAMP(2);
 
             // ---- t1 epilogue of block s: acc[jb] = t1_jb (bias, residual and conv) at position p0 + 16 s + j, channels 4 kg ..; 0 outside the
             // sequence (conv2 zero-pads lrelu(t1)); the running output takes t1 in fp32, the ring lrelu(t1) as bf16
@@ -288,10 +302,8 @@ n16s_stage_kernel(const N16SArgs a) {
                     asm volatile("" ::: "memory");
                     if (pos1 < 0 || pos1 >= L) t1v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                tsum += t1v;
-                const f32x4 tsl = t1v * slope;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[r] = s_max(t1v[r], tsl[r]);
+                for (int r = 0; r < 4; ++r) { tsum[r] = s_add(tsum[r], t1v[r]); t1v[r] = s_max(t1v[r], s_mul(t1v[r], slope)); }
                 const su32x2 w = {s_pack2(t1v[0], t1v[1]), s_pack2(t1v[2], t1v[3])};
                 unsigned char* const d = wbase + S_TOFF + jb * 2 * S_TP;
                 *reinterpret_cast<su32x2*>(d + (I + 1) * S_BLK) = w;
@@ -299,14 +311,14 @@ n16s_stage_kernel(const N16SArgs a) {
                 if constexpr (I == 3) *reinterpret_cast<su32x2*>(d) = w;
             }
             ts[I & 1] = tsum;
+            S_STAMP(3);
             // ---- z epilogue of block s - 2: z = lrelu(sum, post_slope) (the division by 3 sits in the tail's weights), 0 outside the sequence
             {
                 const int pos2 = pos1 - 32;
                 const bool edge2 = p0 + 16 * s - 32 < 0 || p0 + 16 * s - 16 > L;
                 f32x4 z = acc[3];
-                const f32x4 zs = z * pslope;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[r] = s_max(z[r], zs[r]);
+                for (int r = 0; r < 4; ++r) z[r] = s_max(z[r], s_mul(z[r], pslope));
                 if (edge2) {
                     asm volatile("" ::: "memory");
                     if (pos2 < 0 || pos2 >= L) z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -318,6 +330,7 @@ n16s_stage_kernel(const N16SArgs a) {
                 if constexpr (ZS == 0) *reinterpret_cast<su32x2*>(d + 5 * S_BLK) = w;
                 if constexpr (ZS == 3) *reinterpret_cast<su32x2*>(d) = w;
             }
+            S_STAMP(4);
             // ---- the tail of block s - 4: rows 0 / 1 of the accumulator (lanes 0 .. 15) hold the hi / lo weight halves' sums for position j
             {
                 const int pos4 = pos1 - 64;
@@ -327,6 +340,8 @@ n16s_stage_kernel(const N16SArgs a) {
                 const float y = fmaf(-2.f, __builtin_amdgcn_rcpf(t + 1.f), 1.f);
                 if (kg == 0 && s >= 4 && s - 4 < nblk && pos4 < L) *gptr<float>(reinterpret_cast<unsigned char*>(yb) + (unsigned)pos4 * 4u) = y;
             }
+            S_STAMP(5);
+            if (s == 10 && run == (int)blockIdx.x) V2W_STAMP(6);              // (the start of the next step)
         };
 
         // ---- the run: burst -1 (blocks -3 .. 0), steps -2 and -1 (conv1 of the two blocks in front of the run; their conv2 / tail halves work on
@@ -354,6 +369,10 @@ n16s_stage_kernel(const N16SArgs a) {
 }
 
 }  // namespace
+
+#ifdef V2W_TIMELINE
+V2W_TL_SETTER(v2w_timeline_set_n16s)
+#endif
 
 // Called by v2w_resblock2_stage_bf16_n16 (v2w_stage_bf16_n16.hip) for the 16-channel stage WITH the generator's 7-tap tail on bf16 tensors.
 // V2W_E_SHAPE: not served (the caller runs n16_stage_kernel).  Host-only when `stream` is the dry-run sentinel.

@@ -8,9 +8,9 @@
 // accumulator arrays) needs every weight of the stage in registers.  At 32 channels that is 84 KB of bf16 fragments + 6 KB for the upsampler -
 // more than one wave's register file - so FOUR waves form a team and each holds a quarter, by ROLE:
 //   wave 0   conv1 of the k = 11 branch (both 16-channel halves of the output)        + the upsampler's channels 0..7
-//   wave 1   conv1 of the k = 7 and k = 3 branches (they read the SAME seven windows)  + the upsampler's channels 8..15
+//   wave 1   conv1 of the k = 7 and k = 3 branches (they read the SAME seven windows)
 //   wave 2   conv2 of the k = 11 branch, the sum of the branches, z = lrelu(out / 3)   + half of the staging of x
-//   wave 3   conv2 of the k = 7 and k = 3 branches                                     + half of the staging of x
+//   wave 3   conv2 of the k = 7 and k = 3 branches + the upsampler's channels 8..15     + half of the staging of x
 // v_mfma_f32_16x16x32_bf16 with K = the 32 input channels of ONE tap: an operand read (16 positions x 32 channels, 1 KB) feeds both output
 // halves, and for wave 1 both branches.  The waves of a team run in lock step, one s_barrier per step; the pipeline is skewed so that nobody
 // waits for data of the same step: step s runs conv1 of block s, conv2 of block s - 2, the branch sum of block s - 3 (wave 3 hands its partial
@@ -50,7 +50,11 @@ __device__ __forceinline__ unsigned int t_pack2(float lo, float hi) {
 }
 __device__ __forceinline__ float t_lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float t_hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// one-instruction forms: fmaxf canonicalises an MFMA result first (v_max x, x), and -O3 SLP-packs adjacent f32 multiplies into v_pk_mul_f32,
+// which issues slower than two plain multiplies beside matrix work
 __device__ __forceinline__ float t_max(float v, float w) { float t; asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
+__device__ __forceinline__ float t_mul(float v, float w) { float t; asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(v), "v"(w)); return t; }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { float t; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c)); return t; }
 // the team's barrier: LDS traffic only (__syncthreads() would also wait for the acknowledgement of the output stores)
 __device__ __forceinline__ void t_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -60,6 +64,10 @@ template <int... I, class F> __device__ __forceinline__ void t_for(std::integer_
 struct TRd { int base, imm; };              // base register: 0 x ring, 1 raw-x ring, 2 lrelu(t1) / z rings, 3 t1 rings
 struct TMm { int acc, w, rd, first; };
 constexpr int T_MAXR = 16, T_MAXM = 28;
+#ifndef V2W_N32S_RING
+#define V2W_N32S_RING 12
+#endif
+constexpr int T_RING = V2W_N32S_RING;          // operand reads in flight per wave
 template <int ROLE, int I> struct RoleProg {
     int nr, nm;
     TRd rd[T_MAXR]; TMm mm[T_MAXM];
@@ -74,7 +82,7 @@ template <int ROLE, int I> struct RoleProg {
             mm[nm++] = TMm{0, 22, nr, 0}; mm[nm++] = TMm{1, 23, nr, 0};
             ++nr;
             up(2, 24);
-        } else if (ROLE == 1) {                            // conv1, k = 7 (0..13) and k = 3 (14..19) on the same seven windows; identity 20 / 21; upsampler half 1: 22..24
+        } else if (ROLE == 1) {                            // conv1, k = 7 (0..13) and k = 3 (14..19) on the same seven windows; identity 20 / 21
             for (int t = 0; t < 7; ++t) {
                 rd[nr] = TRd{0, T_XOFF + (I + 1) * T_BLK + (t - 3) * 16};
                 mm[nm++] = TMm{0, 2 * t, nr, t == 0}; mm[nm++] = TMm{1, 2 * t + 1, nr, t == 0};
@@ -84,7 +92,6 @@ template <int ROLE, int I> struct RoleProg {
             rd[nr] = TRd{1, I * T_BLK};
             mm[nm++] = TMm{0, 20, nr, 0}; mm[nm++] = TMm{1, 21, nr, 0}; mm[nm++] = TMm{2, 20, nr, 0}; mm[nm++] = TMm{3, 21, nr, 0};
             ++nr;
-            up(4, 22);
         } else if (ROLE == 2) {                            // conv2, k = 11, of block s - 2: lrelu(t1) ring slot (I + 2) & 3; + t1 itself through the identity
             const int cs = (I + 2) & 3;
             for (int t = 0; t < 11; ++t) {
@@ -95,7 +102,7 @@ template <int ROLE, int I> struct RoleProg {
             rd[nr] = TRd{3, T_QOFF + 2 * 4 * T_QP + cs * T_BLK};
             mm[nm++] = TMm{0, 22, nr, 0}; mm[nm++] = TMm{1, 23, nr, 0};
             ++nr;
-        } else {                                           // conv2, k = 7 (0..13) and k = 3 (14..19), ONE pair of accumulators; identity 20 / 21
+        } else {                                           // conv2, k = 7 (0..13) and k = 3 (14..19), ONE pair of accumulators; identity 20 / 21; upsampler half 1: 22..24
             const int cs = (I + 2) & 3;
             for (int t = 0; t < 7; ++t) {
                 rd[nr] = TRd{2, T_AOFF + 1 * 4 * T_AP + (cs + 1) * T_BLK + 3 * (t - 3) * 16};
@@ -112,6 +119,7 @@ template <int ROLE, int I> struct RoleProg {
                 mm[nm++] = TMm{0, 20, nr, 0}; mm[nm++] = TMm{1, 21, nr, 0};
                 ++nr;
             }
+            up(2, 22);
         }
     }
     constexpr void up(int acc, int w0) {                   // the upsampler's 3 virtual taps on the z blocks around block s - 5 (z ring slot (I + 3) & 3)
@@ -129,8 +137,10 @@ template <int ROLE, int I> inline constexpr RoleProg<ROLE, I> kRoleProg{};
 // One role of a team.  Every role runs the same sequence of barriers: one after the lead-in staging of a run, one after each step.
 template <int ROLE>
 __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* const smem_t) {
-    constexpr int NW = ROLE == 0 ? 27 : ROLE == 1 ? 25 : ROLE == 2 ? 24 : 22;
-    constexpr int NACC = ROLE == 0 ? 3 : ROLE == 1 ? 5 : 2;
+    constexpr int NW = ROLE == 0 ? 27 : ROLE == 1 ? 22 : ROLE == 2 ? 24 : 25;
+    constexpr int NACC = ROLE == 0 ? 3 : ROLE == 1 ? 4 : ROLE == 2 ? 2 : 3;
+    constexpr bool UP = ROLE == 0 || ROLE == 3;                                 // this role runs a half of the upsampler: virtual rows 16 UH ..
+    constexpr int UH = ROLE == 3 ? 1 : 0;
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, kg = lane >> 4;
     const int L = __builtin_amdgcn_readfirstlane(a.L), R = __builtin_amdgcn_readfirstlane(a.R), rpr = __builtin_amdgcn_readfirstlane(a.rpr);
@@ -163,9 +173,9 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
             for (int t = 0; t < 3; ++t) { W[14 + 2 * t] = frag(w3, 3, t, 0); W[15 + 2 * t] = frag(w3, 3, t, 1); }
             W[20] = ident[0]; W[21] = ident[1];
         }
-        if constexpr (ROLE < 2) {                                               // the upsampler as a 3-tap conv over the 32 virtual rows co * 2 + phase (v2w_pack_bf16_convt)
+        if constexpr (UP) {                                                     // the upsampler as a 3-tap conv over the 32 virtual rows co * 2 + phase (v2w_pack_bf16_convt)
 #pragma unroll
-            for (int tv = 0; tv < 3; ++tv) W[(ROLE == 0 ? 24 : 22) + tv] = frag(a.up_w, 3, tv, ROLE);
+            for (int tv = 0; tv < 3; ++tv) W[(ROLE == 0 ? 24 : 22) + tv] = frag(a.up_w, 3, tv, UH);
         }
     }
     // initial values of the accumulators: the biases of this lane's channels 16 mh + 4 kg .. + 3
@@ -183,8 +193,8 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
         if constexpr (ROLE == 1) { init[0] = bias4(a.bias1[1], 0); init[1] = bias4(a.bias1[1], 1); init[2] = bias4(a.bias1[0], 0); init[3] = bias4(a.bias1[0], 1); }
         if constexpr (ROLE == 2) { init[0] = bias4(a.bias2[2], 0); init[1] = bias4(a.bias2[2], 1); }
         if constexpr (ROLE == 3) { init[0] = bias4(a.bias2[1], 0) + bias4(a.bias2[0], 0); init[1] = bias4(a.bias2[1], 1) + bias4(a.bias2[0], 1); }
-        if constexpr (ROLE < 2) {           // virtual rows 16 ROLE + 4 kg + r = channel 8 ROLE + 2 kg + (r >> 1), phase r & 1
-            const int c0 = 8 * ROLE + 2 * kg;
+        if constexpr (UP) {                 // virtual rows 16 UH + 4 kg + r = channel 8 UH + 2 kg + (r >> 1), phase r & 1
+            const int c0 = 8 * UH + 2 * kg;
             const float u0 = a.up_bias ? a.up_bias[c0] : 0.f, u1 = a.up_bias ? a.up_bias[c0 + 1] : 0.f;
             init[NACC - 1] = f32x4{u0, u0, u1, u1};
         }
@@ -222,7 +232,7 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
         const int nblk = (min(R, L - p0) + 15) >> 4, ngrp = (nblk + 8) >> 2;       // steps -2 .. 4 ngrp - 1 >= nblk + 4 (the upsampler of the last block)
         const unsigned char* const inb = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * 32 * L * 2;
         unsigned char* const ob = reinterpret_cast<unsigned char*>(a.up_out) + (size_t)b * 16 * Lout * 2;
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};                           // roles 0 / 1: partial sums of the upsampler's output, channels 8 ROLE + 2 kg + {0, 1}
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};                           // roles 0 / 3: partial sums of the upsampler's output, channels 8 UH + 2 kg + {0, 1}
         if constexpr (ROLE >= 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -252,8 +262,8 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float xv = (e & 1) ? t_hi(pf[i][e >> 1]) : t_lo(pf[i][e >> 1]);
-                    y[i] = fmaf(av[i], xv, sv[i]);
-                    v[i] = fmaxf(y[i], y[i] * slope);
+                    y[i] = t_fma(av[i], xv, sv[i]);
+                    v[i] = t_max(y[i], t_mul(y[i], slope));
                 }
                 tu32x2 w = {t_pack2(v[0], v[1]), t_pack2(v[2], v[3])};
                 tu32x2 r = {t_pack2(y[0], y[1]), t_pack2(y[2], y[3])};
@@ -267,7 +277,7 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
         auto step = [&](auto i_c, int s, unsigned bx0, unsigned bx1) __attribute__((always_inline)) {
             using IC = decltype(i_c);                                           // (a type: nested generic lambdas name it without a capture)
             constexpr int I = IC::value;
-            constexpr int RING = 8;
+            constexpr int RING = T_RING;
             using Prog = std::integral_constant<const RoleProg<ROLE, IC::value>*, &kRoleProg<ROLE, IC::value>>;
             constexpr int NR = Prog::value->nr, NM = Prog::value->nm;
             const unsigned bt2 = rbase[2], bt3 = rbase[3];
@@ -279,16 +289,16 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                 constexpr int n = decltype(n_c)::value;
                 constexpr int bs = Prog::value->rd[n].base, imm = Prog::value->rd[n].imm;
                 static_assert(imm >= 0 && imm < 65536, "ds_read offset field");
-                if constexpr (bs == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % 8]) : "v"(bx0), "n"(imm));
-                else if constexpr (bs == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % 8]) : "v"(bx1), "n"(imm));
-                else if constexpr (bs == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % 8]) : "v"(bt2), "n"(imm));
-                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % 8]) : "v"(bt3), "n"(imm));
+                if constexpr (bs == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % T_RING]) : "v"(bx0), "n"(imm));
+                else if constexpr (bs == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % T_RING]) : "v"(bx1), "n"(imm));
+                else if constexpr (bs == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % T_RING]) : "v"(bt2), "n"(imm));
+                else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[n % T_RING]) : "v"(bt3), "n"(imm));
             };
             t_for(std::make_integer_sequence<int, (NR < RING ? NR : RING)>{}, rd);
             t_for(std::make_integer_sequence<int, NM>{}, [&ring, &acc, &init, &W, &rd, &mfma](auto m_c) __attribute__((always_inline)) {
                 constexpr int m = decltype(m_c)::value;
                 constexpr TMm q = Prog::value->mm[m];
-                constexpr int NR = Prog::value->nr, RING = 8;
+                constexpr int NR = Prog::value->nr, RING = T_RING;
                 if constexpr (Prog::value->first_use(q.rd) == m) {
                     constexpr int left = (NR - 1 - q.rd) < (RING - 1) ? (NR - 1 - q.rd) : (RING - 1);      // LDS reads return in order
                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[q.rd % RING]) : "n"(left));
@@ -316,9 +326,8 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                             if (pos1 < 0 || pos1 >= L) t1v = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                         const tu32x2 raw = {t_pack2(t1v[0], t1v[1]), t_pack2(t1v[2], t1v[3])};
-                        const f32x4 tsl = t1v * slope;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) t1v[r] = t_max(t1v[r], tsl[r]);
+                        for (int r = 0; r < 4; ++r) t1v[r] = t_max(t1v[r], t_mul(t1v[r], slope));
                         const tu32x2 w = {t_pack2(t1v[0], t1v[1]), t_pack2(t1v[2], t1v[3])};
                         *reinterpret_cast<tu32x2*>(wq + T_QOFF + jb * 4 * T_QP + mh * 2 * T_QP + I * T_BLK) = raw;
                         unsigned char* const d = wa + T_AOFF + jb * 4 * T_AP + mh * 2 * T_AP;
@@ -327,27 +336,12 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                         if constexpr (I == 3) *reinterpret_cast<tu32x2*>(d) = w;
                     }
                 }
-                // ---- the upsampler's output of block s - 5: registers (0, 1) = channel c0, outputs 2 q + {0, 1}; (2, 3) = channel c0 + 1
-                {
-                    const f32x4 u = acc[NACC - 1];
-                    const int q = pos1 - 80;
-                    const bool valid = s >= 5 && s - 5 < nblk && q < L;
-                    const int c0 = 8 * ROLE + 2 * kg;
-                    if (valid) {
-                        *gptr<unsigned>(ob + (unsigned)(c0 * Lout + 2 * q) * 2u) = t_pack2(u[0], u[1]);
-                        *gptr<unsigned>(ob + (unsigned)((c0 + 1) * Lout + 2 * q) * 2u) = t_pack2(u[2], u[3]);
-                    }
-                    // (a select, not a product: the lead-in steps of a run work on stale rings)
-                    const float v0 = valid ? u[0] : 0.f, v1 = valid ? u[1] : 0.f, v2 = valid ? u[2] : 0.f, v3 = valid ? u[3] : 0.f;
-                    s1[0] += v0 + v1; s2[0] = fmaf(v0, v0, fmaf(v1, v1, s2[0]));
-                    s1[1] += v2 + v3; s2[1] = fmaf(v2, v2, fmaf(v3, v3, s2[1]));
-                }
             } else if constexpr (ROLE == 3) {
                 // ---- this wave's part of the branch sum of block s - 2 to wave 2: [lane][half][4] floats
                 unsigned char* const e = smem_t + T_EOFF + (I & 1) * 2048 + lane * 32;
                 *reinterpret_cast<f32x4*>(e) = acc[0];
                 *reinterpret_cast<f32x4*>(e + 16) = acc[1];
-            } else {
+            } else if constexpr (ROLE == 2) {
                 // ---- role 2: keep the conv2 sums of block s - 2; the branch sum of block s - 3 = last step's sums + wave 3's part of last step;
                 // z = lrelu(out / nk, up_slope), 0 outside the sequence (the transposed conv sees the L positions of the sequence only)
                 osum[I & 1][0] = acc[0]; osum[I & 1][1] = acc[1];
@@ -363,9 +357,8 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z[r] = v2w_div_by(z[r], a.out_div, dinv);
                     }
-                    const f32x4 zs = z * us;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = t_max(z[r], zs[r]);
+                    for (int r = 0; r < 4; ++r) z[r] = t_max(z[r], t_mul(z[r], us));
                     if (edge3) {
                         asm volatile("" ::: "memory");
                         if (pos3 < 0 || pos3 >= L) z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -376,6 +369,27 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                     if constexpr (ZS == 0) *reinterpret_cast<tu32x2*>(d + 5 * T_BLK) = w;
                     if constexpr (ZS == 3) *reinterpret_cast<tu32x2*>(d) = w;
                 }
+            }
+            if constexpr (UP) {
+                // ---- the upsampler's output of block s - 5: registers (0, 1) = channel c0, outputs 2 q + {0, 1}; (2, 3) = channel c0 + 1
+                const f32x4 u = acc[NACC - 1];
+                const int q = pos1 - 80;
+                const bool valid = s >= 5 && s - 5 < nblk && q < L;
+                const int c0 = 8 * UH + 2 * kg;
+                // 8-byte stores: lanes j and j ^ 1 hold the output pairs (2 q, 2 q + 1) of two neighbouring input positions for channels c0 and
+                // c0 + 1 - the even lane takes both pairs of channel c0, the odd lane both of c0 + 1 (one DPP swap): per store instruction a
+                // channel row receives 128 contiguous bytes instead of 64.  (q and q ^ 1 are valid together: blocks and L are multiples of 4.)
+                const unsigned pa = t_pack2(u[0], u[1]), pb = t_pack2(u[2], u[3]);
+                const bool odd = (j & 1) != 0;
+                const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? pa : pb), 0xB1, 0xF, 0xF, false);     // quad_perm [1, 0, 3, 2]
+                if (valid) {
+                    const tu32x2 w2 = odd ? tu32x2{got, pb} : tu32x2{pa, got};
+                    *gptr<tu32x2>(ob + (unsigned)((c0 + (odd ? 1 : 0)) * Lout + 2 * (q & ~1)) * 2u) = w2;
+                }
+                // (a select, not a product: the lead-in steps of a run work on stale rings)
+                const float v0 = valid ? u[0] : 0.f, v1 = valid ? u[1] : 0.f, v2 = valid ? u[2] : 0.f, v3 = valid ? u[3] : 0.f;
+                s1[0] += v0 + v1; s2[0] = fmaf(v0, v0, fmaf(v1, v1, s2[0]));
+                s1[1] += v2 + v3; s2[1] = fmaf(v2, v2, fmaf(v3, v3, s2[1]));
             }
         };
 
@@ -405,7 +419,7 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
             t_barrier();
         }
         // ---- BatchNorm partial sums of this run (one row of up_stats): the 16 lanes of a channel pair in a fixed (butterfly) order
-        if constexpr (ROLE < 2) {
+        if constexpr (UP) {
             if (a.up_stats) {
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) {
@@ -413,7 +427,7 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                     for (int c = 0; c < 2; ++c) { s1[c] += __shfl_xor(s1[c], off, 64); s2[c] += __shfl_xor(s2[c], off, 64); }
                 }
                 if (j == 0) {
-                    float* const d = a.up_stats + ((size_t)run * 16 + 8 * ROLE + 2 * kg) * 2;
+                    float* const d = a.up_stats + ((size_t)run * 16 + 8 * UH + 2 * kg) * 2;
                     *gptr<f32x4>(d) = f32x4{s1[0], s2[0], s1[1], s2[1]};
                 }
             }
