@@ -161,6 +161,30 @@ def traffic_of(kernel: str, suffix: str):
                                                  f'same kernel sources)')
 
 
+def schedule_traffic(per_kernel: dict, suffix: str, step_s: float):
+    """The roofline of the schedule that RAN, beside the layer-granular contract figure of SURVEY 8(d): the fused kernels never move most of
+    the per-layer bytes (a stage kernel reads its input once and writes the next stage's input), so `hbm_frac` on the algorithmic count says
+    how far the forward is from the 8(d) target, not how busy HBM is.  Here: counter bytes (profiles/rNN_<suffix>: FETCH_SIZE x 2 + WRITE_SIZE
+    per launch, collected from the same kernel sources) x launches per step, summed over the step's conv kernels, / step time / 8 TB/s.
+    None (+ the reason) when a kernel of the step has no row in the profile or the profile is stale - a name the library reports and the
+    cited rocprof summary does not hold is an error of the evidence, and is said so."""
+    if not suffix:
+        return None
+    total, missing, src = 0.0, [], None
+    for k, v in per_kernel.items():
+        names = [n.strip() for n in k.split(' + ')]
+        for n in names:
+            t, why = traffic_of(n, suffix)
+            if t is None:
+                missing.append(f'{n}: {why}')
+            else:
+                total += t * v['launches']
+                src = why
+    if missing:
+        return dict(counter_bytes_per_step=None, hbm_frac_counter=None, missing=missing[:4])
+    return dict(counter_bytes_per_step=total, hbm_frac_counter=total / step_s / 1e9 / PEAK_HBM_GBS, source=src)
+
+
 def run_steps(g, inp, steps, warmup, barrier=lambda: None):
     """EXACTLY `steps` forwards between barrier + synchronize pairs (wall clock), HIP events on the launching stream around every
     step as well (event-timed median).  Returns (elapsed seconds, per-step milliseconds)."""
@@ -275,6 +299,7 @@ def roofline_block(g, h, inp, B, T, precision, algo, step_s, traffic_suffix, rec
                                    hbm_frac=tot_b / step_s / 1e9 / PEAK_HBM_GBS))
     if sync_t:
         roof['stat_sync_allreduce_us_mean'] = mean(sync_t) * 1e6
+    roof['schedule'] = schedule_traffic(roof['per_kernel'], traffic_suffix, step_s)
     return roof
 
 
@@ -476,6 +501,9 @@ def compact_roofline(roof):
     wf = roof.get('whole_forward')
     if wf:
         out['whole_forward'] = {k: _r(wf[k]) for k in ('mfma_frac', 'hbm_frac', 'sum_conv_kernel_ms') if k in wf}
+    sc = roof.get('schedule')
+    if isinstance(sc, dict):
+        out['schedule'] = {k: (_r(v) if not isinstance(v, list) else v[:2]) for k, v in sc.items() if k != 'source'}
     return out
 
 
@@ -490,6 +518,9 @@ def compact_block(b):
     r = b.get('roofline')
     if isinstance(r, dict):
         out['dominant'] = {k: _r(r[k]) for k in ('kernel', 'bound', 'frac', 'avg_launch_us', 'traffic') if k in r}
+        sc = r.get('schedule')
+        if isinstance(sc, dict):      # the schedule that ran: counter bytes per step and their fraction of the HBM peak (None + why when the profile is stale)
+            out['schedule'] = {k: (_r(v) if not isinstance(v, list) else v[:2]) for k, v in sc.items() if k != 'source'}
         if b.get('dtype') == 'bf16' and 'resblock' not in str(b.get('workload', '')).lower()[:40] and isinstance(r.get('per_kernel'), dict):
             # the bf16 pipeline's launches, largest first: [kernel, ms per step, TFLOP/s]
             out['kernels'] = [[k.replace(' ', ''), _r(v['ms']), _r(v['tflops'])] for k, v in list(r['per_kernel'].items())[:7]]
@@ -515,10 +546,14 @@ def compact_cpu(c):
 
 
 def summary_of(out, blocks):
-    """{block: [ms_per_step, hbm_frac, mfma_frac]} - the LAST key of the line, so that it survives a record that keeps only the tail."""
+    """{block: [ms_per_step, hbm_frac (SURVEY 8(d) byte count), mfma_frac(, hbm_frac of the counter bytes the schedule really moved)]} - the LAST
+    key of the line, so that it survives a record that keeps only the tail."""
     sm = {}
     wf = (out.get('roofline') or {}).get('whole_forward') or {}
     sm['cfg2_f32'] = [_r(out.get('ms_per_step')), _r(wf.get('hbm_frac')), _r(wf.get('mfma_frac'))]
+    sc0 = (out.get('roofline') or {}).get('schedule') or {}
+    if sc0.get('hbm_frac_counter') is not None:
+        sm['cfg2_f32'].append(_r(sc0['hbm_frac_counter']))
     for name in blocks:
         b = out.get(name)
         if not isinstance(b, dict):
@@ -529,6 +564,9 @@ def summary_of(out, blocks):
             sm[name] = [_r(b.get('stat_sync_ms_per_step')), _r(b.get('allreduce_us_event_mean')), None]
         else:
             sm[name] = [_r(b.get('ms_per_step')), _r(b.get('hbm_frac')), _r(b.get('mfma_frac'))]
+            sc = ((b.get('roofline') or {}).get('schedule') or (b.get('schedule') or {})) if isinstance(b.get('roofline') or b.get('schedule'), dict) else {}
+            if isinstance(sc, dict) and sc.get('hbm_frac_counter') is not None:
+                sm[name].append(_r(sc['hbm_frac_counter']))
             for prec in ('f16x3', 'bf16'):
                 alt = b.get('alt_precision_' + prec)
                 if isinstance(alt, dict) and 'ms_per_step' in alt:

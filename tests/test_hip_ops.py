@@ -513,7 +513,7 @@ def test_resblock2_wide_stage_with_the_next_upsampler_fused(dev, B, C, L, u, wit
         own = out.cpu().double()
         rms = (own * own).mean().sqrt().item()
         assert (sums[:, 0] - own.sum((0, 2))).abs().max().item() <= 2.0 ** -9 * rms * (6 * n ** 0.5 + 8) + 1e-6 * n
-        assert (sums[:, 1] - (own * own).sum((0, 2))).abs().max().item() <= 2e-3 * (own * own).sum((0, 2)).max().item()
+        assert (sums[:, 1] - (own * own).sum((0, 2))).abs().max().item() <= (2e-3 + 1.6e-2 / n ** 0.5) * (own * own).sum((0, 2)).max().item()
         assert (sums[:, 0] - want.sum((0, 2))).abs().max().item() <= 1.5e-2 * n ** 0.5 + 1e-3 * want.sum((0, 2)).abs().max().item()
         assert (sums[:, 1] - (want * want).sum((0, 2))).abs().max().item() <= 4e-3 * (want * want).sum((0, 2)).max().item()
     # shapes the fused form does not exist for are declined by the query (the caller then runs the two kernels)
