@@ -244,6 +244,7 @@ def test_generator_launch_plan_replays_the_planned_forward(dev, training, precis
             assert torch.equal(ya, yb), (step, (ya - yb).abs().max().item())
             if step == 1:
                 assert len(ga._tapes) >= 1 and not gb._tapes
+                assert ga._tape_refused == 0          # every recorded pointer lies in memory the module owns (schedule.TapeNotOwned otherwise)
                 n_launch = max(t.launches for t in ga._tapes.values())
                 assert 0 < n_launch <= 80
             if step == 2:          # an optimizer step's worth of change, in place (version counters move)

@@ -399,3 +399,34 @@ def test_integration_md_stub_runs_against_the_library():
     assert C.sizeof(stub) == C.sizeof(mirror)
     assert [(n, getattr(stub, n).offset, getattr(stub, n).size) for n, _t in stub._fields_] == \
            [(n, getattr(mirror, n).offset, getattr(mirror, n).size) for n, _t in mirror._fields_]
+
+
+def test_tape_refuses_pointers_the_module_does_not_own():
+    """a launch plan replays prebuilt structs; a struct slot that points into memory nobody keeps alive (a scratch tensor a wrapper
+    allocated inside the planned forward) must keep the plan from being stored.  Host-only: ranges and slots are plain integers."""
+    import ctypes as C
+    from wavthruvec_pytorch_amd import schedule
+
+    assert schedule._in_ranges([(100, 200), (300, 400)], 150) and schedule._in_ranges([(100, 200), (300, 400)], 300)
+    assert not schedule._in_ranges([(100, 200), (300, 400)], 200) and not schedule._in_ranges([(100, 200)], 50) and not schedule._in_ranges([], 1)
+
+    class A(C.Structure):
+        _fields_ = [('in_', C.c_void_p), ('w', C.c_void_p * 2), ('out', C.c_void_p), ('n', C.c_int32)]
+
+    def tape_with(a):
+        t = schedule.Tape()
+        t.steps.append(schedule.Step(schedule.K_CALL, fn=None, args=[C.byref(a)], name='v2w_fake'))
+        return t
+
+    owned = [(0x1000, 0x2000), (0x8000, 0x9000)]
+    binds = dict(x=0x5000, y=0x6000)
+    ok = A(0x5000, (C.c_void_p * 2)(0x1100, 0x8800), 0x6000, 7)
+    t = tape_with(ok)
+    t.finalize(binds, owned=owned)
+    assert len(t.patches['x']) == 1 and len(t.patches['y']) == 1 and t.launches == 1
+    bad = A(0x5000, (C.c_void_p * 2)(0x1100, 0x7000), 0x6000, 7)       # 0x7000: nobody's
+    with pytest.raises(schedule.TapeNotOwned):
+        tape_with(bad).finalize(binds, owned=owned)
+    tape_with(bad).finalize(binds)                                        # (no ranges given: the round-5 behaviour)
+    null = A(0x5000, (C.c_void_p * 2)(0x1100, 0), 0x6000, 7)              # NULL slots are optional arguments
+    tape_with(null).finalize(binds, owned=owned)

@@ -227,6 +227,7 @@ class Generator(nn.Module):
         self.use_launch_plan = True           # no-grad forwards: planned once per configuration, replayed from the recorded tape (schedule.py)
         self._tapes: Dict[tuple, object] = {}
         self._ws_epoch = 0                    # bumped whenever a workspace / weight buffer is (re)allocated: recorded tapes point into them
+        self._tape_refused = 0                # plans not kept because a recorded call pointed outside the module's own memory (schedule.TapeNotOwned)
 
     # -------------------------------------------------------------------------------------------
     def __getstate__(self):
@@ -647,11 +648,25 @@ class Generator(nn.Module):
             self._tapes.clear()
         state = self._fold_key.get('state')
         if len(set(binds.values())) == 4 and state is not None:     # (aliased inputs: no tape, the next forward plans again)
-            rec.tape.finalize(binds)
+            try:
+                rec.tape.finalize(binds, owned=self._owned_ranges())
+            except schedule.TapeNotOwned:
+                self._tape_refused += 1                 # a recorded call points at memory this module does not keep alive: never replay it
+                return y
             rec.tape.out = (tuple(y.shape), y.dtype)
             rec.tape.fold_state_tail = tuple(state[1:])
             self._tapes[key] = rec.tape
         return y
+
+    def _owned_ranges(self):
+        """Address ranges of everything a recorded launch plan may point into: parameters, buffers, workspaces, folded weights, the
+        split-over-C_in slabs (retired ones too) and the tensors of the cached fold / split plans."""
+        from . import schedule
+        ts = list(self.parameters()) + list(self.buffers()) + list(self._ws.values()) + list(self._wts.values())
+        for slab in self._slabs.values():
+            ts += [slab.t] + list(slab.retired)
+        ts += list(schedule.tensors_in(self._fold_key))
+        return schedule.owned_ranges(ts)
 
     def _sigma_key(self, dev):
         sn_p = [q for c in self.cbns for q in (c.layer.weight_orig, c.layer.weight_u, c.layer.weight_v)]

@@ -50,6 +50,54 @@ def _struct_slots(obj, out, path=()):
                 _struct_slots(getattr(obj, name), out)
 
 
+class TapeNotOwned(RuntimeError):
+    pass
+
+
+def _in_ranges(ranges, v):
+    import bisect
+    i = bisect.bisect_right(ranges, (v, float('inf'))) - 1
+    return i >= 0 and ranges[i][0] <= v < ranges[i][1]
+
+
+def owned_ranges(tensors):
+    """Sorted, merged [lo, hi) device address ranges of `tensors` (storage extents)."""
+    spans = []
+    for t in tensors:
+        if t is None or not t.is_cuda:
+            continue
+        st = t.untyped_storage()
+        if st.nbytes():
+            spans.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+    spans.sort()
+    out = []
+    for lo, hi in spans:
+        if out and lo <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def tensors_in(obj, depth=4, seen=None):
+    """Every torch.Tensor reachable from `obj` through dicts, sequences and object attributes (the fold caches hold plans whose descriptor
+    tables are tensors)."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen or depth < 0:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from tensors_in(v, depth - 1, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from tensors_in(v, depth - 1, seen)
+    elif hasattr(obj, '__dict__') and not isinstance(obj, type):
+        yield from tensors_in(vars(obj), depth - 1, seen)
+
+
 class Tape:
     """The recorded schedule.  `binds`: name -> device address at record time of the tensors that differ from call to call."""
 
@@ -61,7 +109,11 @@ class Tape:
         self.out = None                      # (shape, dtype) of the output tensor
         self.launches = 0
 
-    def finalize(self, binds: Dict[str, int]):
+    def finalize(self, binds: Dict[str, int], owned=None):
+        """`owned` (optional): sorted, non-overlapping [lo, hi) address ranges of everything the recording module keeps alive (parameters, buffers,
+        workspaces, folded weights, slabs, plan tables).  Every pointer-valued struct slot of a recorded call must then lie in one of them or be a
+        bind: a wrapper that allocated a scratch tensor inside the planned forward would otherwise leave a dangling address in the tape
+        (ADVICE r05).  Raises TapeNotOwned - the caller keeps planning that configuration instead of replaying it."""
         by_addr = {}
         for name, addr in binds.items():
             if addr in by_addr:
@@ -84,6 +136,8 @@ class Tape:
                     v = cont[key] if isinstance(key, int) else getattr(cont, key)
                     if v in by_addr:
                         self.patches[by_addr[v]].append((cont, key))
+                    elif v and owned is not None and not _in_ranges(owned, v):
+                        raise TapeNotOwned(f'schedule: {st.name} was recorded with a pointer ({key} = {v:#x}) into memory the module does not own')
         for name in binds:
             if name != 'y' and not self.patches[name]:
                 raise RuntimeError(f'schedule: no recorded call reads {name}')
