@@ -181,7 +181,7 @@ def schedule_traffic(per_kernel: dict, suffix: str, step_s: float):
                 total += t * v['launches']
                 src = why
     if missing:
-        return dict(counter_bytes_per_step=None, hbm_frac_counter=None, missing=missing[:4])
+        return dict(counter_bytes_per_step=None, hbm_frac_counter=None, missing=missing)
     return dict(counter_bytes_per_step=total, hbm_frac_counter=total / step_s / 1e9 / PEAK_HBM_GBS, source=src)
 
 
@@ -487,6 +487,14 @@ def _r(v, nd=4):
     return v
 
 
+def _compact_schedule(sc):
+    """{counter_bytes_per_step, hbm_frac_counter} - or, when the cited profile is stale / lacks a kernel, how many kernels and the first reason."""
+    out = {k: _r(sc.get(k)) for k in ('counter_bytes_per_step', 'hbm_frac_counter')}
+    if sc.get('missing'):
+        out['missing'] = [len(sc['missing']), str(sc['missing'][0])[:72]]
+    return out
+
+
 def compact_roofline(roof):
     """The keys the contract names (bound, achieved, peak, unit, frac, traffic) + what identifies the kernel; the per-kernel table and
     the launch tag lists stay in the detail file (`--verbose` puts them back into the line)."""
@@ -503,7 +511,7 @@ def compact_roofline(roof):
         out['whole_forward'] = {k: _r(wf[k]) for k in ('mfma_frac', 'hbm_frac', 'sum_conv_kernel_ms') if k in wf}
     sc = roof.get('schedule')
     if isinstance(sc, dict):
-        out['schedule'] = {k: (_r(v) if not isinstance(v, list) else v[:2]) for k, v in sc.items() if k != 'source'}
+        out['schedule'] = _compact_schedule(sc)
     return out
 
 
@@ -520,7 +528,7 @@ def compact_block(b):
         out['dominant'] = {k: _r(r[k]) for k in ('kernel', 'bound', 'frac', 'avg_launch_us', 'traffic') if k in r}
         sc = r.get('schedule')
         if isinstance(sc, dict):      # the schedule that ran: counter bytes per step and their fraction of the HBM peak (None + why when the profile is stale)
-            out['schedule'] = {k: (_r(v) if not isinstance(v, list) else v[:2]) for k, v in sc.items() if k != 'source'}
+            out['schedule'] = _compact_schedule(sc)
         if b.get('dtype') == 'bf16' and 'resblock' not in str(b.get('workload', '')).lower()[:40] and isinstance(r.get('per_kernel'), dict):
             # the bf16 pipeline's launches, largest first: [kernel, ms per step, TFLOP/s]
             out['kernels'] = [[k.replace(' ', ''), _r(v['ms']), _r(v['tflops'])] for k, v in list(r['per_kernel'].items())[:7]]

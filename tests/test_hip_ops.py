@@ -717,6 +717,65 @@ def test_resblock2_stage16_with_the_fused_tail(dev, B, L, kp):
     assert (y2 - y).abs().max().item() <= 2e-2
 
 
+@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('affine,biases,out_div', [(False, True, 3.0), (True, False, 3.0), (True, True, 0.0), (False, False, 0.0)])
+def test_streaming_narrow_stages_optional_arguments(dev, C, affine, biases, out_div):
+    """The round-6 streaming kernels (v2w_stage_bf16_n16s.hip: 16 channels + the 7-tap tail; v2w_stage_bf16_n32s.hip: 32 channels + the
+    stride-2 upsampler) with every optional argument of v2w_stage_split_args absent in turn: no CondBN affine (in_a / in_s NULL), no biases
+    (conv, tail and upsampler), no division of the branch sum (out_div = 0) - against fp64 math on the same bf16 operands.  Run seams: L spans
+    several runs of every wave / team and ends inside a block."""
+    from wavthruvec_pytorch_amd import hipops
+    B, L = 3, 2 * 4096 + 52
+    g = torch.Generator().manual_seed(900 + C + int(affine) + 2 * int(biases))
+    ks, d1, d2 = [3, 7, 11], [1, 1, 1], [3, 3, 3]
+    x = torch.randn(B, C, L, generator=g).bfloat16()
+    a = 1 + 0.2 * torch.randn(B, C, generator=g) if affine else torch.ones(B, C)
+    s = 0.2 * torch.randn(B, C, generator=g) if affine else torch.zeros(B, C)
+    w1 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    w2 = [torch.randn(C, C, k, generator=g) / (C * k) ** 0.5 for k in ks]
+    zero = torch.zeros(C)
+    b1 = [0.1 * torch.randn(C, generator=g) if biases else zero for _ in ks]
+    b2 = [0.1 * torch.randn(C, generator=g) if biases else zero for _ in ks]
+    stage3, _ = _wide_stage_reference(x, a, s, w1, b1, w2, b2, ks, d1, d2, 0.1, C != 16)      # (= sum / 3)
+    stage = stage3 if out_div != 0.0 else stage3 * 3.0
+    br = [dict(wps1=hipops.pack_split(w1[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b1=b1[j].to(dev) if biases else None,
+               wps2=hipops.pack_split(w2[j].permute(2, 1, 0).contiguous().to(dev), bf16=True), b2=b2[j].to(dev) if biases else None,
+               k=ks[j], dil1=d1[j], dil2=d2[j]) for j in range(3)]
+    aff = (a.to(dev), s.to(dev)) if affine else None
+    if C == 16:
+        wpost = torch.randn(1, C, 7, generator=g) / (C * 7) ** 0.5 / (1.0 if out_div != 0.0 else 3.0)
+        bpost = 0.1 * torch.randn(1, generator=g) if biases else None
+        want = torch.tanh(F.conv1d(F.leaky_relu(stage, 0.01), wpost.double(), None if bpost is None else bpost.double(), padding=3))
+        y = torch.full((B, 1, L), float('nan'), device=dev)
+        ok = hipops.resblock2_stage_split(x.to(dev), aff, br, None, slope=0.1, out_div=out_div, bf16=True, io_bf16=3,
+                                          post=(wpost.permute(2, 1, 0).contiguous().to(dev), None if bpost is None else bpost.to(dev), y, 7, 0.01))
+        assert ok and torch.isfinite(y).all()
+        err = (y.cpu().double() - want).abs()
+        assert err.max().item() <= 1.5e-2 and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    else:
+        u = 2
+        wu = torch.randn(C, C // 2, 2 * u, generator=g) / (C * 2) ** 0.5 / (1.0 if out_div != 0.0 else 3.0)
+        bu = 0.3 * torch.randn(C // 2, generator=g) if biases else None
+        z = F.leaky_relu(stage.float(), 0.1).bfloat16().double()
+        want = F.conv_transpose1d(z, wu.bfloat16().double(), None if bu is None else bu.double(), stride=u, padding=u // 2)
+        wpu = hipops.pack_bf16_convt(wu.permute(2, 0, 1).contiguous().to(dev), u)
+        nt = hipops.resblock2_stage_up_tiles(B, C, L, ks, d1, d2, slope=0.1, up_k=2 * u, up_u=u, up_slope=0.1)
+        assert nt > 0
+        out = torch.full((B, C // 2, L * u), float('nan'), device=dev, dtype=torch.bfloat16)
+        part = torch.full((nt * (C // 2) * 2,), float('nan'), device=dev)
+        ok = hipops.resblock2_stage_split(x.to(dev), aff, br, None, slope=0.1, out_div=out_div, bf16=True, io_bf16=3,
+                                          up=(wpu, None if bu is None else bu.to(dev), out, part, 2 * u, u, 0.1))
+        assert ok and torch.isfinite(out.float()).all() and torch.isfinite(part).all()
+        err = (out.cpu().double() - want).abs()
+        assert (err <= 2.0 ** -8 * want.abs() + 4e-2).all() and err.mean().item() <= 6e-3, (err.max().item(), err.mean().item())
+        own = out.cpu().double()
+        sums = part.view(nt, C // 2, 2).double().sum(0).cpu()
+        n = B * L * u
+        rms = (own * own).mean().sqrt().item()
+        assert (sums[:, 0] - own.sum((0, 2))).abs().max().item() <= 2.0 ** -9 * rms * (6 * n ** 0.5 + 8) + 1e-6 * n
+        assert (sums[:, 1] - (own * own).sum((0, 2))).abs().max().item() <= (2e-3 + 1.6e-2 / n ** 0.5) * (own * own).sum((0, 2)).max().item()
+
+
 @pytest.mark.parametrize('B,C,L', [(2, 64, 256), (3, 64, 1000), (2, 128, 512), (3, 128, 1004), (1, 128, 20)])
 def test_branch_convs_bf16(dev, B, C, L):
     """v2w_branch_convs_bf16_fwd: the first convs of all branches of a wide stage in one launch (mode 0: x staged once, three t1

@@ -46,7 +46,7 @@ def main(path, B=32, T=256, which=-2, act_bytes=4):
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         tot += d
         if 'conv_tile' in n or 'conv_post' in n or 'conv1d_direct' in n or 'convt1d_direct' in n or 'resblock_pair' in n or 'resblock2_stage' in n or 'conv_bf16' in n or 'stage_bf16' in n\
-                or 'conv_split' in n or 'stage_split' in n or 'convt_bf16' in n or 'n16_stage' in n:
+                or 'conv_split' in n or 'stage_split' in n or 'convt_bf16' in n or 'n16_stage' in n or 'n16s_stage' in n or 'n32s_stage' in n:
             grp = groups[li]; li += 1
             nm = '+'.join(g.replace('resblocks.', 'rb') for g in grp)
             if len(grp) > 3:                   # a whole stage: first .. last
