@@ -958,9 +958,10 @@ int v2w_conv1d_bf16(const v2w_conv1d_args* a, int n, hipStream_t stream, int32_t
     // a deep layer (conv_pre: 768 / 1024 input channels x 7 taps) on a grid of one 64 x 256 tile per CU or less walks 24+ chunks behind a
     // barrier each: 64 x 128 tiles (twice the workgroups) with 64-channel chunks (half the barriers) - 135-143 -> 88-98 us at B = 32 x T = 256
     if (tiles >= 128 && tiles < 512 && n == 1 && a->C_in >= 512 && a->C_in % 64 == 0 && a->io_bf16 == 2) {
-        // (round 6) from one 64 x 256 tile per CU up: 128 x 128 tiles - at B = 32 x T = 256 exactly one workgroup per CU, each weight fragment
-        // feeds two row blocks: 80 -> 75 us; below that (BASELINE configs[4] at B = 16: 64 workgroups of 128 x 128) the small tile stays (76 against 88 us)
-        if (tiles >= 256 && a->C_out % 128 == 0) return launch_bf16<2, 2, 2, 2, 64>(ps, n, stream, cfg);
+        // (round 6) from one 64 x 256 tile per CU up: 128 x 128 tiles on EIGHT waves (4 x 2, a 32 x 64 block each) - at B = 32 x T = 256 exactly
+        // one workgroup per CU with two waves per SIMD to cover the chunk loop's latencies: 80 -> 69 us (the same tile on four waves: 75); below
+        // that (BASELINE configs[4] at B = 16: 64 workgroups of 128 x 128) the small tile stays (76 against 88 us)
+        if (tiles >= 256 && a->C_out % 128 == 0) return launch_bf16<1, 2, 4, 2, 64>(ps, n, stream, cfg);
         return launch_bf16<1, 2, 2, 2, 64>(ps, n, stream, cfg);
     }
     if (tiles >= 256) return launch_bf16<1, 4, 2, 2>(ps, n, stream, cfg);                                 // 64 x 256

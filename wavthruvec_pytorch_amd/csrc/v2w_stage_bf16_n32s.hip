@@ -249,7 +249,9 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[i] = *gptr<const tu32x2>(inb + (size_t)i * L * 2 + vo);
         };
-        auto commit_x = [&](int k) {
+        // (in two halves - position rows e = 0, 1 then 2, 3 of every quad - in two consecutive steps: the staging waves' extra work per barrier
+        // interval is halved)
+        auto commit_x = [&](int k, int e0, int e1) {
             const int pos = p0 + 64 * k + 16 + 4 * cpos;
             const bool ok = pos >= 0 && pos < L;                                // L % 4 == 0: a position quad is inside or outside as a whole
             const int slot = (4 * (k & 1) + 1 + cblk) & 7;
@@ -258,6 +260,7 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
             const int mir = slot == 7 ? -8 * T_BLK : (slot == 0 ? 8 * T_BLK : 0);      // slot 7 also in front of slot 0, slot 0 also behind slot 7
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (e < e0 || e >= e1) continue;
                 float y[4], v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -348,17 +351,15 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
                 const unsigned char* const e = smem_t + T_EOFF + ((I + 1) & 1) * 2048 + lane * 32;
                 const int pos3 = pos1 - 48;
                 const bool edge3 = p0 + 16 * s - 48 < 0 || p0 + 16 * s - 32 > L;
-                const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f, us = a.up_slope;
+                const float dinv = a.out_div != 0.f ? 1.f / a.out_div : 1.f, dinv_us = dinv * a.up_slope;
                 constexpr int ZS = (I + 1) & 3;
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
                     f32x4 z = osum[(I + 1) & 1][mh] + *reinterpret_cast<const f32x4*>(e + 16 * mh);
-                    if (a.out_div != 0.f) {
+                    // lrelu(sum / nk) = max(sum * (1 / nk), sum * (slope / nk)): two multiplies and a max per element (the quotient by
+                    // multiplication is within an ulp of the division - below the bf16 rounding of z by 2^16)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) z[r] = v2w_div_by(z[r], a.out_div, dinv);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = t_max(z[r], t_mul(z[r], us));
+                    for (int r = 0; r < 4; ++r) z[r] = t_max(t_mul(z[r], dinv), t_mul(z[r], dinv_us));
                     if (edge3) {
                         asm volatile("" ::: "memory");
                         if (pos3 < 0 || pos3 >= L) z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -393,16 +394,17 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
             }
         };
 
-        // ---- the run.  Staging: burst g (blocks 4 g + 1 .. 4 g + 4) is committed in step 4 g - 1, one barrier before conv1 first reads it.
-        if constexpr (ROLE >= 2) { issue_x(-1); commit_x(-1); issue_x(0); }
+        // ---- the run.  Staging: burst g (blocks 4 g + 1 .. 4 g + 4) is committed in steps 4 g - 2 and 4 g - 1 (half each), one barrier before conv1 first reads it.
+        if constexpr (ROLE >= 2) { issue_x(-1); commit_x(-1, 0, 4); issue_x(0); }
         t_barrier();
         {
             unsigned bx0 = rbase[0] + 4u * T_BLK, bx1 = rbase[1] + 4u * T_BLK;
             asm volatile("" : "+v"(bx0), "+v"(bx1));
             step(std::integral_constant<int, 2>{}, -2, bx0, bx1);
+            if constexpr (ROLE >= 2) commit_x(0, 0, 2);
             t_barrier();
             step(std::integral_constant<int, 3>{}, -1, bx0, bx1);
-            if constexpr (ROLE >= 2) { commit_x(0); issue_x(1); }
+            if constexpr (ROLE >= 2) { commit_x(0, 2, 4); issue_x(1); }
             t_barrier();
         }
         for (int g = 0; g < ngrp; ++g) {
@@ -413,9 +415,10 @@ __device__ __forceinline__ void n32s_role(const N32SArgs& a, unsigned char* cons
             step(std::integral_constant<int, 1>{}, 4 * g + 1, bx0, bx1);
             t_barrier();
             step(std::integral_constant<int, 2>{}, 4 * g + 2, bx0, bx1);
+            if constexpr (ROLE >= 2) commit_x(g + 1, 0, 2);
             t_barrier();
             step(std::integral_constant<int, 3>{}, 4 * g + 3, bx0, bx1);
-            if constexpr (ROLE >= 2) { commit_x(g + 1); issue_x(g + 2); }
+            if constexpr (ROLE >= 2) { commit_x(g + 1, 2, 4); issue_x(g + 2); }
             t_barrier();
         }
         // ---- BatchNorm partial sums of this run (one row of up_stats): the 16 lanes of a channel pair in a fixed (butterfly) order
