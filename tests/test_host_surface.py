@@ -430,3 +430,34 @@ def test_tape_refuses_pointers_the_module_does_not_own():
     tape_with(bad).finalize(binds)                                        # (no ranges given: the round-5 behaviour)
     null = A(0x5000, (C.c_void_p * 2)(0x1100, 0), 0x6000, 7)              # NULL slots are optional arguments
     tape_with(null).finalize(binds, owned=owned)
+
+
+def test_bench_schedule_roofline_uses_the_cited_profile_or_says_why_not(tmp_path, monkeypatch):
+    """bench.py `schedule`: counter bytes of the step's kernels (profiles/rNN_<suffix>, FETCH x 2 + WRITE per launch) x launches / step time /
+    8 TB/s - and an explicit `missing` entry, never a silent skip, when a kernel the library names has no row in the profile it cites or the
+    profile was collected from other kernel sources (VERDICT r05 next #5)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    sha = bench.csrc_hash()
+    (prof / 'r99_fake_hbm_traffic.json').write_text(json.dumps({
+        '_meta': dict(commit='abc', date='today', csrc_sha=sha),
+        'kernel_a<1, 2>': dict(launches=3, hbm_bytes_per_launch=4e8),
+        'kernel_b': dict(launches=3, hbm_bytes_per_launch=1e8)}))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    per_kernel = {'kernel_a<1, 2>': dict(launches=2, ms=1.0, tflops=1.0), 'kernel_b': dict(launches=1, ms=0.5, tflops=1.0)}
+    sc = bench.schedule_traffic(per_kernel, 'fake_hbm_traffic.json', 1e-3)
+    assert sc['counter_bytes_per_step'] == 9e8 and abs(sc['hbm_frac_counter'] - 9e8 / 1e-3 / 1e9 / bench.PEAK_HBM_GBS) < 1e-12
+    sc = bench.schedule_traffic(dict(per_kernel, **{'kernel_c + kernel_b': dict(launches=1, ms=0.1, tflops=0.0)}), 'fake_hbm_traffic.json', 1e-3)
+    assert sc['hbm_frac_counter'] is None and len(sc['missing']) == 1 and 'kernel_c' in sc['missing'][0]
+    c = bench._compact_schedule(sc)
+    assert c['missing'][0] == 1 and len(json.dumps(c)) < 200
+    (prof / 'r99_fake_hbm_traffic.json').write_text(json.dumps({'_meta': dict(csrc_sha='other'), 'kernel_a<1, 2>': dict(launches=1, hbm_bytes_per_launch=1.0),
+                                                                'kernel_b': dict(launches=1, hbm_bytes_per_launch=1.0)}))
+    sc = bench.schedule_traffic(per_kernel, 'fake_hbm_traffic.json', 1e-3)
+    assert sc['hbm_frac_counter'] is None and 'stale' in sc['missing'][0]
+    assert bench.schedule_traffic(per_kernel, None, 1e-3) is None
