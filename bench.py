@@ -394,6 +394,34 @@ def config_block(hp, B, T, precision, steps, warmup, dev, workload, parity, traf
                 peaks=dict(hbm_gbs=PEAK_HBM_GBS, mfma_tflops=peak), roofline=roof, parity=parity)
 
 
+def inference_block(dev, steps, warmup):
+    """The forward the inference pipeline runs (synthesize.py; reference inference.py): EVAL mode - running statistics, no spectral-norm step,
+    weights folded once and kept - in the configs[2] arithmetic at the north_star's shape and at configs[2]'s.  Time, throughput and both
+    fractions per shape; the per-kernel rooflines are the train-mode blocks' (same conv kernels, without the statistics launches between them)."""
+    from wavthruvec_pytorch_amd import Generator, synthetic, workmodel
+    h = synthetic.make_hparams(num_wv_feat=768)
+    up = synthetic.total_upsample(h)
+    out = dict(workload='Generator.forward in EVAL mode (running statistics, cached weight fold: the inference pipeline), 768-d latents, x320, '
+                        'bf16 compute / fp32 accumulate, bf16 activation storage', dtype='bf16', steps=steps,
+               parity='tests/test_hip_generator.py::test_generator_cfg2_bf16_full_size_vs_oracle_eval (the reference autocast bar, eval mode)')
+    for name, B, T in (('cfg2', 32, 256), ('cfg3', 64, 512)):
+        g = Generator(h)
+        g.load_state_dict(synthetic.make_state_dict(h, seed=0))
+        g = g.to(dev).eval()
+        g.precision = 'bf16'
+        inp = synthetic.make_inputs(h, B, T, seed=4, device=dev)
+        el, ms = run_steps(g, inp, steps, warmup)
+        fl, by = workmodel.totals(h, B, T, 2)
+        st = el / steps
+        out[name] = dict(B=B, T=T, ms_per_step=st * 1e3, ms_per_step_event_median=median(ms), value=B * T * up / st, unit='samples/s',
+                         hbm_frac=by / st / 1e9 / PEAK_HBM_GBS, mfma_frac=fl / st / 1e12 / PEAK_BF16_MFMA_TFLOPS)
+        del g
+        torch.cuda.empty_cache()
+    # the block's own headline = the north_star shape
+    out.update({k: out['cfg2'][k] for k in ('ms_per_step', 'ms_per_step_event_median', 'value', 'unit', 'hbm_frac', 'mfma_frac')})
+    return out
+
+
 def train_step_block(dev, B, T, steps, precision='f32'):
     """The generator half of a vec2wav/train.py:204-215 step at the cfg2 shape: forward (autograd schedule) + backward through the C ABI +
     AdamW (train.py:100 betas / lr), a weighted-sum loss.  FLOPs = 3 x the forward's (input- and weight-gradient GEMMs).  precision 'f32':
@@ -532,6 +560,10 @@ def compact_block(b):
         if b.get('dtype') == 'bf16' and 'resblock' not in str(b.get('workload', '')).lower()[:40] and isinstance(r.get('per_kernel'), dict):
             # the bf16 pipeline's launches, largest first: [kernel, ms per step, TFLOP/s]
             out['kernels'] = [[k.replace(' ', ''), _r(v['ms']), _r(v['tflops'])] for k, v in list(r['per_kernel'].items())[:7]]
+    for key in ('cfg2', 'cfg3'):          # inference_bf16: [B, T, ms per forward, hbm_frac, mfma_frac] per shape
+        e = b.get(key)
+        if isinstance(e, dict) and 'ms_per_step' in e:
+            out[key] = [e.get('B'), e.get('T'), _r(e['ms_per_step']), _r(e.get('hbm_frac')), _r(e.get('mfma_frac'))]
     for key in ('alt_precision_f16x3', 'alt_precision_bf16'):
         alt = b.get(key)
         if isinstance(alt, dict):
@@ -579,6 +611,11 @@ def summary_of(out, blocks):
                 alt = b.get('alt_precision_' + prec)
                 if isinstance(alt, dict) and 'ms_per_step' in alt:
                     sm[name + '.' + prec] = [_r(alt['ms_per_step']), None, None]
+            e3 = b.get('cfg3')            # inference_bf16: the configs[2] shape beside the north_star shape
+            if isinstance(e3, dict) and 'ms_per_step' in e3:
+                sm[name + '.cfg3'] = [_r(e3['ms_per_step']), _r(e3.get('hbm_frac')), _r(e3.get('mfma_frac'))]
+            elif isinstance(e3, list) and len(e3) == 5:
+                sm[name + '.cfg3'] = e3[2:]
     return sm
 
 
@@ -749,7 +786,7 @@ def main():
     #   the north_star's literal shape B = 32 x T = 256 in that arithmetic                              -> cfg2_bf16
     #   configs[4]  1024-d latents, upsample (8,5,4,2,2) x640, B = 16 x T = 256, exact fp32             -> cfg5_f32
     # and the generator training step at the cfg2 shape                            -> train_step
-    cfg3 = cfg2b = cfg5 = train = rb1b = None
+    cfg3 = cfg2b = cfg5 = train = rb1b = infer = None
     if extras:
         def guarded(fn, *a, **kw):
             try:
@@ -773,6 +810,7 @@ def main():
                        "Generator.forward with ResBlock1 (h.resblock == '1') at B=32 x T=256 in the configs[2] arithmetic: bf16 compute / fp32 "
                        'accumulate, bf16 tensors between all layers, train mode',
                        'tests/test_hip_generator.py::test_generator_resblock1_bf16_full_size_vs_oracle_train (the reference autocast bar)')
+        infer = guarded(inference_block, dev, max(5, 5 * args.steps), max(8, args.warmup))
         train = guarded(train_step_block, dev, B, T, max(4, args.steps // 4))
         if isinstance(train, dict) and 'error' not in train:
             for prec in ('f16x3', 'bf16'):
@@ -800,9 +838,9 @@ def main():
                        'parallelism': (f'dp{world} (batch shards, RCCL all-reduce of CondBN stats)' if world > 1 else
                                        'single GPU' + (', one-rank RCCL group: the CondBN all-reduces are inside the timed region' if args.force_pg else ''))},
             'roofline': roof, 'cpu_baseline': cpu, 'alt_precision': alt, 'stat_sync': sync, 'resblock1_f32': rb1, 'cfg3_bf16': cfg3,
-            'cfg2_bf16': cfg2b, 'cfg5_f32': cfg5, 'train_step': train, 'resblock1_bf16': rb1b,
+            'cfg2_bf16': cfg2b, 'inference_bf16': infer, 'cfg5_f32': cfg5, 'train_step': train, 'resblock1_bf16': rb1b,
         }
-        blocks = ('alt_precision', 'cfg3_bf16', 'cfg2_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync')
+        blocks = ('alt_precision', 'cfg3_bf16', 'cfg2_bf16', 'inference_bf16', 'cfg5_f32', 'resblock1_f32', 'resblock1_bf16', 'train_step', 'stat_sync')
         if not args.verbose:
             detail = write_detail(out)
             out['roofline'] = compact_roofline(roof)

@@ -900,13 +900,13 @@ def test_generator_weights_follow_the_optimizer(dev, precision):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Full-size parity against the pinned oracle (one CPU forward each: cfg2 ~12 s, cfg5 ~12 s, cfg3 ~1 min on the box's cores)
-def _reference_bf16_deviation(sd, h, inp, want):
+def _reference_bf16_deviation(sd, h, inp, want, training=True):
     """How far the REFERENCE's own bf16 arithmetic (the oracle's modules under torch.autocast(bfloat16), the only bf16 mode the
     reference's stack offers; inference.py / train.py run fp32) lands from its fp32 result on these inputs: (max, rms).  The
     deviation grows with the number of samples the max runs over (2e-3 at B=2 x T=50, 7e-3 at B=64 x T=512), so a bf16 bar is
     only meaningful at the same size on the same inputs."""
     with torch.autocast('cpu', dtype=torch.bfloat16):
-        yb, _ = O.generator_forward(dict(sd), h, *inp, training=True)
+        yb, _ = O.generator_forward(dict(sd), h, *inp, training=training)
     e = yb.float() - want
     return e.abs().max().item(), e.pow(2).mean().sqrt().item()
 
@@ -939,7 +939,7 @@ def _full_size_case(dev, h, B, T, seed, precisions, training=True):
         out[prec if storage else 'bf16-operands'] = d
         if bar == 'ref-bf16':
             if 'ref' not in out:
-                out['ref'] = _reference_bf16_deviation(sd, h, inp, want)
+                out['ref'] = _reference_bf16_deviation(sd, h, inp, want, training)
             rmax, rrms = out['ref']
             rms = e.pow(2).mean().sqrt().item()
             print(f'[bf16 vs fp32 oracle @ B={B} T={T}] storage={storage}: max {d:.2e} rms {rms:.2e}; reference autocast: max {rmax:.2e} rms {rrms:.2e}')
@@ -976,6 +976,16 @@ def test_generator_cfg2_full_size_vs_oracle_eval(dev):
     weights folded once): every sample of the batch against the oracle's calibrated-eval forward, buffers unchanged."""
     h = synthetic.make_hparams(num_wv_feat=768)
     _full_size_case(dev, h, 32, 256, 1234, [('f32', TOL), ('f16x3', TOL)], training=False)
+
+
+@pytest.mark.timeout(900)
+def test_generator_cfg2_bf16_full_size_vs_oracle_eval(dev):
+    """The inference schedule bench.py reports as `inference_bf16` - eval mode, bf16 compute / fp32 accumulate, bf16 tensors between the
+    layers, B=32 x T=256: no farther from the fp32 oracle's calibrated-eval forward (max and rms) than the oracle under bf16 autocast in
+    the same mode on the same inputs."""
+    h = synthetic.make_hparams(num_wv_feat=768)
+    d = _full_size_case(dev, h, 32, 256, 1234, [('bf16', 'ref-bf16')], training=False)
+    assert d['bf16'] > 1e-6        # really ran in bf16
 
 
 @pytest.mark.timeout(1200)

@@ -1428,24 +1428,26 @@ def test_conv1d_dgrad_building_block(dev, B, C, L, k, dil):
                                                    (2, 512, 256, 50, 11, 1, 5), (2, 128, 64, 333, 8, 1, 4), (2, 64, 32, 500, 4, 1, 2),
                                                    (2, 32, 16, 1000, 4, 1, 2), (1, 512, 256, 17, 16, 1, 8),
                                                    # the 8-channel stage of a six-stage (x640) generator: 16-row tiles with the missing rows staged as 0
-                                                   (2, 8, 8, 1999, 11, 3, 1), (2, 8, 8, 640, 3, 1, 1), (2, 16, 8, 700, 4, 1, 2)])
+                                                   (2, 8, 8, 1999, 11, 3, 1), (2, 8, 8, 640, 3, 1, 1), (2, 16, 8, 700, 4, 1, 2),
+                                                   # >= 512 staged items of a one-tile layer: 2 048 slabs, summed in two levels (wgrad_reduce_part_kernel)
+                                                   (4, 32, 32, 16384, 3, 1, 1), (3, 16, 16, 22000, 7, 3, 1), (4, 32, 16, 16384, 4, 1, 2)])
 def test_wgrad_matches_autograd(dev, B, cin, cout, L, k, dil, u):
-    """dW of the fused [affine] -> lrelu -> Conv1d / ConvTranspose1d against torch autograd (weights in [k][C_in][C_out] layout)."""
+    """dW of the fused [affine] -> lrelu -> Conv1d / ConvTranspose1d against torch autograd in fp64 (weights in [k][C_in][C_out] layout)."""
     from wavthruvec_pytorch_amd import hipops
     r = _rng(14)
     x = torch.from_numpy(r.standard_normal((B, cin, L), dtype=np.float32))
     a = torch.from_numpy((1 + 0.2 * r.standard_normal((B, cin))).astype(np.float32))
     s = torch.from_numpy((0.3 * r.standard_normal((B, cin))).astype(np.float32))
-    act = F.leaky_relu(a[:, :, None] * x + s[:, :, None], 0.1)
+    act = F.leaky_relu(a[:, :, None].double() * x.double() + s[:, :, None].double(), 0.1)
     if u == 1:
-        w = torch.from_numpy((r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).astype(np.float32)).requires_grad_(True)
+        w = torch.from_numpy(r.standard_normal((cout, cin, k)) / np.sqrt(cin * k)).requires_grad_(True)
         y = F.conv1d(act, w, None, padding=dil * (k - 1) // 2, dilation=dil)
     else:
-        w = torch.from_numpy((r.standard_normal((cin, cout, k)) / np.sqrt(cin * k)).astype(np.float32)).requires_grad_(True)
+        w = torch.from_numpy(r.standard_normal((cin, cout, k)) / np.sqrt(cin * k)).requires_grad_(True)
         y = F.conv_transpose1d(act, w, None, stride=u, padding=(k - u) // 2)
     dy = torch.from_numpy(r.standard_normal(tuple(y.shape), dtype=np.float32))
-    y.backward(dy)
-    want = w.grad.permute(2, 1, 0) if u == 1 else w.grad.permute(2, 0, 1)      # -> [k][C_in][C_out]
+    y.backward(dy.double())
+    want = (w.grad.permute(2, 1, 0) if u == 1 else w.grad.permute(2, 0, 1)).float()      # -> [k][C_in][C_out]
     got = hipops.wgrad(_t(x.numpy(), dev), _t(dy.numpy(), dev), k=k, dil=dil, u=u, slope=0.1,
                        x_affine=(_t(a.numpy(), dev), _t(s.numpy(), dev))).cpu()
     scale = want.abs().max().item()
