@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2W_ABI_VERSION 33
+#define V2W_ABI_VERSION 34
 
 #define V2W_E_ARG      (-1)  /* null pointer / non-positive size */
 #define V2W_E_SHAPE    (-2)  /* shape not supported by the requested algorithm */
@@ -424,6 +424,12 @@ int v2w_bn_finalize(const double* stats, const float* gb,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* a_out, float* s_out, int B, int C, int training,
                     float momentum, float eps, void* stream);
+/* v2w_bn_reduce_partials + v2w_bn_finalize(training = 1) as ONE launch (ABI v34; one block per channel: its rows added in the same fixed
+ * order, `stats` [2C+1] written as v2w_bn_reduce_partials writes it, then the running statistics and (a, s) of that channel): bit-identical
+ * to the two calls.  A data-parallel run, which all-reduces `stats` between them, keeps the two calls. */
+int v2w_bn_reduce_finalize(const float* part, int ntiles, double count, const float* gb,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           double* stats, float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream);
 /* Two-level form for layers with thousands of partial rows (ABI v28; the fused stage kernels write one row per 224 positions):
  * v2w_bn_reduce_slices adds slice s of the rows of `part` ([ntiles][C][2] floats) into slices[s][2 C] fp64 ([sum | sumsq], nslices <= 1024
  * blocks reading whole rows), v2w_bn_finalize_slices is v2w_bn_finalize(training = 1) on those slices, added in slice order, with the element

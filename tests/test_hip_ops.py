@@ -1750,6 +1750,40 @@ def test_disc_dz_and_merge_and_zero_tail(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('C,nt,B', [(256, 256, 32), (128, 480, 32), (32, 512, 300), (16, 1, 1), (24, 777, 5)])
+def test_bn_reduce_finalize_is_the_two_calls_bit_for_bit(C, nt, B):
+    """v2w_bn_reduce_finalize (ABI v34: one launch, one block per channel) == v2w_bn_reduce_partials + v2w_bn_finalize(training = 1): the sums array,
+    (a, s), the running statistics and num_batches_tracked, bit for bit (B > 256: more samples than threads in the block)."""
+    from wavthruvec_pytorch_amd import hipops
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(C * 11 + nt)
+    part = torch.randn(nt, C, 2, generator=g).abs_().mul_(50).to(dev)
+    part[..., 1] += part[..., 0] ** 2 / 100
+    count = nt * 224
+    gb = torch.randn(B, 2 * C, generator=g).to(dev)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.randn(C, generator=g).to(dev), torch.rand(C, generator=torch.Generator().manual_seed(3)).add_(0.5).to(dev)
+        if outs:
+            rm, rv = outs[0][5].clone(), outs[0][6].clone()
+        rm0, rv0 = rm.clone(), rv.clone()
+        nb = torch.full((), 41, dtype=torch.int64, device=dev)
+        a, s = torch.full((B, C), float('nan'), device=dev), torch.full((B, C), float('nan'), device=dev)
+        st = torch.full((2 * C + 1,), float('nan'), dtype=torch.float64, device=dev)
+        if fused:
+            hipops.bn_reduce_finalize(part, nt, count, st, gb, rm, rv, nb, a, s, momentum=0.1, eps=1e-5)
+        else:
+            hipops.bn_reduce_partials(part, nt, C, count, st)
+            hipops.bn_finalize(st, gb, rm, rv, nb, a, s, training=True, momentum=0.1, eps=1e-5)
+        outs.append((a, s, rm, rv, st, rm0, rv0, nb))
+    for x, y in zip(outs[0][:5], outs[1][:5]):
+        assert torch.isfinite(y.double()).all() and torch.equal(x, y)
+    assert outs[0][7].item() == outs[1][7].item() == 42
+    mean = part.double().sum(0)[:, 0] / count                     # and against torch in fp64
+    torch.testing.assert_close(outs[1][2].double(), 0.9 * outs[1][5].double() + 0.1 * mean, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('C,nt,B', [(16, 23424, 32), (32, 4100, 8), (64, 2049, 3), (256, 1024, 2), (24, 1500, 2)])
 def test_bn_two_level_reduce_matches_one_level(C, nt, B):
     """v2w_bn_reduce_slices + v2w_bn_finalize_slices (two short launches for layers with thousands of partial rows) == v2w_bn_reduce_partials +

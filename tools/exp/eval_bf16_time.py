@@ -13,8 +13,9 @@ for B, T in ((32, 256), (64, 512)):
     g = g.to(dev)
     g.precision = 'bf16'
     inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
-    for mode in ('train', 'eval', 'train', 'eval'):
-        g.train(mode == 'train')
+    for mode in ('train', 'train-fold-cached', 'eval', 'train', 'train-fold-cached', 'eval'):
+        g.train(mode != 'eval')
+        g.always_refold = mode == 'train'
         with torch.no_grad():
             for _ in range(5):
                 g(*inp)

@@ -13,7 +13,7 @@ import threading
 
 from . import build as _build
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 V2W_MAX_STAGES = 8
 V2W_BN_SPLITS = 64
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_SPLIT, ALGO_BF16 = 0, 1, 2, 3, 4
@@ -173,6 +173,7 @@ SIGNATURES = {
     'v2w_bn_reduce_partials': (C.c_int, [_fp, C.c_int, C.c_int, C.c_double, _fp, _fp]),
     'v2w_bn_finalize': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, _fp]),
+    'v2w_bn_reduce_finalize': (C.c_int, [_fp, C.c_int, C.c_double, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_float, _fp]),
     'v2w_bn_reduce_slices': (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     'v2w_bn_finalize_slices': (C.c_int, [_fp, C.c_int, C.c_double, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_float, _fp]),
     'v2w_affine_apply': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),

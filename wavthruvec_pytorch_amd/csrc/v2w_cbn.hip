@@ -348,6 +348,49 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float
     }
 }
 
+// bn_reduce_partials_kernel + bn_finalize_kernel(training) as ONE launch (ABI v34): block c adds channel c's partial rows (the same fp64
+// additions in the same order), keeps the sums in stats[] for whoever reads them later, then writes the running statistics and (a, s) of its
+// channel for every sample - nothing of the finalisation crosses channels.  One launch less on the chain producer -> statistics -> consumer that
+// every stage boundary of a train-mode forward waits on (5 us each at B = 32 x T = 256, four of the five boundaries).
+__global__ void __launch_bounds__(256)
+bn_reduce_finalize_kernel(const float* __restrict__ part, double* __restrict__ stats, int ntiles, double count, const float* __restrict__ gb,
+                          float* running_mean, float* running_var, int64_t* nbt, float* __restrict__ a_out, float* __restrict__ s_out,
+                          int B, int C, float momentum, float eps) {
+    __shared__ double red[16];
+    __shared__ double tot[2];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        s1 += (double)part[((size_t)t * C + c) * 2 + 0];
+        s2 += (double)part[((size_t)t * C + c) * 2 + 1];
+    }
+    const double t1 = v2w_block_sum(s1, red);
+    const double t2 = v2w_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        tot[0] = t1; tot[1] = t2;
+        stats[c] = t1;
+        stats[C + c] = t2;
+        if (c == 0) stats[2 * C] = count;
+    }
+    __syncthreads();
+    const double mean = tot[0] / count;
+    double var = tot[1] / count - mean * mean;      // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float gamma = gb[(size_t)b * 2 * C + c], beta = gb[(size_t)b * 2 * C + C + c];
+        const float av = gamma * rstd;
+        a_out[(size_t)b * C + c] = av;
+        s_out[(size_t)b * C + c] = fmaf(-av, (float)mean, beta);
+    }
+    if (threadIdx.x == 0) {
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        if (c == 0 && nbt) *nbt += 1;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ s,
                     float* __restrict__ out, int L) {
@@ -444,6 +487,18 @@ extern "C" int v2w_bn_finalize(const double* stats, const float* gb,
     hipStream_t st = (hipStream_t)stream;
     V2W_LAUNCH(bn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, stats, gb,
                        running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, training, momentum, eps);
+    return v2w_launch_status();
+}
+
+// v2w_bn_reduce_partials + v2w_bn_finalize(training = 1) in one launch (ABI v34): same sums, same (a, s), same running statistics, bit for bit.
+// Not for a data-parallel run (the all-reduce of `stats` sits between the two).
+extern "C" int v2w_bn_reduce_finalize(const float* part, int ntiles, double count, const float* gb,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      double* stats, float* a_out, float* s_out, int B, int C, float momentum, float eps, void* stream) {
+    if (!part || ntiles <= 0 || !(count > 0.0) || !gb || !running_mean || !running_var || !stats || !a_out || !s_out || B <= 0 || C <= 0)
+        return V2W_E_ARG;
+    V2W_LAUNCH(bn_reduce_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, stats, ntiles, count, gb,
+                       running_mean, running_var, num_batches_tracked, a_out, s_out, B, C, momentum, eps);
     return v2w_launch_status();
 }
 

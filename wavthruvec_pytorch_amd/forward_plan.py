@@ -26,20 +26,27 @@ _Z_CHANNEL = 128   # models.py:110
 class DirectStreams:
     """The stream operations of a plan, executed and not taped (schedule.Recorder offers the same five and tapes them)."""
 
-    def __init__(self, main, side):
-        self.main, self.side = main, side
+    def __init__(self, main, side, side2=None):
+        self.main, self.side, self.side2 = main, side, side if side2 is None else side2
         self.events = {}
+        self.nfork = 1
         self.tag = None
 
-    def fork(self):
-        self.side.wait_stream(self.main)
+    def stream(self, sid):
+        return (self.main, self.side, self.side2)[sid]
+
+    def fork(self, sides=1):
+        self.nfork = sides
+        for q in (self.side, self.side2)[:sides]:
+            q.wait_stream(self.main)
 
     def join(self):
-        self.main.wait_stream(self.side)
+        for q in (self.side, self.side2)[:self.nfork]:
+            self.main.wait_stream(q)
 
-    def mark(self, name):
+    def mark(self, name, sid=1):
         ev = torch.cuda.Event()
-        ev.record(self.side)
+        ev.record(self.stream(sid))
         self.events[name] = ev
 
     def need(self, name):
@@ -114,11 +121,11 @@ class ForwardPlanner:
         finally:
             self.S.tag = None
 
-    def on_side(self):
-        return torch.cuda.stream(self.S.side)
+    def on_side(self, sid=1):
+        return torch.cuda.stream(self.S.stream(sid))
 
-    def mark(self, name):
-        self.S.mark(name)
+    def mark(self, name, sid=1):
+        self.S.mark(name, sid)
         self.marked.add(name)
 
     def need(self, *names):
@@ -151,8 +158,12 @@ class ForwardPlanner:
                 and g._bf16_storage_kernels_exist(self.B, self.T)):
             self.adt = torch.bfloat16
         self.st = self.adt == torch.bfloat16
+        # the conditioning chain (fcs -> spectral-norm step -> gamma / beta: three latency-bound launches, 70 - 125 us beside conv_pre) on a queue of
+        # its own in the bf16-storage train-mode plan: behind it on ONE side stream the residual convs' fragments reached the first stage kernel
+        # 35 us late (B = 32 x T = 256, round 6 trace)
+        self.cond_sid = 2 if (self.st and self.training and g.cond_stream) else 1
         self.joined = False
-        self.S.fork()
+        self.S.fork(self.cond_sid)
         self.slab = g._slab(self.dev)
         self.y = None
         self.wps32 = {}
@@ -164,8 +175,8 @@ class ForwardPlanner:
     # ---------------------------------------------------------------------------------------------------------------------------
     def weights(self):
         """K0 + K3.  bf16 storage: the side stream's work is ordered by first use - conv_post's fold, ups.0's fragments, the conditioning
-        chain, the Conv1d batch, ups.1 .. - with an event behind each step, and the main stream waits for exactly the step its next launch
-        reads (`need`).  fp32: the folds run in front of conv_pre (8.55 against 8.65 ms with them beside it), the conditioning chain on the
+        chain (train mode: on the second side stream), the Conv1d batch, ups.1 .. - with an event behind each step, and the main stream waits
+        for exactly the step its next launch reads (`need`).  fp32: the folds run in front of conv_pre (8.55 against 8.65 ms with them beside it), the conditioning chain on the
         side stream, joined as late as its first use."""
         g, st, dev = self.g, self.st, self.dev
         B, ns = self.B, self.ns
@@ -174,6 +185,8 @@ class ForwardPlanner:
         self.sigma_ws = self.buf('sigma_ws', (ns,))
         self.affs = None
         self.cond_ran = False
+        if self.cond_sid == 2:
+            self.cond()                # its own queue: issued first, it runs beside everything below
         with (self.on_side() if st else contextlib.nullcontext()):
             self.wf, self.wp = g._fold_weights(dev, need_wf=self.save is not None, bf16_only=st)
         if st:
@@ -190,7 +203,7 @@ class ForwardPlanner:
             return
         self.cond_ran = True
         g, dev, ns, B = self.g, self.dev, self.ns, self.B
-        with self.on_side():
+        with self.on_side(self.cond_sid):
             if not self.training and self.save is None:
                 sn_p = [q for c in g.cbns for q in (c.layer.weight_orig, c.layer.weight_u, c.layer.weight_v)]
                 skey = (tuple((q.data_ptr(), q._version) for q in sn_p), str(dev))
@@ -211,7 +224,7 @@ class ForwardPlanner:
                     [c.layer.weight_orig.detach() for c in g.cbns], [c.layer.bias.detach() for c in g.cbns],
                     [c.layer.weight_u for c in g.cbns], [c.layer.weight_v for c in g.cbns], self.gbs, self.z_ws, self.sigma_ws, self.training)
         if self.st:
-            self.mark('cond')
+            self.mark('cond', self.cond_sid)
 
     def ck(self, nm, io=3):
         """Kernel choice of one Conv1d layer: bf16 / split-f16 fragments when prepared, else the f32 MFMA stream."""
@@ -286,9 +299,13 @@ class ForwardPlanner:
         # thousands of partial rows, nothing to all-reduce, no backward that reads the array: the two-level form
         sliced = self.training and nt_stats >= 1024 and g.stat_sync is None and self.save is None
         stats = None
+        # ... hundreds of rows, nothing to all-reduce: the reduction and the finalisation as one launch
+        fused = g.fuse_bn_finalize and self.training and not sliced and nt_stats and g.stat_sync is None and self.affs is None
         if self.training and not sliced:
             stats = self.buf(f'bn.stats{i}', (2 * C + 1,), dtype=torch.float64)
-            if nt_stats:
+            if fused:
+                pass
+            elif nt_stats:
                 hipops.bn_reduce_partials(part, nt_stats, C, B * Lo, stats)
             else:
                 hipops.bn_stats(self.xr, stats, self.buf('bn.partial', (2 * max(C, 256) * 64,), dtype=torch.float64))
@@ -303,6 +320,9 @@ class ForwardPlanner:
             sl = self.buf(f'bn.slices{i}', (hipops.BN_SLICES * 2 * C,), dtype=torch.float64)
             hipops.bn_reduce_finalize_slices(part, nt_stats, B * Lo, sl, self.gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                              a_t, s_t, momentum=bn.momentum, eps=bn.eps)
+        elif fused:
+            hipops.bn_reduce_finalize(part, nt_stats, B * Lo, stats, self.gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      a_t, s_t, momentum=bn.momentum, eps=bn.eps)
         elif self.affs is None:
             hipops.bn_finalize(stats, self.gbs[i], bn.running_mean, bn.running_var, bn.num_batches_tracked, a_t, s_t,
                                training=self.training, momentum=bn.momentum, eps=bn.eps)

@@ -482,6 +482,15 @@ def bn_reduce_partials(part, ntiles, Cc, count, stats):
     return stats
 
 
+def bn_reduce_finalize(part, ntiles, count, stats, gb, running_mean, running_var, num_batches_tracked, a_out, s_out, *, momentum=0.1, eps=1e-5):
+    """bn_reduce_partials + bn_finalize(training=True) in one launch (v2w_bn_reduce_finalize): same values, bit for bit."""
+    B, C2 = gb.shape
+    _hip.check(_hip.load().v2w_bn_reduce_finalize(part.data_ptr(), ntiles, float(count), gb.data_ptr(), running_mean.data_ptr(),
+                                                  running_var.data_ptr(), _hip.ptr(num_batches_tracked), stats.data_ptr(), a_out.data_ptr(),
+                                                  s_out.data_ptr(), B, C2 // 2, momentum, eps, _stream(gb)), 'v2w_bn_reduce_finalize')
+    return a_out, s_out
+
+
 class FoldPlan:
     """Device-resident descriptor table for v2w_fold_pack_batch: every MFMA layer folded + packed in two launches."""
 

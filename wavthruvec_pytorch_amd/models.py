@@ -212,6 +212,8 @@ class Generator(nn.Module):
         self.fuse_wide_stage = True           # bf16 storage: the whole residual section of a wide stage (C = 64 / 128 / 256) as ONE kernel
         self.fuse_up = True                   # bf16 storage: the NEXT stage's transposed conv (stride 2 / 4) inside the kernel of a stage (C = 32 .. 256):
                                               # the stage's output never leaves the chip, one launch less per stage
+        self.fuse_bn_finalize = True          # train mode: a stage's statistics reduction and its finalisation as one launch (v2w_bn_reduce_finalize) where nothing is all-reduced in between
+        self.cond_stream = False              # bf16 storage, train mode: the conditioning chain on a second side stream, beside the weight folds instead of between them (measured with tools/exp/plan_switch_ab.py: -8 us at B = 32 x T = 256 with fuse_bn_finalize, +55 us at B = 64 x T = 512: off)
         self.fuse_post = True                 # leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage (bf16 storage, and - round 5 - the fp32 stage kernel): the stage's
                                               # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
         self.fuse_stage_backward = False      # exact fp32 backward of a narrow stage (C in fuse_stage): both input-gradient convs of all branches in
@@ -315,10 +317,11 @@ class Generator(nn.Module):
 
     # -------------------------------------------------------------------------------------------
     @staticmethod
-    def _side_stream(device):
-        st = _SIDE_STREAMS.get(str(device))      # per process and device, not per module: modules stay deep-copyable / picklable
+    def _side_stream(device, index=0):
+        key = str(device) if index == 0 else f'{device}#{index}'
+        st = _SIDE_STREAMS.get(key)              # per process and device, not per module: modules stay deep-copyable / picklable
         if st is None:
-            st = _SIDE_STREAMS[str(device)] = torch.cuda.Stream(device=device)
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
         return st
 
     def _buf(self, name, shape, dtype=torch.float32, device=None):
@@ -604,7 +607,8 @@ class Generator(nn.Module):
         storage of every parameter and buffer (a `.to()`, a `load_state_dict(assign=True)` or a replaced Parameter moves them)."""
         ptrs = tuple(p.data_ptr() for p in self.parameters()) + tuple(b.data_ptr() for b in self.buffers())
         return (tuple(x.shape), str(x.device), torch.cuda.current_stream(x.device).cuda_stream, self.training, self.precision, self.algo, self.bf16_storage, tuple(self.fuse_stage), tuple(self.fuse_pairs),
-                self.fuse_wide, self.fuse_wide_stage, self.fuse_up, self.fuse_post, self.split_min_channels, self.always_refold, ptrs)
+                self.fuse_wide, self.fuse_wide_stage, self.fuse_up, self.fuse_post, self.fuse_bn_finalize, self.cond_stream, self.split_min_channels,
+                self.always_refold, ptrs)
 
     def _forward_hip(self, x, spk, nz, save):
         """One forward through the C ABI.  `save` (a dict) asks for the back-propagatable form (forward_plan.py).  A no-grad forward is PLANNED
@@ -613,14 +617,14 @@ class Generator(nn.Module):
         from .forward_plan import ForwardPlanner, DirectStreams
         from . import schedule
         dev = x.device
-        main, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        main, side, side2 = torch.cuda.current_stream(dev), self._side_stream(dev), self._side_stream(dev, 1)
         if save is not None or not self.use_launch_plan or self.stat_sync is not None:
-            return ForwardPlanner(self, x, spk, nz, save, DirectStreams(main, side)).run()
+            return ForwardPlanner(self, x, spk, nz, save, DirectStreams(main, side, side2)).run()
         key, refold = self._tape_key(x)
         tape = self._tapes.get(key)
         if tape is not None:
             y = torch.empty(tape.out[0], device=dev, dtype=tape.out[1])
-            tape.replay(main, side, dict(x=x.data_ptr(), spk=spk.data_ptr(), nz=nz.data_ptr(), y=y.data_ptr()), self._profile)
+            tape.replay(main, side, dict(x=x.data_ptr(), spk=spk.data_ptr(), nz=nz.data_ptr(), y=y.data_ptr()), self._profile, side2)
             if self._profile_names is not None:
                 self._profile_names.update(tape.kernel_names())
             if refold is not None:                      # the replay folded what was stale: what the fold cache must say now
@@ -635,8 +639,8 @@ class Generator(nn.Module):
                 self._fold_key.pop('sigma', None)       # (sigma_ws now holds this forward's own power-iteration values, as the planned forward notes)
             return y
         if self._profile is not None:                   # (a profiled forward of a configuration without a plan yet: planned, timed, not recorded)
-            return ForwardPlanner(self, x, spk, nz, None, DirectStreams(main, side)).run()
-        rec = schedule.Recorder(_hip.load(), main, side)
+            return ForwardPlanner(self, x, spk, nz, None, DirectStreams(main, side, side2)).run()
+        rec = schedule.Recorder(_hip.load(), main, side, side2)
         epoch = self._ws_epoch
         prev = _hip.set_recorder(rec)
         try:

@@ -22,7 +22,7 @@ import torch
 from . import _hip
 
 K_CALL, K_FORK, K_JOIN, K_MARK, K_NEED, K_PY = range(6)
-MAIN, SIDE = 0, 1
+MAIN, SIDE, SIDE2 = 0, 1, 2        # SIDE2: the conditioning chain's own queue in the bf16-storage train-mode plan (forward_plan.weights)
 
 
 class Step:
@@ -152,14 +152,15 @@ class Tape:
                 out.setdefault(st.tag, []).extend(names)
         return out
 
-    def replay(self, main, side, binds: Dict[str, int], profile: Optional[list] = None):
+    def replay(self, main, side, binds: Dict[str, int], profile: Optional[list] = None, side2=None):
         for name, addr in binds.items():
             for cont, key in self.patches[name]:
                 if isinstance(key, int):
                     cont[key] = addr
                 else:
                     setattr(cont, key, addr)
-        mh, sh = main.cuda_stream, side.cuda_stream
+        streams = (main, side, side if side2 is None else side2)
+        handles = tuple(q.cuda_stream for q in streams)
         open_tag, e0 = None, None
         for st in self.steps:
             k = st.kind
@@ -173,17 +174,19 @@ class Tape:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(main)
             if k == K_CALL:
-                rc = st.fn(*st.args, mh if st.sid == MAIN else sh)
+                rc = st.fn(*st.args, handles[st.sid])
                 if rc != 0:
                     _hip.check(rc, st.name)
             elif k == K_NEED:
                 main.wait_event(self.events[st.name])
             elif k == K_MARK:
-                self.events[st.name].record(side)
+                self.events[st.name].record(streams[st.sid])
             elif k == K_FORK:
-                side.wait_stream(main)
+                for q in streams[1:1 + st.args]:
+                    q.wait_stream(main)
             elif k == K_JOIN:
-                main.wait_stream(side)
+                for q in streams[1:1 + st.args]:
+                    main.wait_stream(q)
             else:
                 st.fn()
         if profile is not None and open_tag is not None:
@@ -215,11 +218,12 @@ class NameProbe:
 class Recorder:
     """Stands in front of the library while a planner runs: launching calls that succeed are taped (and executed), queries pass through."""
 
-    def __init__(self, lib, main, side):
+    def __init__(self, lib, main, side, side2=None):
         self._lib = lib
         self.tape = Tape()
-        self.main, self.side = main, side
-        self._mh, self._sh = main.cuda_stream, side.cuda_stream
+        self.main, self.side, self.side2 = main, side, side if side2 is None else side2
+        self._sid = {self.side2.cuda_stream: SIDE2, side.cuda_stream: SIDE, main.cuda_stream: MAIN}
+        self.nfork = 1
         self.tag = None
 
     def __getattr__(self, name):
@@ -232,31 +236,35 @@ class Recorder:
             if rc == 0:
                 h = args[-1]
                 h = h.value if isinstance(h, C.c_void_p) else h
-                if h == self._mh:
-                    sid = MAIN
-                elif h == self._sh:
-                    sid = SIDE
-                else:
+                sid = self._sid.get(h)
+                if sid is None:
                     raise RuntimeError(f'schedule: {name} launched on a stream the plan does not know')
                 self.tape.steps.append(Step(K_CALL, fn, list(args[:-1]), sid, self.tag if sid == MAIN else None, name))
             return rc
         return call
 
     # ---- stream operations of the plan (executed now, taped for the replays)
-    def fork(self):
-        self.side.wait_stream(self.main)
-        self.tape.steps.append(Step(K_FORK))
+    def stream(self, sid):
+        return (self.main, self.side, self.side2)[sid]
+
+    def fork(self, sides=1):
+        """The first `sides` side streams wait for the main stream (and `join` brings the same ones back)."""
+        self.nfork = sides
+        for q in (self.side, self.side2)[:sides]:
+            q.wait_stream(self.main)
+        self.tape.steps.append(Step(K_FORK, args=sides))
 
     def join(self):
-        self.main.wait_stream(self.side)
-        self.tape.steps.append(Step(K_JOIN))
+        for q in (self.side, self.side2)[:self.nfork]:
+            self.main.wait_stream(q)
+        self.tape.steps.append(Step(K_JOIN, args=self.nfork))
 
-    def mark(self, name):
+    def mark(self, name, sid=SIDE):
         ev = self.tape.events.get(name)
         if ev is None:
             ev = self.tape.events[name] = torch.cuda.Event()
-        ev.record(self.side)
-        self.tape.steps.append(Step(K_MARK, name=name))
+        ev.record(self.stream(sid))
+        self.tape.steps.append(Step(K_MARK, name=name, sid=sid))
 
     def need(self, name):
         self.main.wait_event(self.tape.events[name])
