@@ -1,4 +1,5 @@
-"""In-process A/B of the round-6 plan switches on the bf16 train-mode forward (same box, same clocks): fuse_bn_finalize, cond_stream.  tools/exp."""
+"""In-process A/B of the round-6 plan switches on the bf16 train-mode forward (same box, same clocks): fuse_bn_finalize, cond_stream.  (Round 6 also tried ONE wait per side stream from the
+second stage on - the remaining folds are starved by the first stage kernel and finish with it: +10-14 us at B = 32 x T = 256, reverted.)  tools/exp."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
