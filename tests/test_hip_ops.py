@@ -187,6 +187,31 @@ def test_conv1d_bf16_operands(dev, B, cin, cout, L, k, dil):
     assert err <= 2e-5, f'max err {err}'
 
 
+@pytest.mark.parametrize('B,cin,L', [(4, 512, 2044), (32, 768, 256), (2, 1024, 4096)])
+def test_conv_pre_bf16_one_tile_per_cu(dev, B, cin, L):
+    """conv_pre of the bf16 pipeline (fp32 latents in, bf16 out: io_bf16 = 2, k = 7) on a grid of about one 128 x 128 tile per CU - the eight-wave
+    instantiation conv_bf16_kernel<1, 2, 4, 2, .., 64, true> the dispatcher picks there (round 6) - against an fp64 convolution of the bf16-rounded
+    operands, to the rounding of the bf16 store; ragged last tiles, sequence ends inside a tile; two launches agree bit for bit."""
+    from wavthruvec_pytorch_amd import hipops
+    r = _rng(77)
+    x = r.standard_normal((B, cin, L), dtype=np.float32)
+    w = (r.standard_normal((512, cin, 7)) / np.sqrt(cin * 7)).astype(np.float32)
+    bias = r.standard_normal(512).astype(np.float32)
+    want = F.conv1d(torch.from_numpy(x).bfloat16().double(), torch.from_numpy(w).bfloat16().double(), torch.from_numpy(bias).double(), padding=3)
+    wf = _t(_relayout(torch.from_numpy(w)).numpy(), dev)
+    wps = hipops.pack_split(wf, bf16=True)
+    name = hipops.conv_bf16_config(B, 1, cin, 512, L, 7, 1, 1, io_bf16=2)
+    assert name.startswith('conv_bf16_kernel<1, 2, 4, 2,'), name                 # the 128 x 128 tile on eight waves is what this shape takes
+    out = torch.full((B, 512, L), float('nan'), device=dev, dtype=torch.bfloat16)
+    hipops.conv1d(_t(x, dev), None, _t(bias, dev), out, k=7, dil=1, slope=1.0, algo=hipops.ALGO_BF16, wps=wps, io_bf16=2)
+    assert torch.isfinite(out.float()).all()
+    err = (out.cpu().double() - want).abs()
+    assert (err <= 2.0 ** -8 * want.abs() + 1e-4).all(), f'max err {err.max().item()}'
+    out2 = torch.full_like(out, float('nan'))
+    hipops.conv1d(_t(x, dev), None, _t(bias, dev), out2, k=7, dil=1, slope=1.0, algo=hipops.ALGO_BF16, wps=wps, io_bf16=2)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize('B,C,L,k,dil,streams', [(3, 128, 2560, 7, 3, 'res'), (3, 128, 2560, 11, 1, 'res+add2+div'), (2, 64, 1028, 3, 1, 'acc'),
                                                   (2, 256, 300, 7, 1, 'res+add2+div'), (1, 64, 132, 3, 3, 'plain')])
 def test_conv1d_bf16_activation_storage(dev, B, C, L, k, dil, streams):
