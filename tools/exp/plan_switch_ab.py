@@ -13,8 +13,8 @@ for B, T in ((32, 256), (64, 512)):
     g.precision = 'bf16'
     inp = synthetic.make_inputs(h, B, T, seed=1, device=dev)
     for rep in range(2):
-        for bn, cs in ((False, False), (True, False), (False, True), (True, True)):
-            g.fuse_bn_finalize, g.cond_stream = bn, cs
+        for bn, cs, mw in ((False, False, False), (True, False, False), (True, False, True), (True, True, True)):
+            g.fuse_bn_finalize, g.cond_stream, g.merge_waits = bn, cs, mw
             with torch.no_grad():
                 for _ in range(5):
                     g(*inp)
@@ -26,4 +26,4 @@ for B, T in ((32, 256), (64, 512)):
                         g(*inp)
                     e1.record(); torch.cuda.synchronize()
                     best = min(best, e0.elapsed_time(e1) / 50)
-            print(f'B={B} T={T} fuse_bn_finalize={bn!s:5} cond_stream={cs!s:5}: {best * 1e3:.1f} us / forward', flush=True)
+            print(f'B={B} T={T} fuse_bn_finalize={bn!s:5} cond_stream={cs!s:5} merge_waits={mw!s:5}: {best * 1e3:.1f} us / forward', flush=True)

@@ -73,6 +73,7 @@ class ForwardPlanner:
         self.algo = g.algo
         self.nk, self.ns = g.num_kernels, g.num_upsamples
         self.marked = set()        # side-stream steps with an event behind them ...
+        self.order = []            # ... (name, stream) in the order they were recorded
         self.needed = set()        # ... and the ones the main stream has already waited for
 
     # ---------------------------------------------------------------------------------------------------------------------------
@@ -127,13 +128,24 @@ class ForwardPlanner:
     def mark(self, name, sid=1):
         self.S.mark(name, sid)
         self.marked.add(name)
+        self.order.append((name, sid))
 
     def need(self, *names):
-        """The main stream waits for exactly these steps of the side stream (each once)."""
-        for nm in names:
-            if nm in self.marked and nm not in self.needed:
+        """The main stream waits for these steps of the side streams - for nothing more, and for each stream at most once per call: the event
+        behind a step of an in-order stream stands for every earlier step of that stream (`post` is behind `ups.0`, `rest` behind `ups.1`), so
+        the latest of `names` on a stream is the one waited for and the earlier ones count as met (a wait costs the main queue ~3 us even when
+        long satisfied: eight per forward before, five now)."""
+        want = [nm for nm in names if nm in self.marked and nm not in self.needed]
+        if not self.g.merge_waits:
+            for nm in want:
                 self.needed.add(nm)
                 self.S.need(nm)
+            return
+        for sid in sorted({s for n, s in self.order if n in want}):
+            seq = [n for n, s in self.order if s == sid]
+            last = max(seq.index(n) for n in want if n in seq)
+            self.S.need(seq[last])
+            self.needed.update(seq[:last + 1])
 
     def join_side(self):
         if not self.joined:
@@ -161,7 +173,8 @@ class ForwardPlanner:
         # the conditioning chain (fcs -> spectral-norm step -> gamma / beta: three latency-bound launches, 70 - 125 us beside conv_pre) on a queue of
         # its own in the bf16-storage train-mode plan: behind it on ONE side stream the residual convs' fragments reached the first stage kernel
         # 35 us late (B = 32 x T = 256, round 6 trace)
-        self.cond_sid = 2 if (self.st and self.training and g.cond_stream) else 1
+        cs = g.cond_stream if g.cond_stream is not None else 3072 <= self.B * self.T <= 10240
+        self.cond_sid = 2 if (self.st and self.training and cs) else 1
         self.joined = False
         self.S.fork(self.cond_sid)
         self.slab = g._slab(self.dev)

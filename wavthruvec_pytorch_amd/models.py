@@ -213,7 +213,8 @@ class Generator(nn.Module):
         self.fuse_up = True                   # bf16 storage: the NEXT stage's transposed conv (stride 2 / 4) inside the kernel of a stage (C = 32 .. 256):
                                               # the stage's output never leaves the chip, one launch less per stage
         self.fuse_bn_finalize = True          # train mode: a stage's statistics reduction and its finalisation as one launch (v2w_bn_reduce_finalize) where nothing is all-reduced in between
-        self.cond_stream = False              # bf16 storage, train mode: the conditioning chain on a second side stream, beside the weight folds instead of between them (measured with tools/exp/plan_switch_ab.py: -8 us at B = 32 x T = 256 with fuse_bn_finalize, +55 us at B = 64 x T = 512: off)
+        self.merge_waits = True               # bf16 storage: one wait per side stream and call, earlier steps of the stream count as met (forward_plan.need)
+        self.cond_stream = None               # bf16 storage, train mode: the conditioning chain on a second side stream, beside the weight folds instead of between them.  None: where it pays - while conv_pre + ups.0 are shorter than the one side stream's chain + folds (measured, tools/exp/cond_stream_sweep.py: -26 / -12 us at B x T = 4 096 / 8 192 frames, +8 at 2 048, +13 .. +28 from 12 288 up); True / False: always / never
         self.fuse_post = True                 # leaky_relu -> conv_post -> tanh inside the kernel of the last (C = 16) stage (bf16 storage, and - round 5 - the fp32 stage kernel): the stage's
                                               # output (335 MB at configs[2]) is never written nor read back (v2w_stage_bf16_n16.hip, 7-tap tail)
         self.fuse_stage_backward = False      # exact fp32 backward of a narrow stage (C in fuse_stage): both input-gradient convs of all branches in
@@ -607,7 +608,7 @@ class Generator(nn.Module):
         storage of every parameter and buffer (a `.to()`, a `load_state_dict(assign=True)` or a replaced Parameter moves them)."""
         ptrs = tuple(p.data_ptr() for p in self.parameters()) + tuple(b.data_ptr() for b in self.buffers())
         return (tuple(x.shape), str(x.device), torch.cuda.current_stream(x.device).cuda_stream, self.training, self.precision, self.algo, self.bf16_storage, tuple(self.fuse_stage), tuple(self.fuse_pairs),
-                self.fuse_wide, self.fuse_wide_stage, self.fuse_up, self.fuse_post, self.fuse_bn_finalize, self.cond_stream, self.split_min_channels,
+                self.fuse_wide, self.fuse_wide_stage, self.fuse_up, self.fuse_post, self.fuse_bn_finalize, self.cond_stream, self.merge_waits, self.split_min_channels,
                 self.always_refold, ptrs)
 
     def _forward_hip(self, x, spk, nz, save):
