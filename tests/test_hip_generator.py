@@ -267,6 +267,35 @@ def test_generator_launch_plan_replays_the_planned_forward(dev, training, precis
             assert folded.launches < refold.launches
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'f32'])
+def test_plan_switches_change_the_schedule_not_the_result(dev, precision):
+    """Round-6 switches of the launch plan - the statistics reduction + finalisation as one launch (fuse_bn_finalize), the conditioning chain on a
+    second side stream (cond_stream), merged waits for side-stream events (merge_waits) - re-order launches and stream waits only: the output, the
+    BatchNorm running statistics and the spectral-norm vectors of a train-mode forward are bit-identical in every setting, planned and replayed
+    (B x T = 4 096 frames: where `cond_stream = None` turns the second stream on by itself)."""
+    import itertools
+    h = synthetic.make_hparams(num_wv_feat=768)
+    sd = synthetic.make_state_dict(h, seed=0)
+    inp = to_dev(synthetic.make_inputs(h, 16, 256, seed=9), dev)
+    ref = None
+    for bn, cs, mw in itertools.chain([(True, None, True)], itertools.product((False, True), (False, True), (False, True))):
+        g = build_generator(h, sd, dev, training=True)
+        g.precision = precision
+        g.fuse_bn_finalize, g.cond_stream, g.merge_waits = bn, cs, mw
+        with torch.no_grad():
+            y1 = g(*inp)              # planned and recorded
+            y2 = g(*inp)              # replayed
+        torch.cuda.synchronize()
+        state = {k: v.clone() for k, v in g.state_dict().items() if 'cbns' in k}
+        assert torch.isfinite(y1).all()
+        if ref is None:
+            ref = (y1.clone(), y2.clone(), state)
+            continue
+        assert torch.equal(y1, ref[0]) and torch.equal(y2, ref[1]), (bn, cs, mw)
+        for k, v in state.items():
+            assert torch.equal(v, ref[2][k]), (k, bn, cs, mw)
+
+
 def test_launch_plan_key_separates_weight_folds_from_sigma(dev):
     """what is stale when a plan is recorded is part of its key, separately for the conv weight folds ('w') and for sigma of the
     spectral norm ('s').  A train-mode no-grad forward leaves the folds cached and sigma_ws holding its own values: the next eval forward

@@ -461,3 +461,41 @@ def test_bench_schedule_roofline_uses_the_cited_profile_or_says_why_not(tmp_path
     sc = bench.schedule_traffic(per_kernel, 'fake_hbm_traffic.json', 1e-3)
     assert sc['hbm_frac_counter'] is None and 'stale' in sc['missing'][0]
     assert bench.schedule_traffic(per_kernel, None, 1e-3) is None
+
+
+def test_planner_waits_once_per_side_stream_and_never_for_more_than_asked():
+    """forward_plan.ForwardPlanner.need (round 6): the event behind a step of an in-order stream stands for the earlier steps of THAT stream -
+    the latest of the asked steps is waited for, the earlier ones count as met and are never waited for again; steps of another stream keep
+    their own wait; a later step is never waited for on behalf of an earlier one."""
+    import types
+    import torch
+    from wavthruvec_pytorch_amd.forward_plan import ForwardPlanner
+
+    class FakeStreams:
+        def __init__(self):
+            self.log = []
+
+        def mark(self, name, sid=1):
+            self.log.append(('mark', name, sid))
+
+        def need(self, name):
+            self.log.append(('need', name))
+
+    for merge in (True, False):
+        g = types.SimpleNamespace(training=True, algo=0, num_kernels=3, num_upsamples=5, merge_waits=merge)
+        S = FakeStreams()
+        pl = ForwardPlanner(g, torch.zeros(2, 3, 4), None, None, None, S)
+        for name, sid in (('post', 1), ('ups.0', 1), ('cond', 2), ('rest', 1), ('ups.1', 1), ('ups.2', 1)):
+            pl.mark(name, sid)
+        pl.need('ups.0')
+        pl.need('cond')
+        pl.need('rest', 'ups.1')
+        pl.need('post')                  # behind ups.0 on its stream
+        pl.need('ups.2', 'nothing-marked-under-this-name')
+        pl.need('ups.2')                 # each step once
+        waits = [e[1] for e in S.log if e[0] == 'need']
+        if merge:
+            assert waits == ['ups.0', 'cond', 'ups.1', 'ups.2']
+        else:
+            assert waits == ['ups.0', 'cond', 'rest', 'ups.1', 'post', 'ups.2']
+        assert pl.needed >= {'post', 'ups.0', 'cond', 'rest', 'ups.1', 'ups.2'}
