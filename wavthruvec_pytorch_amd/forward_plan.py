@@ -606,8 +606,14 @@ class ForwardPlanner:
     def tail(self):
         """K8: leaky_relu(0.01) -> conv_post -> tanh (unless the last stage's kernel has already done it)."""
         g = self.g
-        if self.st or not self.joined:
-            self.S.join()        # (bf16 storage: whatever step nobody asked for; the side stream has long finished)
+        if self.st:
+            # bf16 storage: every launch on a side stream has an event behind it (weights(), cond()); when the main stream has waited for all of
+            # them - and every forked stream has one, so each has rejoined - there is nothing left to join (two waits on the main queue less)
+            forked = range(1, 1 + self.cond_sid)
+            if not (self.g.merge_waits and self.marked <= self.needed and all(any(s == sid for _n, s in self.order) for sid in forked)):
+                self.S.join()    # (whatever step nobody asked for; the side streams have long finished)
+        elif not self.joined:
+            self.S.join()
         if self.y is None:
             self.y = torch.empty((self.B, 1, self.L), device=self.dev, dtype=torch.float32)
             self.timed('conv_post', hipops.conv_post_tanh, self.cur, self.wf['conv_post'], g.conv_post.bias.detach(), self.y, k=7, slope=0.01)
