@@ -448,7 +448,7 @@ class Generator(nn.Module):
         `ups_stream`: the upsamplers' fold + pack launches (ten latency-bound kernels, ~55 us at five stages) go to that stream - the
         caller joins it before the first upsampler; they then run beside the Conv1d batch and conv_pre.
         `mark` (the planner's: records an event on the side stream under a name) + `between` (a callable): the order on `ups_stream` becomes
-        ups.0 -> between() -> every Conv1d but conv_pre -> ups.1 .. ups.n, with an event behind each step ('ups.i', 'rest'): the caller waits for exactly what its next launch
+        ups.0 -> between() -> ups.1 .. ups.n -> every Conv1d but conv_pre, with an event behind each step ('ups.i', 'rest'): the caller waits for exactly what its next launch
         reads instead of for the whole stream (at B = 32 x T = 256 the stream's 230 us of small kernels outlast conv_pre by 90 us)."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
@@ -529,10 +529,13 @@ class Generator(nn.Module):
             fold_up(*ups_bf.pop(0))
         if between is not None:
             between()
-        run_plan('split_plan_rest', rest, ups_stream)
-        mark('rest')
+        # the other upsamplers' folds (ten latency-bound launches on small layers) in FRONT of the Conv1d batch: the event behind `rest` then stands
+        # for every fold of the stream and the first stage's wait is the last one of the forward (round 6: -8 us at B = 32 x T = 256, -3 at
+        # B = 64 x T = 512 against folding them behind it, tools/exp/ups_first_ab.py)
         for i, m in ups_bf:
             fold_up(i, m)
+        run_plan('split_plan_rest', rest, ups_stream)
+        mark('rest')
         self._fold_key['wps'] = (gen, out)
         return out
 
