@@ -187,9 +187,9 @@ class ForwardPlanner:
 
     # ---------------------------------------------------------------------------------------------------------------------------
     def weights(self):
-        """K0 + K3.  bf16 storage: the side stream's work is ordered by first use - conv_post's fold, ups.0's fragments, the conditioning
-        chain (train mode: on the second side stream), the Conv1d batch, ups.1 .. - with an event behind each step, and the main stream waits
-        for exactly the step its next launch reads (`need`).  fp32: the folds run in front of conv_pre (8.55 against 8.65 ms with them beside it), the conditioning chain on the
+        """K0 + K3.  bf16 storage: the side stream's work - conv_post's fold, ups.0's fragments, the conditioning chain (train mode at mid sizes:
+        on the second side stream), the other upsamplers' fragments, the Conv1d batch - with an event behind ups.0, the conditioning chain and
+        the last step, and the main stream waits for exactly the event its next launch needs (`need`): three waits per forward.  fp32: the folds run in front of conv_pre (8.55 against 8.65 ms with them beside it), the conditioning chain on the
         side stream, joined as late as its first use."""
         g, st, dev = self.g, self.st, self.dev
         B, ns = self.B, self.ns
@@ -202,8 +202,7 @@ class ForwardPlanner:
             self.cond()                # its own queue: issued first, it runs beside everything below
         with (self.on_side() if st else contextlib.nullcontext()):
             self.wf, self.wp = g._fold_weights(dev, need_wf=self.save is not None, bf16_only=st)
-        if st:
-            self.mark('post')
+        # (no event of its own behind conv_post's fold: it is the first thing on the side stream, the event behind ups.0 stands for it)
         self.wps = g._split_weights(dev, all_ups=st, ups_stream=self.S.side, mark=self.mark if st else None,
                                     between=self.cond if st else None)
         self.cond()

@@ -448,7 +448,8 @@ class Generator(nn.Module):
         `ups_stream`: the upsamplers' fold + pack launches (ten latency-bound kernels, ~55 us at five stages) go to that stream - the
         caller joins it before the first upsampler; they then run beside the Conv1d batch and conv_pre.
         `mark` (the planner's: records an event on the side stream under a name) + `between` (a callable): the order on `ups_stream` becomes
-        ups.0 -> between() -> ups.1 .. ups.n -> every Conv1d but conv_pre, with an event behind each step ('ups.i', 'rest'): the caller waits for exactly what its next launch
+        ups.0 -> between() -> ups.1 .. ups.n -> every Conv1d but conv_pre, with an event behind ups.0 ('ups.0') and behind the last step ('rest': it stands for the
+        upsamplers in front of it too): the caller waits for exactly what its next launch
         reads instead of for the whole stream (at B = 32 x T = 256 the stream's 230 us of small kernels outlast conv_pre by 90 us)."""
         if self.precision == 'f32' or self.algo == hipops.ALGO_DIRECT:
             return {}
@@ -519,7 +520,8 @@ class Generator(nn.Module):
                     self._drop_tapes()
                 self._ws[f'wpsbf.ups.{i}'] = w
                 out[f'ups.{i}'] = w
-            mark(f'ups.{i}')
+            if i == 0:           # (the later upsamplers sit in front of `rest`, whose event stands for them: an event record between two
+                mark(f'ups.{i}')   # folds costs the side stream 6 - 7 us, five of them made `rest` late for the first stage kernel)
 
         # the transposed convs run on the bf16 matrix pipe too (v2w_convt1d_bf16_fwd); the narrow upsamplers are memory-side: with fp32
         # tensors the f32 kernel's epilogue moves their bytes faster; with bf16 storage every upsampler runs there
