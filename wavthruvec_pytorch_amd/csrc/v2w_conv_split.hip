@@ -675,6 +675,24 @@ split_pack_batch_kernel(const v2w_split_desc* __restrict__ descs, const int32_t*
     const float scale = bf ? 1.f : split_scale_from_bits(reinterpret_cast<const unsigned int*>(d.sc)[2]);
     if (blk == 0 && threadIdx.x == 0) { d.sc[0] = 1.f / scale; d.sc[1] = scale; }
     const int rlen = V2W_SPLIT_CK * K, rstride = rlen + 1;
+    if ((reinterpret_cast<uintptr_t>(d.v) & 15) == 0) {
+        // a row's 16 K floats are contiguous and 16-byte aligned (16 K * 4 bytes per (row, chunk)): float4 loads, a quarter of the loads and of the
+        // index divisions (round 6: conv_pre's pack is on the forward's critical path)
+        const int r4 = rlen >> 2;
+        for (int q = threadIdx.x; q < 32 * r4; q += 256) {
+            const int r = q / r4, x = (q - r * r4) * 4;
+            const int row = mb * 32 + r;                         // rows past C_out (C_out = 16): MFMA padding
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (row < d.c_out) {
+                const float rs = d.rowscale[row];
+                w = *reinterpret_cast<const f32x4*>(d.v + ((size_t)row * d.c_in + ch * V2W_SPLIT_CK) * K + x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = w[e] * rs * scale;        // (the scalar form's products, in its order)
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r * rstride + x + e] = w[e];
+        }
+    } else
     for (int idx = threadIdx.x; idx < 32 * rlen; idx += 256) {
         const int r = idx / rlen, x = idx - r * rlen;
         const int row = mb * 32 + r;                             // rows past C_out (C_out = 16): MFMA padding
