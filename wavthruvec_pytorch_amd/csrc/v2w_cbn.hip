@@ -216,16 +216,33 @@ __global__ void bn_reduce_kernel(const double* __restrict__ partial, double* __r
     stats[C + c] = s2;
 }
 
+// This thread's rows (threadIdx.x, + 256, ..) of channel c: the (sum, sumsq) pairs added in row order - the plain loop's order -, four 8-byte loads
+// in flight (a layer with thousands of rows gives a thread a dozen: one exposed latency each when taken one at a time).  Round 6: with it the
+// one-level kernels serve up to 4 096 rows (the 2 944 of the 64-channel stage at B = 32 x T = 256: one launch of ~6 us instead of the two-level pair's 12)
+typedef float bn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bn_rows_of_channel(const float* __restrict__ part, int ntiles, int C, int c, double& s1, double& s2) {
+    const bn_f2* p = reinterpret_cast<const bn_f2*>(part) + c;
+    int t = threadIdx.x;
+    for (; t + 768 < ntiles; t += 1024) {
+        const bn_f2 a = p[(size_t)t * C], b = p[(size_t)(t + 256) * C], d = p[(size_t)(t + 512) * C], e = p[(size_t)(t + 768) * C];
+        s1 += (double)a[0]; s2 += (double)a[1];
+        s1 += (double)b[0]; s2 += (double)b[1];
+        s1 += (double)d[0]; s2 += (double)d[1];
+        s1 += (double)e[0]; s2 += (double)e[1];
+    }
+    for (; t < ntiles; t += 256) {
+        const bn_f2 a = p[(size_t)t * C];
+        s1 += (double)a[0]; s2 += (double)a[1];
+    }
+}
+
 // stats[c] = sum over tiles of part[tile][c][0..1] in fp64, fixed order; one block per channel
 __global__ void __launch_bounds__(256)
 bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ stats, int ntiles, int C, double count) {
     __shared__ double red[16];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = threadIdx.x; t < ntiles; t += 256) {
-        s1 += (double)part[((size_t)t * C + c) * 2 + 0];
-        s2 += (double)part[((size_t)t * C + c) * 2 + 1];
-    }
+    bn_rows_of_channel(part, ntiles, C, c, s1, s2);
     const double t1 = v2w_block_sum(s1, red);
     const double t2 = v2w_block_sum(s2, red);
     if (threadIdx.x == 0) {
@@ -360,10 +377,7 @@ bn_reduce_finalize_kernel(const float* __restrict__ part, double* __restrict__ s
     __shared__ double tot[2];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = threadIdx.x; t < ntiles; t += 256) {
-        s1 += (double)part[((size_t)t * C + c) * 2 + 0];
-        s2 += (double)part[((size_t)t * C + c) * 2 + 1];
-    }
+    bn_rows_of_channel(part, ntiles, C, c, s1, s2);
     const double t1 = v2w_block_sum(s1, red);
     const double t2 = v2w_block_sum(s2, red);
     if (threadIdx.x == 0) {

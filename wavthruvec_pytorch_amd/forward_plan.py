@@ -308,8 +308,9 @@ class ForwardPlanner:
         """K4: batch statistics (train) -> [all-reduce] -> folded per-sample affine a, s (modules.py:20-30)."""
         g, C, B, Lo = self.g, self.C, self.B, self.Lo
         bn = g.cbns[i].batch_nrom
-        # thousands of partial rows, nothing to all-reduce, no backward that reads the array: the two-level form
-        sliced = self.training and nt_stats >= 1024 and g.stat_sync is None and self.save is None
+        # many thousands of partial rows, nothing to all-reduce, no backward that reads the array: the two-level form (below that the one-level
+        # kernels keep four row loads in flight: one launch)
+        sliced = self.training and nt_stats >= 4096 and g.stat_sync is None and self.save is None
         stats = None
         # ... hundreds of rows, nothing to all-reduce: the reduction and the finalisation as one launch
         fused = g.fuse_bn_finalize and self.training and not sliced and nt_stats and g.stat_sync is None and self.affs is None
