@@ -1,5 +1,5 @@
 """Order of the side stream's folds: the small upsampler folds in front of the Conv1d batch (one event then stands for all of them) against behind it.
-Needs the experiment's env switch V2W_UPS_FIRST in Generator._split_weights (adopted since: upsamplers first; then the same A/B for the events between the upsampler folds - V2W_FEW_MARKS, also adopted: -14.3 / +1.8 / -1.9 us;
+Needs the experiment's env switch V2W_UPS_FIRST in Generator._split_weights (adopted since: upsamplers first; then the same A/B for the events between the upsampler folds - V2W_FEW_MARKS, also adopted: -14.3 / +1.8 / -1.9 us; and V2W_REST_EARLY - the Conv1d batch in front of ups.1 .. 4 with the one event behind all of them - not adopted: +12.2 / -7.1 / +1.4 us;
 measured -8.4 / -2.6 / -6.2 us at B x T = 32 x 256 / 64 x 512 / 16 x 256).  tools/exp."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
